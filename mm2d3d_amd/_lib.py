@@ -1,0 +1,116 @@
+"""ctypes binding of the C-ABI library ``libmm2d3d_hip.so`` (declared in ``include/mm2d3d.h``).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, every
+operator raises.  PyTorch is used only for device memory and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmm2d3d_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lib = None
+
+vp, i32, i64, sz, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+
+# name -> (restype, argtypes); mirrors include/mm2d3d.h
+_PROTOS = {
+    "mm_last_error": (C.c_char_p, []),
+    "mm_hash_capacity": (i64, [i64]),
+    "mm_dedupe_ws_bytes": (sz, [i64]),
+    "mm_voxel_dedupe": (i32, [vp, i32, i64, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_subm_neighbors": (i32, [vp, i64, i32, vp, vp, i64, vp, vp]),
+    "mm_down_neighbors": (i32, [vp, i64, vp, i64, vp, vp]),
+    "mm_rulebook_ws_bytes": (sz, [i64, i32]),
+    "mm_rulebook_compact": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_spconv_ws_bytes": (sz, [i64, i32]),
+    "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
+    "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
+    "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_bn_ws_bytes": (sz, [i32]),
+    "mm_bn_fwd_train": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn_fwd_eval": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
+    "mm_bn_bwd": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_point_ws_bytes": (sz, [i32, i32]),
+    "mm_gate_fwd": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
+    "mm_gate_bwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "mm_segment_reduce": (i32, [vp, i32, i32, vp, vp, i64, i32, vp, i32, vp]),
+    "mm_row_gather": (i32, [vp, i32, i32, vp, vp, i32, i64, vp, i32, vp]),
+    "mm_linear_fwd": (i32, [vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]),
+    "mm_linear_bwd": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp, sz, vp]),
+}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile every .hip source for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=not verbose, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libmm2d3d_hip.so failed:\n" + (r.stdout or "") + (r.stderr or ""))
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C mm2d3d_amd/csrc`). There is no CPU fallback in the product path."
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_PROTOS)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().mm_last_error()
+        raise RuntimeError(f"libmm2d3d_hip {what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device; kernels that use it are serialised on the current stream."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes: int, device, slot: str = "main"):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
+            self.bufs[key] = buf
+        return buf
+
+
+workspace = _Workspace()
+
+
+def require_cuda(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"mm2d3d_amd: {name} must live on the GPU (HIP path only, no CPU fallback)")

@@ -1,0 +1,304 @@
+// Row-major [N, C] batch normalisation + (leaky) ReLU over the active rows of the whole batch
+// (reference call sites scn_unet.py:42,44,51,66,73,116).
+// HBM-bound: two passes over x in training (stats, then normalise+activate), fp64 accumulation of the
+// per-channel sums so the variance does not lose digits at N ~ 2.5e5 rows.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int T = 256;
+constexpr int MAX_PART = 1024;
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<4> {
+  typedef f32x4 type;
+};
+template <>
+struct Vec<1> {
+  typedef float type;
+};
+
+template <int VEC>
+__device__ inline void ldv(const float* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    f32x4 t = *(const f32x4*)p;
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = *p;
+  }
+}
+template <int VEC>
+__device__ inline void stv(float* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *(f32x4*)p = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    *p = v[0];
+  }
+}
+
+// partial[block][0][C] = sum a, partial[block][1][C] = sum b  where (a, b) are produced by F per element
+// MODE 0: a = x, b = x*x            (forward statistics)
+// MODE 1: a = dy', b = dy' * xhat    (backward reductions), dy' = dy * act'(y)
+template <int VEC, int MODE>
+__global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
+                                                  int ld_dy, int64_t N, int C, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ weight,
+                                                  const float* __restrict__ bias, float leak,
+                                                  double* __restrict__ partial) {
+  __shared__ double red[2 * T];  // reused once per vector lane below
+  const int CV = C / VEC;
+  const int rs = T / CV;  // row slots per block
+  const int tid = threadIdx.x;
+  const int slot = tid / CV, cv = tid - slot * CV;
+  double a[VEC], b[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; i++) a[i] = b[i] = 0.0;
+  float m[VEC], is[VEC], w[VEC], bs[VEC];
+  if (MODE == 1 && slot < rs) {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      m[i] = mean[cv * VEC + i];
+      is[i] = invstd[cv * VEC + i];
+      w[i] = weight ? weight[cv * VEC + i] : 1.f;
+      bs[i] = bias ? bias[cv * VEC + i] : 0.f;
+    }
+  }
+  const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  if (slot < rs) {
+    for (int64_t r = r0 + slot; r < r1; r += rs) {
+      float xv[VEC];
+      ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          a[i] += (double)xv[i];
+          b[i] += (double)xv[i] * (double)xv[i];
+        }
+      } else {
+        float dv[VEC];
+        ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
+#pragma unroll
+        for (int i = 0; i < VEC; i++) {
+          float xh = (xv[i] - m[i]) * is[i];
+          float y = xh * w[i] + bs[i];
+          float g = y > 0.f ? dv[i] : dv[i] * leak;
+          a[i] += (double)g;
+          b[i] += (double)g * (double)xh;
+        }
+      }
+    }
+  }
+  // reduce over row slots through LDS, one vector lane at a time
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    __syncthreads();
+    red[tid] = a[i];
+    red[T + tid] = b[i];
+    __syncthreads();
+    if (tid < CV) {
+      double sa = 0.0, sb = 0.0;
+      for (int s = 0; s < rs; s++) {
+        sa += red[s * CV + tid];
+        sb += red[T + s * CV + tid];
+      }
+      partial[((int64_t)blockIdx.x * 2 + 0) * C + tid * VEC + i] = sa;
+      partial[((int64_t)blockIdx.x * 2 + 1) * C + tid * VEC + i] = sb;
+    }
+  }
+}
+
+__global__ void k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; b++) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    q += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  double mean = N > 0 ? s / (double)N : 0.0;
+  double var = N > 0 ? q / (double)N - mean * mean : 0.0;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
+    running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * (float)mean;
+    running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)unbiased;
+  }
+}
+
+__global__ void k_bn_finalize_bwd(const double* __restrict__ partial, int nblk, int C, float* __restrict__ sum_dy,
+                                   float* __restrict__ sum_dy_xhat, float* __restrict__ dweight,
+                                   float* __restrict__ dbias, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int b = 0; b < nblk; b++) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    q += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  sum_dy[c] = (float)s;
+  sum_dy_xhat[c] = (float)q;
+  if (dweight) dweight[c] = accumulate ? dweight[c] + (float)q : (float)q;
+  if (dbias) dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+}
+
+// y = act((x - mean) * invstd * w + b)
+template <int VEC>
+__global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int ld_x, int64_t N, int C,
+                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                 int invstd_is_var, float eps, const float* __restrict__ weight,
+                                                 const float* __restrict__ bias, float leak, float* __restrict__ y,
+                                                 int ld_y) {
+  const int CV = C / VEC;
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t r = gid / CV;
+  int cv = (int)(gid - r * CV);
+  if (r >= N) return;
+  float xv[VEC], yv[VEC];
+  ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    int c = cv * VEC + i;
+    float is = invstd_is_var ? rsqrtf(invstd[c] + eps) : invstd[c];
+    float v = (xv[i] - mean[c]) * is * (weight ? weight[c] : 1.f) + (bias ? bias[c] : 0.f);
+    yv[i] = v > 0.f ? v : v * leak;
+  }
+  stv<VEC>(y + r * ld_y + cv * VEC, yv);
+}
+
+// dx = w*invstd * (dy' - sum_dy/N - xhat * sum_dy_xhat/N)
+template <int VEC>
+__global__ __launch_bounds__(T) void k_bn_bwd_apply(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
+                                                     int ld_dy, int64_t N, int C, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, const float* __restrict__ weight,
+                                                     const float* __restrict__ bias, float leak,
+                                                     const float* __restrict__ sum_dy,
+                                                     const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
+                                                     int ld_dx) {
+  const int CV = C / VEC;
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t r = gid / CV;
+  int cv = (int)(gid - r * CV);
+  if (r >= N) return;
+  float xv[VEC], dv[VEC], ov[VEC];
+  ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+  ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
+  const float invN = 1.f / (float)N;
+#pragma unroll
+  for (int i = 0; i < VEC; i++) {
+    int c = cv * VEC + i;
+    float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
+    float xh = (xv[i] - mean[c]) * invstd[c];
+    float yy = xh * w + b;
+    float g = yy > 0.f ? dv[i] : dv[i] * leak;
+    ov[i] = w * invstd[c] * (g - sum_dy[c] * invN - xh * sum_dy_xhat[c] * invN);
+  }
+  stv<VEC>(dx + r * ld_dx + cv * VEC, ov);
+}
+
+inline int stat_blocks(int64_t N, int C, int VEC) {
+  int rs = T / (C / VEC);
+  int64_t nb = mm_cdiv(N, (int64_t)rs * 8);
+  if (nb < 1) nb = 1;
+  if (nb > MAX_PART) nb = MAX_PART;
+  return (int)nb;
+}
+}  // namespace
+
+extern "C" {
+
+size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + 256; }
+
+// training forward: batch statistics over N rows; running stats updated in place (scn "momentum" = keep fraction)
+int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                    float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
+                    float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_y >= C, "bn_fwd: bad shape C=%d", C);
+  if (ws_bytes < mm_bn_ws_bytes(C) - 256) {
+    mm_set_error("bn_fwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  double* partial = (double*)ws;
+  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  int nb = stat_blocks(N, C, v4 ? 4 : 1);
+  if (v4)
+    hipLaunchKernelGGL((k_bn_reduce<4, 0>), dim3(nb), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
+                       nullptr, 0.f, partial);
+  else
+    hipLaunchKernelGGL((k_bn_reduce<1, 0>), dim3(nb), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
+                       nullptr, 0.f, partial);
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((unsigned)mm_cdiv(C, 64)), dim3(64), 0, s, partial, nb, N, C, eps, momentum,
+                     running_mean, running_var, save_mean, save_invstd);
+  if (N > 0) {
+    if (v4)
+      hipLaunchKernelGGL(k_bn_apply<4>, dim3((unsigned)mm_cdiv(N * (C / 4), T)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
+                         save_invstd, 0, eps, weight, bias, leak, y, ld_y);
+    else
+      hipLaunchKernelGGL(k_bn_apply<1>, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
+                         save_invstd, 0, eps, weight, bias, leak, y, ld_y);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                   const float* running_mean, const float* running_var, float eps, float leak, float* y, int ld_y,
+                   hipStream_t s) {
+  MM_CHECK_ARG(C > 0 && ld_x >= C && ld_y >= C, "bn_eval: bad shape");
+  if (N == 0) return MM_OK;
+  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  if (v4)
+    hipLaunchKernelGGL(k_bn_apply<4>, dim3((unsigned)mm_cdiv(N * (C / 4), T)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
+                       running_var, 1, eps, weight, bias, leak, y, ld_y);
+  else
+    hipLaunchKernelGGL(k_bn_apply<1>, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
+                       running_var, 1, eps, weight, bias, leak, y, ld_y);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// training backward; dweight/dbias may be null; accumulate != 0 adds into them
+int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int C, const float* weight,
+              const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
+              float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_dy >= C && ld_dx >= C, "bn_bwd: bad shape");
+  size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
+  if (ws_bytes < need + 2 * C * sizeof(float)) {
+    mm_set_error("bn_bwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  double* partial = (double*)ws;
+  float* sum_dy = (float*)((char*)ws + need);
+  float* sum_dy_xhat = sum_dy + C;
+  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) &&
+                  (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0);
+  int nb = stat_blocks(N, C, v4 ? 4 : 1);
+  if (v4)
+    hipLaunchKernelGGL((k_bn_reduce<4, 1>), dim3(nb), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd,
+                       weight, bias, leak, partial);
+  else
+    hipLaunchKernelGGL((k_bn_reduce<1, 1>), dim3(nb), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd,
+                       weight, bias, leak, partial);
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((unsigned)mm_cdiv(C, 64)), dim3(64), 0, s, partial, nb, C, sum_dy, sum_dy_xhat,
+                     dweight, dbias, accumulate);
+  if (N > 0) {
+    if (v4)
+      hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3((unsigned)mm_cdiv(N * (C / 4), T)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
+                         save_mean, save_invstd, weight, bias, leak, sum_dy, sum_dy_xhat, dx, ld_dx);
+    else
+      hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
+                         save_mean, save_invstd, weight, bias, leak, sum_dy, sum_dy_xhat, dx, ld_dx);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

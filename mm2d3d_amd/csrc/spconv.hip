@@ -1,0 +1,411 @@
+// Sparse convolution engines for gfx950 (Appendix A.2-A.4).
+//
+// One rulebook format serves SubmanifoldConvolution, Convolution and Deconvolution, forward and backward:
+//   k-major rule lists (src[r], dst[r]), bucket offsets[K+1], and a CSR over destination rows.
+// Engines:
+//   G  gather-GEMM   : per bucket k, rows in[src[r]] (coalesced 16-B row gathers straight into MFMA operands)
+//                      times W[k] (staged in LDS in MFMA-fragment order) -> tmp[r] (contiguous) or out[dst[r]]
+//                      when every destination row has exactly one rule (Deconvolution fwd, Convolution dX).
+//   R  CSR reduce    : out[o] = sum over the rules of row o, ascending k (canonical order A.8 iv) - plain
+//                      stores, no float atomics, bit-stable run to run.
+//   dW               : per bucket k, in[src]^T . dout[dst] on fp32 MFMA from LDS-staged row tiles, partial
+//                      slabs per block + ordered reduce (deterministic).
+// Arithmetic is exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (no reduced precision).
+// Generic VALU kernels cover channel counts that are not multiples of 16 (the 3-channel stem).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAXK = 32;
+struct KSeg {
+  int32_t blk_start[MAXK + 1];
+  int32_t rule_off[MAXK + 1];
+};
+
+constexpr int TR = 256;    // rules per workgroup, engine G
+constexpr int TRW = 1024;  // rules per workgroup, dW
+constexpr int DW_MAXB = 18;  // 16x16 output blocks per wave, dW
+
+__device__ inline int find_k(const KSeg& seg, int b, int K) {
+  int k = 0;
+  while (k + 1 < K && b >= seg.blk_start[k + 1]) k++;
+  return k;
+}
+
+// ------------------------------------------------------------------------------------------------ engine G (MFMA)
+template <int NCB>
+__global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ in, int ld_in,
+                                                      const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                      float* __restrict__ out, int ld_out, const float* __restrict__ W,
+                                                      int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin,
+                                                      KSeg seg) {
+  extern __shared__ float wl[];  // [Cin/16][NCB][64 lanes][4]
+  const int tid = threadIdx.x;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * TR;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + TR);
+  const int co_base = blockIdx.y * (NCB * 16);
+  const float* Wk = W + (int64_t)(kflip ? K - 1 - k : k) * w_kstride;
+  const int ncol = NCB * 16;
+  for (int e = tid; e < Cin * ncol; e += 256) {
+    int ci = e / ncol, c = e - ci * ncol;
+    float v = Wk[(int64_t)ci * s_ci + (int64_t)(co_base + c) * s_co];
+    int q = ci >> 4, s4 = (ci >> 2) & 3, j = ci & 3, cb = c >> 4, cc = c & 15;
+    wl[(((q * NCB + cb) * 64) + s4 * 16 + cc) * 4 + j] = v;
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  const int nq = Cin >> 4;
+  for (int g = r_begin + wave * 16; g < r_end; g += 64) {
+    const int r = g + rl;
+    const bool valid = r < r_end;
+    const int sidx = valid ? src[r] : 0;
+    const float* row = in + (int64_t)sidx * ld_in + sl * 4;
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nq; q++) {
+      f32x4 x = valid ? *(const f32x4*)(row + q * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        f32x4 w = *(const f32x4*)&wl[((q * NCB + cb) * 64 + lane) * 4];
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc[cb], 0, 0, 0);
+        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc[cb], 0, 0, 0);
+      }
+    }
+    if (valid) {
+      const int64_t orow = dst ? (int64_t)dst[r] : (int64_t)r;
+      float* o = out + orow * ld_out + co_base + sl * 4;
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) *(f32x4*)(o + cb * 16) = acc[cb];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ engine R
+__global__ __launch_bounds__(256) void k_csr_reduce(const float* __restrict__ tmp, int ld_tmp,
+                                                     const int32_t* __restrict__ csr_off,
+                                                     const int32_t* __restrict__ csr_pos, int64_t n_out,
+                                                     float* __restrict__ out, int ld_out, int C4) {
+  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = gid / C4;
+  int c4 = (int)(gid - row * C4);
+  if (row >= n_out) return;
+  int a = csr_off[row], b = csr_off[row + 1];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int e = a; e < b; e++) acc += *(const f32x4*)(tmp + (int64_t)csr_pos[e] * ld_tmp + c4 * 4);
+  *(f32x4*)(out + row * ld_out + c4 * 4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ generic VALU engines
+__device__ inline int k_of_pos(const int32_t* __restrict__ offsets, int K, int pos) {
+  int k = 0;
+  while (k + 1 < K && pos >= offsets[k + 1]) k++;
+  return k;
+}
+
+// output-stationary: thread = (out row, co); rules of the row visited in ascending k
+__global__ __launch_bounds__(256) void k_generic_rows(const float* __restrict__ in, int ld_in,
+                                                       const int32_t* __restrict__ src,
+                                                       const int32_t* __restrict__ offsets, int K,
+                                                       const int32_t* __restrict__ csr_off,
+                                                       const int32_t* __restrict__ csr_pos, int64_t n_out,
+                                                       float* __restrict__ out, int ld_out, const float* __restrict__ W,
+                                                       int64_t w_kstride, int s_ci, int s_co, int kflip, int Cin,
+                                                       int Cout) {
+  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = gid / Cout;
+  int co = (int)(gid - row * Cout);
+  if (row >= n_out) return;
+  float acc = 0.f;
+  for (int e = csr_off[row]; e < csr_off[row + 1]; e++) {
+    int pos = csr_pos[e];
+    int k = k_of_pos(offsets, K, pos);
+    const float* Wk = W + (int64_t)(kflip ? K - 1 - k : k) * w_kstride + (int64_t)co * s_co;
+    const float* x = in + (int64_t)src[pos] * ld_in;
+    for (int ci = 0; ci < Cin; ci++) acc = fmaf(x[ci], Wk[(int64_t)ci * s_ci], acc);
+  }
+  out[row * ld_out + co] = acc;
+}
+
+// unique destinations: thread = (rule, co)
+__global__ __launch_bounds__(256) void k_generic_rules(const float* __restrict__ in, int ld_in,
+                                                        const int32_t* __restrict__ src,
+                                                        const int32_t* __restrict__ dst,
+                                                        const int32_t* __restrict__ offsets, int K, int64_t n_rules,
+                                                        float* __restrict__ out, int ld_out, const float* __restrict__ W,
+                                                        int64_t w_kstride, int s_ci, int s_co, int kflip, int Cin,
+                                                        int Cout) {
+  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t r = gid / Cout;
+  int co = (int)(gid - r * Cout);
+  if (r >= n_rules) return;
+  int k = k_of_pos(offsets, K, (int)r);
+  const float* Wk = W + (int64_t)(kflip ? K - 1 - k : k) * w_kstride + (int64_t)co * s_co;
+  const float* x = in + (int64_t)src[r] * ld_in;
+  float acc = 0.f;
+  for (int ci = 0; ci < Cin; ci++) acc = fmaf(x[ci], Wk[(int64_t)ci * s_ci], acc);
+  out[(int64_t)dst[r] * ld_out + co] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ dW (MFMA)
+__global__ __launch_bounds__(256) void k_dw_mfma(const float* __restrict__ in, int ld_in,
+                                                  const float* __restrict__ dout, int ld_do,
+                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                  int Cin, int Cout, int K, KSeg seg, float* __restrict__ partial) {
+  extern __shared__ float sm[];
+  const int sa = Cin + ((Cin & 31) == 16 ? 0 : 16);
+  const int sb = Cout + ((Cout & 31) == 16 ? 0 : 16);
+  float* As = sm;            // [64][sa]
+  float* Bs = sm + 64 * sa;  // [64][sb]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * TRW;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + TRW);
+  const int ncob = Cout >> 4, nblk = (Cin >> 4) * ncob;
+  f32x4 acc[DW_MAXB];
+#pragma unroll
+  for (int t = 0; t < DW_MAXB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ca4 = Cin >> 2, cb4 = Cout >> 2;
+  for (int t0 = r_begin; t0 < r_end; t0 += 64) {
+    __syncthreads();
+    for (int e = tid; e < 64 * ca4; e += 256) {
+      int rr = e / ca4, c = e - rr * ca4;
+      int r = t0 + rr;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < r_end) v = *(const f32x4*)(in + (int64_t)src[r] * ld_in + c * 4);
+      *(f32x4*)&As[rr * sa + c * 4] = v;
+    }
+    for (int e = tid; e < 64 * cb4; e += 256) {
+      int rr = e / cb4, c = e - rr * cb4;
+      int r = t0 + rr;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (r < r_end) v = *(const f32x4*)(dout + (int64_t)dst[r] * ld_do + c * 4);
+      *(f32x4*)&Bs[rr * sb + c * 4] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < DW_MAXB; t++) {
+      int blk = wave + 4 * t;
+      if (blk < nblk) {
+        int cib = blk / ncob, cob = blk - cib * ncob;
+        const float* ap = As + sl * sa + cib * 16 + rl;
+        const float* bp = Bs + sl * sb + cob * 16 + rl;
+#pragma unroll 4
+        for (int r4 = 0; r4 < 16; r4++)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r4 * 4 * sa], bp[r4 * 4 * sb], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  float* P = partial + (int64_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+  for (int t = 0; t < DW_MAXB; t++) {
+    int blk = wave + 4 * t;
+    if (blk < nblk) {
+      int cib = blk / ncob, cob = blk - cib * ncob;
+#pragma unroll
+      for (int r = 0; r < 4; r++) P[(int64_t)(cib * 16 + sl * 4 + r) * Cout + cob * 16 + rl] = acc[t][r];
+    }
+  }
+}
+
+// generic dW: thread = (ci, co) pairs strided over the block; rules staged in LDS 64 at a time
+__global__ __launch_bounds__(256) void k_dw_generic(const float* __restrict__ in, int ld_in,
+                                                     const float* __restrict__ dout, int ld_do,
+                                                     const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                     int Cin, int Cout, int K, KSeg seg, float* __restrict__ partial) {
+  extern __shared__ float sm[];
+  float* As = sm;             // [64][Cin]
+  float* Bs = sm + 64 * Cin;  // [64][Cout]
+  const int tid = threadIdx.x;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * TRW;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + TRW);
+  const int ne = Cin * Cout;
+  float* P = partial + (int64_t)blockIdx.x * ne;
+  for (int e0 = 0; e0 < ne; e0 += 256) {  // usually one pass (3x16 = 48 elements)
+    const int e = e0 + tid;
+    const int ci = e / Cout, co = e - ci * Cout;
+    float acc = 0.f;
+    for (int t0 = r_begin; t0 < r_end; t0 += 64) {
+      __syncthreads();
+      for (int x = tid; x < 64 * Cin; x += 256) {
+        int rr = x / Cin, c = x - rr * Cin, r = t0 + rr;
+        As[x] = r < r_end ? in[(int64_t)src[r] * ld_in + c] : 0.f;
+      }
+      for (int x = tid; x < 64 * Cout; x += 256) {
+        int rr = x / Cout, c = x - rr * Cout, r = t0 + rr;
+        Bs[x] = r < r_end ? dout[(int64_t)dst[r] * ld_do + c] : 0.f;
+      }
+      __syncthreads();
+      if (e < ne)
+        for (int rr = 0; rr < 64; rr++) acc = fmaf(As[rr * Cin + ci], Bs[rr * Cout + co], acc);
+    }
+    if (e < ne) P[e] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ partial, int ne, int K, KSeg seg,
+                                                    float* __restrict__ dW, int accumulate) {
+  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int k = (int)(gid / ne);
+  int e = (int)(gid - (int64_t)k * ne);
+  if (k >= K) return;
+  float acc = 0.f;
+  for (int b = seg.blk_start[k]; b < seg.blk_start[k + 1]; b++) acc += partial[(int64_t)b * ne + e];
+  float* d = dW + (int64_t)k * ne + e;
+  *d = accumulate ? *d + acc : acc;
+}
+
+int make_seg(const int32_t* offsets_host, int K, int rules_per_block, KSeg* seg) {
+  int nb = 0;
+  for (int k = 0; k < K; k++) {
+    seg->blk_start[k] = nb;
+    seg->rule_off[k] = offsets_host[k];
+    nb += (int)mm_cdiv(offsets_host[k + 1] - offsets_host[k], rules_per_block);
+  }
+  for (int k = K; k <= MAXK; k++) {
+    seg->blk_start[k] = nb;
+    seg->rule_off[k] = offsets_host[K];
+  }
+  return nb;
+}
+
+template <int NCB>
+int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src, const int32_t* dst, float* out,
+             int ld_out, const float* W, int64_t wks, int s_ci, int s_co, int kflip, int K, int Cin, const KSeg& seg,
+             hipStream_t s) {
+  size_t lds = (size_t)Cin * NCB * 16 * sizeof(float);
+  if (lds > 64 * 1024)
+    MM_HIP(hipFuncSetAttribute((const void*)k_gather_gemm<NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_gather_gemm<NCB>, dim3(nb, nchunk), dim3(256), lds, s, in, ld_in, src, dst, out, ld_out, W, wks,
+                     s_ci, s_co, kflip, K, Cin, seg);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the tmp buffer engine G+R needs for a layer
+size_t mm_spconv_ws_bytes(int64_t n_rules, int Cout) { return mm_align((size_t)n_rules * Cout * sizeof(float)) + 256; }
+
+// out[dst] (+)= in[src] . W[k]   over a k-major rulebook.
+//   unique_dst != 0 : every destination row has exactly one rule -> direct row writes, no reduction
+//   unique_dst == 0 : destinations reduced through the CSR (csr_off/csr_pos over n_out rows), k ascending
+//   weight element (k, ci, co) is W[kk*w_kstride + ci*s_ci + co*s_co], kk = kflip ? K-1-k : k
+//   rows of out without a rule are written as zeros (CSR path) or left untouched (unique path: caller pre-zeros if needed)
+int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
+                    const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
+                    int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
+                    int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && ld_in >= Cin && ld_out >= Cout, "spconv_apply: bad shape");
+  const int64_t R = offsets_host[K];
+  if (n_out == 0) return MM_OK;
+  const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
+                       (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
+  int ncb = Cout / 16, nchunk = 1;
+  if (mfma_ok && ncb > 8) {
+    nchunk = 0;
+    for (int d = 2; d <= ncb; d++)
+      if (ncb % d == 0 && ncb / d <= 8) {
+        nchunk = d;
+        break;
+      }
+  }
+  if (!mfma_ok || nchunk == 0 || (size_t)Cin * (ncb / (nchunk ? nchunk : 1)) * 64 > 150 * 1024) {
+    if (unique_dst) {
+      if (R) hipLaunchKernelGGL(k_generic_rules, dim3((unsigned)mm_cdiv(R * Cout, 256)), dim3(256), 0, s, in, ld_in, src, dst,
+                                offsets_dev, K, R, out, ld_out, W, w_kstride, s_ci, s_co, kflip, Cin, Cout);
+    } else {
+      hipLaunchKernelGGL(k_generic_rows, dim3((unsigned)mm_cdiv(n_out * Cout, 256)), dim3(256), 0, s, in, ld_in, src,
+                         offsets_dev, K, csr_off, csr_pos, n_out, out, ld_out, W, w_kstride, s_ci, s_co, kflip, Cin, Cout);
+    }
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
+  KSeg seg;
+  int nb = make_seg(offsets_host, K, TR, &seg);
+  float* tgt = out;
+  int ld_t = ld_out;
+  const int32_t* d = dst;
+  if (!unique_dst) {
+    if (ws_bytes < (size_t)R * Cout * sizeof(float)) {
+      mm_set_error("spconv_apply: workspace too small (%zu < %zu)", ws_bytes, (size_t)R * Cout * sizeof(float));
+      return MM_ERR_WORKSPACE;
+    }
+    tgt = (float*)ws;
+    ld_t = Cout;
+    d = nullptr;
+    MM_CHECK_ARG(((uintptr_t)ws % 16) == 0, "spconv_apply: workspace must be 16-B aligned");
+  }
+  if (nb > 0) {
+    int rc = MM_OK;
+    switch (ncb / nchunk) {
+#define CASE(N)                                                                                                   \
+  case N:                                                                                                         \
+    rc = launch_g<N>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, W, w_kstride, s_ci, s_co, kflip, K, Cin, seg, s); \
+    break;
+      CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
+#undef CASE
+      default:
+        mm_set_error("spconv_apply: unsupported Cout %d", Cout);
+        return MM_ERR_UNSUPPORTED;
+    }
+    if (rc) return rc;
+  }
+  if (!unique_dst) {
+    hipLaunchKernelGGL(k_csr_reduce, dim3((unsigned)mm_cdiv(n_out * (Cout / 4), 256)), dim3(256), 0, s, tgt, Cout, csr_off,
+                       csr_pos, n_out, out, ld_out, Cout / 4);
+    MM_LAUNCH_CHECK();
+  }
+  return MM_OK;
+}
+
+size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout) {
+  KSeg seg;
+  int nb = make_seg(offsets_host, K, TRW, &seg);
+  return mm_align((size_t)(nb > 0 ? nb : 1) * Cin * Cout * sizeof(float)) + 256;
+}
+
+// dW[k][ci][co] (+)= sum over rules r of bucket k of in[src[r]][ci] * dout[dst[r]][co]
+int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_do, int Cout, const int32_t* src,
+                 const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                 size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0, "spconv_dw: bad shape");
+  KSeg seg;
+  int nb = make_seg(offsets_host, K, TRW, &seg);
+  const int ne = Cin * Cout;
+  if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
+    mm_set_error("spconv_dw: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  float* partial = (float*)ws;
+  if (nb > 0) {
+    const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0) && (ld_in % 4 == 0) && (ld_do % 4 == 0) &&
+                         (((uintptr_t)in | (uintptr_t)dout) % 16 == 0) && ((Cin / 16) * (Cout / 16) <= 4 * DW_MAXB);
+    if (mfma_ok) {
+      const int sa = Cin + ((Cin & 31) == 16 ? 0 : 16), sb = Cout + ((Cout & 31) == 16 ? 0 : 16);
+      size_t lds = (size_t)64 * (sa + sb) * sizeof(float);
+      if (lds > 64 * 1024)
+        MM_HIP(hipFuncSetAttribute((const void*)k_dw_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_dw_mfma, dim3(nb), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, K, seg, partial);
+    } else {
+      size_t lds = (size_t)64 * (Cin + Cout) * sizeof(float);
+      MM_CHECK_ARG(lds <= 150 * 1024, "spconv_dw: channels too wide for the generic kernel");
+      if (lds > 64 * 1024)
+        MM_HIP(hipFuncSetAttribute((const void*)k_dw_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_dw_generic, dim3(nb), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, K, seg, partial);
+    }
+  }
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv((int64_t)K * ne, 256)), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

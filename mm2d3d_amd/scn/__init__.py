@@ -1,0 +1,266 @@
+"""``sparseconvnet``-shaped operator surface backed by hand-written gfx950 kernels.
+
+Drop-in for the subset of facebookresearch/SparseConvNet the reference uses
+(``import sparseconvnet as scn`` at /root/reference/.../3d_net/scn_unet.py:1): same class names,
+constructor signatures, parameter shapes (``weight [K, 1, nIn, nOut]``), init and tensor
+conventions (coords LongTensor [N, dim+1] with the batch index in the LAST column, scn_unet.py:131-138).
+``mm2d3d_amd.scn.install_as_sparseconvnet()`` registers this module under the name
+``sparseconvnet`` so the reference's ``scn_unet.py`` imports it unchanged.
+
+Every op runs on the current HIP stream through ``libmm2d3d_hip.so``; there is no CPU path.
+"""
+from __future__ import annotations
+
+import sys
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .metadata import Level, Metadata, Rulebook
+
+__all__ = [
+    "SparseConvNetTensor", "Sequential", "InputLayer", "OutputLayer", "SubmanifoldConvolution", "Convolution",
+    "Deconvolution", "BatchNormalization", "BatchNormReLU", "BatchNormLeakyReLU", "Identity", "ConcatTable",
+    "JoinTable", "AddTable", "NetworkInNetwork", "install_as_sparseconvnet",
+]
+
+
+class SparseConvNetTensor:
+    """features [n_active, C] + the metadata that owns the active sets / rulebooks (scn_unet.py:29-31)."""
+
+    def __init__(self, features=None, metadata=None, spatial_size=None, level=None):
+        self.features = features
+        self.metadata = metadata
+        self.spatial_size = spatial_size
+        self.level = level
+
+    def _with(self, features, level=None, spatial_size=None):
+        return SparseConvNetTensor(features, self.metadata, spatial_size if spatial_size is not None else self.spatial_size,
+                                   level if level is not None else self.level)
+
+    def cuda(self):
+        self.features = self.features.cuda()
+        return self
+
+    def type(self, t=None):
+        if t is None:
+            return self.features.type()
+        self.features = self.features.type(t)
+        return self
+
+    def __repr__(self):
+        return f"SparseConvNetTensor(features={tuple(self.features.shape)}, spatial_size={self.spatial_size})"
+
+
+class Sequential(nn.Sequential):
+    def add(self, module):
+        self._modules[str(len(self._modules))] = module
+        return self
+
+    def insert(self, index, module):
+        mods = list(self._modules.values())
+        mods.insert(index, module)
+        self._modules.clear()
+        for i, m in enumerate(mods):
+            self._modules[str(i)] = m
+        return self
+
+
+class Identity(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class ConcatTable(nn.Sequential):
+    def add(self, module):
+        self._modules[str(len(self._modules))] = module
+        return self
+
+    def forward(self, x):
+        return [m(x) for m in self._modules.values()]
+
+
+class JoinTable(nn.Module):
+    def forward(self, xs):
+        return xs[0]._with(torch.cat([t.features for t in xs], 1))
+
+
+class AddTable(nn.Module):
+    def forward(self, xs):
+        f = xs[0].features
+        for t in xs[1:]:
+            f = f + t.features
+        return xs[0]._with(f)
+
+
+class InputLayer(nn.Module):
+    """mode 0 assume-unique / 1 last / 2 first / 3 sum / 4 mean; active ids = first occurrence."""
+
+    def __init__(self, dimension, spatial_size, mode=3):
+        super().__init__()
+        if dimension != 3:
+            raise NotImplementedError("only dimension 3 is on the hot path")
+        self.dimension = dimension
+        self.spatial_size = spatial_size
+        self.mode = mode
+        self.prebuild_levels = 7
+
+    def forward(self, x):
+        coords, feats = x[0], x[1]
+        if not feats.is_cuda:
+            raise RuntimeError("mm2d3d_amd.scn.InputLayer: features must be on the GPU (no CPU fallback)")
+        dev = feats.device
+        coords = coords.to(device=dev, dtype=torch.int64)
+        if coords.shape[1] == self.dimension:
+            coords = torch.cat([coords, coords.new_zeros((coords.shape[0], 1))], 1)
+        coords = coords.contiguous()
+        S = int(self.spatial_size if not torch.is_tensor(self.spatial_size) else self.spatial_size.max())
+        md = Metadata(dev, S, self.prebuild_levels)
+        lv0 = md.build_levels(coords)
+        if self.mode in (3, 4):
+            f = ops.InputMeanFunction.apply(feats, lv0, self.mode == 4)
+        elif self.mode in (0, 2):  # first occurrence: the smallest point index of each list
+            f = feats.index_select(0, lv0.csr_items[lv0.csr_off[:-1].long()].long())
+        elif self.mode == 1:
+            f = feats.index_select(0, lv0.csr_items[(lv0.csr_off[1:] - 1).long()].long())
+        else:
+            raise ValueError(f"InputLayer mode {self.mode}")
+        return SparseConvNetTensor(f, md, self.spatial_size, lv0)
+
+
+class OutputLayer(nn.Module):
+    def __init__(self, dimension):
+        super().__init__()
+        self.dimension = dimension
+
+    def forward(self, x):
+        return ops.OutputGatherFunction.apply(x.features, x.metadata.levels[0])
+
+
+class _ConvBase(nn.Module):
+    K = 0
+
+    def __init__(self, dimension, nIn, nOut, bias):
+        super().__init__()
+        if dimension != 3:
+            raise NotImplementedError("only dimension 3 is on the hot path")
+        self.dimension, self.nIn, self.nOut = dimension, nIn, nOut
+        std = (2.0 / nIn / self.K) ** 0.5
+        self.weight = nn.Parameter(torch.empty(self.K, 1, nIn, nOut).normal_(0, std))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(nOut))
+
+    def _bias(self, f):
+        return f + self.bias if hasattr(self, "bias") else f
+
+
+class SubmanifoldConvolution(_ConvBase):
+    K = 27
+
+    def __init__(self, dimension, nIn, nOut, filter_size, bias, groups=1):
+        if filter_size != 3 or groups != 1:
+            raise NotImplementedError("hot path: filter_size 3, groups 1")
+        super().__init__(dimension, nIn, nOut, bias)
+        self.filter_size = filter_size
+
+    def forward(self, x):
+        lv = x.level
+        rb = x.metadata.subm_rulebook(lv)
+        f = ops.SparseConvFunction.apply(x.features, self.weight, rb, "subm", lv.n, lv.n)
+        return x._with(self._bias(f))
+
+    def __repr__(self):
+        return f"SubmanifoldConvolution {self.nIn}->{self.nOut} C3"
+
+
+class Convolution(_ConvBase):
+    K = 8
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias, groups=1):
+        if filter_size != 2 or filter_stride != 2 or groups != 1:
+            raise NotImplementedError("hot path: filter_size 2, stride 2, groups 1")
+        super().__init__(dimension, nIn, nOut, bias)
+
+    def forward(self, x):
+        lv = x.level
+        rb, coarse = x.metadata.down_rulebook(lv)
+        f = ops.SparseConvFunction.apply(x.features, self.weight, rb, "down", lv.n, coarse.n)
+        return x._with(self._bias(f), coarse, coarse.spatial_size)
+
+    def __repr__(self):
+        return f"Convolution {self.nIn}->{self.nOut} C2/2"
+
+
+class Deconvolution(_ConvBase):
+    K = 8
+
+    def __init__(self, dimension, nIn, nOut, filter_size, filter_stride, bias, groups=1):
+        if filter_size != 2 or filter_stride != 2 or groups != 1:
+            raise NotImplementedError("hot path: filter_size 2, stride 2, groups 1")
+        super().__init__(dimension, nIn, nOut, bias)
+
+    def forward(self, x):
+        coarse = x.level
+        fine = coarse.fine
+        if fine is None or fine.down is None:
+            raise RuntimeError("Deconvolution needs the rulebook of the matching Convolution (SURVEY.md A.4)")
+        f = ops.SparseConvFunction.apply(x.features, self.weight, fine.down, "up", coarse.n, fine.n)
+        return x._with(self._bias(f), fine, fine.spatial_size)
+
+    def __repr__(self):
+        return f"Deconvolution {self.nIn}->{self.nOut} C2/2"
+
+
+class BatchNormalization(nn.Module):
+    """eps 1e-4, momentum 0.9 = keep fraction of the running stats; leakiness 1 = no activation."""
+
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1):
+        super().__init__()
+        self.nPlanes, self.eps, self.momentum, self.leakiness = nPlanes, eps, momentum, leakiness
+        self.register_buffer("running_mean", torch.zeros(nPlanes))
+        self.register_buffer("running_var", torch.ones(nPlanes))
+        if affine:
+            self.weight = nn.Parameter(torch.ones(nPlanes))
+            self.bias = nn.Parameter(torch.zeros(nPlanes))
+        else:
+            self.register_parameter("weight", None)
+            self.register_parameter("bias", None)
+
+    def forward(self, x):
+        f = ops.BatchNormActFunction.apply(x.features, self.weight, self.bias, self.running_mean, self.running_var,
+                                           self.training, float(self.eps), float(self.momentum), float(self.leakiness))
+        return x._with(f)
+
+    def __repr__(self):
+        return f"BatchNorm({self.nPlanes},eps={self.eps},momentum={self.momentum},leakiness={self.leakiness})"
+
+
+class BatchNormReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9):
+        super().__init__(nPlanes, eps, momentum, True, 0)
+
+
+class BatchNormLeakyReLU(BatchNormalization):
+    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333):
+        super().__init__(nPlanes, eps, momentum, True, leakiness)
+
+
+class NetworkInNetwork(nn.Module):
+    def __init__(self, nIn, nOut, bias):
+        super().__init__()
+        self.nIn, self.nOut = nIn, nOut
+        std = (2.0 / nIn) ** 0.5
+        self.weight = nn.Parameter(torch.empty(nIn, nOut).normal_(0, std))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(nOut))
+
+    def forward(self, x):
+        f = ops.LinearFunction.apply(x.features, self.weight.t(), getattr(self, "bias", None))
+        return x._with(f)
+
+
+def install_as_sparseconvnet():
+    """Make ``import sparseconvnet`` resolve to this module (the drop-in boundary of SURVEY.md section 8b)."""
+    sys.modules["sparseconvnet"] = sys.modules[__name__]
+    return sys.modules[__name__]

@@ -1,0 +1,210 @@
+"""Device-side sparse metadata: active sets per scale, voxel hashes and rulebooks.
+
+SparseConvNet keeps this in a C++ ``Metadata`` object filled by host hash maps
+(reference call sites: scn_unet.py:113 InputLayer, :43/:68/:75 convolutions).  Here every
+structure is built by HIP kernels (csrc/meta.hip) and stays in HBM; the host only learns the
+row counts (two small D2H copies per batch: one after the dedupe chain, one after the rulebooks).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream
+
+I32 = torch.int32
+
+
+class Rulebook:
+    """k-major rule lists + CSR over destination rows (csrc/spconv.hip header)."""
+
+    __slots__ = ("K", "rin", "rout", "offsets_dev", "offsets_host", "csr_off", "csr_pos", "n_rules", "n_out", "_keep")
+
+    def __init__(self, K):
+        self.K = K
+
+    @property
+    def offsets_ptr(self):
+        return self.offsets_host.ctypes.data
+
+
+class Level:
+    """One spatial scale: n active sites, int32 coords [n,4] (x,y,z,batch), hash table, rulebooks."""
+
+    def __init__(self, spatial_size):
+        self.spatial_size = int(spatial_size)
+        self.n = 0
+        self.coords = None
+        self.tkeys = self.tvals = None
+        self.cap = 0
+        self.item2vox = None   # items of the finer level (points for level 0) -> site id here
+        self.csr_off = None    # site -> items (ascending)
+        self.csr_items = None
+        self.n_items = 0
+        self.subm = None
+        self.down = None       # Rulebook (K=8) to self.coarse
+        self.coarse = None
+        self.fine = None
+
+
+class Metadata:
+    def __init__(self, device, spatial_size, prebuild_levels=7):
+        self.device = device
+        self.spatial_size = int(spatial_size)
+        self.prebuild_levels = prebuild_levels
+        self.levels = []
+        self._rulebooks_built = False
+
+    # ------------------------------------------------------------------ active sets
+    def build_levels(self, coords_i64: torch.Tensor):
+        """Dedupe chain: points -> level 0 -> level 1 ... (A.8 i, ii).  One host sync at the end."""
+        L = _lib.lib()
+        dev = self.device
+        n_pts = coords_i64.shape[0]
+        nlev = max(1, min(self.prebuild_levels, max(1, int(np.log2(max(self.spatial_size, 2))))))
+        counts = torch.zeros(nlev + 1, dtype=I32, device=dev)  # [n_0..n_{L-1}, err]
+        err = counts[nlev:]
+        cap = int(L.mm_hash_capacity(n_pts))
+        ws = _lib.workspace.get(int(L.mm_dedupe_ws_bytes(n_pts)), dev)
+        S = self.spatial_size
+        prev = None
+        for l in range(nlev):
+            lv = Level(S)
+            lv.cap = cap
+            lv.tkeys = torch.empty(cap, dtype=torch.int64, device=dev)
+            lv.tvals = torch.empty(cap, dtype=I32, device=dev)
+            lv.item2vox = torch.empty(max(n_pts, 1), dtype=I32, device=dev)
+            lv.coords = torch.empty((max(n_pts, 1), 4), dtype=I32, device=dev)
+            lv.csr_off = torch.empty(n_pts + 1, dtype=I32, device=dev)
+            lv.csr_items = torch.empty(max(n_pts, 1), dtype=I32, device=dev)
+            if l == 0:
+                src, is64, ndev, shift = coords_i64, 1, None, 0
+            else:
+                src, is64, ndev, shift = prev.coords, 0, ptr(counts[l - 1 : l]), 1
+            check(
+                L.mm_voxel_dedupe(ptr(src), is64, n_pts, ndev, shift, ptr(lv.tkeys), ptr(lv.tvals), cap,
+                                  ptr(lv.item2vox), ptr(lv.coords), ptr(lv.csr_off), ptr(lv.csr_items),
+                                  ptr(counts[l : l + 1]), ptr(err), ptr(ws), ws.numel(), stream()),
+                "voxel_dedupe",
+            )
+            if prev is not None:
+                prev.coarse, lv.fine = lv, prev
+            self.levels.append(lv)
+            prev = lv
+            S = max(S // 2, 1)
+        host = counts.cpu().numpy()  # sync #1
+        if host[nlev] != 0:
+            raise ValueError("InputLayer: coordinates must satisfy 0 <= x,y,z,batch < 65536")
+        n_items = n_pts
+        for l, lv in enumerate(self.levels):
+            lv.n = int(host[l])
+            lv.n_items = n_items
+            lv.coords = lv.coords[: lv.n]
+            lv.item2vox = lv.item2vox[:n_items]
+            lv.csr_off = lv.csr_off[: lv.n + 1]
+            lv.csr_items = lv.csr_items[:n_items]
+            n_items = lv.n
+        return self.levels[0]
+
+    def _extend(self, fine: Level):
+        """Lazily add one more (coarser) level beyond the prebuilt chain."""
+        L = _lib.lib()
+        dev = self.device
+        n = fine.n
+        lv = Level(max(fine.spatial_size // 2, 1))
+        lv.cap = int(L.mm_hash_capacity(n))
+        lv.tkeys = torch.empty(lv.cap, dtype=torch.int64, device=dev)
+        lv.tvals = torch.empty(lv.cap, dtype=I32, device=dev)
+        lv.item2vox = torch.empty(max(n, 1), dtype=I32, device=dev)
+        lv.coords = torch.empty((max(n, 1), 4), dtype=I32, device=dev)
+        lv.csr_off = torch.empty(n + 1, dtype=I32, device=dev)
+        lv.csr_items = torch.empty(max(n, 1), dtype=I32, device=dev)
+        cnt = torch.zeros(2, dtype=I32, device=dev)
+        ws = _lib.workspace.get(int(L.mm_dedupe_ws_bytes(n)), dev)
+        check(
+            L.mm_voxel_dedupe(ptr(fine.coords), 0, n, None, 1, ptr(lv.tkeys), ptr(lv.tvals), lv.cap, ptr(lv.item2vox),
+                              ptr(lv.coords), ptr(lv.csr_off), ptr(lv.csr_items), ptr(cnt[0:1]), ptr(cnt[1:2]), ptr(ws),
+                              ws.numel(), stream()),
+            "voxel_dedupe",
+        )
+        lv.n = int(cnt[0].item())
+        lv.n_items = n
+        lv.coords = lv.coords[: lv.n]
+        lv.csr_off = lv.csr_off[: lv.n + 1]
+        fine.coarse, lv.fine = lv, fine
+        self.levels.append(lv)
+        return lv
+
+    # ------------------------------------------------------------------ rulebooks
+    def _launch_rulebook(self, K, n_out, nbr, offsets_dev):
+        L = _lib.lib()
+        dev = self.device
+        rb = Rulebook(K)
+        cap = max(K * n_out, 1)
+        rb.rin = torch.empty(cap, dtype=I32, device=dev)
+        rb.rout = torch.empty(cap, dtype=I32, device=dev)
+        rb.csr_pos = torch.empty(cap, dtype=I32, device=dev)
+        rb.csr_off = torch.empty(n_out + 1, dtype=I32, device=dev)
+        rb.offsets_dev = offsets_dev
+        rb.n_out = n_out
+        ws = _lib.workspace.get(int(L.mm_rulebook_ws_bytes(n_out, K)), dev)
+        check(
+            L.mm_rulebook_compact(ptr(nbr), K, n_out, ptr(rb.rin), ptr(rb.rout), ptr(offsets_dev), ptr(rb.csr_off),
+                                  ptr(rb.csr_pos), ptr(ws), ws.numel(), stream()),
+            "rulebook_compact",
+        )
+        return rb
+
+    def build_rulebooks(self, levels=None):
+        """Submanifold (K=27) rulebook of every level + strided (K=8) rulebook between consecutive levels."""
+        L = _lib.lib()
+        dev = self.device
+        levels = [lv for lv in (levels or self.levels) if lv.subm is None]
+        if not levels:
+            return
+        offs = torch.zeros((len(levels), 28 + 9), dtype=I32, device=dev)
+        pending = []
+        for j, lv in enumerate(levels):
+            nbr = torch.empty(max(27 * lv.n, 1), dtype=I32, device=dev)
+            check(L.mm_subm_neighbors(ptr(lv.coords), lv.n, lv.spatial_size, ptr(lv.tkeys), ptr(lv.tvals), lv.cap,
+                                      ptr(nbr), stream()), "subm_neighbors")
+            subm = self._launch_rulebook(27, lv.n, nbr, offs[j, :28])
+            down = None
+            if lv.coarse is not None and lv.down is None:
+                c = lv.coarse
+                nbr8 = torch.empty(max(8 * c.n, 1), dtype=I32, device=dev)
+                check(L.mm_down_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), c.n, ptr(nbr8), stream()),
+                      "down_neighbors")
+                down = self._launch_rulebook(8, c.n, nbr8, offs[j, 28:37])
+            pending.append((lv, subm, down))
+        host = offs.cpu().numpy()  # sync #2
+        for j, (lv, subm, down) in enumerate(pending):
+            for rb, row in ((subm, host[j, :28]), (down, host[j, 28:37])):
+                if rb is None:
+                    continue
+                rb.offsets_host = np.ascontiguousarray(row[: rb.K + 1], dtype=np.int32)
+                rb.n_rules = int(rb.offsets_host[rb.K])
+                rb.rin = rb.rin[: max(rb.n_rules, 1)]
+                rb.rout = rb.rout[: max(rb.n_rules, 1)]
+                rb.csr_pos = rb.csr_pos[: max(rb.n_rules, 1)]
+            lv.subm = subm
+            if down is not None:
+                lv.down = down
+
+    def subm_rulebook(self, lv: Level) -> Rulebook:
+        if lv.subm is None:
+            self.build_rulebooks()
+            if lv.subm is None:
+                self.build_rulebooks([lv])
+        return lv.subm
+
+    def down_rulebook(self, lv: Level):
+        if lv.coarse is None:
+            self._extend(lv)
+        if lv.down is None:
+            self.build_rulebooks()
+            if lv.down is None:  # level added lazily after the batch build
+                lv.subm = None
+                self.build_rulebooks([lv])
+        return lv.down, lv.coarse

@@ -1,0 +1,257 @@
+"""Autograd functions over the C-ABI kernels (csrc/spconv.hip, bn.hip, point.hip)."""
+from __future__ import annotations
+
+import torch
+
+from .. import _lib
+from .._lib import check, ptr, stream
+
+F32 = torch.float32
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_csr_of=None):
+    """out[dst] (+)= x[src] . W[k].  w_kcc: [K, Cin_w, Cout_w] contiguous; transpose_w uses W[k]^T."""
+    L = _lib.lib()
+    cin = x.shape[1]
+    K = rb.K
+    cw_in, cw_out = w_kcc.shape[1], w_kcc.shape[2]
+    if transpose_w:
+        s_ci, s_co = 1, cw_out  # element (ci', co') = W[k][co'][ci']
+    else:
+        s_ci, s_co = cw_out, 1
+    out = torch.empty((n_out, cout), dtype=F32, device=x.device)
+    ws = _lib.workspace.get(int(L.mm_spconv_ws_bytes(rb.n_rules, cout)), x.device)
+    check(
+        L.mm_spconv_apply(ptr(x), x.stride(0), cin, ptr(out), cout, cout, n_out, ptr(src), ptr(dst), ptr(rb.offsets_dev),
+                          rb.offsets_ptr, K, ptr(rb.csr_off), ptr(rb.csr_pos), 1 if unique else 0, ptr(w_kcc),
+                          cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, ptr(ws), ws.numel(), stream()),
+        "spconv_apply",
+    )
+    return out
+
+
+def _dw(x, dout, rb, src, dst, cin, cout):
+    L = _lib.lib()
+    dW = torch.empty((rb.K, cin, cout), dtype=F32, device=x.device)
+    ws = _lib.workspace.get(int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), x.device)
+    check(
+        L.mm_spconv_dw(ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
+                       ptr(dW), 0, ptr(ws), ws.numel(), stream()),
+        "spconv_dw",
+    )
+    return dW
+
+
+class SparseConvFunction(torch.autograd.Function):
+    """mode 'subm' | 'down' | 'up' over one rulebook."""
+
+    @staticmethod
+    def forward(ctx, x, weight, rb, mode, n_in, n_out):
+        _lib.require_cuda(x, "features")
+        x = _c(x.to(F32))
+        w = _c(weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).to(F32))
+        cout = w.shape[2]
+        if mode == "subm":
+            out = _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False)
+        elif mode == "down":
+            out = _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False)
+        elif mode == "up":  # roles swapped, every fine row has exactly one rule
+            out = _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False)
+        else:
+            raise ValueError(mode)
+        ctx.save_for_backward(x, w)
+        ctx.rb, ctx.mode, ctx.n_in, ctx.wshape = rb, mode, n_in, weight.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        rb, mode, n_in = ctx.rb, ctx.mode, ctx.n_in
+        dout = _c(dout.to(F32))
+        cin, cout = w.shape[1], w.shape[2]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if mode == "subm":  # symmetric rulebook: (k,i,o) <-> (26-k,o,i)
+                dx = _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True)
+            elif mode == "down":
+                dx = _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False)
+            else:
+                dx = _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False)
+        if ctx.needs_input_grad[1]:
+            if mode == "up":
+                dw = _dw(x, dout, rb, rb.rout, rb.rin, cin, cout)
+            else:
+                dw = _dw(x, dout, rb, rb.rin, rb.rout, cin, cout)
+            dw = dw.reshape(ctx.wshape)
+        return dx, dw, None, None, None, None
+
+
+class BatchNormActFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, momentum, leak):
+        _lib.require_cuda(x, "features")
+        L = _lib.lib()
+        x = _c(x.to(F32))
+        N, C = x.shape
+        y = torch.empty_like(x)
+        if training:
+            stats = torch.empty((2, C), dtype=F32, device=x.device)
+            ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
+            check(
+                L.mm_bn_fwd_train(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
+                                  leak, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()),
+                "bn_fwd_train",
+            )
+            ctx.save_for_backward(x, weight, bias, stats)
+            ctx.leak = leak
+        else:
+            check(
+                L.mm_bn_fwd_eval(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, leak,
+                                 ptr(y), C, stream()),
+                "bn_fwd_eval",
+            )
+            ctx.save_for_backward()
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("BatchNorm backward in eval mode is not part of the hot path")
+        L = _lib.lib()
+        x, weight, bias, stats = ctx.saved_tensors
+        dy = _c(dy.to(F32))
+        N, C = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty(C, dtype=F32, device=x.device) if weight is not None else None
+        db = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
+        ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
+        check(
+            L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
+                        ptr(dw), ptr(db), 0, ptr(ws), ws.numel(), stream()),
+            "bn_bwd",
+        )
+        return dx, dw, db, None, None, None, None, None, None
+
+
+class InputMeanFunction(torch.autograd.Function):
+    """InputLayer modes 3 (sum) / 4 (mean) over the voxel->points CSR of level 0."""
+
+    @staticmethod
+    def forward(ctx, feats, level, mean):
+        L = _lib.lib()
+        feats = _c(feats.to(F32))
+        C = feats.shape[1]
+        out = torch.empty((level.n, C), dtype=F32, device=feats.device)
+        check(L.mm_segment_reduce(ptr(feats), C, C, ptr(level.csr_off), ptr(level.csr_items), level.n, 1 if mean else 0,
+                                  ptr(out), C, stream()), "segment_reduce")
+        ctx.level, ctx.mean, ctx.n_pts = level, mean, feats.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        dout = _c(dout.to(F32))
+        C = dout.shape[1]
+        lv = ctx.level
+        dfeats = torch.empty((ctx.n_pts, C), dtype=F32, device=dout.device)
+        check(L.mm_row_gather(ptr(dout), C, C, ptr(lv.item2vox), ptr(lv.csr_off), 1 if ctx.mean else 0, ctx.n_pts, ptr(dfeats),
+                              C, stream()), "row_gather")
+        return dfeats, None, None
+
+
+class OutputGatherFunction(torch.autograd.Function):
+    """OutputLayer: every original point receives its voxel's row (no division); bwd = ordered segmented sum."""
+
+    @staticmethod
+    def forward(ctx, vox, level):
+        L = _lib.lib()
+        vox = _c(vox.to(F32))
+        C = vox.shape[1]
+        n_pts = level.n_items
+        out = torch.empty((n_pts, C), dtype=F32, device=vox.device)
+        check(L.mm_row_gather(ptr(vox), C, C, ptr(level.item2vox), ptr(level.csr_off), 0, n_pts, ptr(out), C, stream()),
+              "row_gather")
+        ctx.level = level
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        dout = _c(dout.to(F32))
+        C = dout.shape[1]
+        lv = ctx.level
+        dvox = torch.empty((lv.n, C), dtype=F32, device=dout.device)
+        check(L.mm_segment_reduce(ptr(dout), C, C, ptr(lv.csr_off), ptr(lv.csr_items), lv.n, 0, ptr(dvox), C, stream()),
+              "segment_reduce")
+        return dvox, None
+
+
+class GateFunction(torch.autograd.Function):
+    """y = x * sigmoid(x.w + b)   (3d_net/model.py:46-48)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _lib.require_cuda(x, "feats")
+        L = _lib.lib()
+        x = _c(x.to(F32))
+        N, C = x.shape
+        wv = _c(w.reshape(-1).to(F32))
+        y = torch.empty_like(x)
+        mask = torch.empty((N, 1), dtype=F32, device=x.device)
+        check(L.mm_gate_fwd(ptr(x), N, C, ptr(wv), ptr(b), ptr(y), ptr(mask), stream()), "gate_fwd")
+        ctx.save_for_backward(x, mask, wv)
+        ctx.wshape = w.shape
+        ctx.mark_non_differentiable(mask)
+        return y, mask
+
+    @staticmethod
+    def backward(ctx, dy, _dmask):
+        L = _lib.lib()
+        x, mask, wv = ctx.saved_tensors
+        dy = _c(dy.to(F32))
+        N, C = x.shape
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty(C, dtype=F32, device=x.device)
+        db = torch.empty(1, dtype=F32, device=x.device)
+        ws = _lib.workspace.get(int(L.mm_point_ws_bytes(C, 1)), x.device)
+        check(L.mm_gate_bwd(ptr(x), ptr(mask), ptr(dy), N, C, ptr(wv), ptr(dx), ptr(dw), ptr(db), 0, ptr(ws), ws.numel(),
+                            stream()), "gate_bwd")
+        return dx, dw.reshape(ctx.wshape), db
+
+
+class LinearFunction(torch.autograd.Function):
+    """Row-wise y = x W^T + b for the small per-point heads (3d_net/model.py:50,85)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        _lib.require_cuda(x, "x")
+        L = _lib.lib()
+        x = _c(x.to(F32))
+        w = _c(w.to(F32))
+        N, cin = x.shape
+        cout = w.shape[0]
+        y = torch.empty((N, cout), dtype=F32, device=x.device)
+        check(L.mm_linear_fwd(ptr(x), cin, N, cin, cout, ptr(w), ptr(b), ptr(y), cout, stream()), "linear_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        x, w = ctx.saved_tensors
+        dy = _c(dy.to(F32))
+        N, cin = x.shape
+        cout = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=F32, device=x.device) if ctx.has_bias else None
+        ws = _lib.workspace.get(int(L.mm_point_ws_bytes(cin, cout)), x.device)
+        check(L.mm_linear_bwd(ptr(x), cin, ptr(dy), cout, N, cin, cout, ptr(w), ptr(dx), cin, 0, ptr(dw), ptr(db), 0, ptr(ws),
+                              ws.numel(), stream()), "linear_bwd")
+        return dx, dw, db

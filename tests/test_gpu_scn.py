@@ -1,0 +1,204 @@
+"""GPU parity: HIP sparse operators (through the C-ABI) vs the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): integer voxel / rulebook indices bit-exact under the canonical
+order of SURVEY.md A.8; fp32 features / logits / gradients within 1e-3 (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import scn_ref  # noqa: E402
+from oracle.net3d_ref import Net3DSegRef  # noqa: E402
+
+ATOL = 1e-3
+
+
+def _dev():
+    import mm2d3d_amd  # noqa: F401  (fails loudly when libmm2d3d_hip.so is missing)
+
+    return torch.device("cuda:0")
+
+
+def _random_sparse(seed, S=24, B=3, n=600, C=3, dup=True):
+    g = np.random.default_rng(seed)
+    coords = np.concatenate([g.integers(0, S, (n, 3)), g.integers(0, B, (n, 1))], 1).astype(np.int64)
+    if dup:
+        coords = np.concatenate([coords, coords[g.integers(0, n, n // 3)]], 0)
+    feats = torch.from_numpy(g.standard_normal((len(coords), C)).astype(np.float32))
+    return torch.from_numpy(coords), feats
+
+
+def _close(a, b, tol=ATOL, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    scale = max(1.0, b.abs().max().item() if b.numel() else 1.0)
+    assert err <= tol * scale, f"{what}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def _lidar_batch(n_scenes=2):
+    from mm2d3d_amd.synthetic import make_batch
+
+    return make_batch(1, n_scenes, "nuscenes", img_hw=(32, 48))
+
+
+@pytest.mark.parametrize("case", ["random", "lidar", "single_point", "empty"])
+def test_metadata_bit_exact(case):
+    from mm2d3d_amd.scn.metadata import Metadata
+
+    dev = _dev()
+    if case == "random":
+        coords, _ = _random_sparse(0, S=64, B=3, n=3000)
+        S, nlev = 64, 5
+    elif case == "lidar":
+        coords = _lidar_batch(2)["x"][0]
+        S, nlev = 4096, 7
+    elif case == "single_point":
+        coords, S, nlev = torch.tensor([[5, 6, 7, 0]]), 16, 3
+    else:
+        coords, S, nlev = torch.zeros((0, 4), dtype=torch.int64), 16, 2
+    md = Metadata(dev, S, nlev)
+    md.build_levels(coords.to(dev).contiguous())
+    md.build_rulebooks()
+    # oracle chain
+    p2v, first = scn_ref.first_occurrence_ids(scn_ref.pack_keys(coords.numpy()))
+    lv = scn_ref.Level(coords.numpy()[first], S)
+    assert np.array_equal(md.levels[0].item2vox.cpu().numpy(), p2v)
+    for l in range(nlev):
+        g = md.levels[l]
+        assert g.n == lv.n, (l, g.n, lv.n)
+        assert np.array_equal(g.coords.cpu().numpy().astype(np.int64).reshape(-1, 4), lv.coords)
+        rb = scn_ref.subm_rulebook(lv)
+        assert np.array_equal(g.subm.offsets_host.astype(np.int64), rb.offsets)
+        R = rb.n_rules
+        assert np.array_equal(g.subm.rin.cpu().numpy()[:R], rb.rin) and np.array_equal(g.subm.rout.cpu().numpy()[:R], rb.rout)
+        if l + 1 < nlev:
+            rb8, coarse = scn_ref.down_rulebook(lv)
+            assert np.array_equal(g.down.offsets_host.astype(np.int64), rb8.offsets)
+            assert np.array_equal(g.down.rin.cpu().numpy()[: rb8.n_rules], rb8.rin)
+            assert np.array_equal(g.down.rout.cpu().numpy()[: rb8.n_rules], rb8.rout)
+            lv = coarse
+
+
+def test_out_of_range_coordinates_raise():
+    from mm2d3d_amd.scn.metadata import Metadata
+
+    dev = _dev()
+    md = Metadata(dev, 16, 2)
+    with pytest.raises(ValueError):
+        md.build_levels(torch.tensor([[1, 2, 3, 0], [-1, 0, 0, 0]], device=dev))
+
+
+def _pair(mod_ref, mod_hip):
+    mod_hip.load_state_dict(mod_ref.state_dict())
+    return mod_ref, mod_hip.cuda()
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 16), (16, 16), (32, 16), (16, 32), (48, 48), (5, 7), (64, 192), (192, 96)])
+def test_conv_ops_forward_backward(cin, cout):
+    from mm2d3d_amd import scn
+
+    dev = _dev()
+    torch.manual_seed(cin * 100 + cout)
+    coords, feats = _random_sparse(cin + cout, S=32, B=2, n=1500, C=cin)
+
+    def run(mod, f, cuda):
+        inp = mod.InputLayer(3, 32, mode=4)
+        sub = mod.SubmanifoldConvolution(3, cin, cout, 3, False)
+        down = mod.Convolution(3, cout, cin, 2, 2, False)
+        up = mod.Deconvolution(3, cin, cout, 2, 2, False)
+        return inp, sub, down, up
+
+    ri, rs, rd, ru = run(scn_ref, feats, False)
+    hi, hs, hd, hu = run(scn, feats, True)
+    for a, b in ((rs, hs), (rd, hd), (ru, hu)):
+        b.load_state_dict(a.state_dict())
+        b.cuda()
+    fr = feats.clone().requires_grad_(True)
+    fh = feats.clone().to(dev).requires_grad_(True)
+    xr = ri([coords, fr])
+    xh = hi([coords, fh])
+    _close(xh.features, xr.features, what="input mean")
+    yr1, yh1 = rs(xr), hs(xh)
+    _close(yh1.features, yr1.features, what="subm fwd")
+    yr2, yh2 = rd(yr1), hd(yh1)
+    _close(yh2.features, yr2.features, what="down fwd")
+    yr3, yh3 = ru(yr2), hu(yh2)
+    _close(yh3.features, yr3.features, what="up fwd")
+    g = torch.randn_like(yr3.features)
+    (yr3.features * g).sum().backward()
+    (yh3.features * g.to(dev)).sum().backward()
+    _close(fh.grad, fr.grad, what="d feats")
+    for name, a, b in (("subm", rs, hs), ("down", rd, hd), ("up", ru, hu)):
+        _close(b.weight.grad, a.weight.grad, what=f"dW {name}")
+
+
+@pytest.mark.parametrize("C,leak", [(16, 0.0), (48, 0.333), (7, 0.0), (224, 0.0)])
+def test_batchnorm_forward_backward_running_stats(C, leak):
+    from mm2d3d_amd import scn
+
+    dev = _dev()
+    torch.manual_seed(C)
+    x = torch.randn(3001, C) * 2 + 0.5
+    r, h = scn_ref.BatchNormLeakyReLU(C, leakiness=leak), scn.BatchNormLeakyReLU(C, leakiness=leak)
+    with torch.no_grad():
+        r.weight.uniform_(0.5, 1.5)
+        r.bias.uniform_(-0.5, 0.5)
+    h.load_state_dict(r.state_dict())
+    h.cuda()
+    xr = x.clone().requires_grad_(True)
+    xh = x.clone().to(dev).requires_grad_(True)
+    tr = scn_ref.SparseConvNetTensor(xr, scn_ref.Level(np.zeros((0, 4), np.int64), 8), 8)
+    tr.root = None
+    th = scn.SparseConvNetTensor(xh, None, 8, None)
+    yr, yh = r(tr).features, h(th).features
+    _close(yh, yr, what="bn fwd")
+    g = torch.randn_like(yr)
+    (yr * g).sum().backward()
+    (yh * g.to(dev)).sum().backward()
+    _close(xh.grad, xr.grad, what="bn dx")
+    _close(h.weight.grad, r.weight.grad, tol=2e-3, what="bn dgamma")
+    _close(h.bias.grad, r.bias.grad, tol=2e-3, what="bn dbeta")
+    _close(h.running_mean, r.running_mean, what="running_mean")
+    _close(h.running_var, r.running_var, what="running_var")
+    r.eval(), h.eval()
+    _close(h(th).features, r(tr).features, what="bn eval")
+
+
+@pytest.mark.parametrize("residual", [False, True])
+def test_net3d_forward_backward_vs_oracle(residual):
+    from mm2d3d_amd.net3d import Net3DSeg
+
+    dev = _dev()
+    torch.manual_seed(0)
+    batch = _lidar_batch(2)
+    kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7, residual_blocks=residual)
+    ref = Net3DSegRef(6, True, kw)
+    hip = Net3DSeg(6, True, kw)
+    missing = hip.load_state_dict(ref.state_dict(), strict=True)
+    hip.cuda()
+    coords, feats = batch["x"]
+    bh = {"x": [coords.to(dev), feats.clone().to(dev)]}
+    br = {"x": [coords, feats.clone()]}
+    pr, fr, ar = ref(br)
+    ph, fh, ah = hip(bh)
+    _close(bh["x"][1], br["x"][1], what="gated feats written back to the batch dict")
+    _close(fh, fr, what="3D features")
+    _close(ph["seg_logit"], pr["seg_logit"], what="seg_logit")  # north_star: logits within 1e-3
+    _close(ah["seg_logit_point"], ar["seg_logit_point"], what="seg_logit_point")
+    _close(ph["confidence"], pr["confidence"], what="confidence")
+    w = torch.randn_like(pr["seg_logit"])
+    (pr["seg_logit"] * w).sum().add((ar["seg_logit_point"] * w).sum()).backward()
+    (ph["seg_logit"] * w.to(dev)).sum().add((ah["seg_logit_point"] * w.to(dev)).sum()).backward()
+    gr = dict(ref.named_parameters())
+    for name, p in hip.named_parameters():
+        if "linear_global" in name:
+            assert p.grad is None
+            continue
+        assert p.grad is not None, name
+        _close(p.grad, gr[name].grad, tol=5e-3, what=f"grad {name}")
+    for (n1, b1), (n2, b2) in zip(sorted(hip.named_buffers()), sorted(ref.named_buffers())):
+        assert n1 == n2
+        _close(b1, b2, what=f"buffer {n1}")
