@@ -1,0 +1,128 @@
+/* mm2d3d.h - C ABI of libmm2d3d_hip.so: the MI355X (gfx950) hot path of CVLAB-Unibo/MM2D3D.
+ *
+ * The reference has no FFI of its own: its 3D arithmetic is reached through the Python module
+ * `sparseconvnet` (un-vendored dependency, /root/reference/environment.yml:37) and its 2D arithmetic through
+ * torch.nn.  This header declares the entry points a binding for that path uses; each cites the reference
+ * call site it replaces (EXP = /root/reference/experiments_USA_SING/rgbd_rgbxyz_sigmoid_for_rgb).
+ * INTEGRATION.md shows the ctypes stub (mm2d3d_amd/_lib.py is the shipped one).
+ *
+ * Conventions
+ *   - every pointer named *_dev or documented "device" is a HIP device pointer; *_host is host memory;
+ *   - feature matrices are row-major fp32 with an explicit row stride `ld_*` in floats;
+ *   - the library never allocates: outputs and workspaces are supplied by the caller
+ *     (size queries: mm_*_ws_bytes); all work is enqueued on `stream` and returns immediately;
+ *   - return value 0 = ok, negative = error (MM_ERR_*), message via mm_last_error() (thread-local);
+ *   - integer results (ids, rulebooks) are deterministic and follow the canonical orders of SURVEY.md A.8;
+ *     floating-point reductions run in a fixed order (no float atomics): results are bit-stable run to run.
+ */
+#ifndef MM2D3D_H
+#define MM2D3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mm_stream_t; /* hipStream_t */
+
+#define MM_OK 0
+#define MM_ERR_ARG (-1)
+#define MM_ERR_HIP (-2)
+#define MM_ERR_WORKSPACE (-3)
+#define MM_ERR_UNSUPPORTED (-4)
+
+const char* mm_last_error(void);
+
+/* ---------------------------------------------------------------- active sets and rulebooks (csrc/meta.hip)
+ * Replaces the host hash-map work of scn.InputLayer(3, full_scale, mode=4) (EXP/3d_net/scn_unet.py:113,121)
+ * and the rulebook construction of scn.SubmanifoldConvolution / Convolution / Deconvolution
+ * (scn_unet.py:43,45,52,114 / :68-70 / :75-77). */
+
+/* power-of-two capacity >= 2*n_items for the open-addressing table */
+int64_t mm_hash_capacity(int64_t n_items);
+size_t mm_dedupe_ws_bytes(int64_t n_bound);
+
+/* Dedupe items into active sites, ids in order of first occurrence.
+ *   coords        device [n,4] (x,y,z,batch), int64 when coords_is_i64 else int32; 0 <= value < 65536
+ *   n_bound       rows allocated; n_dev (device int32, may be NULL) = actual row count <= n_bound
+ *   shift         x,y,z >> shift before keying (0: InputLayer; 1: parents of a stride-2 Convolution)
+ *   tkeys/tvals   device table [cap] (uint64 / int32), cap = mm_hash_capacity(n_bound); afterwards key -> site id
+ *   item2vox      device [n]   site id of every item
+ *   vox_coords    device [n,4] int32 coords of the sites (first n_active rows)
+ *   csr_off/items device [n+1]/[n]  site -> its items, ascending
+ *   n_active_dev  device int32 [1];  err_dev device int32 [1] set non-zero on out-of-range coordinates */
+int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, const int32_t* n_dev, int shift,
+                    uint64_t* tkeys, int32_t* tvals, int64_t cap, int32_t* item2vox, int32_t* vox_coords,
+                    int32_t* csr_off, int32_t* csr_items, int32_t* n_active_dev, int32_t* err_dev, void* ws,
+                    size_t ws_bytes, mm_stream_t stream);
+
+/* nbr[k*n + o] = id of the active site at coord(o) + offset(k), k = ((dx+1)*3 + (dy+1))*3 + (dz+1), or -1 */
+int mm_subm_neighbors(const int32_t* vox_coords, int64_t n, int32_t spatial_size, const uint64_t* tkeys,
+                      const int32_t* tvals, int64_t cap, int32_t* nbr, mm_stream_t stream);
+
+/* nbr[k*n_coarse + parent] = child with offset k = ((x&1)*2 + (y&1))*2 + (z&1), or -1 */
+int mm_down_neighbors(const int32_t* vox_coords_fine, int64_t n_fine, const int32_t* fine2coarse, int64_t n_coarse,
+                      int32_t* nbr, mm_stream_t stream);
+
+size_t mm_rulebook_ws_bytes(int64_t n_out, int K);
+/* neighbour table -> k-major rule lists rin/rout (capacity K*n_out, pairs sorted by out id inside a bucket),
+ * offsets[K+1] (device), CSR over out rows: csr_off[n_out+1], csr_pos[R] = rule positions in ascending k */
+int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, int32_t* rout, int32_t* offsets,
+                        int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes, mm_stream_t stream);
+
+/* ---------------------------------------------------------------- sparse convolution engines (csrc/spconv.hip)
+ * scn.SubmanifoldConvolution / Convolution / Deconvolution forward and backward. */
+size_t mm_spconv_ws_bytes(int64_t n_rules, int Cout);
+/* out[dst[r]] (+)= in[src[r]] . W[k(r)] over a k-major rulebook (offsets_host = host copy of offsets[K+1]).
+ *   unique_dst != 0: every destination row has exactly one rule (direct writes);
+ *   else destinations are reduced through csr_off/csr_pos in ascending k and rows without rules become 0.
+ *   weight element (k,ci,co) = W[kk*w_kstride + ci*s_ci + co*s_co], kk = kflip ? K-1-k : k. */
+int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
+                    const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
+                    int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
+                    int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, mm_stream_t stream);
+size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout);
+/* dW[k][ci][co] (+)= sum over rules r of bucket k: in[src[r]][ci] * dout[dst[r]][co] */
+int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_do, int Cout, const int32_t* src,
+                 const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                 size_t ws_bytes, mm_stream_t stream);
+
+/* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
+ * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */
+size_t mm_bn_ws_bytes(int C);
+int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                    float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
+                    float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                   const float* running_mean, const float* running_var, float eps, float leak, float* y, int ld_y,
+                   mm_stream_t stream);
+int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int C, const float* weight,
+              const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
+              float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+
+/* ---------------------------------------------------------------- per-point rows (csrc/point.hip) */
+size_t mm_point_ws_bytes(int Cin, int Cout);
+/* y = x * sigmoid(x.w + b), mask = sigmoid(...)   (EXP/3d_net/model.py:46-48) */
+int mm_gate_fwd(const float* x, int64_t N, int C, const float* w, const float* b, float* y, float* mask,
+                mm_stream_t stream);
+int mm_gate_bwd(const float* x, const float* mask, const float* dy, int64_t N, int C, const float* w, float* dx,
+                float* dw, float* db, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* site rows = mean (or sum) of their items' rows: InputLayer mode 4 / 3 forward, OutputLayer backward */
+int mm_segment_reduce(const float* feats, int ld_f, int C, const int32_t* csr_off, const int32_t* csr_items,
+                      int64_t n_vox, int mean, float* out, int ld_o, mm_stream_t stream);
+/* item rows = their site's row (optionally / count): OutputLayer forward (scn_unet.py:117), InputLayer backward */
+int mm_row_gather(const float* vox, int ld_v, int C, const int32_t* p2v, const int32_t* csr_off, int div_count,
+                  int64_t N, float* out, int ld_o, mm_stream_t stream);
+/* y = x W^T + b with torch nn.Linear layout W [Cout, Cin]  (EXP/3d_net/model.py:50,85) */
+int mm_linear_fwd(const float* x, int ld_x, int64_t N, int Cin, int Cout, const float* w, const float* b, float* y,
+                  int ld_y, mm_stream_t stream);
+int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int Cin, int Cout, const float* w,
+                  float* dx, int ld_dx, int accumulate_dx, float* dw, float* db, int accumulate_w, void* ws,
+                  size_t ws_bytes, mm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MM2D3D_H */

@@ -112,16 +112,26 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
   }
 }
 
-__global__ void k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C, float eps,
-                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                   float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;  // lane 0 holds the sum; fixed tree order -> bit-stable
+}
+
+// one wave per channel: lane l sums partials l, l+64, ... then a fixed shuffle tree
+__global__ __launch_bounds__(64) void k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C,
+                                                         float eps, float momentum, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                         float* __restrict__ save_invstd) {
+  const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; b++) {
+  for (int b = threadIdx.x; b < nblk; b += 64) {
     s += partial[((int64_t)b * 2 + 0) * C + c];
     q += partial[((int64_t)b * 2 + 1) * C + c];
   }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (threadIdx.x != 0) return;
   double mean = N > 0 ? s / (double)N : 0.0;
   double var = N > 0 ? q / (double)N - mean * mean : 0.0;
   if (var < 0.0) var = 0.0;
@@ -134,16 +144,19 @@ __global__ void k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, 
   }
 }
 
-__global__ void k_bn_finalize_bwd(const double* __restrict__ partial, int nblk, int C, float* __restrict__ sum_dy,
-                                   float* __restrict__ sum_dy_xhat, float* __restrict__ dweight,
-                                   float* __restrict__ dbias, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void k_bn_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
+                                                         float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat,
+                                                         float* __restrict__ dweight, float* __restrict__ dbias,
+                                                         int accumulate) {
+  const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; b++) {
+  for (int b = threadIdx.x; b < nblk; b += 64) {
     s += partial[((int64_t)b * 2 + 0) * C + c];
     q += partial[((int64_t)b * 2 + 1) * C + c];
   }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (threadIdx.x != 0) return;
   sum_dy[c] = (float)s;
   sum_dy_xhat[c] = (float)q;
   if (dweight) dweight[c] = accumulate ? dweight[c] + (float)q : (float)q;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
     int c = cv * VEC + i;
-    float is = invstd_is_var ? rsqrtf(invstd[c] + eps) : invstd[c];
+    float is = invstd_is_var ? 1.f / sqrtf(invstd[c] + eps) : invstd[c];
     float v = (xv[i] - mean[c]) * is * (weight ? weight[c] : 1.f) + (bias ? bias[c] : 0.f);
     yv[i] = v > 0.f ? v : v * leak;
   }
@@ -235,7 +248,7 @@ int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int C, const float* wei
   else
     hipLaunchKernelGGL((k_bn_reduce<1, 0>), dim3(nb), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
                        nullptr, 0.f, partial);
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((unsigned)mm_cdiv(C, 64)), dim3(64), 0, s, partial, nb, N, C, eps, momentum,
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb, N, C, eps, momentum,
                      running_mean, running_var, save_mean, save_invstd);
   if (N > 0) {
     if (v4)
@@ -287,7 +300,7 @@ int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, i
   else
     hipLaunchKernelGGL((k_bn_reduce<1, 1>), dim3(nb), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd,
                        weight, bias, leak, partial);
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((unsigned)mm_cdiv(C, 64)), dim3(64), 0, s, partial, nb, C, sum_dy, sum_dy_xhat,
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sum_dy, sum_dy_xhat,
                      dweight, dbias, accumulate);
   if (N > 0) {
     if (v4)

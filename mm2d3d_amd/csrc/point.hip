@@ -228,7 +228,9 @@ int mm_linear_fwd(const float* x, int ld_x, int64_t N, int Cin, int Cout, const 
 int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int Cin, int Cout, const float* w,
                   float* dx, int ld_dx, int accumulate_dx, float* dw, float* db, int accumulate_w, void* ws, size_t ws_bytes,
                   hipStream_t s) {
-  MM_CHECK_ARG(Cin > 0 && Cout > 0 && (size_t)64 * (Cin + Cout) * 4 <= 64 * 1024, "linear_bwd: channels too wide");
+  MM_CHECK_ARG(Cin > 0 && Cout > 0 && (size_t)64 * (Cin + Cout) * 4 <= 150 * 1024, "linear_bwd: channels too wide");
+  if ((size_t)64 * (Cin + Cout) * 4 > 64 * 1024)
+    MM_HIP(hipFuncSetAttribute((const void*)k_linear_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (Cin + Cout) * 4));
   if (dx && N)
     hipLaunchKernelGGL(k_linear_bwd_x, dim3((unsigned)mm_cdiv(N * Cin, T)), dim3(T), 0, s, dy, ld_dy, N, Cin, Cout, w, dx, ld_dx,
                        accumulate_dx);

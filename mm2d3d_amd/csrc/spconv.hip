@@ -26,7 +26,6 @@ struct KSeg {
 
 constexpr int TR = 256;    // rules per workgroup, engine G
 constexpr int TRW = 1024;  // rules per workgroup, dW
-constexpr int DW_MAXB = 18;  // 16x16 output blocks per wave, dW
 
 __device__ inline int find_k(const KSeg& seg, int b, int K) {
   int k = 0;
@@ -153,63 +152,66 @@ __global__ __launch_bounds__(256) void k_generic_rules(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ dW (MFMA)
-__global__ __launch_bounds__(256) void k_dw_mfma(const float* __restrict__ in, int ld_in,
-                                                  const float* __restrict__ dout, int ld_do,
-                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-                                                  int Cin, int Cout, int K, KSeg seg, float* __restrict__ partial) {
-  extern __shared__ float sm[];
-  const int sa = Cin + ((Cin & 31) == 16 ? 0 : 16);
-  const int sb = Cout + ((Cout & 31) == 16 ? 0 : 16);
-  float* As = sm;            // [64][sa]
-  float* Bs = sm + 64 * sa;  // [64][sb]
+// dW[k] = in[src]^T . dout[dst] over the rules of bucket k.  One workgroup = `chunk` rules of one bucket and a
+// TI x TJ rectangle of 16x16 output blocks (blockIdx.y); its four waves interleave 4-rule MFMA steps and feed the
+// operands straight from global memory (16 lanes = one contiguous 64-B row segment, no LDS staging, no barriers
+// in the loop), then combine their accumulators through LDS in wave order (deterministic) into one partial slab.
+template <int TI, int TJ>
+__global__ __launch_bounds__(256) void k_dw_direct(const float* __restrict__ in, int ld_in,
+                                                    const float* __restrict__ dout, int ld_do,
+                                                    const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                    int Cin, int Cout, int K, KSeg seg, int chunk,
+                                                    float* __restrict__ partial) {
+  extern __shared__ float red[];  // [3 waves][TI*TJ][64 lanes] f32x4
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
   const int k = find_k(seg, blockIdx.x, K);
-  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * TRW;
-  const int r_end = min(seg.rule_off[k + 1], r_begin + TRW);
-  const int ncob = Cout >> 4, nblk = (Cin >> 4) * ncob;
-  f32x4 acc[DW_MAXB];
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * chunk;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + chunk);
+  const int ncib = Cin >> 4, ncob = Cout >> 4;
+  const int nrj = (ncob + TJ - 1) / TJ;
+  const int ci0 = (blockIdx.y / nrj) * TI, co0 = (blockIdx.y % nrj) * TJ;
+  f32x4 acc[TI][TJ];
 #pragma unroll
-  for (int t = 0; t < DW_MAXB; t++) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ca4 = Cin >> 2, cb4 = Cout >> 2;
-  for (int t0 = r_begin; t0 < r_end; t0 += 64) {
-    __syncthreads();
-    for (int e = tid; e < 64 * ca4; e += 256) {
-      int rr = e / ca4, c = e - rr * ca4;
-      int r = t0 + rr;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < r_end) v = *(const f32x4*)(in + (int64_t)src[r] * ld_in + c * 4);
-      *(f32x4*)&As[rr * sa + c * 4] = v;
-    }
-    for (int e = tid; e < 64 * cb4; e += 256) {
-      int rr = e / cb4, c = e - rr * cb4;
-      int r = t0 + rr;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (r < r_end) v = *(const f32x4*)(dout + (int64_t)dst[r] * ld_do + c * 4);
-      *(f32x4*)&Bs[rr * sb + c * 4] = v;
-    }
-    __syncthreads();
+  for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int t = 0; t < DW_MAXB; t++) {
-      int blk = wave + 4 * t;
-      if (blk < nblk) {
-        int cib = blk / ncob, cob = blk - cib * ncob;
-        const float* ap = As + sl * sa + cib * 16 + rl;
-        const float* bp = Bs + sl * sb + cob * 16 + rl;
-#pragma unroll 4
-        for (int r4 = 0; r4 < 16; r4++)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r4 * 4 * sa], bp[r4 * 4 * sb], acc[t], 0, 0, 0);
-      }
-    }
+    for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r0 = r_begin + wave * 4; r0 < r_end; r0 += 16) {
+    const int r = r0 + sl;
+    const bool valid = r < r_end;
+    const int si = valid ? src[r] : 0, di = valid ? dst[r] : 0;
+    const float* ap = in + (int64_t)si * ld_in + rl;
+    const float* bp = dout + (int64_t)di * ld_do + rl;
+    float a[TI], b[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++) a[i] = (valid && ci0 + i < ncib) ? ap[(ci0 + i) * 16] : 0.f;
+#pragma unroll
+    for (int j = 0; j < TJ; j++) b[j] = (valid && co0 + j < ncob) ? bp[(co0 + j) * 16] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
-  float* P = partial + (int64_t)blockIdx.x * Cin * Cout;
+  if (wave > 0) {
 #pragma unroll
-  for (int t = 0; t < DW_MAXB; t++) {
-    int blk = wave + 4 * t;
-    if (blk < nblk) {
-      int cib = blk / ncob, cob = blk - cib * ncob;
+    for (int i = 0; i < TI; i++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) P[(int64_t)(cib * 16 + sl * 4 + r) * Cout + cob * 16 + rl] = acc[t][r];
-    }
+      for (int j = 0; j < TJ; j++) *(f32x4*)&red[(((wave - 1) * TI * TJ + i * TJ + j) * 64 + lane) * 4] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* P = partial + (int64_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) {
+        f32x4 v = acc[i][j];
+#pragma unroll
+        for (int w = 0; w < 3; w++) v += *(const f32x4*)&red[((w * TI * TJ + i * TJ + j) * 64 + lane) * 4];
+        if (ci0 + i < ncib && co0 + j < ncob) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) P[(int64_t)((ci0 + i) * 16 + sl * 4 + r) * Cout + (co0 + j) * 16 + rl] = v[r];
+        }
+      }
   }
 }
 
@@ -367,9 +369,23 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
   return MM_OK;
 }
 
+static inline int dw_tile(int n) { return (n + ((n + 3) / 4) - 1) / ((n + 3) / 4); }  // balanced split, <= 4
+
+// rules per workgroup for dW: aim at ~1024 workgroups, 16-rule granularity
+static int dw_chunk(int64_t R, int Cin, int Cout) {
+  if (Cin % 16 || Cout % 16) return TRW;
+  int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
+  int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
+  int64_t c = mm_cdiv(R, 1024 / ny > 0 ? 1024 / ny : 1);
+  c = mm_cdiv(c, 16) * 16;
+  if (c < 64) c = 64;
+  if (c > 8192) c = 8192;
+  return (int)c;
+}
+
 size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout) {
   KSeg seg;
-  int nb = make_seg(offsets_host, K, TRW, &seg);
+  int nb = make_seg(offsets_host, K, dw_chunk(offsets_host[K], Cin, Cout), &seg);
   return mm_align((size_t)(nb > 0 ? nb : 1) * Cin * Cout * sizeof(float)) + 256;
 }
 
@@ -379,7 +395,8 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
                  size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0, "spconv_dw: bad shape");
   KSeg seg;
-  int nb = make_seg(offsets_host, K, TRW, &seg);
+  const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
+  int nb = make_seg(offsets_host, K, chunk, &seg);
   const int ne = Cin * Cout;
   if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
     mm_set_error("spconv_dw: workspace too small");
@@ -387,14 +404,18 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
   }
   float* partial = (float*)ws;
   if (nb > 0) {
-    const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0) && (ld_in % 4 == 0) && (ld_do % 4 == 0) &&
-                         (((uintptr_t)in | (uintptr_t)dout) % 16 == 0) && ((Cin / 16) * (Cout / 16) <= 4 * DW_MAXB);
+    const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
     if (mfma_ok) {
-      const int sa = Cin + ((Cin & 31) == 16 ? 0 : 16), sb = Cout + ((Cout & 31) == 16 ? 0 : 16);
-      size_t lds = (size_t)64 * (sa + sb) * sizeof(float);
-      if (lds > 64 * 1024)
-        MM_HIP(hipFuncSetAttribute((const void*)k_dw_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_dw_mfma, dim3(nb), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, K, seg, partial);
+      const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
+      const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
+      const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
+#define DWCASE(I, J)                                                                                                  \
+  if (ti == I && tj == J)                                                                                             \
+    hipLaunchKernelGGL((k_dw_direct<I, J>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, \
+                       K, seg, chunk, partial);
+      DWCASE(1, 1) DWCASE(1, 2) DWCASE(1, 3) DWCASE(1, 4) DWCASE(2, 1) DWCASE(2, 2) DWCASE(2, 3) DWCASE(2, 4)
+      DWCASE(3, 1) DWCASE(3, 2) DWCASE(3, 3) DWCASE(3, 4) DWCASE(4, 1) DWCASE(4, 2) DWCASE(4, 3) DWCASE(4, 4)
+#undef DWCASE
     } else {
       size_t lds = (size_t)64 * (Cin + Cout) * sizeof(float);
       MM_CHECK_ARG(lds <= 150 * 1024, "spconv_dw: channels too wide for the generic kernel");
