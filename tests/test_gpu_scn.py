@@ -169,6 +169,11 @@ def test_batchnorm_forward_backward_running_stats(C, leak):
 
 @pytest.mark.parametrize("residual", [False, True])
 def test_net3d_forward_backward_vs_oracle(residual):
+    """Forward: logits within 1e-3 of the fp32 oracle (north_star).  Backward: this 50-layer BN network's fp32
+    gradients are only conditioned to ~1e-2 (the fp32 oracle itself differs from the fp64 oracle by that much), so
+    each HIP gradient must be as close to the fp64 oracle as the fp32 oracle is (factor 3), floor 1e-3."""
+    import copy
+
     from mm2d3d_amd.net3d import Net3DSeg
 
     dev = _dev()
@@ -176,14 +181,16 @@ def test_net3d_forward_backward_vs_oracle(residual):
     batch = _lidar_batch(2)
     kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7, residual_blocks=residual)
     ref = Net3DSegRef(6, True, kw)
+    ref64 = copy.deepcopy(ref).double()
     hip = Net3DSeg(6, True, kw)
-    missing = hip.load_state_dict(ref.state_dict(), strict=True)
+    hip.load_state_dict(ref.state_dict(), strict=True)
     hip.cuda()
     coords, feats = batch["x"]
     bh = {"x": [coords.to(dev), feats.clone().to(dev)]}
     br = {"x": [coords, feats.clone()]}
     pr, fr, ar = ref(br)
     ph, fh, ah = hip(bh)
+    p64, _, a64 = ref64({"x": [coords, feats.clone().double()]})
     _close(bh["x"][1], br["x"][1], what="gated feats written back to the batch dict")
     _close(fh, fr, what="3D features")
     _close(ph["seg_logit"], pr["seg_logit"], what="seg_logit")  # north_star: logits within 1e-3
@@ -192,13 +199,19 @@ def test_net3d_forward_backward_vs_oracle(residual):
     w = torch.randn_like(pr["seg_logit"])
     (pr["seg_logit"] * w).sum().add((ar["seg_logit_point"] * w).sum()).backward()
     (ph["seg_logit"] * w.to(dev)).sum().add((ah["seg_logit_point"] * w.to(dev)).sum()).backward()
-    gr = dict(ref.named_parameters())
+    (p64["seg_logit"] * w.double()).sum().add((a64["seg_logit_point"] * w.double()).sum()).backward()
+    g32 = dict(ref.named_parameters())
+    g64 = dict(ref64.named_parameters())
     for name, p in hip.named_parameters():
         if "linear_global" in name:
             assert p.grad is None
             continue
         assert p.grad is not None, name
-        _close(p.grad, gr[name].grad, tol=5e-3, what=f"grad {name}")
+        t = g64[name].grad
+        scale = max(1.0, t.abs().max().item())
+        e_hip = (p.grad.detach().cpu().double() - t).abs().max().item() / scale
+        e_ref = (g32[name].grad.double() - t).abs().max().item() / scale
+        assert e_hip <= max(3.0 * e_ref, 1e-3), f"grad {name}: hip-vs-fp64 {e_hip:.3e}, fp32-oracle-vs-fp64 {e_ref:.3e}"
     for (n1, b1), (n2, b2) in zip(sorted(hip.named_buffers()), sorted(ref.named_buffers())):
         assert n1 == n2
         _close(b1, b2, what=f"buffer {n1}")
