@@ -1,0 +1,185 @@
+"""Headline benchmark: LiDAR scenes/sec of the reference's full training step (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = the reference's two-domain step (train.py:186-292): B source + B target scenes, 2D and 3D forward on each,
+2 weighted CE + 4 cross-modal KL, one backward, gradient all-reduce (N>1), two AdamW updates + OneCycle ticks.
+Workload = BASELINE.json configs[1]: NuScenes-shaped scenes (34,880 points, 5 cm voxels, 480x302 RGB), 8 source +
+8 target scenes per GPU (run/train.yaml: batch 16 on 2 GPUs = 8/GPU per loader).  value = 2*B*N / step time.
+Weak scaling: every rank processes its own 2*B scenes; the only collective is the gradient all-reduce.
+
+Extra legs (rank 0, N=1): `roofline` = sparse-conv engine kernels timed with HIP events against SURVEY.md 8d's
+algorithmic bytes; `cpu_baseline` = the CPU oracle timed on a bounded sample (1 source + 1 target scene).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLASS_WEIGHTS = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]  # EXP/config/config.yaml:45
+NET3D_KW = dict(in_channels=3, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def build_trainer(dev, total_steps=49047):
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.train import TrainModel
+
+    torch.manual_seed(42)
+    nets = {"2d_net": Net2DSeg(6, pretrained=True).to(dev), "3d_net": Net3DSeg(6, True, NET3D_KW).to(dev)}
+    opts = {}
+    for k in nets:
+        o = Optimizer("adamw", lr=0.001)
+        o.set_scheduler("one_cycle", max_lr=0.005, total_steps=total_steps)
+        opts[k] = o
+    loss = Loss([{"name": "cross_entropy", "weight": 1.0, "target": "segmentation", "args": {"weight": CLASS_WEIGHTS}}])
+    nets["2d_net"].amp_dtype = torch.bfloat16  # reference runs this branch under AMP (run/train.yaml: precision 16)
+    tm = TrainModel(nets, opts, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
+    tm.configure_optimizers()
+    return tm
+
+
+def fresh(batch):
+    """A loader hands over new tensors every step; the 3D net gates ``x[1]`` in place, so clone the features."""
+    out = {}
+    for dom, b in batch.items():
+        nb = dict(b)
+        nb["x"] = [b["x"][0], b["x"][1].clone()]
+        out[dom] = nb
+    return out
+
+
+def conv_roofline(tm, batch, dev):
+    """Times every sparse-conv engine call of one step with HIP events (torch's current stream = the launch stream)."""
+    from mm2d3d_amd.scn import ops
+
+    rec = []
+    ops.PROFILE = rec
+    tm.fit_step(fresh(batch))
+    torch.cuda.synchronize()
+    ops.PROFILE = None
+    alg_bytes = sum(r["bytes"] for r in rec)
+    ms = sum(r["e0"].elapsed_time(r["e1"]) for r in rec)
+    by_kind = {}
+    for r in rec:
+        k = by_kind.setdefault(r["kind"], [0.0, 0.0, 0])
+        k[0] += r["bytes"]
+        k[1] += r["e0"].elapsed_time(r["e1"])
+        k[2] += 1
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {
+        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+        "traffic": None,
+        "kernel": "sparse-conv engines: k_gather_gemm<*> + k_csr_reduce (fwd, dX), k_dw_direct<*> + k_dw_reduce (dW)",
+        "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
+        "by_pass": {k: {"GB/s": round(v[0] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else 0.0, "ms": round(v[1], 3), "calls": v[2]}
+                    for k, v in by_kind.items()},
+    }
+
+
+def cpu_baseline():
+    """The CPU oracle (a port, not the reference) on 1 source + 1 target scene of the same workload, fwd+bwd."""
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.synthetic import make_batch
+    from oracle.net3d_ref import Net3DSegRef
+    from oracle.step_ref import generic_step
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k)
+          for k, v in Net2DSeg(6, pretrained=True).state_dict().items()}
+    net3d = Net3DSegRef(6, True, NET3D_KW)
+    batch = {"source": make_batch(2, 1, "nuscenes", (302, 480)), "target": make_batch(3, 1, "nuscenes", (302, 480))}
+    t0 = time.perf_counter()
+    loss, _ = generic_step(sd, net3d, fresh(batch), CLASS_WEIGHTS)
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(2 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": "CPU oracle (torch-CPU 2D + oracle sparse ops), 1 source + 1 target NuScenes-shaped scene at 480x302, "
+                      "one fwd+bwd of the full two-domain step, no optimiser step", "seconds": round(dt, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scenes", type=int, default=8, help="scenes per domain per GPU")
+    ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mm2d3d_amd.synthetic import make_batch
+
+    tm = build_trainer(dev)
+    B = a.scenes
+    batch = {
+        "source": make_batch(2, B, "nuscenes", (302, 480), rank=rank, device=dev, augment=True),
+        "target": make_batch(3, B, "nuscenes", (302, 480), rank=rank, device=dev, augment=True),
+    }
+    n_pts = batch["source"]["x"][0].shape[0] + batch["target"]["x"][0].shape[0]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        tm.fit_step(fresh(batch))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = tm.fit_step(fresh(batch))
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / a.steps * 1e3
+    out = {
+        "metric": "LiDAR scenes/sec fwd+bwd (NuScenes ~35k pts, 5cm voxel)", "value": round(2 * B * world / (ms * 1e-3), 3),
+        "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3D sparse branch: fp32 MFMA), bf16 autocast (2D branch, interim torch layers)",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: NuScenes-shaped (32x1090 sweep, 34,880 pts/scene), 5 cm voxels, 480x302 RGB + "
+                               "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "
+                               "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
+                   "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss)},
+    }
+    if rank == 0 and world == 1 and not a.no_extras:
+        out["roofline"] = conv_roofline(tm, batch, dev)
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
 
-vp, i32, i64, sz, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float
+vp, i32, i64, sz, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_float, C.c_double
 
 # name -> (restype, argtypes); mirrors include/mm2d3d.h
 _PROTOS = {
@@ -44,6 +44,14 @@ _PROTOS = {
     "mm_row_gather": (i32, [vp, i32, i32, vp, vp, i32, i64, vp, i32, vp]),
     "mm_linear_fwd": (i32, [vp, i32, i64, i32, i32, vp, vp, vp, i32, vp]),
     "mm_linear_bwd": (i32, [vp, i32, vp, i32, i64, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_loss_ws_bytes": (sz, []),
+    "mm_ce_fwd": (i32, [vp, i32, vp, vp, i64, i32, i64, vp, vp, sz, vp]),
+    "mm_ce_bwd": (i32, [vp, i32, vp, vp, i64, i32, i64, vp, vp, vp, i32, vp]),
+    "mm_kl_fwd": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, sz, vp]),
+    "mm_kl_bwd": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, i32, vp]),
+    "mm_lift_gather": (i32, [vp, i64, vp, i64, i32, vp, vp]),
+    "mm_lift_scatter": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp]),
+    "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp]),
 }
 
 

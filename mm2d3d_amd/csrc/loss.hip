@@ -1,0 +1,279 @@
+// Row-wise losses over per-point logits [N, C]:
+//   weighted cross entropy, ignore_index, weighted-mean reduction   (/root/reference/lib/losses.py:55-68)
+//   cross-modal KL( softmax(target) || softmax(pred) ).sum(1).mean() (/root/reference/.../train.py:157-184)
+// plus the 2D->3D lifting gather and its deterministic backward (2d_net/model.py:131-137,166-173)
+// and the fused flat AdamW update (K16; train.py:627-636 -> torch.optim.AdamW).
+// Block partial sums are fp64 and combined in a fixed order: bit-stable run to run.
+#include "common.h"
+
+namespace {
+constexpr int T = 256;
+constexpr int MAX_PART = 1024;
+constexpr int MAXC = 32;
+
+__device__ inline double block_sum(double v, double* red) {
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = T / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  return red[0];
+}
+
+// partial[b] = (sum w*nll, sum w)
+__global__ __launch_bounds__(T) void k_ce_fwd(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                               const float* __restrict__ weight, int64_t N, int C, int64_t ignore,
+                                               double* __restrict__ partial) {
+  __shared__ double red[T];
+  double sl = 0.0, sw = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < N; i += (int64_t)gridDim.x * T) {
+    int64_t y = labels[i];
+    if (y == ignore || y < 0 || y >= C) continue;
+    const float* x = logits + i * ld;
+    float m = x[0];
+    for (int c = 1; c < C; c++) m = fmaxf(m, x[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; c++) s += expf(x[c] - m);
+    float nll = (m + logf(s)) - x[y];
+    float w = weight ? weight[y] : 1.f;
+    sl += (double)(w * nll);
+    sw += (double)w;
+  }
+  double a = block_sum(sl, red);
+  double b = block_sum(sw, red);
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = a;
+    partial[2 * blockIdx.x + 1] = b;
+  }
+}
+
+__global__ void k_ce_finalize(const double* __restrict__ partial, int nb, float* __restrict__ out /*[2]: loss, sum_w*/) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0, b = 0.0;
+  for (int i = 0; i < nb; i++) {
+    a += partial[2 * i];
+    b += partial[2 * i + 1];
+  }
+  out[0] = (float)(a / b);  // 0/0 = nan, as torch does when every label is ignored
+  out[1] = (float)b;
+}
+
+// dlogits = gscale * w[y] * (softmax - onehot) / sum_w
+__global__ __launch_bounds__(T) void k_ce_bwd(const float* __restrict__ logits, int ld, const int64_t* __restrict__ labels,
+                                               const float* __restrict__ weight, int64_t N, int C, int64_t ignore,
+                                               const float* __restrict__ stats, const float* __restrict__ gout,
+                                               float* __restrict__ dlogits, int ld_d) {
+  int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (i >= N) return;
+  int64_t y = labels[i];
+  float* d = dlogits + i * ld_d;
+  if (y == ignore || y < 0 || y >= C) {
+    for (int c = 0; c < C; c++) d[c] = 0.f;
+    return;
+  }
+  const float* x = logits + i * ld;
+  float m = x[0];
+  for (int c = 1; c < C; c++) m = fmaxf(m, x[c]);
+  float s = 0.f;
+  for (int c = 0; c < C; c++) s += expf(x[c] - m);
+  float k = gout[0] * (weight ? weight[y] : 1.f) / stats[1];
+  float inv = 1.f / s;
+  for (int c = 0; c < C; c++) d[c] = k * (expf(x[c] - m) * inv - (c == y ? 1.f : 0.f));
+}
+
+// partial[b] = sum_i sum_c q_ic (log q_ic - log p_ic)
+__global__ __launch_bounds__(T) void k_kl_fwd(const float* __restrict__ pred, int ld_p, const float* __restrict__ tgt,
+                                               int ld_t, int64_t N, int C, double* __restrict__ partial) {
+  __shared__ double red[T];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < N; i += (int64_t)gridDim.x * T) {
+    const float* p = pred + i * ld_p;
+    const float* t = tgt + i * ld_t;
+    float mp = p[0], mt = t[0];
+    for (int c = 1; c < C; c++) {
+      mp = fmaxf(mp, p[c]);
+      mt = fmaxf(mt, t[c]);
+    }
+    float sp = 0.f, st = 0.f;
+    for (int c = 0; c < C; c++) {
+      sp += expf(p[c] - mp);
+      st += expf(t[c] - mt);
+    }
+    float lp = mp + logf(sp), lt = mt + logf(st);
+    float r = 0.f;
+    for (int c = 0; c < C; c++) {
+      float lq = t[c] - lt;
+      r += expf(lq) * (lq - (p[c] - lp));
+    }
+    acc += (double)r;
+  }
+  double a = block_sum(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+__global__ void k_kl_finalize(const double* __restrict__ partial, int nb, int64_t N, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a = 0.0;
+  for (int i = 0; i < nb; i++) a += partial[i];
+  out[0] = (float)(a / (double)N);
+}
+
+// dpred = gscale/N * (softmax(pred) - softmax(tgt))
+__global__ __launch_bounds__(T) void k_kl_bwd(const float* __restrict__ pred, int ld_p, const float* __restrict__ tgt,
+                                               int ld_t, int64_t N, int C, const float* __restrict__ gout,
+                                               float* __restrict__ dpred, int ld_d) {
+  int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (i >= N) return;
+  const float* p = pred + i * ld_p;
+  const float* t = tgt + i * ld_t;
+  float mp = p[0], mt = t[0];
+  for (int c = 1; c < C; c++) {
+    mp = fmaxf(mp, p[c]);
+    mt = fmaxf(mt, t[c]);
+  }
+  float sp = 0.f, st = 0.f;
+  for (int c = 0; c < C; c++) {
+    sp += expf(p[c] - mp);
+    st += expf(t[c] - mt);
+  }
+  float k = gout[0] / (float)N, ip = 1.f / sp, it = 1.f / st;
+  for (int c = 0; c < C; c++) dpred[i * ld_d + c] = k * (expf(p[c] - mp) * ip - expf(t[c] - mt) * it);
+}
+
+// ---- lifting: out[p][c] = seg[pix_off[p] + c*sc]
+__global__ __launch_bounds__(T) void k_lift_gather(const float* __restrict__ seg, int64_t sc,
+                                                    const int64_t* __restrict__ pix_off, int64_t N, int C,
+                                                    float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t p = gid / C;
+  int c = (int)(gid - p * C);
+  if (p >= N) return;
+  out[p * C + c] = seg[pix_off[p] + c * sc];
+}
+
+// dseg[upix_off[u] + c*sc] = sum over the points of unique pixel u (ascending point order)
+__global__ __launch_bounds__(T) void k_lift_scatter(const float* __restrict__ dout, int C,
+                                                     const int64_t* __restrict__ upix_off,
+                                                     const int32_t* __restrict__ csr_off,
+                                                     const int32_t* __restrict__ csr_pts, int64_t n_unique, int64_t sc,
+                                                     float* __restrict__ dseg) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t u = gid / C;
+  int c = (int)(gid - u * C);
+  if (u >= n_unique) return;
+  float s = 0.f;
+  for (int e = csr_off[u]; e < csr_off[u + 1]; e++) s += dout[(int64_t)csr_pts[e] * C + c];
+  dseg[upix_off[u] + c * sc] = s;
+}
+
+// ---- AdamW over flat fp32 arenas (torch.optim.AdamW semantics, amsgrad off; same op order as torch's
+// single-tensor path: p*=1-lr*wd; m.lerp_(g,1-b1); v=b2*v+(1-b2)*g*g; p-=step_size*m/(sqrt(v)/sqrt(bc2)+eps))
+__global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, int64_t n, float decay, float omb1, float beta2,
+                                              float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
+  int64_t i = ((int64_t)blockIdx.x * T + threadIdx.x) * 4;
+  if (i >= n) return;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (i + j >= n) break;
+    float gi = g[i + j] * grad_scale;
+    float pi = p[i + j] * decay;
+    float mi = m[i + j] + omb1 * (gi - m[i + j]);
+    float vi = beta2 * v[i + j] + omb2 * gi * gi;
+    float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i + j] = pi - step_size * (mi / denom);
+    m[i + j] = mi;
+    v[i + j] = vi;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+size_t mm_loss_ws_bytes() { return mm_align((size_t)MAX_PART * 2 * sizeof(double)) + 256; }
+
+static inline int loss_blocks(int64_t N) {
+  int64_t nb = mm_cdiv(N > 0 ? N : 1, (int64_t)T * 4);
+  return (int)(nb > MAX_PART ? MAX_PART : nb);
+}
+
+// stats[0] = loss, stats[1] = sum of weights of the non-ignored rows
+int mm_ce_fwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t N, int C, int64_t ignore_index,
+              float* stats, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C > 0 && C <= MAXC && ld >= C, "ce: bad C");
+  if (ws_bytes < (size_t)MAX_PART * 2 * sizeof(double)) {
+    mm_set_error("ce: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  int nb = loss_blocks(N);
+  hipLaunchKernelGGL(k_ce_fwd, dim3(nb), dim3(T), 0, s, logits, ld, labels, weight, N, C, ignore_index, (double*)ws);
+  hipLaunchKernelGGL(k_ce_finalize, dim3(1), dim3(64), 0, s, (const double*)ws, nb, stats);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t N, int C, int64_t ignore_index,
+              const float* stats, const float* grad_out, float* dlogits, int ld_d, hipStream_t s) {
+  if (N == 0) return MM_OK;
+  hipLaunchKernelGGL(k_ce_bwd, dim3((unsigned)mm_cdiv(N, T)), dim3(T), 0, s, logits, ld, labels, weight, N, C, ignore_index, stats,
+                     grad_out, dlogits, ld_d);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_kl_fwd(const float* pred, int ld_p, const float* tgt, int ld_t, int64_t N, int C, float* loss, void* ws, size_t ws_bytes,
+              hipStream_t s) {
+  MM_CHECK_ARG(C > 0 && C <= MAXC, "kl: bad C");
+  if (ws_bytes < (size_t)MAX_PART * sizeof(double)) {
+    mm_set_error("kl: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  int nb = loss_blocks(N);
+  hipLaunchKernelGGL(k_kl_fwd, dim3(nb), dim3(T), 0, s, pred, ld_p, tgt, ld_t, N, C, (double*)ws);
+  hipLaunchKernelGGL(k_kl_finalize, dim3(1), dim3(64), 0, s, (const double*)ws, nb, N, loss);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_kl_bwd(const float* pred, int ld_p, const float* tgt, int ld_t, int64_t N, int C, const float* grad_out, float* dpred,
+              int ld_d, hipStream_t s) {
+  if (N == 0) return MM_OK;
+  hipLaunchKernelGGL(k_kl_bwd, dim3((unsigned)mm_cdiv(N, T)), dim3(T), 0, s, pred, ld_p, tgt, ld_t, N, C, grad_out, dpred, ld_d);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// out[p][c] = seg[pix_off[p] + c*chan_stride]   (pix_off = element offset of channel 0 of the point's pixel)
+int mm_lift_gather(const float* seg, int64_t chan_stride, const int64_t* pix_off, int64_t N, int C, float* out, hipStream_t s) {
+  if (N == 0) return MM_OK;
+  hipLaunchKernelGGL(k_lift_gather, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, seg, chan_stride, pix_off, N, C, out);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// dseg must be zero-filled by the caller; duplicate pixels accumulate in ascending point order
+int mm_lift_scatter(const float* dout, int C, const int64_t* upix_off, const int32_t* csr_off, const int32_t* csr_pts,
+                    int64_t n_unique, int64_t chan_stride, float* dseg, hipStream_t s) {
+  if (n_unique == 0) return MM_OK;
+  hipLaunchKernelGGL(k_lift_scatter, dim3((unsigned)mm_cdiv(n_unique * C, T)), dim3(T), 0, s, dout, C, upix_off, csr_off, csr_pts,
+                     n_unique, chan_stride, dseg);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                  double weight_decay, int64_t step, double grad_scale, hipStream_t s) {
+  MM_CHECK_ARG(step >= 1, "adamw: step counts from 1");
+  if (n == 0) return MM_OK;
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2 = 1.0 - pow(beta2, (double)step);
+  hipLaunchKernelGGL(k_adamw, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
+                     (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

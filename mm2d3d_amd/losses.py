@@ -1,0 +1,173 @@
+"""Loss registry with the reference's API (lib/losses.py:81-153) over fused HIP row kernels (csrc/loss.hip).
+
+``Loss(cfg)``; ``loss("segmentation", pred=, gt=)``; ``split_by_target()``; ``update_loss_params()`` behave as
+in the reference; ``cross_entropy`` (weighted, ignore_index -100, weighted-mean reduction = torch's
+``F.cross_entropy`` default) and the cross-modal KL of train.py:157-184 run as single fused kernels.
+"""
+from __future__ import annotations
+
+from copy import deepcopy
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+F32 = torch.float32
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight, ignore_index):
+        _lib.require_cuda(logits, "pred")
+        L = _lib.lib()
+        logits = logits.to(F32).contiguous()
+        labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        N, C = logits.shape
+        stats = torch.empty(2, dtype=F32, device=logits.device)
+        ws = _lib.workspace.get(int(L.mm_loss_ws_bytes()), logits.device)
+        check(L.mm_ce_fwd(ptr(logits), C, ptr(labels), ptr(weight), N, C, ignore_index, ptr(stats), ptr(ws), ws.numel(),
+                          stream()), "ce_fwd")
+        ctx.save_for_backward(logits, labels, weight, stats)
+        ctx.ignore_index = ignore_index
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        logits, labels, weight, stats = ctx.saved_tensors
+        N, C = logits.shape
+        d = torch.empty_like(logits)
+        g = g.to(F32).contiguous()
+        check(L.mm_ce_bwd(ptr(logits), C, ptr(labels), ptr(weight), N, C, ctx.ignore_index, ptr(stats), ptr(g), ptr(d), C,
+                          stream()), "ce_bwd")
+        return d, None, None, None
+
+
+def cross_entropy(pred, gt, weight=None, ignore_index=-100):
+    if isinstance(weight, (list, tuple)):
+        weight = torch.tensor(weight, dtype=F32, device=pred.device)
+    elif weight is not None:
+        weight = weight.to(device=pred.device, dtype=F32).contiguous()
+    return _CrossEntropyFn.apply(pred, gt, weight, ignore_index)
+
+
+class _KLFn(torch.autograd.Function):
+    """mean_i sum_c softmax(t)_ic * (log_softmax(t)_ic - log_softmax(p)_ic); gradient flows to p only (t is detached)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        _lib.require_cuda(pred, "pred")
+        L = _lib.lib()
+        pred = pred.to(F32).contiguous()
+        target = target.detach().to(F32).contiguous()
+        N, C = pred.shape
+        out = torch.empty(1, dtype=F32, device=pred.device)
+        ws = _lib.workspace.get(int(L.mm_loss_ws_bytes()), pred.device)
+        check(L.mm_kl_fwd(ptr(pred), C, ptr(target), C, N, C, ptr(out), ptr(ws), ws.numel(), stream()), "kl_fwd")
+        ctx.save_for_backward(pred, target)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        pred, target = ctx.saved_tensors
+        N, C = pred.shape
+        d = torch.empty_like(pred)
+        g = g.to(F32).contiguous()
+        check(L.mm_kl_bwd(ptr(pred), C, ptr(target), C, N, C, ptr(g), ptr(d), C, stream()), "kl_bwd")
+        return d, None
+
+
+def kl_to_detached(pred, target):
+    return _KLFn.apply(pred, target)
+
+
+def cross_modal_loss(gt_for_2d, prediction_avg, gt_for_3d, prediction_3d):
+    """train.py:157-184: each branch's aux head mimics the other branch's detached main head."""
+    return kl_to_detached(prediction_avg, gt_for_2d), kl_to_detached(prediction_3d, gt_for_3d)
+
+
+# ---------------------------------------------------------------------------------------------- registry (reference API)
+class _GenericLoss:
+    def __init__(self, **args):
+        self.other_args = args
+
+    def __repr__(self):
+        r = self.name
+        if self.other_args:
+            r += "[" + ",".join(f"{n}={v}" for n, v in self.other_args.items()) + "]"
+        return r
+
+
+class L1(_GenericLoss):
+    name, default_target = "l1", "depth"
+
+    def __call__(self, pred, gt, **kw):
+        mask = gt > 0
+        return torch.mean(torch.abs(pred[mask] - gt[mask]))
+
+
+class L2(_GenericLoss):
+    name, default_target = "l2", "depth"
+
+    def __call__(self, pred, gt, **kw):
+        mask = gt > 0
+        return torch.mean(torch.square(pred[mask] - gt[mask]))
+
+
+class CrossEntropy(_GenericLoss):
+    name, default_target = "cross_entropy", "segmentation"
+
+    def __call__(self, pred, gt, weight=None, **kw):
+        return cross_entropy(pred, gt, weight)
+
+
+_LOSSES = {"l1": L1, "l2": L2, "cross_entropy": CrossEntropy}
+
+
+class Loss:
+    def __init__(self, cfg):
+        if isinstance(cfg, str):
+            fn = _LOSSES[cfg]()
+            self._losses = [(1.0, fn.default_target, fn)]
+        elif isinstance(cfg, (list, tuple)):
+            self._losses = []
+            for item in cfg:
+                if isinstance(item, str):
+                    fn = _LOSSES[item]()
+                    self._losses.append((1.0, fn.default_target, fn))
+                else:
+                    cls = _LOSSES[item["name"]]
+                    self._losses.append((item.get("weight", 1.0), item.get("target", cls.default_target),
+                                         cls(**dict(item.get("args", {}) or {}))))
+        else:
+            raise ValueError(f"not recognized cfg {cfg}")
+
+    def update_loss_params(self, loss_name, loss_target, **kwargs):
+        for _, target, loss in self._losses:
+            if loss.name == loss_name and target == loss_target:
+                loss.other_args.update(**kwargs)
+
+    def __call__(self, target, image=None, pred=None, gt=None):
+        sel = [(w, l) for w, t, l in self._losses if t == target]
+        if not sel:
+            raise RuntimeError(f"no losses for loss target {target}")
+        out = 0.0
+        for w, l in sel:
+            out = out + w * l(image=image, pred=pred, gt=gt, **l.other_args)
+        return out
+
+    def __repr__(self):
+        if len(self._losses) == 1:
+            w, _, l = self._losses[0]
+            return (str(w) if w != 1.0 else "") + str(l)
+        return "+".join(f"{w if w != 1.0 else ''}{l}" for w, _, l in self._losses)
+
+    def split_by_target(self):
+        out = {}
+        for t in {t for _, t, _ in self._losses}:
+            c = deepcopy(self)
+            c._losses = [deepcopy(l) for l in self._losses if l[1] == t]
+            out[t] = c
+        return out

@@ -1,0 +1,194 @@
+"""2D RGB-D branch: two ResNet34 encoders (RGB, sparse depth) + U-Net decoder + 5x5-avgpool/1x1 heads + lifting.
+
+Mirrors the plugin the reference loads by name (``2d_net``: /root/reference/.../2d_net/model.py:35-180,
+backbones.py:13-65): same constructor arguments, same ``state_dict`` keys (the encoder keys equal torchvision's
+resnet34: ``layer1.0.conv1.weight`` ...), same return tuple.  torchvision is not a dependency: the ResNet34
+BasicBlock stack [3,4,6,3] is built here.  Recorded parity decisions:
+  * ``segm_last`` is bound also when no padding was needed (the reference raises UnboundLocalError then);
+  * no ImageNet weights exist offline: ``pretrained=True`` only selects the 3-channel stem.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nn2d
+from .lifting import PixelIndex, lift
+
+signature = (
+    {"img": np.zeros([1, 3, 480, 640], dtype=np.float32)},
+    {"segm": np.zeros([1, 1, 480, 640], dtype=np.float32)},
+)
+dependencies = [f"numpy>={np.__version__}", f"torch=={torch.__version__}"]
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Affine with fixed statistics (torchvision.ops.FrozenBatchNorm2d semantics: eps 1e-5, buffers only)."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, norm_layer=None):
+        super().__init__()
+        norm_layer = norm_layer or nn2d.BatchNorm2d
+        self.conv1 = nn2d.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.relu = nn2d.ReLU(inplace=True)
+        self.conv2 = nn2d.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+def _make_layer(inplanes, planes, blocks, stride, norm_layer):
+    down = None
+    if stride != 1 or inplanes != planes:
+        down = nn.Sequential(nn2d.Conv2d(inplanes, planes, 1, stride, bias=False), (norm_layer or nn2d.BatchNorm2d)(planes))
+    layers = [BasicBlock(inplanes, planes, stride, down, norm_layer)]
+    layers += [BasicBlock(planes, planes, norm_layer=norm_layer) for _ in range(1, blocks)]
+    return nn.Sequential(*layers)
+
+
+def _resnet_init(module):
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class Backbone(nn.Module):
+    """ResNet34 encoder whose stem does NOT downsample: conv 7x7 stride 1 (backbones.py:23-25)."""
+
+    def __init__(self, num_channel=3, pretrained=True, norm_layer=None):
+        super().__init__()
+        self.conv1 = nn2d.Conv2d(num_channel, 64, kernel_size=7, stride=1, padding=3, bias=False)
+        self.bn1 = (norm_layer or nn2d.BatchNorm2d)(64)
+        self.relu = nn2d.ReLU(inplace=True)
+        self.maxpool = nn2d.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = _make_layer(64, 64, 3, 1, norm_layer)
+        self.layer2 = _make_layer(64, 128, 4, 2, norm_layer)
+        self.layer3 = _make_layer(128, 256, 6, 2, norm_layer)
+        self.layer4 = _make_layer(256, 512, 3, 2, norm_layer)
+        self.dropout = nn2d.Dropout(p=0.4)
+        _resnet_init(self)
+
+    @property
+    def channels(self):
+        return 64, 64, 128, 256, 512
+
+    def forward(self, x):
+        feats = []
+        x = self.relu(self.bn1(self.conv1(x)))
+        feats.append(x)
+        x = self.layer1(self.maxpool(x))
+        feats.append(x)
+        x = self.layer2(x)
+        feats.append(x)
+        x = self.dropout(self.layer3(x))
+        feats.append(x)
+        x = self.dropout(self.layer4(x))
+        feats.append(x)
+        return feats
+
+
+def _pixel_index(data_batch, h, w, device):
+    idx = data_batch.get("_pixel_index")
+    if idx is None or (idx.H, idx.W) != (h, w) or idx.device != device:
+        idx = PixelIndex(data_batch["img_indices"], h, w, device)
+        data_batch["_pixel_index"] = idx
+    return idx
+
+
+class L2G_classifier_2D(nn.Module):
+    def __init__(self, input_channels, num_classes):
+        super().__init__()
+        self.con1_1_avg = nn2d.Conv2d(input_channels, num_classes, kernel_size=1, stride=1)
+        self.linear = nn.Linear(input_channels, num_classes)  # unused by forward, kept for checkpoint parity
+        self.dow_avg = nn2d.AvgPool2d((5, 5), stride=(1, 1), padding=(2, 2))
+
+    def forward(self, input_2D_feature, pixel_index):
+        avg = self.con1_1_avg(self.dow_avg(input_2D_feature))
+        return {"seg_logit_avg": lift(avg, pixel_index), "seg_logit_avg_2d": avg}
+
+
+class Net2DSeg(nn.Module):
+    def __init__(self, num_classes, pretrained=True, frozen_batch_norm=False):
+        super().__init__()
+        feat_channels = 64
+        norm_layer = FrozenBatchNorm2d if frozen_batch_norm else None
+        self.rgb_backbone = Backbone(pretrained=pretrained, norm_layer=norm_layer)
+        self.depth_backbone = Backbone(num_channel=1, pretrained=False)
+        _, self.dec_t_conv_stage5 = self.dec_stage(self.rgb_backbone.layer4, num_concat=1, num_concat_t=2)
+        self.dec_conv_stage4, self.dec_t_conv_stage4 = self.dec_stage(self.rgb_backbone.layer3, num_concat=3)
+        self.dec_conv_stage3, self.dec_t_conv_stage3 = self.dec_stage(self.rgb_backbone.layer2, num_concat=3)
+        self.dec_conv_stage2, self.dec_t_conv_stage2 = self.dec_stage(self.rgb_backbone.layer1, num_concat=3)
+        self.dec_conv_stage1 = nn2d.Conv2d(3 * 64, 64, kernel_size=3, padding=1)
+        self.dow_avg = nn2d.AvgPool2d((5, 5), stride=(1, 1), padding=(2, 2))
+        self.con1_1_avg = nn2d.Conv2d(64, num_classes, kernel_size=1, stride=1)
+        self.aux = L2G_classifier_2D(feat_channels, num_classes)
+        self.amp_dtype = None  # torch.bfloat16 = the reference's `precision: 16` run mode for this branch
+
+    @staticmethod
+    def dec_stage(enc_stage, num_concat, num_concat_t=1):
+        cin = enc_stage[0].conv1.in_channels
+        cout = enc_stage[-1].conv2.out_channels
+        conv = nn.Sequential(nn2d.Conv2d(num_concat * cout, cout, kernel_size=3, padding=1), nn2d.BatchNorm2d(cout),
+                             nn2d.ReLU(inplace=True))
+        t_conv = nn.Sequential(nn2d.ConvTranspose2d(cout * num_concat_t, cin, kernel_size=2, stride=2), nn2d.BatchNorm2d(cin),
+                               nn2d.ReLU(inplace=True))
+        return conv, t_conv
+
+    def forward(self, data_batch):
+        if self.amp_dtype is not None and not torch.is_autocast_enabled():
+            with torch.autocast("cuda", dtype=self.amp_dtype):
+                return self.forward(data_batch)
+        img, hints, img_indices = data_batch["img"], data_batch["depth"], data_batch["img_indices"]
+        h, w = img.shape[2], img.shape[3]
+        pad_h, pad_w = (-h) % 16, (-w) % 16
+        if pad_h or pad_w:
+            img = F.pad(img, [0, pad_w, 0, pad_h])
+            hints = F.pad(hints, [0, pad_w, 0, pad_h])
+        r = self.rgb_backbone(img)
+        d = self.depth_backbone(hints)
+        # decoder: concat order is [depth, upsampled, rgb] (model.py:107,112,117,122)
+        x = self.dec_t_conv_stage5(torch.cat([d[4], r[4]], 1))
+        x = self.dec_conv_stage4(torch.cat([d[3], x, r[3]], 1))
+        x = self.dec_t_conv_stage4(x)
+        x = self.dec_conv_stage3(torch.cat([d[2], x, r[2]], 1))
+        x = self.dec_t_conv_stage3(x)
+        x = self.dec_conv_stage2(torch.cat([d[1], x, r[1]], 1))
+        x = self.dec_t_conv_stage2(x)
+        x = self.dec_conv_stage1(torch.cat([d[0], x, r[0]], 1))
+        segm_last = x[:, :, 0:h, 0:w] if (pad_h or pad_w) else x
+        segm_last = segm_last.float()
+        segm = self.con1_1_avg(self.dow_avg(segm_last))
+        pix = _pixel_index(data_batch, h, w, segm.device)
+        preds = {"seg_logit": lift(segm, pix), "seg_logit_2d": segm}
+        return preds, segm_last, img_indices, self.aux(segm_last, pix)
+
+
+Model = Net2DSeg

@@ -1,0 +1,154 @@
+"""Optimiser / scheduler factory with the reference's API (lib/optimizers.py:11-42).
+
+``Optimizer(name, **kw).set_scheduler(name, **kw).build(params) -> (optimizer, scheduler | None)``.
+``adamw`` / ``adam`` build :class:`FlatAdamW`: parameters, gradients and both moments live in flat fp32 arenas
+(one allocation each), so the update is ONE fused HIP kernel per step (csrc/loss.hip k_adamw) instead of
+torch 1.11's per-tensor loop, and the data-parallel all-reduce runs on slices of the same
+gradient arena without packing copies (mm2d3d_amd/ddp.py).  Schedulers are torch's own host-side classes, as in
+the reference (``one_cycle`` cycles lr AND beta1, which FlatAdamW reads from ``param_groups`` every step).
+"""
+from __future__ import annotations
+
+import torch
+from torch import optim
+from torch.optim import lr_scheduler
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+__all__ = ["Optimizer", "FlatAdamW"]
+
+
+class FlatAdamW(optim.Optimizer):
+    """AdamW (decoupled weight decay, torch semantics) over flat arenas.  ``adam_l2=True`` gives plain Adam (L2 in grad)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not on the hot path")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._arenas = []
+        self._step = 0
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                self._arenas.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != "cuda":
+                raise RuntimeError("FlatAdamW: parameters must be on the GPU (no CPU fallback)")
+            n = sum(p.numel() for p in ps)
+            flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+            flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+            spans, off = [], 0
+            for p in ps:
+                k = p.numel()
+                flat_p[off : off + k].copy_(p.data.reshape(-1))
+                p.data = flat_p[off : off + k].view(p.shape)
+                p.grad = flat_g[off : off + k].view(p.shape)
+                spans.append((off, off + k))
+                off += k
+            arena = dict(params=ps, p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), spans=spans,
+                         touched=[False] * len(ps))
+            for i, p in enumerate(ps):
+                p.register_post_accumulate_grad_hook(self._make_hook(arena, i))
+            self._arenas.append(arena)
+
+    @staticmethod
+    def _make_hook(arena, i):
+        def hook(param):
+            arena["touched"][i] = True
+            lo, hi = arena["spans"][i]
+            if param.grad is not None and param.grad.data_ptr() != arena["g"].data_ptr() + 4 * lo:
+                # autograd replaced .grad (it was None): fold it back into the arena
+                arena["g"][lo:hi].copy_(param.grad.reshape(-1))
+                param.grad = arena["g"][lo:hi].view(param.shape)
+
+        return hook
+
+    def grad_arenas(self):
+        """Flat gradient buffers (one per param group) - what the data-parallel all-reduce works on."""
+        return [a["g"] for a in self._arenas if a is not None]
+
+    def zero_grad(self, set_to_none: bool = False):
+        for a in self._arenas:
+            if a is None:
+                continue
+            a["g"].zero_()
+            a["touched"] = [False] * len(a["params"])
+            for (lo, hi), p in zip(a["spans"], a["params"]):
+                if p.grad is None or p.grad.data_ptr() != a["g"].data_ptr() + 4 * lo:
+                    p.grad = a["g"][lo:hi].view(p.shape)
+
+    def mark_all_touched(self):
+        for a in self._arenas:
+            if a is not None:
+                a["touched"] = [True] * len(a["params"])
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        L = _lib.lib()
+        self._step += 1
+        for group, a in zip(self.param_groups, self._arenas):
+            if a is None:
+                continue
+            b1, b2 = group["betas"]
+            # parameters that took part in no backward keep weights and moments (torch skips grad=None params)
+            ranges, cur = [], None
+            for t, (lo, hi) in zip(a["touched"], a["spans"]):
+                if t:
+                    cur = [lo, hi] if cur is None else [cur[0], hi]
+                elif cur is not None:
+                    ranges.append(cur)
+                    cur = None
+            if cur is not None:
+                ranges.append(cur)
+            for lo, hi in ranges:
+                check(L.mm_adamw_step(ptr(a["p"][lo:hi]), ptr(a["g"][lo:hi]), ptr(a["m"][lo:hi]), ptr(a["v"][lo:hi]), hi - lo,
+                                      float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                      float(group["weight_decay"]), self._step, float(grad_scale), stream()), "adamw_step")
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["flat"] = [None if a is None else dict(m=a["m"].clone(), v=a["v"].clone()) for a in self._arenas]
+        sd["step"] = self._step
+        return sd
+
+    def load_state_dict(self, sd):
+        flat, step = sd.get("flat"), sd.get("step", 0)
+        super().load_state_dict({k: v for k, v in sd.items() if k not in ("flat", "step")})
+        self._step = step
+        if flat:
+            for a, f in zip(self._arenas, flat):
+                if a is not None and f is not None:
+                    a["m"].copy_(f["m"])
+                    a["v"].copy_(f["v"])
+
+
+class Optimizer:
+    def __init__(self, name: str, **kwargs):
+        self._optim_name = name
+        self._optim_args = kwargs
+        self._use_scheduler = False
+
+    def set_scheduler(self, name: str, **kwargs):
+        self._scheduler_name = name
+        self._scheduler_args = kwargs
+        self._use_scheduler = True
+        return self
+
+    def build(self, params):
+        table = {"adamw": FlatAdamW, "adam": optim.Adam, "sgd": optim.SGD, "rmsprop": optim.RMSprop}
+        optimizer = table[self._optim_name](params, **self._optim_args)
+        scheduler = None
+        if self._use_scheduler:
+            scheduler = {
+                "step": lr_scheduler.StepLR,
+                "cosine_annealing": lr_scheduler.CosineAnnealingLR,
+                "cyclic": lr_scheduler.CyclicLR,
+                "reduce_on_plateau": lr_scheduler.ReduceLROnPlateau,
+                "multi_step_lr": lr_scheduler.MultiStepLR,
+                "one_cycle": lr_scheduler.OneCycleLR,
+            }[self._scheduler_name](optimizer, **self._scheduler_args)
+        return optimizer, scheduler

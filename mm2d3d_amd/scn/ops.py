@@ -8,6 +8,23 @@ from .._lib import check, ptr, stream
 
 F32 = torch.float32
 
+# bench.py's roofline leg: when a list is installed here every sparse-conv engine call is bracketed by HIP events on the
+# launch stream and logged with its ALGORITHMIC bytes (R*(Cin+Cout)*4 + 8*R + K*Cin*Cout*4 per pass).
+PROFILE = None
+
+
+def _timed(kind, rb, cin, cout, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    R = rb.n_rules
+    PROFILE.append(dict(kind=kind, R=R, cin=cin, cout=cout, K=rb.K, e0=e0, e1=e1,
+                        bytes=R * (cin + cout) * 4 + 8 * R + rb.K * cin * cout * 4))
+    return out
+
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
@@ -55,12 +72,11 @@ class SparseConvFunction(torch.autograd.Function):
         x = _c(x.to(F32))
         w = _c(weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).to(F32))
         cout = w.shape[2]
-        if mode == "subm":
-            out = _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False)
-        elif mode == "down":
-            out = _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False)
+        cin = w.shape[1]
+        if mode in ("subm", "down"):
+            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False))
         elif mode == "up":  # roles swapped, every fine row has exactly one rule
-            out = _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False)
+            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False))
         else:
             raise ValueError(mode)
         ctx.save_for_backward(x, w)
@@ -76,16 +92,16 @@ class SparseConvFunction(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if mode == "subm":  # symmetric rulebook: (k,i,o) <-> (26-k,o,i)
-                dx = _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True)
+                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True))
             elif mode == "down":
-                dx = _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False)
+                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False))
             else:
-                dx = _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False)
+                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False))
         if ctx.needs_input_grad[1]:
             if mode == "up":
-                dw = _dw(x, dout, rb, rb.rout, rb.rin, cin, cout)
+                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rout, rb.rin, cin, cout))
             else:
-                dw = _dw(x, dout, rb, rb.rin, rb.rout, cin, cout)
+                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rin, rb.rout, cin, cout))
             dw = dw.reshape(ctx.wshape)
         return dx, dw, None, None, None, None
 
