@@ -98,7 +98,8 @@ def cpu_baseline():
     from oracle.net3d_ref import Net3DSegRef
     from oracle.step_ref import generic_step
 
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    cores = max(1, min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16))
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k)
@@ -170,10 +171,12 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: NuScenes-shaped (32x1090 sweep, 34,880 pts/scene), 5 cm voxels, 480x302 RGB + "
                                "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "
                                "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
-                   "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss)},
+                   "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
     }
     if rank == 0 and world == 1 and not a.no_extras:
+        print(f"[bench] timed region done: {ms:.2f} ms/step; roofline leg ...", file=sys.stderr, flush=True)
         out["roofline"] = conv_roofline(tm, batch, dev)
+        print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
