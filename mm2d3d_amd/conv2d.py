@@ -1,0 +1,145 @@
+"""Autograd functions for the dense 2D convolutions on the bf16 MFMA implicit-GEMM kernels (csrc/conv2d.hip).
+
+Tensors keep torch's logical NCHW shape with ``channels_last`` strides (= NHWC in memory) and dtype bfloat16;
+weights stay fp32 masters in torch's layout and are packed to the kernel layouts every call (k_pack_weights).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+BF16 = torch.bfloat16
+CL = torch.channels_last
+
+
+def _arr(v):
+    return (C.c_int * len(v))(*v)
+
+
+def as_nhwc_bf16(x):
+    if x.dtype != BF16:
+        x = x.to(BF16)
+    if not x.is_contiguous(memory_format=CL):
+        x = x.contiguous(memory_format=CL)
+    return x
+
+
+def _pack(w, Z, N, T, K, sz, sn, st, sk):
+    out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
+    check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
+    return out
+
+
+def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None):
+    check(
+        _lib.lib().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
+                                  Hg, Wg, so, 0, 0, sa, fr, len(ty), _arr(ty), _arr(tx), ptr(Wp), nz, wz, zpar, ptr(bias), stream()),
+        "conv2d_gemm",
+    )
+
+
+def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk):
+    L = _lib.lib()
+    ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * Hg * Wg, Cn, Ck, len(ty))), X.device)
+    check(
+        L.mm_conv2d_wgrad(ptr(X), Bn, Hi, Wi, Ck, Ck, ptr(dY), Hg, Wg, Cn, Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(dW), sn, st, sk, 0,
+                          ptr(ws), ws.numel(), stream()),
+        "conv2d_wgrad",
+    )
+
+
+def hip_eligible(cin, cout, kh, kw, stride, padding, dilation=1, groups=1):
+    return (cin % 64 == 0 and cout % 64 == 0 and kh == kw and kh * kw <= 16 and dilation == 1 and groups == 1
+            and stride in (1, 2) and 0 <= padding < kh)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = conv2d(x, w, b, stride, padding), square kernel, Cin and Cout multiples of 64."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, padding):
+        _lib.require_cuda(x, "x")
+        x = as_nhwc_bf16(x)
+        Bn, Cin, H, W = x.shape
+        Cout, _, KH, KW = weight.shape
+        Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+        w = weight.detach().float().contiguous()
+        T = KH * KW
+        Wp = _pack(w, 1, Cout, T, Cin, 0, Cin * T, 1, T)  # [co][t][ci]
+        y = torch.empty((Bn, Cout, Ho, Wo), dtype=BF16, device=x.device, memory_format=CL)
+        ty = [kh - padding for kh in range(KH) for _ in range(KW)]
+        tx = [kw - padding for _ in range(KH) for kw in range(KW)]
+        b = bias.detach().float().contiguous() if bias is not None else None
+        _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding, has_bias = ctx.cfg
+        dy = as_nhwc_bf16(dy)
+        Bn, Cin, H, W = x.shape
+        Cout, _, KH, KW = w.shape
+        Ho, Wo = dy.shape[2], dy.shape[3]
+        T = KH * KW
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T)  # [ci][t][co]
+            dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
+            ty = [padding - kh for kh in range(KH) for _ in range(KW)]
+            tx = [padding - kw for _ in range(KH) for kw in range(KW)]
+            _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ty = [kh - padding for kh in range(KH) for _ in range(KW)]
+            tx = [kw - padding for _ in range(KH) for kw in range(KW)]
+            _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 2, 3))
+        return dx, dw, db, None, None
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """y = conv_transpose2d(x, w, b, stride=2), kernel 2x2: four 1x1 GEMMs with a pixel-shuffle store (blockIdx.z = parity)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _lib.require_cuda(x, "x")
+        x = as_nhwc_bf16(x)
+        Bn, Cin, H, W = x.shape
+        _, Cout, KH, KW = weight.shape
+        assert (KH, KW) == (2, 2)
+        w = weight.detach().float().contiguous()  # [ci][co][a][b]
+        Wp = _pack(w, 4, Cout, 1, Cin, 1, 4, 0, Cout * 4)  # [z=(a,b)][co][ci]
+        y = torch.empty((Bn, Cout, 2 * H, 2 * W), dtype=BF16, device=x.device, memory_format=CL)
+        b = bias.detach().float().contiguous() if bias is not None else None
+        _gemm(x, Bn, H, W, Cin, y, 2 * H, 2 * W, Cout, H, W, 2, 1, 1, [0], [0], Wp, nz=4, wz=Cout * Cin, zpar=1, bias=b)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = as_nhwc_bf16(dy)
+        Bn, Cin, H, W = x.shape
+        Cout = w.shape[1]
+        dx = dw = db = None
+        ty, tx = [0, 0, 1, 1], [0, 1, 0, 1]
+        if ctx.needs_input_grad[0]:
+            Wd = _pack(w, 1, Cin, 4, Cout, 0, Cout * 4, 1, 4)  # [ci][t=(a,b)][co]
+            dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
+            _gemm(dy, Bn, 2 * H, 2 * W, Cout, dx, H, W, Cin, H, W, 1, 2, 1, ty, tx, Wd)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            # roles: "dY" := x (base grid H x W, n = ci), "X" := dy (source pixel (2y+a, 2x+b), k = co)
+            _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, dw, Cout * 4, 1, 4)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 2, 3))
+        return dx, dw, db

@@ -1,0 +1,423 @@
+// Dense 2D convolutions of the RGB-D branch as bf16 MFMA implicit GEMMs.
+// Reference call sites: torch.nn.Conv2d / ConvTranspose2d inside 2d_net/backbones.py:43-65 (ResNet34 blocks) and
+// 2d_net/model.py:64-82,104-123 (decoder), executed by cuDNN under AMP in the reference.
+//
+// Layout: activations NHWC bf16 (torch channels_last), fp32 accumulate, bf16 (or fp32) out.
+//   G1  k_conv_gemm  out[m][n] = sum_{tap,k} A[src(m,tap)][k] * Wp[n][tap][k]
+//       one kernel for Conv2d forward, Conv2d data-gradient (stride 1 and 2), ConvTranspose2d forward (per output
+//       parity, blockIdx.z) and its data-gradient: they differ only in the pixel maps and in the packed weight
+//       layout Wp (produced by k_pack_weights from the fp32 master weights every step).
+//       128 x BN x 64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16_bf16, double-buffered LDS with register prefetch
+//       (global loads of tile s+1 are in flight while tile s is multiplied), XOR-swizzled 128-B LDS rows so the
+//       ds_read_b128 fragment reads are bank-conflict free.
+//   G2  k_conv_wgrad dW[n][tap][k] = sum_m dY[m][n] * X[src(m,tap)][k]
+//       reduction over pixels: both MFMA operands are read from pixel-major LDS tiles with the hardware transpose
+//       read ds_read_b64_tr_b16; split over pixel chunks into fp32 partial slabs, reduced in a fixed order.
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+
+namespace {
+
+constexpr int MAXT = 16;  // taps (3x3 = 9, 2x2 = 4, 1x1 = 1)
+
+struct ConvP {
+  const u16* A;  // gathered activation, NHWC bf16
+  int B, Hi, Wi, Ca, lda;
+  void* O;  // output NHWC
+  int Ho, Wo, Cn, ldo;
+  int Hg, Wg;        // GEMM row m -> (b, gy, gx) on this base grid
+  int so, ooy, oox;  // output pixel = (gy*so + ooy, gx*so + oox); blockIdx.z adds parity when zpar != 0
+  int sa, fr;        // source pixel = ((gy*sa + ty)/fr, (gx*sa + tx)/fr), valid iff divisible and in bounds
+  int ntaps;
+  short ty[MAXT], tx[MAXT];
+  const u16* W;  // packed weights [z][n][tap][Ca]
+  int64_t wz;    // stride between z slices (elements)
+  int zpar;
+  const float* bias;
+  int out_f32;
+};
+
+__device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ inline u16 f2bf(float f) {  // round to nearest even (inputs are finite)
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  u16* As = smem;                 // [2][128*64]
+  u16* Bs = smem + 2 * 128 * 64;  // [2][BN*64]
+  constexpr int NBI = BN / 32;    // B staging chunks per thread
+  constexpr int TN = BN / 64;     // 32-wide MFMA tiles per wave along n
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t M = (int64_t)p.B * p.Hg * p.Wg;
+  const int64_t m0 = (int64_t)blockIdx.x * 128;
+  const int n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+  const u16* Wz = p.W + (int64_t)z * p.wz;
+  const int ooy = p.ooy + (p.zpar ? (z >> 1) : 0), oox = p.oox + (p.zpar ? (z & 1) : 0);
+
+  // staging assignment: thread owns 16-B chunk cc of rows r0 + 32*i
+  const int cc = tid & 7, r0 = tid >> 3;
+  int ab[4], ay[4], ax[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int64_t m = m0 + r0 + 32 * i;
+    if (m < M) {
+      int gx = (int)(m % p.Wg);
+      int64_t t = m / p.Wg;
+      ay[i] = (int)(t % p.Hg);
+      ab[i] = (int)(t / p.Hg);
+      ax[i] = gx;
+    } else {
+      ab[i] = -1;
+      ay[i] = ax[i] = 0;
+    }
+  }
+  const int kcn = p.Ca >> 6;
+  const int nsteps = p.ntaps * kcn;
+  uint4 ra[4], rb[NBI];
+
+  auto gload = [&](int s) {
+    const int tap = s / kcn, kc = s - tap * kcn;
+    const int ty = p.ty[tap], tx = p.tx[tap];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int sy = ay[i] * p.sa + ty, sx = ax[i] * p.sa + tx;
+      bool ok = ab[i] >= 0 && sy >= 0 && sx >= 0;
+      if (p.fr == 2) {
+        ok = ok && !((sy | sx) & 1);
+        sy >>= 1;
+        sx >>= 1;
+      }
+      ok = ok && sy < p.Hi && sx < p.Wi;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) v = *(const uint4*)(p.A + ((int64_t)(ab[i] * p.Hi + sy) * p.Wi + sx) * p.lda + kc * 64 + cc * 8);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; i++) {
+      int n = n0 + r0 + 32 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n < p.Cn) v = *(const uint4*)(Wz + ((int64_t)n * p.ntaps + tap) * p.Ca + kc * 64 + cc * 8);
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int row = r0 + 32 * i;
+      *(uint4*)&As[buf * 128 * 64 + row * 64 + ((cc ^ ((row >> 1) & 7)) << 3)] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NBI; i++) {
+      int row = r0 + 32 * i;
+      *(uint4*)&Bs[buf * BN * 64 + row * 64 + ((cc ^ ((row >> 1) & 7)) << 3)] = rb[i];
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  const int fr_ = lane & 31, fh = lane >> 5;
+  for (int s = 0; s < nsteps; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) gload(s + 1);
+    const u16* Ab = As + buf * 128 * 64;
+    const u16* Bb = Bs + buf * BN * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      bf16x8 af[2], bf[TN];
+      const int ch = kk * 2 + fh;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        int row = wm * 64 + i * 32 + fr_;
+        af[i] = *(const bf16x8*)&Ab[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        int row = wn * (BN / 2) + j * 32 + fr_;
+        bf[j] = *(const bf16x8*)&Bb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nsteps) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: acc[i][j][reg]: pixel row = wm*64 + i*32 + (reg&3) + 8*(reg>>2) + 4*fh ; channel = n0 + wn*BN/2 + j*32 + fr_
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fh;
+      if (m >= M) continue;
+      int64_t orow = m;
+      if (p.so != 1 || ooy || oox || p.Ho != p.Hg || p.Wo != p.Wg) {
+        int gx = (int)(m % p.Wg);
+        int64_t t = m / p.Wg;
+        int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
+        orow = ((int64_t)b * p.Ho + gy * p.so + ooy) * p.Wo + gx * p.so + oox;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        int n = n0 + wn * (BN / 2) + j * 32 + fr_;
+        if (n < p.Cn) {
+          float v = acc[i][j][reg] + (p.bias ? p.bias[n] : 0.f);
+          if (p.out_f32)
+            ((float*)p.O)[orow * p.ldo + n] = v;
+          else
+            ((u16*)p.O)[orow * p.ldo + n] = f2bf(v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+struct WgP {
+  const u16* X;   // [B,Hi,Wi,Ck]
+  const u16* DY;  // [B,Hg,Wg,Cn] (base grid = dY pixels)
+  int B, Hi, Wi, Ck, ldx, Hg, Wg, Cn, ldy;
+  int sa, ntaps;
+  short ty[MAXT], tx[MAXT];
+  float* partial;  // [nsplit][Cn][ntaps][Ck]
+  int64_t mchunk;  // pixels per split
+};
+
+// tile: 64 (n) x 64 (k), 4 waves 2x2 of one 32x32 MFMA tile; K' = pixels in steps of 64
+__global__ __launch_bounds__(256) void k_conv_wgrad(WgP p) {
+  __shared__ __attribute__((aligned(16))) u16 Ys[64 * 64];  // [pixel][n]  128-B rows
+  __shared__ __attribute__((aligned(16))) u16 Xs[64 * 64];  // [pixel][k]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int nkt = p.Ck >> 6;
+  const int n0 = (blockIdx.y / nkt) * 64, k0 = (blockIdx.y % nkt) * 64;
+  const int tap = blockIdx.z;
+  const int ty = p.ty[tap], tx = p.tx[tap];
+  const int64_t M = (int64_t)p.B * p.Hg * p.Wg;
+  const int64_t mb = (int64_t)blockIdx.x * p.mchunk;
+  const int64_t me = mb + p.mchunk < M ? mb + p.mchunk : M;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; r++) acc[r] = 0.f;
+  // staging: 64 rows x 8 chunks = 512 chunks per tile -> 2 per thread
+  const int cc = tid & 7, r0 = tid >> 3;  // rows r0, r0+32
+  // transpose-read lane roles
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  for (int64_t t0 = mb; t0 < me; t0 += 64) {
+    uint4 vy[2], vx[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int64_t m = t0 + r0 + 32 * i;
+      vy[i] = vx[i] = make_uint4(0, 0, 0, 0);
+      if (m < me) {
+        int gx = (int)(m % p.Wg);
+        int64_t t = m / p.Wg;
+        int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
+        vy[i] = *(const uint4*)(p.DY + m * p.ldy + n0 + cc * 8);
+        int sy = gy * p.sa + ty, sx = gx * p.sa + tx;
+        if (sy >= 0 && sx >= 0 && sy < p.Hi && sx < p.Wi)
+          vx[i] = *(const uint4*)(p.X + ((int64_t)(b * p.Hi + sy) * p.Wi + sx) * p.ldx + k0 + cc * 8);
+      }
+    }
+    __syncthreads();  // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int row = r0 + 32 * i;
+      *(uint4*)&Ys[row * 64 + cc * 8] = vy[i];
+      *(uint4*)&Xs[row * 64 + cc * 8] = vx[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {  // 16 pixels per MFMA
+      // operand A[i = n (32)][k = pixel (16)], lane (r = lane&31, h = lane>>5) holds pixels 8h..8h+7 of channel r.
+      // tr read: 16-lane group gq covers channels 16*(gq&1).., pixel rows 8*(gq>>1) + {0..3} then +4
+      const int prow = kk * 16 + 8 * (g >> 1) + q;
+      const int ncol = wn * 32 + 16 * (g & 1) + 4 * pp;
+      const int kcol = wk * 32 + 16 * (g & 1) + 4 * pp;
+      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[prow * 64 + ncol]);
+      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[(prow + 4) * 64 + ncol]);
+      s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xs[prow * 64 + kcol]);
+      s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xs[(prow + 4) * 64 + kcol]);
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+    }
+  }
+  // acc: row i = n: (reg&3) + 8*(reg>>2) + 4*(lane>>5); col j = k: lane&31
+  float* P = p.partial + (int64_t)blockIdx.x * p.Cn * p.ntaps * p.Ck;
+#pragma unroll
+  for (int reg = 0; reg < 16; reg++) {
+    int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+    int k = k0 + wk * 32 + (lane & 31);
+    if (n < p.Cn) P[((int64_t)n * p.ntaps + tap) * p.Ck + k] = acc[reg];
+  }
+}
+
+// dW_torch[idx(n,tap,k)] (+)= sum_splits partial[s][n][tap][k];  out strides (sn, st, sk) express the torch layout
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
+                                                       float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
+                                                       int accumulate) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t ne = (int64_t)Cn * ntaps * Ck;
+  if (e >= ne) return;
+  float s = 0.f;
+  for (int i = 0; i < nsplit; i++) s += partial[(int64_t)i * ne + e];
+  int k = (int)(e % Ck);
+  int64_t r = e / Ck;
+  int t = (int)(r % ntaps), n = (int)(r / ntaps);
+  float* d = dW + n * sn + t * st + k * sk;
+  *d = accumulate ? *d + s : s;
+}
+
+// packed bf16 weights: out[((z*N + n)*T + t)*K + k] = bf16(in[z*sz + n*sn + t*st + k*sk])
+__global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ in, u16* __restrict__ out, int Z, int N, int T,
+                                                       int K, int64_t sz, int64_t sn, int64_t st, int64_t sk) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t ne = (int64_t)Z * N * T * K;
+  if (e >= ne) return;
+  int k = (int)(e % K);
+  int64_t r = e / K;
+  int t = (int)(r % T);
+  r /= T;
+  int n = (int)(r % N), z = (int)(r / N);
+  out[e] = f2bf(in[z * sz + n * sn + t * st + k * sk]);
+}
+
+// NCHW fp32 -> NHWC bf16 and back (model boundary)
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc_bf16(const float* __restrict__ in, u16* __restrict__ out, int B, int C, int H,
+                                                            int W, int ldo) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t ne = (int64_t)B * H * W * C;
+  if (e >= ne) return;
+  int c = (int)(e % C);
+  int64_t pix = e / C;
+  int64_t hw = (int64_t)H * W;
+  int b = (int)(pix / hw);
+  int64_t r = pix - b * hw;
+  out[pix * ldo + c] = f2bf(in[((int64_t)b * C + c) * hw + r]);
+}
+
+int fill_taps(ConvP* p, const int* ty, const int* tx, int nt) {
+  if (nt > MAXT) return -1;
+  p->ntaps = nt;
+  for (int i = 0; i < nt; i++) {
+    p->ty[i] = (short)ty[i];
+    p->tx[i] = (short)tx[i];
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Generic implicit GEMM (see ConvP).  ty/tx: host arrays of ntaps tap offsets.
+int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
+                   int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
+                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, hipStream_t s) {
+  MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
+               "conv2d_gemm: Ca must be a multiple of 64 and pointers 16-B aligned (Ca=%d lda=%d)", Ca, lda);
+  MM_CHECK_ARG(fr == 1 || fr == 2, "conv2d_gemm: fr must be 1 or 2");
+  ConvP p;
+  p.A = (const u16*)A; p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ca = Ca; p.lda = lda;
+  p.O = O; p.Ho = Ho; p.Wo = Wo; p.Cn = Cn; p.ldo = ldo; p.out_f32 = out_f32;
+  p.Hg = Hg; p.Wg = Wg; p.so = so; p.ooy = ooy; p.oox = oox; p.sa = sa; p.fr = fr;
+  p.W = (const u16*)Wp; p.wz = wz; p.zpar = zpar; p.bias = bias;
+  if (fill_taps(&p, ty, tx, ntaps)) {
+    mm_set_error("conv2d_gemm: too many taps");
+    return MM_ERR_ARG;
+  }
+  const int64_t M = (int64_t)B * Hg * Wg;
+  if (M == 0) return MM_OK;
+  if (Cn <= 64) {
+    size_t lds = (size_t)(2 * 128 * 64 + 2 * 64 * 64) * 2;
+    hipLaunchKernelGGL(k_conv_gemm<64>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 64), nz), dim3(256), lds, s, p);
+  } else {
+    size_t lds = (size_t)(2 * 128 * 64 + 2 * 128 * 64) * 2;
+    static bool once = false;
+    if (!once) {
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once = true;
+    }
+    hipLaunchKernelGGL(k_conv_gemm<128>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 128), nz), dim3(256), lds, s, p);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
+  int64_t tiles = (int64_t)mm_cdiv(Cn, 64) * (Ck / 64) * ntaps;
+  int64_t want = mm_cdiv(2048, tiles);  // ~2048 workgroups in total
+  if (want < 1) want = 1;
+  int64_t c = mm_cdiv(mm_cdiv(M, want), 64) * 64;
+  if (c < 256) c = 256;
+  return c;
+}
+
+size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps) {
+  int64_t c = wgrad_chunk(M, Cn, Ck, ntaps);
+  return mm_align((size_t)mm_cdiv(M, c) * Cn * ntaps * Ck * sizeof(float)) + 256;
+}
+
+// dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k];   base grid = dY pixels (B,Hg,Wg), src = (gy*sa+ty, gx*sa+tx)
+int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+                    int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st, int64_t sk,
+                    int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(Ck % 64 == 0 && Cn % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ntaps <= MAXT, "conv2d_wgrad: bad shape");
+  MM_CHECK_ARG(Cn % 64 == 0, "conv2d_wgrad: Cn must be a multiple of 64");
+  WgP p;
+  p.X = (const u16*)X; p.DY = (const u16*)dY; p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ck = Ck; p.ldx = ldx;
+  p.Hg = Hg; p.Wg = Wg; p.Cn = Cn; p.ldy = ldy; p.sa = sa; p.ntaps = ntaps;
+  for (int i = 0; i < ntaps; i++) {
+    p.ty[i] = (short)ty[i];
+    p.tx[i] = (short)tx[i];
+  }
+  const int64_t M = (int64_t)B * Hg * Wg;
+  p.mchunk = wgrad_chunk(M, Cn, Ck, ntaps);
+  const int nsplit = (int)mm_cdiv(M, p.mchunk);
+  if ((size_t)nsplit * Cn * ntaps * Ck * sizeof(float) > ws_bytes) {
+    mm_set_error("conv2d_wgrad: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  p.partial = (float*)ws;
+  if (M > 0)
+    hipLaunchKernelGGL(k_conv_wgrad, dim3(nsplit, (Cn / 64) * (Ck / 64), ntaps), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 256)), dim3(256), 0, s, p.partial,
+                     M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st, int64_t sk,
+                         hipStream_t s) {
+  int64_t ne = (int64_t)Z * N * T * K;
+  if (ne == 0) return MM_OK;
+  hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)mm_cdiv(ne, 256)), dim3(256), 0, s, in, (u16*)out, Z, N, T, K, sz, sn, st, sk);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

@@ -253,14 +253,23 @@ __global__ __launch_bounds__(256) void k_dw_generic(const float* __restrict__ in
 
 __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ partial, int ne, int K, KSeg seg,
                                                     float* __restrict__ dW, int accumulate) {
-  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int k = (int)(gid / ne);
-  int e = (int)(gid - (int64_t)k * ne);
-  if (k >= K) return;
-  float acc = 0.f;
-  for (int b = seg.blk_start[k]; b < seg.blk_start[k + 1]; b++) acc += partial[(int64_t)b * ne + e];
-  float* d = dW + (int64_t)k * ne + e;
-  *d = accumulate ? *d + acc : acc;
+  // block = 32 consecutive elements x 8 chunk slices; fp64 accumulation, slices combined in a fixed order
+  __shared__ double red[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int k = blockIdx.y;
+  const int e = blockIdx.x * 32 + el;
+  double acc = 0.0;
+  if (e < ne)
+    for (int b = seg.blk_start[k] + sl; b < seg.blk_start[k + 1]; b += 8) acc += (double)partial[(int64_t)b * ne + e];
+  red[sl][el] = acc;
+  __syncthreads();
+  if (sl == 0 && e < ne) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t += red[i][el];
+    float* d = dW + (int64_t)k * ne + e;
+    *d = accumulate ? *d + (float)t : (float)t;
+  }
 }
 
 int make_seg(const int32_t* offsets_host, int K, int rules_per_block, KSeg* seg) {
@@ -424,7 +433,7 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
       hipLaunchKernelGGL(k_dw_generic, dim3(nb), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, K, seg, partial);
     }
   }
-  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv((int64_t)K * ne, 256)), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -167,6 +167,9 @@ class Net2DSeg(nn.Module):
             with torch.autocast("cuda", dtype=self.amp_dtype):
                 return self.forward(data_batch)
         img, hints, img_indices = data_batch["img"], data_batch["depth"], data_batch["img_indices"]
+        if img.is_cuda:  # NHWC in memory: what the implicit-GEMM kernels read
+            img = img.contiguous(memory_format=torch.channels_last)
+            hints = hints.contiguous(memory_format=torch.channels_last)
         h, w = img.shape[2], img.shape[3]
         pad_h, pad_w = (-h) % 16, (-w) % 16
         if pad_h or pad_w:
