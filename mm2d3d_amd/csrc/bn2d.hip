@@ -1,0 +1,274 @@
+// BatchNorm2d (+ residual add) (+ ReLU) on NHWC bf16 activations, fp32 parameters and statistics
+// (torch.nn.BatchNorm2d + ReLU inside the ResNet34 blocks, backbones.py:49-63, and the decoder
+// stages, 2d_net/model.py:68-81).  HBM-bound: training forward = one statistics pass + one fused
+// normalise/add/activate pass; backward = one reduction pass + one pass that writes dx and the residual gradient.
+// Rows = B*H*W pixels, 16-B (8 x bf16) accesses, fp64 combination of the per-block partial sums (bit-stable).
+#include "common.h"
+
+typedef unsigned short u16;
+
+namespace {
+constexpr int T = 256;
+constexpr int MAX_PART = 2048;
+
+__device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ inline u16 f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+__device__ inline void ld8(const u16* p, float (&v)[8]) {
+  uint4 t = *(const uint4*)p;
+  unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+  }
+}
+__device__ inline void st8(u16* p, const float (&v)[8]) {
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) w[i] = (unsigned)f2bf(v[2 * i]) | ((unsigned)f2bf(v[2 * i + 1]) << 16);
+  *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * (yout > 0 if relu)
+template <int MODE>
+__global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
+                                                    const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
+                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                    double* __restrict__ partial) {
+  __shared__ float red[2][T];
+  const int CV = C >> 3;
+  const int rs = T / CV;
+  const int tid = threadIdx.x;
+  const int slot = tid / CV, cv = tid - slot * CV;
+  float a[8], b[8], m[8], is[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = b[i] = 0.f;
+  if (MODE == 1 && slot < rs) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      m[i] = mean[cv * 8 + i];
+      is[i] = invstd[cv * 8 + i];
+    }
+  }
+  const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  if (slot < rs) {
+    for (int64_t r = r0 + slot; r < r1; r += rs) {
+      float xv[8];
+      ld8(x + r * ld_x + cv * 8, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          a[i] += xv[i];
+          b[i] = fmaf(xv[i], xv[i], b[i]);
+        }
+      } else {
+        float dv[8], yv[8];
+        ld8(dy + r * ld_dy + cv * 8, dv);
+        if (relu) ld8(yout + r * ld_y + cv * 8, yv);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          float g = (relu && !(yv[i] > 0.f)) ? 0.f : dv[i];
+          a[i] += g;
+          b[i] = fmaf(g, (xv[i] - m[i]) * is[i], b[i]);
+        }
+      }
+    }
+  }
+  // per-thread fp32 partials cover <= rows_per_block/rs rows (a few hundred); block and grid combination in fp64
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    __syncthreads();
+    red[0][tid] = a[i];
+    red[1][tid] = b[i];
+    __syncthreads();
+    if (tid < CV) {
+      double sa = 0.0, sb = 0.0;
+      for (int s = 0; s < rs; s++) {
+        sa += (double)red[0][s * CV + tid];
+        sb += (double)red[1][s * CV + tid];
+      }
+      partial[((int64_t)blockIdx.x * 2 + 0) * C + tid * 8 + i] = sa;
+      partial[((int64_t)blockIdx.x * 2 + 1) * C + tid * 8 + i] = sb;
+    }
+  }
+}
+
+__device__ inline double wave_sum(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+  return v;
+}
+
+// torch semantics: running = (1-momentum)*running + momentum*batch (unbiased variance)
+__global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C, float eps,
+                                                           float momentum, float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var, float* __restrict__ save_mean,
+                                                           float* __restrict__ save_invstd) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    q += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (threadIdx.x != 0) return;
+  double mean = N > 0 ? s / (double)N : 0.0;
+  double var = N > 0 ? q / (double)N - mean * mean : 0.0;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
+                                                           float* __restrict__ sums /*[2][C]*/, float* __restrict__ dweight,
+                                                           float* __restrict__ dbias) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) {
+    s += partial[((int64_t)b * 2 + 0) * C + c];
+    q += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if (threadIdx.x != 0) return;
+  sums[c] = (float)s;
+  sums[C + c] = (float)q;
+  if (dweight) dweight[c] = (float)q;
+  if (dbias) dbias[c] = (float)s;
+}
+
+// y = act((x - mean) * invstd * w + b + res)
+__global__ __launch_bounds__(T) void k_bn2d_apply(const u16* __restrict__ x, int ld_x, const u16* __restrict__ res, int ld_r,
+                                                   int64_t N, int C, const float* __restrict__ mean,
+                                                   const float* __restrict__ invstd, int stat_is_var, float eps,
+                                                   const float* __restrict__ weight, const float* __restrict__ bias, int relu,
+                                                   u16* __restrict__ y, int ld_y) {
+  const int CV = C >> 3;
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t r = gid / CV;
+  int cv = (int)(gid - r * CV);
+  if (r >= N) return;
+  float xv[8], rv[8], yv[8];
+  ld8(x + r * ld_x + cv * 8, xv);
+  if (res) ld8(res + r * ld_r + cv * 8, rv);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int c = cv * 8 + i;
+    float is = stat_is_var ? 1.f / sqrtf(invstd[c] + eps) : invstd[c];
+    float v = (xv[i] - mean[c]) * is * (weight ? weight[c] : 1.f) + (bias ? bias[c] : 0.f);
+    if (res) v += rv[i];
+    yv[i] = (relu && !(v > 0.f)) ? 0.f : v;
+  }
+  st8(y + r * ld_y + cv * 8, yv);
+}
+
+// g = dy * relu'(yout); dx = w*invstd*(g - sum_g/N - xhat*sum_gx/N); dres = g
+__global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
+                                                       const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ weight, const float* __restrict__ sums,
+                                                       u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr) {
+  const int CV = C >> 3;
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t r = gid / CV;
+  int cv = (int)(gid - r * CV);
+  if (r >= N) return;
+  float xv[8], dv[8], yv[8], ov[8], gv[8];
+  ld8(x + r * ld_x + cv * 8, xv);
+  ld8(dy + r * ld_dy + cv * 8, dv);
+  if (relu) ld8(yout + r * ld_y + cv * 8, yv);
+  const float invN = 1.f / (float)N;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int c = cv * 8 + i;
+    float g = (relu && !(yv[i] > 0.f)) ? 0.f : dv[i];
+    float xh = (xv[i] - mean[c]) * invstd[c];
+    gv[i] = g;
+    ov[i] = (weight ? weight[c] : 1.f) * invstd[c] * (g - sums[c] * invN - xh * sums[C + c] * invN);
+  }
+  st8(dx + r * ld_dx + cv * 8, ov);
+  if (dres) st8(dres + r * ld_dr + cv * 8, gv);
+}
+
+inline int stat_blocks(int64_t N, int C) {
+  int rs = T / (C / 8);
+  int64_t nb = mm_cdiv(N, (int64_t)rs * 64);
+  if (nb < 1) nb = 1;
+  if (nb > MAX_PART) nb = MAX_PART;
+  return (int)nb;
+}
+}  // namespace
+
+extern "C" {
+
+size_t mm_bn2d_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(2 * C * sizeof(float)) + 256; }
+
+// y = act(BN_train(x) + res); x,res,y NHWC bf16 [N rows, C]; save_* fp32 [C]; momentum = torch's (0.1)
+int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
+                      float* running_mean, float* running_var, float eps, float momentum, int relu, void* y, int ld_y,
+                      float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_y % 8 == 0, "bn2d: C must be a multiple of 8, <= 2048");
+  if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
+    mm_set_error("bn2d: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  double* partial = (double*)ws;
+  int nb = stat_blocks(N, C);
+  hipLaunchKernelGGL(k_bn2d_reduce<0>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr, nullptr,
+                     partial);
+  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb, N, C, eps, momentum, running_mean, running_var,
+                     save_mean, save_invstd);
+  if (N > 0)
+    hipLaunchKernelGGL(k_bn2d_apply, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r,
+                       N, C, save_mean, save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
+                     const float* running_mean, const float* running_var, float eps, int relu, void* y, int ld_y, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0, "bn2d: C must be a multiple of 8");
+  if (N == 0) return MM_OK;
+  hipLaunchKernelGGL(k_bn2d_apply, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N,
+                     C, running_mean, running_var, 1, eps, weight, bias, relu, (u16*)y, ld_y);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// dx (and dres = relu-masked dy when dres != NULL), dweight, dbias
+int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N, int C,
+                const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
+                float* dweight, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T, "bn2d: C must be a multiple of 8, <= 2048");
+  size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
+  if (ws_bytes < need + 2 * C * sizeof(float)) {
+    mm_set_error("bn2d_bwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  double* partial = (double*)ws;
+  float* sums = (float*)((char*)ws + need);
+  int nb = stat_blocks(N, C);
+  hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y, relu,
+                     N, C, save_mean, save_invstd, partial);
+  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sums, dweight, dbias);
+  if (N > 0)
+    hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy,
+                       ld_dy, (const u16*)yout, ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres,
+                       ld_dr);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,297 @@
+// Memory-bound glue of the 2D branch on NHWC bf16:
+//   channel concat / split          torch.cat([depth, up, rgb], 1) in the decoder (2d_net/model.py:107,112,117,122)
+//   max-pool 3x3 s2 p1 (+ backward)  backbones.py:53
+//   segmentation heads               AvgPool2d(5,1,2) -> Conv2d 1x1 64->C, twice (model.py:59-60,129-130; aux :158,163-164)
+// The two heads share their input, and a 1x1 convolution commutes with the (linear) box filter, so both heads are
+// computed as ONE 64 -> 2C projection per pixel followed by a 5x5 box filter on 2C channels (10x less filter traffic);
+// the bias is added after the filter, which is exact for count_include_pad=True zero padding.
+#include "common.h"
+
+typedef unsigned short u16;
+
+namespace {
+constexpr int T = 256;
+constexpr int MAXJ = 32;
+
+__device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
+__device__ inline u16 f2bf(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (u16)(u >> 16);
+}
+
+// dst[r][0..C) = src[r][0..C), 16-B vectors (C multiple of 8 elements of 2 bytes)
+__global__ __launch_bounds__(T) void k_copy_rows(const u16* __restrict__ src, int64_t ld_s, u16* __restrict__ dst, int64_t ld_d,
+                                                  int64_t N, int C8) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t r = gid / C8;
+  int c = (int)(gid - r * C8);
+  if (r >= N) return;
+  *(uint4*)(dst + r * ld_d + c * 8) = *(const uint4*)(src + r * ld_s + c * 8);
+}
+
+// ---- max-pool 3x3 stride 2 pad 1, NHWC bf16; idx = winning tap (kh*3+kw), first maximum in scan order (torch)
+__global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, int B, int H, int W, int C, u16* __restrict__ y,
+                                                    unsigned char* __restrict__ idx, int Ho, int Wo) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t total = (int64_t)B * Ho * Wo * C;
+  if (gid >= total) return;
+  int c = (int)(gid % C);
+  int64_t pix = gid / C;
+  int ox = (int)(pix % Wo);
+  int64_t t = pix / Wo;
+  int oy = (int)(t % Ho), b = (int)(t / Ho);
+  float best = -INFINITY;
+  int bi = 0;
+  bool any = false;
+  for (int kh = 0; kh < 3; kh++) {
+    int iy = oy * 2 - 1 + kh;
+    if (iy < 0 || iy >= H) continue;
+    for (int kw = 0; kw < 3; kw++) {
+      int ix = ox * 2 - 1 + kw;
+      if (ix < 0 || ix >= W) continue;
+      float v = bf2f(x[((int64_t)(b * H + iy) * W + ix) * C + c]);
+      if (!any || v > best) {
+        best = v;
+        bi = kh * 3 + kw;
+        any = true;
+      }
+    }
+  }
+  y[gid] = f2bf(best);
+  idx[gid] = (unsigned char)bi;
+}
+
+__global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, const unsigned char* __restrict__ idx, int B, int H,
+                                                    int W, int C, int Ho, int Wo, u16* __restrict__ dx) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t total = (int64_t)B * H * W * C;
+  if (gid >= total) return;
+  int c = (int)(gid % C);
+  int64_t pix = gid / C;
+  int ix = (int)(pix % W);
+  int64_t t = pix / W;
+  int iy = (int)(t % H), b = (int)(t / H);
+  float s = 0.f;
+  for (int oy = (iy) / 2; oy <= (iy + 1) / 2; oy++) {  // windows with oy*2-1 <= iy <= oy*2+1
+    if (oy < 0 || oy >= Ho) continue;
+    int kh = iy - (oy * 2 - 1);
+    if (kh < 0 || kh > 2) continue;
+    for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ox++) {
+      if (ox < 0 || ox >= Wo) continue;
+      int kw = ix - (ox * 2 - 1);
+      if (kw < 0 || kw > 2) continue;
+      int64_t o = ((int64_t)(b * Ho + oy) * Wo + ox) * C + c;
+      if (idx[o] == kh * 3 + kw) s += bf2f(dy[o]);
+    }
+  }
+  dx[gid] = f2bf(s);
+}
+
+// ---- heads: z[pix][j] = sum_c x[pix][c] * Wj[j][c]   (x NHWC bf16 with row pitch; region h x w of an Hp x Wp map)
+__global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w, int C,
+                                                  const float* __restrict__ Wj, int NJ, float* __restrict__ z) {
+  extern __shared__ float ws[];  // [NJ][C]
+  for (int i = threadIdx.x; i < NJ * C; i += T) ws[i] = Wj[i];
+  __syncthreads();
+  int64_t pix = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t total = (int64_t)B * h * w;
+  if (pix >= total) return;
+  int xx = (int)(pix % w);
+  int64_t t = pix / w;
+  int yy = (int)(t % h), b = (int)(t / h);
+  const u16* row = x + ((int64_t)(b * Hp + yy) * Wp + xx) * ld;
+  float acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; j++) acc[j] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    uint4 v = *(const uint4*)(row + c0);
+    unsigned wv[4] = {v.x, v.y, v.z, v.w};
+    float xv[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      xv[2 * i] = __uint_as_float(wv[i] << 16);
+      xv[2 * i + 1] = __uint_as_float(wv[i] & 0xFFFF0000u);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXJ; j++)
+      if (j < NJ) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[j] = fmaf(xv[i], ws[j * C + c0 + i], acc[j]);
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < MAXJ; j++)
+    if (j < NJ) z[pix * NJ + j] = acc[j];
+}
+
+// 5x5 box / 25 with zero padding.  to_nchw: in z [B,h,w,NJ] -> out [B,NJ,h,w] (+bias);  else in [B,NJ,h,w] -> out [B,h,w,NJ]
+__global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B, int h, int w, int NJ, const float* __restrict__ bias,
+                                             int to_nchw, float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t total = (int64_t)B * h * w * NJ;
+  if (gid >= total) return;
+  int j, xx, yy, b;
+  if (to_nchw) {  // gid enumerates the output [b][j][y][x]
+    xx = (int)(gid % w);
+    int64_t t = gid / w;
+    yy = (int)(t % h);
+    t /= h;
+    j = (int)(t % NJ);
+    b = (int)(t / NJ);
+  } else {  // gid enumerates the output [b][y][x][j]
+    j = (int)(gid % NJ);
+    int64_t t = gid / NJ;
+    xx = (int)(t % w);
+    t /= w;
+    yy = (int)(t % h);
+    b = (int)(t / h);
+  }
+  float s = 0.f;
+  for (int dy = -2; dy <= 2; dy++) {
+    int y2 = yy + dy;
+    if (y2 < 0 || y2 >= h) continue;
+    for (int dx = -2; dx <= 2; dx++) {
+      int x2 = xx + dx;
+      if (x2 < 0 || x2 >= w) continue;
+      s += to_nchw ? in[((int64_t)(b * h + y2) * w + x2) * NJ + j] : in[((int64_t)(b * NJ + j) * h + y2) * w + x2];
+    }
+  }
+  out[gid] = s * (1.f / 25.f) + (bias ? bias[j] : 0.f);
+}
+
+// dx[pix][c] = sum_j dz[pix][j] * Wj[j][c]  (bf16, zero outside the h x w region), partial dW[j][c] = sum_pix dz*x
+__global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w, int C,
+                                                 const float* __restrict__ Wj, int NJ, const float* __restrict__ dz,
+                                                 u16* __restrict__ dx, double* __restrict__ partial, int64_t pix_per_block) {
+  extern __shared__ float sm[];  // [4][NJ][C] reduction buffer
+  const int c = threadIdx.x % C, slot = threadIdx.x / C;  // C = 64 -> 4 pixel slots
+  const int nslot = T / C;
+  float wc[MAXJ], acc[MAXJ];
+#pragma unroll
+  for (int j = 0; j < MAXJ; j++) {
+    wc[j] = j < NJ ? Wj[j * C + c] : 0.f;
+    acc[j] = 0.f;
+  }
+  const int64_t total = (int64_t)B * Hp * Wp;
+  const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
+  const int64_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
+  for (int64_t pp = p0 + slot; pp < p1; pp += nslot) {
+    int xx = (int)(pp % Wp);
+    int64_t t = pp / Wp;
+    int yy = (int)(t % Hp), b = (int)(t / Hp);
+    float o = 0.f;
+    if (yy < h && xx < w) {
+      const float* g = dz + ((int64_t)(b * h + yy) * w + xx) * NJ;
+      float xv = bf2f(x[pp * ld + c]);
+#pragma unroll
+      for (int j = 0; j < MAXJ; j++)
+        if (j < NJ) {
+          float gj = g[j];
+          o = fmaf(gj, wc[j], o);
+          acc[j] = fmaf(gj, xv, acc[j]);
+        }
+    }
+    dx[pp * ld + c] = f2bf(o);
+  }
+  for (int j = 0; j < NJ; j++) sm[(slot * NJ + j) * C + c] = acc[j];
+  __syncthreads();
+  for (int e = threadIdx.x; e < NJ * C; e += T) {
+    double s = 0.0;
+    for (int sl = 0; sl < nslot; sl++) s += (double)sm[sl * NJ * C + e];
+    partial[(int64_t)blockIdx.x * NJ * C + e] = s;
+  }
+}
+
+__global__ void k_sum_dbl_partials(const double* __restrict__ partial, int nblk, int ne, float* __restrict__ out) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; b++) s += partial[(int64_t)b * ne + e];
+  out[e] = (float)s;
+}
+}  // namespace
+
+extern "C" {
+
+// strided 2-byte-element row copy (channel concat / split of NHWC tensors); C multiple of 8
+int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, int64_t N, int C, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && ld_s % 8 == 0 && ld_d % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+               "copy_rows: C and pitches must be multiples of 8 elements");
+  if (N == 0) return MM_OK;
+  hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)src, ld_s, (u16*)dst, ld_d, N, C / 8);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_maxpool3x3s2_fwd(const void* x, int B, int H, int W, int C, void* y, void* idx, hipStream_t s) {
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int64_t total = (int64_t)B * Ho * Wo * C;
+  if (total == 0) return MM_OK;
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)x, B, H, W, C, (u16*)y,
+                     (unsigned char*)idx, Ho, Wo);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, hipStream_t s) {
+  int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int64_t total = (int64_t)B * H * W * C;
+  if (total == 0) return MM_OK;
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)dy, (const unsigned char*)idx, B, H, W,
+                     C, Ho, Wo, (u16*)dx);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ) {
+  size_t z = mm_align((size_t)B * h * w * NJ * sizeof(float));
+  size_t part = mm_align((size_t)2048 * NJ * C * sizeof(double));
+  return z + part + 256;
+}
+
+// out [B,NJ,h,w] fp32 = box5x5( x[.., :h, :w, :] . Wj^T ) + bias      (x: NHWC bf16 [B,Hp,Wp,C] with pitch ld)
+int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias, int NJ,
+                float* out, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C % 8 == 0 && (size_t)NJ * C * 4 <= 60 * 1024, "head: bad NJ/C");
+  size_t zb = mm_align((size_t)B * h * w * NJ * sizeof(float));
+  if (ws_bytes < zb) {
+    mm_set_error("head_fwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  float* z = (float*)ws;
+  int64_t npix = (int64_t)B * h * w;
+  if (npix == 0) return MM_OK;
+  hipLaunchKernelGGL(k_head_proj, dim3((unsigned)mm_cdiv(npix, T)), dim3(T), (size_t)NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C,
+                     Wj, NJ, z);
+  hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, z, B, h, w, NJ, bias, 1, out);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// dout [B,NJ,h,w] fp32 -> dx NHWC bf16 [B,Hp,Wp,C] (zero outside h x w), dWj [NJ,C], dbias [NJ]
+int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ, const float* dout,
+                void* dx, float* dWj, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C == 64, "head_bwd: C must be 64");
+  size_t zb = mm_align((size_t)B * h * w * NJ * sizeof(float));
+  const int64_t total = (int64_t)B * Hp * Wp;
+  int nblk = (int)mm_cdiv(total, 1024);
+  if (nblk > 2048) nblk = 2048;
+  if (nblk < 1) nblk = 1;
+  const int64_t ppb = mm_cdiv(total, nblk);
+  if (ws_bytes < zb + (size_t)nblk * NJ * C * sizeof(double)) {
+    mm_set_error("head_bwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  float* dz = (float*)ws;
+  double* partial = (double*)((char*)ws + zb);
+  int64_t npix = (int64_t)B * h * w;
+  if (npix) hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, dout, B, h, w, NJ, nullptr, 0, dz);
+  hipLaunchKernelGGL(k_head_bwd, dim3(nblk), dim3(T), (size_t)(T / C) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, NJ, dz,
+                     (u16*)dx, partial, ppb);
+  hipLaunchKernelGGL(k_sum_dbl_partials, dim3((unsigned)mm_cdiv(NJ * C, 64)), dim3(64), 0, s, partial, nblk, NJ * C, dWj);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // extern "C"

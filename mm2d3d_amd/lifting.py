@@ -40,21 +40,14 @@ class PixelIndex:
         self.device = device
         self._cache = {}
 
-    def offsets(self, C, channels_last=False):
-        """Element offsets of channel 0 for every point / unique pixel, and the channel stride, for a [B,C,H,W] map."""
-        k = (C, channels_last)
+    def offsets(self, batch_stride, unique=False):
+        """Element offset of channel 0 of every point's (or unique pixel's) pixel in a [B,C,H,W] map whose H,W dims are
+        dense (stride W, 1) and whose batch stride is ``batch_stride`` elements."""
+        k = (int(batch_stride), unique)
         if k not in self._cache:
             HW = self.H * self.W
-
-            def off(key):
-                b, pix = key // HW, key % HW
-                return (b * HW + pix) * C if channels_last else b * C * HW + pix
-
-            self._cache[k] = (
-                torch.from_numpy(off(self.key)).to(self.device),
-                torch.from_numpy(off(self.ukey)).to(self.device),
-                1 if channels_last else HW,
-            )
+            key = self.ukey if unique else self.key
+            self._cache[k] = torch.from_numpy((key // HW) * int(batch_stride) + key % HW).to(self.device)
         return self._cache[k]
 
 
@@ -63,12 +56,14 @@ class _LiftFn(torch.autograd.Function):
     def forward(ctx, seg, index: PixelIndex):
         _lib.require_cuda(seg, "seg")
         L = _lib.lib()
-        seg = seg.to(F32).contiguous()
+        seg = seg.to(F32)
         B, C, H, W = seg.shape
         assert (H, W) == (index.H, index.W)
-        pix, upix, sc = index.offsets(C)
+        if seg.stride(3) != 1 or seg.stride(2) != W or seg.stride(1) != H * W:  # channel slices of an NCHW map are fine as is
+            seg = seg.contiguous()
+        pix = index.offsets(seg.stride(0))
         out = torch.empty((index.n, C), dtype=F32, device=seg.device)
-        check(L.mm_lift_gather(ptr(seg), sc, ptr(pix), index.n, C, ptr(out), stream()), "lift_gather")
+        check(L.mm_lift_gather(ptr(seg), H * W, ptr(pix), index.n, C, ptr(out), stream()), "lift_gather")
         ctx.index, ctx.shape = index, seg.shape
         return out
 
@@ -78,9 +73,9 @@ class _LiftFn(torch.autograd.Function):
         index = ctx.index
         B, C, H, W = ctx.shape
         dout = dout.to(F32).contiguous()
-        pix, upix, sc = index.offsets(C)
+        upix = index.offsets(C * H * W, unique=True)
         dseg = torch.zeros(ctx.shape, dtype=F32, device=dout.device)
-        check(L.mm_lift_scatter(ptr(dout), C, ptr(upix), ptr(index.csr_off), ptr(index.csr_pts), len(index.ukey), sc, ptr(dseg),
+        check(L.mm_lift_scatter(ptr(dout), C, ptr(upix), ptr(index.csr_off), ptr(index.csr_pts), len(index.ukey), H * W, ptr(dseg),
                                 stream()), "lift_scatter")
         return dseg, None
 

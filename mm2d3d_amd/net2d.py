@@ -54,9 +54,16 @@ class BasicBlock(nn.Module):
         self.bn2 = norm_layer(planes)
         self.downsample = downsample
         self.stride = stride
+        self._fused = isinstance(self.bn1, nn2d.BatchNorm2d)
+        if self._fused:  # ReLU after bn1, and (+identity, ReLU) after bn2, run inside the BN apply kernel
+            self.bn1.relu = True
+            self.bn2.relu = True
 
     def forward(self, x):
         identity = x if self.downsample is None else self.downsample(x)
+        if self._fused:
+            out = self.bn1(self.conv1(x))
+            return self.bn2(self.conv2(out), identity)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         return self.relu(out + identity)
@@ -94,6 +101,9 @@ class Backbone(nn.Module):
         self.layer3 = _make_layer(128, 256, 6, 2, norm_layer)
         self.layer4 = _make_layer(256, 512, 3, 2, norm_layer)
         self.dropout = nn2d.Dropout(p=0.4)
+        self._fused = isinstance(self.bn1, nn2d.BatchNorm2d)
+        if self._fused:
+            self.bn1.relu = True
         _resnet_init(self)
 
     @property
@@ -102,7 +112,7 @@ class Backbone(nn.Module):
 
     def forward(self, x):
         feats = []
-        x = self.relu(self.bn1(self.conv1(x)))
+        x = self.bn1(self.conv1(x)) if self._fused else self.relu(self.bn1(self.conv1(x)))
         feats.append(x)
         x = self.layer1(self.maxpool(x))
         feats.append(x)
@@ -130,8 +140,10 @@ class L2G_classifier_2D(nn.Module):
         self.linear = nn.Linear(input_channels, num_classes)  # unused by forward, kept for checkpoint parity
         self.dow_avg = nn2d.AvgPool2d((5, 5), stride=(1, 1), padding=(2, 2))
 
-    def forward(self, input_2D_feature, pixel_index):
-        avg = self.con1_1_avg(self.dow_avg(input_2D_feature))
+    def forward(self, input_2D_feature, pixel_index, avg=None):
+        if avg is None:  # standalone use; inside Net2DSeg both heads are computed by one fused pass
+            h, w = input_2D_feature.shape[2], input_2D_feature.shape[3]
+            avg = nn2d.fused_heads(input_2D_feature, h, w, self.con1_1_avg, self.con1_1_avg)[0]
         return {"seg_logit_avg": lift(avg, pixel_index), "seg_logit_avg_2d": avg}
 
 
@@ -150,26 +162,20 @@ class Net2DSeg(nn.Module):
         self.dow_avg = nn2d.AvgPool2d((5, 5), stride=(1, 1), padding=(2, 2))
         self.con1_1_avg = nn2d.Conv2d(64, num_classes, kernel_size=1, stride=1)
         self.aux = L2G_classifier_2D(feat_channels, num_classes)
-        self.amp_dtype = None  # torch.bfloat16 = the reference's `precision: 16` run mode for this branch
 
     @staticmethod
     def dec_stage(enc_stage, num_concat, num_concat_t=1):
         cin = enc_stage[0].conv1.in_channels
         cout = enc_stage[-1].conv2.out_channels
-        conv = nn.Sequential(nn2d.Conv2d(num_concat * cout, cout, kernel_size=3, padding=1), nn2d.BatchNorm2d(cout),
-                             nn2d.ReLU(inplace=True))
-        t_conv = nn.Sequential(nn2d.ConvTranspose2d(cout * num_concat_t, cin, kernel_size=2, stride=2), nn2d.BatchNorm2d(cin),
-                               nn2d.ReLU(inplace=True))
+        # index 2 of each Sequential is the reference's ReLU; here it is fused into the BatchNorm apply kernel
+        conv = nn.Sequential(nn2d.Conv2d(num_concat * cout, cout, kernel_size=3, padding=1), nn2d.BatchNorm2d(cout, relu=True),
+                             nn2d.FusedAway())
+        t_conv = nn.Sequential(nn2d.ConvTranspose2d(cout * num_concat_t, cin, kernel_size=2, stride=2),
+                               nn2d.BatchNorm2d(cin, relu=True), nn2d.FusedAway())
         return conv, t_conv
 
     def forward(self, data_batch):
-        if self.amp_dtype is not None and not torch.is_autocast_enabled():
-            with torch.autocast("cuda", dtype=self.amp_dtype):
-                return self.forward(data_batch)
         img, hints, img_indices = data_batch["img"], data_batch["depth"], data_batch["img_indices"]
-        if img.is_cuda:  # NHWC in memory: what the implicit-GEMM kernels read
-            img = img.contiguous(memory_format=torch.channels_last)
-            hints = hints.contiguous(memory_format=torch.channels_last)
         h, w = img.shape[2], img.shape[3]
         pad_h, pad_w = (-h) % 16, (-w) % 16
         if pad_h or pad_w:
@@ -177,21 +183,21 @@ class Net2DSeg(nn.Module):
             hints = F.pad(hints, [0, pad_w, 0, pad_h])
         r = self.rgb_backbone(img)
         d = self.depth_backbone(hints)
+        cat = nn2d.cat_channels
         # decoder: concat order is [depth, upsampled, rgb] (model.py:107,112,117,122)
-        x = self.dec_t_conv_stage5(torch.cat([d[4], r[4]], 1))
-        x = self.dec_conv_stage4(torch.cat([d[3], x, r[3]], 1))
+        x = self.dec_t_conv_stage5(cat([d[4], r[4]]))
+        x = self.dec_conv_stage4(cat([d[3], x, r[3]]))
         x = self.dec_t_conv_stage4(x)
-        x = self.dec_conv_stage3(torch.cat([d[2], x, r[2]], 1))
+        x = self.dec_conv_stage3(cat([d[2], x, r[2]]))
         x = self.dec_t_conv_stage3(x)
-        x = self.dec_conv_stage2(torch.cat([d[1], x, r[1]], 1))
+        x = self.dec_conv_stage2(cat([d[1], x, r[1]]))
         x = self.dec_t_conv_stage2(x)
-        x = self.dec_conv_stage1(torch.cat([d[0], x, r[0]], 1))
-        segm_last = x[:, :, 0:h, 0:w] if (pad_h or pad_w) else x
-        segm_last = segm_last.float()
-        segm = self.con1_1_avg(self.dow_avg(segm_last))
+        x = self.dec_conv_stage1(cat([d[0], x, r[0]]))
+        segm_last = x[:, :, 0:h, 0:w]  # crop of the padding (a view; the heads read the padded map with bounds h, w)
+        segm, avg = nn2d.fused_heads(x, h, w, self.con1_1_avg, self.aux.con1_1_avg)
         pix = _pixel_index(data_batch, h, w, segm.device)
         preds = {"seg_logit": lift(segm, pix), "seg_logit_2d": segm}
-        return preds, segm_last, img_indices, self.aux(segm_last, pix)
+        return preds, segm_last, img_indices, self.aux(segm_last, pix, avg)
 
 
 Model = Net2DSeg

@@ -1,58 +1,238 @@
-"""Dense 2D layer modules of the RGB-D branch.
+"""Dense 2D layer modules of the RGB-D branch on hand-written gfx950 kernels.
 
 One module class per torch.nn layer the reference's 2D net instantiates (2d_net/backbones.py:13-65,
-2d_net/model.py:35-82): same constructor signatures, parameter names, shapes and default init, so
-``state_dict``s interchange with the reference (and with torchvision's resnet34 keys).
+2d_net/model.py:35-82): same constructor signatures, parameter names, shapes and default init, so ``state_dict``s
+interchange with the reference (and with torchvision's resnet34 keys).  Activations are bfloat16 with torch's
+``channels_last`` strides (NHWC in memory); parameters and BN statistics stay fp32.
 
-STATUS (round 1): these classes currently inherit torch.nn's forward (MIOpen / rocBLAS underneath) - an INTERIM
-so the full training step can be measured end to end.  The hand-written MFMA implicit-GEMM kernels replace the
-forwards class by class (tracked in DESIGN.md, section "2D branch"); nothing else in the package calls torch.nn
-convolution directly.
+Kernels: csrc/conv2d.hip (implicit-GEMM MFMA convolutions), csrc/bn2d.hip (BatchNorm + residual + ReLU),
+csrc/misc2d.hip (concat, max-pool, fused segmentation heads).  GPU tensors always take the HIP path; CPU tensors are
+refused (no CPU fallback).  Still on torch ops (interim, listed in DESIGN.md): the 3-/1-channel 7x7 stem convolutions
+and Dropout's mask generation.
 """
 from __future__ import annotations
 
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from . import _lib
 from . import conv2d as _c2d
+from ._lib import check, ptr, stream
+
+BF16 = torch.bfloat16
+CL = torch.channels_last
+F32 = torch.float32
+
+
+def _need_gpu(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(f"mm2d3d_amd.nn2d.{what}: input must be on the GPU (HIP path only, no CPU fallback)")
 
 
 class Conv2d(nn.Conv2d):
-    """HIP implicit-GEMM (bf16 MFMA) when Cin, Cout are multiples of 64; the 3/1-channel stems and the 6-class 1x1
-    heads still take torch's path (interim, 1.3 % of the branch's FLOPs)."""
-
     def forward(self, x):
+        _need_gpu(x, "Conv2d")
         k = self.kernel_size
-        if x.is_cuda and _c2d.hip_eligible(self.in_channels, self.out_channels, k[0], k[1], self.stride[0], self.padding[0],
-                                          self.dilation[0], self.groups) and self.stride[0] == self.stride[1] \
-                and self.padding[0] == self.padding[1] and self.padding_mode == "zeros":
+        if _c2d.hip_eligible(self.in_channels, self.out_channels, k[0], k[1], self.stride[0], self.padding[0], self.dilation[0],
+                             self.groups) and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] \
+                and self.padding_mode == "zeros":
             return _c2d.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
-        return super().forward(x)
+        # interim: 7x7 stems (Cin 3 / 1); bf16 NHWC in and out so the rest of the branch stays on the HIP kernels
+        x = _c2d.as_nhwc_bf16(x)
+        return F.conv2d(x, self.weight.to(BF16), None if self.bias is None else self.bias.to(BF16), self.stride, self.padding)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, output_size=None):
-        if x.is_cuda and self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) \
-                and self.output_padding == (0, 0) and self.groups == 1 and self.in_channels % 64 == 0 \
-                and self.out_channels % 64 == 0 and output_size is None:
-            return _c2d.ConvTranspose2dFn.apply(x, self.weight, self.bias)
-        return super().forward(x, output_size)
+        _need_gpu(x, "ConvTranspose2d")
+        if not (self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and self.output_padding == (0, 0)
+                and self.groups == 1 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0 and output_size is None):
+            raise NotImplementedError("hot path: ConvTranspose2d kernel 2, stride 2, channels multiple of 64")
+        return _c2d.ConvTranspose2dFn.apply(x, self.weight, self.bias)
+
+
+class _BN2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu):
+        L = _lib.lib()
+        x = _c2d.as_nhwc_bf16(x)
+        B, C, H, W = x.shape
+        N = B * H * W
+        if res is not None:
+            res = _c2d.as_nhwc_bf16(res)
+        y = torch.empty_like(x)
+        if training:
+            stats = torch.empty((2, C), dtype=F32, device=x.device)
+            ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
+            check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps,
+                                      momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
+                                      stream()), "bn2d_fwd_train")
+            ctx.save_for_backward(x, y, weight, stats)
+        else:
+            check(L.mm_bn2d_fwd_eval(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps,
+                                     1 if relu else 0, ptr(y), C, stream()), "bn2d_fwd_eval")
+        ctx.training, ctx.relu, ctx.has_res = training, relu, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("BatchNorm2d backward in eval mode is not part of the hot path")
+        L = _lib.lib()
+        x, y, weight, stats = ctx.saved_tensors
+        dy = _c2d.as_nhwc_bf16(dy)
+        B, C, H, W = x.shape
+        N = B * H * W
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        dw = torch.empty(C, dtype=F32, device=x.device)
+        db = torch.empty(C, dtype=F32, device=x.device)
+        ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
+        check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(y), C, 1 if ctx.relu else 0, N, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
+                            ptr(dx), C, ptr(dres), C, ptr(dw), ptr(db), ptr(ws), ws.numel(), stream()), "bn2d_bwd")
+        return dx, dres, dw, db, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
-    pass
+    """nn.BatchNorm2d parameters/buffers; ``relu=True`` fuses the following ReLU, ``forward(x, residual)`` fuses the
+    BasicBlock's ``out + identity`` before it.  One statistics pass + one fused apply pass (csrc/bn2d.hip)."""
+
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True, relu=False):
+        super().__init__(num_features, eps, momentum, affine, track_running_stats)
+        self.relu = relu
+
+    def forward(self, x, residual=None):
+        _need_gpu(x, "BatchNorm2d")
+        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        use_batch = self.training or not self.track_running_stats
+        return _BN2dFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, use_batch, float(self.eps),
+                             float(self.momentum if self.momentum is not None else 0.1), bool(self.relu))
+
+
+class FusedAway(nn.Module):
+    """Placeholder that keeps a Sequential's indices: the preceding BatchNorm2d(relu=True) already applied the ReLU."""
+
+    def forward(self, x):
+        return x
 
 
 class ReLU(nn.ReLU):
     pass
 
 
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        x = _c2d.as_nhwc_bf16(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((B, C, Ho, Wo), dtype=BF16, device=x.device, memory_format=CL)
+        idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        check(L.mm_maxpool3x3s2_fwd(ptr(x), B, H, W, C, ptr(y), ptr(idx), stream()), "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        dy = _c2d.as_nhwc_bf16(dy)
+        dx = torch.empty((B, C, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+        check(L.mm_maxpool3x3s2_bwd(ptr(dy), ptr(idx), B, H, W, C, ptr(dx), stream()), "maxpool_bwd")
+        return dx
+
+
 class MaxPool2d(nn.MaxPool2d):
-    pass
+    def forward(self, x):
+        _need_gpu(x, "MaxPool2d")
+        if (self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode) != (3, 2, 1, 1, False):
+            raise NotImplementedError("hot path: MaxPool2d(3, 2, 1)")
+        return _MaxPoolFn.apply(x)
 
 
 class AvgPool2d(nn.AvgPool2d):
-    pass
+    """Only ever used fused with the 1x1 head convolution: see ``fused_heads``."""
 
 
 class Dropout(nn.Dropout):
     pass
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        L = _lib.lib()
+        xs = [_c2d.as_nhwc_bf16(x) for x in xs]
+        B, _, H, W = xs[0].shape
+        cs = [x.shape[1] for x in xs]
+        Ct = sum(cs)
+        out = torch.empty((B, Ct, H, W), dtype=BF16, device=xs[0].device, memory_format=CL)
+        N, off = B * H * W, 0
+        for x, c in zip(xs, cs):
+            check(L.mm_copy_rows_bf16(ptr(x), c, out.data_ptr() + 2 * off, Ct, N, c, stream()), "copy_rows")
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        dy = _c2d.as_nhwc_bf16(dy)
+        B, Ct, H, W = dy.shape
+        N, off, outs = B * H * W, 0, []
+        for c in ctx.cs:
+            g = torch.empty((B, c, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+            check(L.mm_copy_rows_bf16(dy.data_ptr() + 2 * off, Ct, ptr(g), c, N, c, stream()), "copy_rows")
+            outs.append(g)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(xs):
+    """torch.cat(xs, dim=1) for NHWC bf16 maps (decoder concat [depth, up, rgb])."""
+    return _CatFn.apply(*xs)
+
+
+class _HeadsFn(torch.autograd.Function):
+    """[main | aux] = Conv1x1(AvgPool5x5(x[:, :, :h, :w])) for both heads in one pass (csrc/misc2d.hip header)."""
+
+    @staticmethod
+    def forward(ctx, x, h, w, w1, b1, w2, b2):
+        L = _lib.lib()
+        x = _c2d.as_nhwc_bf16(x)
+        B, C, Hp, Wp = x.shape
+        nc = w1.shape[0]
+        Wj = torch.cat([w1.reshape(nc, C), w2.reshape(nc, C)], 0).float().contiguous()
+        bj = torch.cat([b1, b2], 0).float().contiguous()
+        out = torch.empty((B, 2 * nc, h, w), dtype=F32, device=x.device)
+        ws = _lib.workspace.get(int(L.mm_head_ws_bytes(B, h, w, Hp, Wp, C, 2 * nc)), x.device)
+        check(L.mm_head_fwd(ptr(x), B, Hp, Wp, C, h, w, C, ptr(Wj), ptr(bj), 2 * nc, ptr(out), ptr(ws), ws.numel(), stream()), "head_fwd")
+        ctx.save_for_backward(x, Wj)
+        ctx.dims = (h, w, nc, w1.shape)
+        return out[:, :nc], out[:, nc:]
+
+    @staticmethod
+    def backward(ctx, d1, d2):
+        L = _lib.lib()
+        x, Wj = ctx.saved_tensors
+        h, w, nc, wshape = ctx.dims
+        B, C, Hp, Wp = x.shape
+        dout = torch.cat([d1, d2], 1).float().contiguous()
+        dx = torch.empty_like(x)
+        dWj = torch.empty_like(Wj)
+        ws = _lib.workspace.get(int(L.mm_head_ws_bytes(B, h, w, Hp, Wp, C, 2 * nc)), x.device)
+        check(L.mm_head_bwd(ptr(x), B, Hp, Wp, C, h, w, C, ptr(Wj), 2 * nc, ptr(dout), ptr(dx), ptr(dWj), ptr(ws), ws.numel(), stream()),
+              "head_bwd")
+        db = dout.sum((0, 2, 3))
+        return dx, None, None, dWj[:nc].reshape(wshape), db[:nc], dWj[nc:].reshape(wshape), db[nc:]
+
+
+def fused_heads(x, h, w, conv_main: nn.Conv2d, conv_aux: nn.Conv2d):
+    """(seg_logit_2d, seg_logit_avg_2d), each fp32 [B, num_classes, h, w], from the decoder output x (NHWC bf16, padded)."""
+    _need_gpu(x, "fused_heads")
+    return _HeadsFn.apply(x, h, w, conv_main.weight, conv_main.bias, conv_aux.weight, conv_aux.bias)
