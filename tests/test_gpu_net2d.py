@@ -93,7 +93,8 @@ def test_maxpool_cat_heads():
     B, Hp, Wp, h, w = 2, 32, 48, 30, 44
     x = torch.randn(B, 64, Hp, Wp, device=dev).bfloat16().contiguous(memory_format=CL)
     c1, c2 = nn2d.Conv2d(64, 6, 1).to(dev), nn2d.Conv2d(64, 6, 1).to(dev)
-    xh, xr = x.clone().requires_grad_(True), x.float().requires_grad_(True)
+    # reference on a plain NCHW-contiguous fp32 copy (torch's NHWC avg-pool backward on a cropped view is not trusted)
+    xh, xr = x.clone().requires_grad_(True), x.float().contiguous(memory_format=torch.contiguous_format).requires_grad_(True)
     o1, o2 = nn2d.fused_heads(xh, h, w, c1, c2)
     pooled = F.avg_pool2d(xr[:, :, :h, :w], 5, 1, 2)
     r1, r2 = F.conv2d(pooled, c1.weight, c1.bias), F.conv2d(pooled, c2.weight, c2.bias)
