@@ -149,6 +149,10 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restri
   if (dbias) dbias[c] = (float)s;
 }
 
+// Apply kernels: thread = (row slot, 8-channel group); the per-channel scale/shift live in registers and the thread
+// walks rows with a fixed stride, so the only per-row work is the 16-B loads/stores (pure streaming).
+constexpr int APPLY_ROWS = 8;  // rows per thread
+
 // y = act((x - mean) * invstd * w + b + res)
 __global__ __launch_bounds__(T) void k_bn2d_apply(const u16* __restrict__ x, int ld_x, const u16* __restrict__ res, int ld_r,
                                                    int64_t N, int C, const float* __restrict__ mean,
@@ -156,22 +160,33 @@ __global__ __launch_bounds__(T) void k_bn2d_apply(const u16* __restrict__ x, int
                                                    const float* __restrict__ weight, const float* __restrict__ bias, int relu,
                                                    u16* __restrict__ y, int ld_y) {
   const int CV = C >> 3;
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t r = gid / CV;
-  int cv = (int)(gid - r * CV);
-  if (r >= N) return;
-  float xv[8], rv[8], yv[8];
-  ld8(x + r * ld_x + cv * 8, xv);
-  if (res) ld8(res + r * ld_r + cv * 8, rv);
+  const int rs = T / CV;
+  const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
+  if (slot >= rs) return;
+  float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     int c = cv * 8 + i;
     float is = stat_is_var ? 1.f / sqrtf(invstd[c] + eps) : invstd[c];
-    float v = (xv[i] - mean[c]) * is * (weight ? weight[c] : 1.f) + (bias ? bias[c] : 0.f);
-    if (res) v += rv[i];
-    yv[i] = (relu && !(v > 0.f)) ? 0.f : v;
+    sc[i] = is * (weight ? weight[c] : 1.f);
+    sh[i] = (bias ? bias[c] : 0.f) - mean[c] * sc[i];
   }
-  st8(y + r * ld_y + cv * 8, yv);
+  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+#pragma unroll 4
+  for (int k = 0; k < APPLY_ROWS; k++) {
+    const int64_t r = r0 + (int64_t)k * rs;
+    if (r >= N) break;
+    float xv[8], rv[8], yv[8];
+    ld8(x + r * ld_x + cv * 8, xv);
+    if (res) ld8(res + r * ld_r + cv * 8, rv);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float v = fmaf(xv[i], sc[i], sh[i]);
+      if (res) v += rv[i];
+      yv[i] = (relu && !(v > 0.f)) ? 0.f : v;
+    }
+    st8(y + r * ld_y + cv * 8, yv);
+  }
 }
 
 // g = dy * relu'(yout); dx = w*invstd*(g - sum_g/N - xhat*sum_gx/N); dres = g
@@ -181,30 +196,48 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
                                                        const float* __restrict__ weight, const float* __restrict__ sums,
                                                        u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr) {
   const int CV = C >> 3;
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t r = gid / CV;
-  int cv = (int)(gid - r * CV);
-  if (r >= N) return;
-  float xv[8], dv[8], yv[8], ov[8], gv[8];
-  ld8(x + r * ld_x + cv * 8, xv);
-  ld8(dy + r * ld_dy + cv * 8, dv);
-  if (relu) ld8(yout + r * ld_y + cv * 8, yv);
+  const int rs = T / CV;
+  const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
+  if (slot >= rs) return;
+  // dx = a*g + b*x + c0 with a = w*is, b = -w*is^2*sgx/N, c0 = -a*sg/N - b*mean
+  float ka[8], kb[8], kc[8];
   const float invN = 1.f / (float)N;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     int c = cv * 8 + i;
-    float g = (relu && !(yv[i] > 0.f)) ? 0.f : dv[i];
-    float xh = (xv[i] - mean[c]) * invstd[c];
-    gv[i] = g;
-    ov[i] = (weight ? weight[c] : 1.f) * invstd[c] * (g - sums[c] * invN - xh * sums[C + c] * invN);
+    float is = invstd[c], w = weight ? weight[c] : 1.f;
+    ka[i] = w * is;
+    kb[i] = -w * is * is * sums[C + c] * invN;
+    kc[i] = -ka[i] * sums[c] * invN - kb[i] * mean[c];
   }
-  st8(dx + r * ld_dx + cv * 8, ov);
-  if (dres) st8(dres + r * ld_dr + cv * 8, gv);
+  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+#pragma unroll 4
+  for (int k = 0; k < APPLY_ROWS; k++) {
+    const int64_t r = r0 + (int64_t)k * rs;
+    if (r >= N) break;
+    float xv[8], dv[8], yv[8], ov[8], gv[8];
+    ld8(x + r * ld_x + cv * 8, xv);
+    ld8(dy + r * ld_dy + cv * 8, dv);
+    if (relu) ld8(yout + r * ld_y + cv * 8, yv);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float g = (relu && !(yv[i] > 0.f)) ? 0.f : dv[i];
+      gv[i] = g;
+      ov[i] = fmaf(ka[i], g, fmaf(kb[i], xv[i], kc[i]));
+    }
+    st8(dx + r * ld_dx + cv * 8, ov);
+    if (dres) st8(dres + r * ld_dr + cv * 8, gv);
+  }
+}
+
+inline unsigned apply_blocks(int64_t N, int C) {
+  int rs = T / (C / 8);
+  return (unsigned)mm_cdiv(N, (int64_t)rs * APPLY_ROWS);
 }
 
 inline int stat_blocks(int64_t N, int C) {
   int rs = T / (C / 8);
-  int64_t nb = mm_cdiv(N, (int64_t)rs * 64);
+  int64_t nb = mm_cdiv(N, (int64_t)rs * 16);
   if (nb < 1) nb = 1;
   if (nb > MAX_PART) nb = MAX_PART;
   return (int)nb;
@@ -231,7 +264,7 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
   hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb, N, C, eps, momentum, running_mean, running_var,
                      save_mean, save_invstd);
   if (N > 0)
-    hipLaunchKernelGGL(k_bn2d_apply, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r,
+    hipLaunchKernelGGL(k_bn2d_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r,
                        N, C, save_mean, save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -241,7 +274,7 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
                      const float* running_mean, const float* running_var, float eps, int relu, void* y, int ld_y, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0, "bn2d: C must be a multiple of 8");
   if (N == 0) return MM_OK;
-  hipLaunchKernelGGL(k_bn2d_apply, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N,
+  hipLaunchKernelGGL(k_bn2d_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N,
                      C, running_mean, running_var, 1, eps, weight, bias, relu, (u16*)y, ld_y);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -264,7 +297,7 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
                      N, C, save_mean, save_invstd, partial);
   hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sums, dweight, dbias);
   if (N > 0)
-    hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy,
+    hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy,
                        ld_dy, (const u16*)yout, ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres,
                        ld_dr);
   MM_LAUNCH_CHECK();

@@ -43,6 +43,8 @@ struct ConvP {
   int out_f32;
 };
 
+__device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
+
 __device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
 __device__ inline u16 f2bf(float f) {  // round to nearest even (inputs are finite)
   unsigned u = __float_as_uint(f);
@@ -85,13 +87,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   }
   const int kcn = p.Ca >> 6;
   const int nsteps = p.ntaps * kcn;
-  uint4 ra[4], rb[NBI];
 
-  auto gload = [&](int s) {
+  // Stage tile s into LDS buffer `buf` with LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.
+  // One wave-instruction writes 1 KiB = 8 consecutive 128-B rows linearly, so the bank swizzle is applied to the
+  // SOURCE chunk (lane (row, pc) fetches chunk pc ^ ((row>>1)&7)) and again on the fragment reads below.
+  auto issue = [&](int s, int buf) {
     const int tap = s / kcn, kc = s - tap * kcn;
     const int ty = p.ty[tap], tx = p.tx[tap];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+      const int row = r0 + 32 * i;
       int sy = ay[i] * p.sa + ty, sx = ax[i] * p.sa + tx;
       bool ok = ab[i] >= 0 && sy >= 0 && sx >= 0;
       if (p.fr == 2) {
@@ -100,28 +105,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
         sx >>= 1;
       }
       ok = ok && sy < p.Hi && sx < p.Wi;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = *(const uint4*)(p.A + ((int64_t)(ab[i] * p.Hi + sy) * p.Wi + sx) * p.lda + kc * 64 + cc * 8);
-      ra[i] = v;
+      const u16* g = ok ? p.A + ((int64_t)(ab[i] * p.Hi + sy) * p.Wi + sx) * p.lda + kc * 64 + ((cc ^ ((row >> 1) & 7)) << 3)
+                        : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(As + buf * 128 * 64 + (wave * 8 + 32 * i) * 64), 16, 0,
+                                       0);
     }
 #pragma unroll
     for (int i = 0; i < NBI; i++) {
-      int n = n0 + r0 + 32 * i;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n < p.Cn) v = *(const uint4*)(Wz + ((int64_t)n * p.ntaps + tap) * p.Ca + kc * 64 + cc * 8);
-      rb[i] = v;
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      int row = r0 + 32 * i;
-      *(uint4*)&As[buf * 128 * 64 + row * 64 + ((cc ^ ((row >> 1) & 7)) << 3)] = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < NBI; i++) {
-      int row = r0 + 32 * i;
-      *(uint4*)&Bs[buf * BN * 64 + row * 64 + ((cc ^ ((row >> 1) & 7)) << 3)] = rb[i];
+      const int row = r0 + 32 * i;
+      const int n = n0 + row;
+      const u16* g = n < p.Cn ? Wz + ((int64_t)n * p.ntaps + tap) * p.Ca + kc * 64 + ((cc ^ ((row >> 1) & 7)) << 3)
+                              : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Bs + buf * BN * 64 + (wave * 8 + 32 * i) * 64), 16, 0,
+                                       0);
     }
   };
 
@@ -133,13 +131,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  issue(0, 0);
   const int fr_ = lane & 31, fh = lane >> 5;
   for (int s = 0; s < nsteps; s++) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) gload(s + 1);
+    __syncthreads();  // (vmcnt(0) + barrier) tile s has landed; every wave is done reading buffer buf^1
+    if (s + 1 < nsteps) issue(s + 1, buf ^ 1);
     const u16* Ab = As + buf * 128 * 64;
     const u16* Bb = Bs + buf * BN * 64;
 #pragma unroll
@@ -161,8 +158,6 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 #pragma unroll
         for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < nsteps) lstore(buf ^ 1);
-    __syncthreads();
   }
 
   // epilogue: acc[i][j][reg]: pixel row = wm*64 + i*32 + (reg&3) + 8*(reg>>2) + 4*fh ; channel = n0 + wn*BN/2 + j*32 + fr_
