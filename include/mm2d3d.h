@@ -122,6 +122,71 @@ int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t 
                   float* dx, int ld_dx, int accumulate_dx, float* dw, float* db, int accumulate_w, void* ws,
                   size_t ws_bytes, mm_stream_t stream);
 
+/* ---------------------------------------------------------------- losses, lifting, optimiser (csrc/loss.hip) */
+size_t mm_loss_ws_bytes(void);
+/* weighted cross entropy, ignore_index, weighted-mean reduction (lib/losses.py:55-68 -> F.cross_entropy).
+ * stats[0] = loss, stats[1] = sum of the class weights of the counted rows */
+int mm_ce_fwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t N, int C,
+              int64_t ignore_index, float* stats, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_ce_bwd(const float* logits, int ld, const int64_t* labels, const float* weight, int64_t N, int C,
+              int64_t ignore_index, const float* stats, const float* grad_out, float* dlogits, int ld_d,
+              mm_stream_t stream);
+/* mean_i sum_c softmax(tgt)_ic (log softmax(tgt)_ic - log softmax(pred)_ic)  (EXP/train.py:157-184) */
+int mm_kl_fwd(const float* pred, int ld_p, const float* tgt, int ld_t, int64_t N, int C, float* loss, void* ws,
+              size_t ws_bytes, mm_stream_t stream);
+int mm_kl_bwd(const float* pred, int ld_p, const float* tgt, int ld_t, int64_t N, int C, const float* grad_out,
+              float* dpred, int ld_d, mm_stream_t stream);
+/* 2D->3D lifting (EXP/2d_net/model.py:131-137,166-173): out[p][c] = seg[pix_off[p] + c*chan_stride];
+ * backward: dseg[upix_off[u] + c*chan_stride] = sum over the points of unique pixel u (CSR, ascending) */
+int mm_lift_gather(const float* seg, int64_t chan_stride, const int64_t* pix_off, int64_t N, int C, float* out,
+                   mm_stream_t stream);
+int mm_lift_scatter(const float* dout, int C, const int64_t* upix_off, const int32_t* csr_off,
+                    const int32_t* csr_pts, int64_t n_unique, int64_t chan_stride, float* dseg, mm_stream_t stream);
+/* torch.optim.AdamW update over flat fp32 arenas (EXP/train.py:627-636); step counts from 1; g is multiplied by grad_scale */
+int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int64_t step, double grad_scale, mm_stream_t stream);
+
+/* ---------------------------------------------------------------- dense 2D convolutions (csrc/conv2d.hip)
+ * torch.nn.Conv2d / ConvTranspose2d of EXP/2d_net/backbones.py:43-65 and EXP/2d_net/model.py:64-82,104-123.
+ * NHWC bf16 activations, fp32 accumulate.  mm_conv2d_gemm: out[m][n] = sum_{tap,k} A[src(m,tap)][k] * Wp[n][tap][k]
+ * with m -> (b,gy,gx) on the base grid Hg x Wg, src = ((gy*sa+ty)/fr, (gx*sa+tx)/fr), out pixel = (gy*so+ooy(+z>>1),
+ * gx*so+oox(+z&1)); covers Conv2d fwd / dgrad (stride 1, 2) and ConvTranspose2d(k2,s2) fwd / dgrad. */
+int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
+                   int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
+                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, mm_stream_t stream);
+size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps);
+/* dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k], base grid = dY pixels */
+int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
+                    int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
+                    int64_t sk, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* out[((z*N+n)*T+t)*K+k] = bf16(in[z*sz + n*sn + t*st + k*sk]) : fp32 master weights -> kernel layouts */
+int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st,
+                         int64_t sk, mm_stream_t stream);
+
+/* ---------------------------------------------------------------- BatchNorm2d (+residual) (+ReLU), NHWC bf16 (csrc/bn2d.hip) */
+size_t mm_bn2d_ws_bytes(int C);
+int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
+                      const float* bias, float* running_mean, float* running_var, float eps, float momentum, int relu,
+                      void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                      mm_stream_t stream);
+int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
+                     const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
+                     int ld_y, mm_stream_t stream);
+int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N,
+                int C, const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
+                void* dres, int ld_dr, float* dweight, float* dbias, void* ws, size_t ws_bytes, mm_stream_t stream);
+
+/* ---------------------------------------------------------------- concat, max-pool, fused heads (csrc/misc2d.hip) */
+int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, int64_t N, int C, mm_stream_t stream);
+int mm_maxpool3x3s2_fwd(const void* x, int B, int H, int W, int C, void* y, void* idx, mm_stream_t stream);
+int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, mm_stream_t stream);
+size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ);
+/* AvgPool2d(5,1,2) + Conv2d 1x1 of both heads (EXP/2d_net/model.py:59-60,129-130,158,163-164): out NHWC fp32 [B,h,w,NJ] */
+int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias,
+                int NJ, float* out, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ,
+                const float* dout, void* dx, float* dWj, void* ws, size_t ws_bytes, mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

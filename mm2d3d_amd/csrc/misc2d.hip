@@ -125,36 +125,26 @@ __global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int 
     if (j < NJ) z[pix * NJ + j] = acc[j];
 }
 
-// 5x5 box / 25 with zero padding.  to_nchw: in z [B,h,w,NJ] -> out [B,NJ,h,w] (+bias);  else in [B,NJ,h,w] -> out [B,h,w,NJ]
+// 5x5 box / 25 with zero padding on NHWC fp32 maps [B,h,w,NJ] (+ bias): thread = (pixel, j), j fastest, so both the
+// 25 reads and the write are coalesced across the wave
 __global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B, int h, int w, int NJ, const float* __restrict__ bias,
-                                             int to_nchw, float* __restrict__ out) {
+                                             float* __restrict__ out) {
   int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
   int64_t total = (int64_t)B * h * w * NJ;
   if (gid >= total) return;
-  int j, xx, yy, b;
-  if (to_nchw) {  // gid enumerates the output [b][j][y][x]
-    xx = (int)(gid % w);
-    int64_t t = gid / w;
-    yy = (int)(t % h);
-    t /= h;
-    j = (int)(t % NJ);
-    b = (int)(t / NJ);
-  } else {  // gid enumerates the output [b][y][x][j]
-    j = (int)(gid % NJ);
-    int64_t t = gid / NJ;
-    xx = (int)(t % w);
-    t /= w;
-    yy = (int)(t % h);
-    b = (int)(t / h);
-  }
+  int j = (int)(gid % NJ);
+  int64_t t = gid / NJ;
+  int xx = (int)(t % w);
+  t /= w;
+  int yy = (int)(t % h), b = (int)(t / h);
   float s = 0.f;
   for (int dy = -2; dy <= 2; dy++) {
     int y2 = yy + dy;
     if (y2 < 0 || y2 >= h) continue;
+    const float* rowp = in + ((int64_t)(b * h + y2) * w) * NJ + j;
     for (int dx = -2; dx <= 2; dx++) {
       int x2 = xx + dx;
-      if (x2 < 0 || x2 >= w) continue;
-      s += to_nchw ? in[((int64_t)(b * h + y2) * w + x2) * NJ + j] : in[((int64_t)(b * NJ + j) * h + y2) * w + x2];
+      if (x2 >= 0 && x2 < w) s += rowp[(int64_t)x2 * NJ];
     }
   }
   out[gid] = s * (1.f / 25.f) + (bias ? bias[j] : 0.f);
@@ -250,7 +240,7 @@ size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ) {
   return z + part + 256;
 }
 
-// out [B,NJ,h,w] fp32 = box5x5( x[.., :h, :w, :] . Wj^T ) + bias      (x: NHWC bf16 [B,Hp,Wp,C] with pitch ld)
+// out [B,h,w,NJ] fp32 (NHWC) = box5x5( x[.., :h, :w, :] . Wj^T ) + bias      (x: NHWC bf16 [B,Hp,Wp,C] with pitch ld)
 int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias, int NJ,
                 float* out, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C % 8 == 0 && (size_t)NJ * C * 4 <= 60 * 1024, "head: bad NJ/C");
@@ -264,12 +254,12 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   if (npix == 0) return MM_OK;
   hipLaunchKernelGGL(k_head_proj, dim3((unsigned)mm_cdiv(npix, T)), dim3(T), (size_t)NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C,
                      Wj, NJ, z);
-  hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, z, B, h, w, NJ, bias, 1, out);
+  hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, z, B, h, w, NJ, bias, out);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-// dout [B,NJ,h,w] fp32 -> dx NHWC bf16 [B,Hp,Wp,C] (zero outside h x w), dWj [NJ,C], dbias [NJ]
+// dout [B,h,w,NJ] fp32 (NHWC) -> dx NHWC bf16 [B,Hp,Wp,C] (zero outside h x w), dWj [NJ,C]
 int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ, const float* dout,
                 void* dx, float* dWj, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C == 64, "head_bwd: C must be 64");
@@ -286,7 +276,7 @@ int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   float* dz = (float*)ws;
   double* partial = (double*)((char*)ws + zb);
   int64_t npix = (int64_t)B * h * w;
-  if (npix) hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, dout, B, h, w, NJ, nullptr, 0, dz);
+  if (npix) hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, dout, B, h, w, NJ, nullptr, dz);
   hipLaunchKernelGGL(k_head_bwd, dim3(nblk), dim3(T), (size_t)(T / C) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, NJ, dz,
                      (u16*)dx, partial, ppb);
   hipLaunchKernelGGL(k_sum_dbl_partials, dim3((unsigned)mm_cdiv(NJ * C, 64)), dim3(64), 0, s, partial, nblk, NJ * C, dWj);

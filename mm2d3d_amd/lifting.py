@@ -40,14 +40,15 @@ class PixelIndex:
         self.device = device
         self._cache = {}
 
-    def offsets(self, batch_stride, unique=False):
-        """Element offset of channel 0 of every point's (or unique pixel's) pixel in a [B,C,H,W] map whose H,W dims are
-        dense (stride W, 1) and whose batch stride is ``batch_stride`` elements."""
-        k = (int(batch_stride), unique)
+    def offsets(self, sb, sy, sx, unique=False):
+        """Element offset of channel 0 of every point's (or unique pixel's) pixel in a [B,C,H,W] map with strides
+        (sb, *, sy, sx) - NCHW and NHWC maps (and channel slices of either) are both served without a copy."""
+        k = (int(sb), int(sy), int(sx), unique)
         if k not in self._cache:
             HW = self.H * self.W
             key = self.ukey if unique else self.key
-            self._cache[k] = torch.from_numpy((key // HW) * int(batch_stride) + key % HW).to(self.device)
+            b, r = key // HW, key % HW
+            self._cache[k] = torch.from_numpy(b * int(sb) + (r // self.W) * int(sy) + (r % self.W) * int(sx)).to(self.device)
         return self._cache[k]
 
 
@@ -59,11 +60,9 @@ class _LiftFn(torch.autograd.Function):
         seg = seg.to(F32)
         B, C, H, W = seg.shape
         assert (H, W) == (index.H, index.W)
-        if seg.stride(3) != 1 or seg.stride(2) != W or seg.stride(1) != H * W:  # channel slices of an NCHW map are fine as is
-            seg = seg.contiguous()
-        pix = index.offsets(seg.stride(0))
+        pix = index.offsets(seg.stride(0), seg.stride(2), seg.stride(3))
         out = torch.empty((index.n, C), dtype=F32, device=seg.device)
-        check(L.mm_lift_gather(ptr(seg), H * W, ptr(pix), index.n, C, ptr(out), stream()), "lift_gather")
+        check(L.mm_lift_gather(ptr(seg), seg.stride(1), ptr(pix), index.n, C, ptr(out), stream()), "lift_gather")
         ctx.index, ctx.shape = index, seg.shape
         return out
 
@@ -73,10 +72,11 @@ class _LiftFn(torch.autograd.Function):
         index = ctx.index
         B, C, H, W = ctx.shape
         dout = dout.to(F32).contiguous()
-        upix = index.offsets(C * H * W, unique=True)
-        dseg = torch.zeros(ctx.shape, dtype=F32, device=dout.device)
-        check(L.mm_lift_scatter(ptr(dout), C, ptr(upix), ptr(index.csr_off), ptr(index.csr_pts), len(index.ukey), H * W, ptr(dseg),
-                                stream()), "lift_scatter")
+        # gradient map in NHWC (what the fused heads' backward reads coalesced); logical shape stays [B,C,H,W]
+        dseg = torch.zeros((B, H, W, C), dtype=F32, device=dout.device).permute(0, 3, 1, 2)
+        upix = index.offsets(dseg.stride(0), dseg.stride(2), dseg.stride(3), unique=True)
+        check(L.mm_lift_scatter(ptr(dout), C, ptr(upix), ptr(index.csr_off), ptr(index.csr_pts), len(index.ukey), dseg.stride(1),
+                                ptr(dseg), stream()), "lift_scatter")
         return dseg, None
 
 

@@ -209,12 +209,13 @@ class _HeadsFn(torch.autograd.Function):
         nc = w1.shape[0]
         Wj = torch.cat([w1.reshape(nc, C), w2.reshape(nc, C)], 0).float().contiguous()
         bj = torch.cat([b1, b2], 0).float().contiguous()
-        out = torch.empty((B, 2 * nc, h, w), dtype=F32, device=x.device)
+        out = torch.empty((B, h, w, 2 * nc), dtype=F32, device=x.device)  # NHWC; returned as logical [B,C,h,w] views
         ws = _lib.workspace.get(int(L.mm_head_ws_bytes(B, h, w, Hp, Wp, C, 2 * nc)), x.device)
         check(L.mm_head_fwd(ptr(x), B, Hp, Wp, C, h, w, C, ptr(Wj), ptr(bj), 2 * nc, ptr(out), ptr(ws), ws.numel(), stream()), "head_fwd")
         ctx.save_for_backward(x, Wj)
         ctx.dims = (h, w, nc, w1.shape)
-        return out[:, :nc], out[:, nc:]
+        o = out.permute(0, 3, 1, 2)
+        return o[:, :nc], o[:, nc:]
 
     @staticmethod
     def backward(ctx, d1, d2):
@@ -222,13 +223,15 @@ class _HeadsFn(torch.autograd.Function):
         x, Wj = ctx.saved_tensors
         h, w, nc, wshape = ctx.dims
         B, C, Hp, Wp = x.shape
-        dout = torch.cat([d1, d2], 1).float().contiguous()
+        dout = torch.empty((B, h, w, 2 * nc), dtype=F32, device=x.device)  # NHWC
+        dout[..., :nc] = d1.permute(0, 2, 3, 1)
+        dout[..., nc:] = d2.permute(0, 2, 3, 1)
         dx = torch.empty_like(x)
         dWj = torch.empty_like(Wj)
         ws = _lib.workspace.get(int(L.mm_head_ws_bytes(B, h, w, Hp, Wp, C, 2 * nc)), x.device)
         check(L.mm_head_bwd(ptr(x), B, Hp, Wp, C, h, w, C, ptr(Wj), 2 * nc, ptr(dout), ptr(dx), ptr(dWj), ptr(ws), ws.numel(), stream()),
               "head_bwd")
-        db = dout.sum((0, 2, 3))
+        db = dout.sum((0, 1, 2))
         return dx, None, None, dWj[:nc].reshape(wshape), db[:nc], dWj[nc:].reshape(wshape), db[nc:]
 
 

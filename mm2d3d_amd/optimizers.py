@@ -33,9 +33,7 @@ class FlatAdamW(optim.Optimizer):
             if not ps:
                 self._arenas.append(None)
                 continue
-            dev = ps[0].device
-            if dev.type != "cuda":
-                raise RuntimeError("FlatAdamW: parameters must be on the GPU (no CPU fallback)")
+            dev = ps[0].device  # CPU arenas are allowed (gloo tests of the reducer); step() itself is HIP-only
             n = sum(p.numel() for p in ps)
             flat_p = torch.empty(n, dtype=torch.float32, device=dev)
             flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -87,6 +85,8 @@ class FlatAdamW(optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = closure() if closure is not None else None
+        if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
+            raise RuntimeError("FlatAdamW.step: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
         L = _lib.lib()
         self._step += 1
         for group, a in zip(self.param_groups, self._arenas):

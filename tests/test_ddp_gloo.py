@@ -1,0 +1,83 @@
+"""Data-parallel path on CPU: world_size 2, gloo backend (the N>1 logic of mm2d3d_amd/ddp.py without GPUs)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mm2d3d_amd.ddp import GradAllReducer
+        from mm2d3d_amd.optimizers import FlatAdamW
+
+        torch.manual_seed(0)  # identical init on every rank (DDP broadcasts at construction; same seed is equivalent)
+        net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 16), nn.ReLU(), nn.Linear(16, 4))
+        unused = nn.Linear(4, 4)  # never part of the graph: the find_unused_parameters case
+        opt = FlatAdamW(list(net.parameters()) + list(unused.parameters()), lr=1e-3)
+        red = GradAllReducer([opt], bucket_bytes=300, overlap=overlap)  # several buckets
+        assert len(red.buckets) >= 3
+        torch.manual_seed(100 + rank)  # different data per rank
+        x = torch.randn(5, 8)
+        for it in range(2):
+            opt.zero_grad()
+            (net(x) ** 2).sum().backward()
+            local = opt.grad_arenas()[0].clone()
+            red.finish()
+            summed = opt.grad_arenas()[0].clone()
+            gathered = [torch.zeros_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local)
+            assert torch.allclose(summed, sum(gathered), atol=1e-6), "bucketed all-reduce != sum of local gradients"
+            assert torch.equal(summed[-20:], torch.zeros(20)), "unused parameters must stay zero"
+        assert abs(red.grad_scale - 1.0 / world) < 1e-12
+        bufmod = nn.BatchNorm1d(3)
+        bufmod.running_mean.fill_(float(rank + 1))
+        red.broadcast_buffers([bufmod])
+        assert torch.equal(bufmod.running_mean, torch.ones(3))
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_bucketed_allreduce_world2_gloo(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == "ok" for r in res), res
+
+
+def test_shard_indices_matches_distributed_sampler():
+    from torch.utils.data.distributed import DistributedSampler
+
+    from mm2d3d_amd.ddp import shard_indices
+
+    data = list(range(37))
+    for epoch in (0, 3):
+        for world in (1, 2, 8):
+            for rank in range(world):
+                s = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, seed=0)
+                s.set_epoch(epoch)
+                assert shard_indices(len(data), rank, world, epoch=epoch, shuffle=True, seed=0) == list(iter(s))
