@@ -68,7 +68,12 @@ def conv_roofline(tm, batch, dev):
 
     rec = []
     ops.PROFILE = rec
-    tm.fit_step(fresh(batch))
+    b = fresh(batch)
+    torch.cuda.synchronize()
+    # keep the GPU busy while the host enqueues the whole step, so that the event pairs bracket kernel execution only
+    # (otherwise short launches measure the host's launch cadence, not the kernel)
+    torch.cuda._sleep(int(2.0e9 * 0.25))
+    tm.fit_step(b)
     torch.cuda.synchronize()
     ops.PROFILE = None
     alg_bytes = sum(r["bytes"] for r in rec)
@@ -80,6 +85,11 @@ def conv_roofline(tm, batch, dev):
         k[1] += r["e0"].elapsed_time(r["e1"])
         k[2] += 1
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    if os.environ.get("MM_BENCH_LAYERS"):
+        for r in rec[: len(rec) // 2 if os.environ["MM_BENCH_LAYERS"] == "half" else len(rec)]:
+            t = r["e0"].elapsed_time(r["e1"])
+            print(f"[layer] {r['kind']:3s} K={r['K']:2d} R={r['R']:8d} {r['cin']:3d}->{r['cout']:3d} {t*1e3:8.1f} us "
+                  f"{r['bytes']/t/1e6:8.1f} GB/s  {2*r['R']*r['cin']*r['cout']/t/1e9:6.1f} TF/s", file=sys.stderr)
     return {
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "traffic": None,

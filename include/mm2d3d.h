@@ -74,7 +74,7 @@ int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, 
 
 /* ---------------------------------------------------------------- sparse convolution engines (csrc/spconv.hip)
  * scn.SubmanifoldConvolution / Convolution / Deconvolution forward and backward. */
-size_t mm_spconv_ws_bytes(int64_t n_rules, int Cout);
+size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K);
 /* out[dst[r]] (+)= in[src[r]] . W[k(r)] over a k-major rulebook (offsets_host = host copy of offsets[K+1]).
  *   unique_dst != 0: every destination row has exactly one rule (direct writes);
  *   else destinations are reduced through csr_off/csr_pos in ascending k and rows without rules become 0.

@@ -29,7 +29,7 @@ _PROTOS = {
     "mm_down_neighbors": (i32, [vp, i64, vp, i64, vp, vp]),
     "mm_rulebook_ws_bytes": (sz, [i64, i32]),
     "mm_rulebook_compact": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "mm_spconv_ws_bytes": (sz, [i64, i32]),
+    "mm_spconv_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
     "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),

@@ -34,29 +34,49 @@ __device__ inline int find_k(const KSeg& seg, int b, int K) {
 }
 
 // ------------------------------------------------------------------------------------------------ engine G (MFMA)
-template <int NCB>
+// Weights are first packed (k_pack_frag, one small launch per call) into MFMA-fragment order
+//   Wf[k][q][cb][lane][j] = W[kk][ci = 16q + 4(lane>>4) + j][co = 16cb + (lane&15)]   (0 beyond Cin / Cout)
+// so a workgroup stages W[k] with coalesced 16-B copies and every lane reads its A operand with one ds_read_b128.
+__global__ __launch_bounds__(256) void k_pack_frag(const float* __restrict__ W, int64_t w_kstride, int s_ci, int s_co, int kflip,
+                                                    int K, int Cin, int Cout, int nq, int ncb, float* __restrict__ Wf) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = (int64_t)K * nq * ncb * 256;
+  if (e >= total) return;
+  int j = (int)(e & 3), lane = (int)((e >> 2) & 63);
+  int64_t t = e >> 8;
+  int cb = (int)(t % ncb);
+  t /= ncb;
+  int q = (int)(t % nq), k = (int)(t / nq);
+  int ci = 16 * q + 4 * (lane >> 4) + j, co = 16 * cb + (lane & 15);
+  float v = 0.f;
+  if (ci < Cin && co < Cout) v = W[(int64_t)(kflip ? K - 1 - k : k) * w_kstride + (int64_t)ci * s_ci + (int64_t)co * s_co];
+  Wf[e] = v;
+}
+
+// EDGE: Cin or Cout not a multiple of 16 (the 3-channel stem and its dX): guarded scalar row loads / stores
+template <int NCB, bool EDGE>
 __global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ in, int ld_in,
                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
-                                                      float* __restrict__ out, int ld_out, const float* __restrict__ W,
-                                                      int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin,
-                                                      KSeg seg) {
-  extern __shared__ float wl[];  // [Cin/16][NCB][64 lanes][4]
+                                                      float* __restrict__ out, int ld_out, const float* __restrict__ Wf,
+                                                      int ncb_tot, int K, int Cin, int Cout, KSeg seg) {
+  extern __shared__ float wl[];  // [nq][NCB][64 lanes][4]
   const int tid = threadIdx.x;
   const int k = find_k(seg, blockIdx.x, K);
   const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * TR;
   const int r_end = min(seg.rule_off[k + 1], r_begin + TR);
-  const int co_base = blockIdx.y * (NCB * 16);
-  const float* Wk = W + (int64_t)(kflip ? K - 1 - k : k) * w_kstride;
-  const int ncol = NCB * 16;
-  for (int e = tid; e < Cin * ncol; e += 256) {
-    int ci = e / ncol, c = e - ci * ncol;
-    float v = Wk[(int64_t)ci * s_ci + (int64_t)(co_base + c) * s_co];
-    int q = ci >> 4, s4 = (ci >> 2) & 3, j = ci & 3, cb = c >> 4, cc = c & 15;
-    wl[(((q * NCB + cb) * 64) + s4 * 16 + cc) * 4 + j] = v;
+  const int cb0 = blockIdx.y * NCB;
+  const int co_base = cb0 * 16;
+  const int nq = (Cin + 15) >> 4;
+  {
+    const f32x4* Wk = (const f32x4*)Wf + ((int64_t)k * nq * ncb_tot + cb0) * 64;
+    f32x4* wl4 = (f32x4*)wl;
+    for (int e = tid; e < nq * NCB * 64; e += 256) {
+      int q = e / (NCB * 64), r = e - q * (NCB * 64);
+      wl4[e] = Wk[(int64_t)q * ncb_tot * 64 + r];
+    }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
-  const int nq = Cin >> 4;
   for (int g = r_begin + wave * 16; g < r_end; g += 64) {
     const int r = g + rl;
     const bool valid = r < r_end;
@@ -66,7 +86,17 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ i
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int q = 0; q < nq; q++) {
-      f32x4 x = valid ? *(const f32x4*)(row + q * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 x = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        if (EDGE) {
+          const int c0 = q * 16 + sl * 4;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (c0 + j < Cin) x[j] = row[q * 16 + j];
+        } else {
+          x = *(const f32x4*)(row + q * 16);
+        }
+      }
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) {
         f32x4 w = *(const f32x4*)&wl[((q * NCB + cb) * 64 + lane) * 4];
@@ -80,7 +110,15 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ i
       const int64_t orow = dst ? (int64_t)dst[r] : (int64_t)r;
       float* o = out + orow * ld_out + co_base + sl * 4;
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++) *(f32x4*)(o + cb * 16) = acc[cb];
+      for (int cb = 0; cb < NCB; cb++) {
+        if (EDGE) {
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (co_base + cb * 16 + sl * 4 + j < Cout) o[cb * 16 + j] = acc[cb][j];
+        } else {
+          *(f32x4*)(o + cb * 16) = acc[cb];
+        }
+      }
     }
   }
 }
@@ -98,6 +136,19 @@ __global__ __launch_bounds__(256) void k_csr_reduce(const float* __restrict__ tm
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int e = a; e < b; e++) acc += *(const f32x4*)(tmp + (int64_t)csr_pos[e] * ld_tmp + c4 * 4);
   *(f32x4*)(out + row * ld_out + c4 * 4) = acc;
+}
+
+__global__ __launch_bounds__(256) void k_csr_reduce_scalar(const float* __restrict__ tmp, int ld_tmp,
+                                                            const int32_t* __restrict__ csr_off,
+                                                            const int32_t* __restrict__ csr_pos, int64_t n_out,
+                                                            float* __restrict__ out, int ld_out, int C) {
+  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = gid / C;
+  int c = (int)(gid - row * C);
+  if (row >= n_out) return;
+  float acc = 0.f;
+  for (int e = csr_off[row]; e < csr_off[row + 1]; e++) acc += tmp[(int64_t)csr_pos[e] * ld_tmp + c];
+  out[row * ld_out + c] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------ generic VALU engines
@@ -286,15 +337,14 @@ int make_seg(const int32_t* offsets_host, int K, int rules_per_block, KSeg* seg)
   return nb;
 }
 
-template <int NCB>
-int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src, const int32_t* dst, float* out,
-             int ld_out, const float* W, int64_t wks, int s_ci, int s_co, int kflip, int K, int Cin, const KSeg& seg,
-             hipStream_t s) {
-  size_t lds = (size_t)Cin * NCB * 16 * sizeof(float);
+template <int NCB, bool EDGE>
+int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src, const int32_t* dst, float* out, int ld_out,
+             const float* Wf, int ncb_tot, int K, int Cin, int Cout, const KSeg& seg, hipStream_t s) {
+  size_t lds = (size_t)((Cin + 15) / 16) * 16 * NCB * 16 * sizeof(float);
   if (lds > 64 * 1024)
-    MM_HIP(hipFuncSetAttribute((const void*)k_gather_gemm<NCB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_gather_gemm<NCB>, dim3(nb, nchunk), dim3(256), lds, s, in, ld_in, src, dst, out, ld_out, W, wks,
-                     s_ci, s_co, kflip, K, Cin, seg);
+    MM_HIP(hipFuncSetAttribute((const void*)k_gather_gemm<NCB, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL((k_gather_gemm<NCB, EDGE>), dim3(nb, nchunk), dim3(256), lds, s, in, ld_in, src, dst, out, ld_out, Wf, ncb_tot, K,
+                     Cin, Cout, seg);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -303,8 +353,14 @@ int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src,
 
 extern "C" {
 
-// bytes of the tmp buffer engine G+R needs for a layer
-size_t mm_spconv_ws_bytes(int64_t n_rules, int Cout) { return mm_align((size_t)n_rules * Cout * sizeof(float)) + 256; }
+static inline size_t frag_floats(int K, int Cin, int Cout) {
+  return (size_t)K * ((Cin + 15) / 16) * ((Cout + 15) / 16) * 256;
+}
+
+// bytes of the workspace (tmp rows + packed weight fragments) one mm_spconv_apply call needs
+size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K) {
+  return mm_align((size_t)n_rules * Cout * sizeof(float)) + mm_align(frag_floats(K, Cin, Cout) * sizeof(float)) + 512;
+}
 
 // out[dst] (+)= in[src] . W[k]   over a k-major rulebook.
 //   unique_dst != 0 : every destination row has exactly one rule -> direct row writes, no reduction
@@ -318,10 +374,11 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && ld_in >= Cin && ld_out >= Cout, "spconv_apply: bad shape");
   const int64_t R = offsets_host[K];
   if (n_out == 0) return MM_OK;
-  const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0) && (ld_in % 4 == 0) && (ld_out % 4 == 0) &&
-                       (((uintptr_t)in | (uintptr_t)out) % 16 == 0);
-  int ncb = Cout / 16, nchunk = 1;
-  if (mfma_ok && ncb > 8) {
+  const bool edge = (Cin % 16 != 0) || (Cout % 16 != 0) || (ld_in % 4 != 0) || (ld_out % 4 != 0) ||
+                    (((uintptr_t)in | (uintptr_t)out) % 16 != 0);
+  const int nq = (Cin + 15) / 16, ncb = (Cout + 15) / 16;
+  int nchunk = 1;
+  if (ncb > 8) {
     nchunk = 0;
     for (int d = 2; d <= ncb; d++)
       if (ncb % d == 0 && ncb / d <= 8) {
@@ -329,7 +386,10 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
         break;
       }
   }
-  if (!mfma_ok || nchunk == 0 || (size_t)Cin * (ncb / (nchunk ? nchunk : 1)) * 64 > 150 * 1024) {
+  const size_t tmp_bytes = unique_dst ? 0 : mm_align((size_t)R * Cout * sizeof(float));
+  const size_t need = tmp_bytes + frag_floats(K, Cin, Cout) * sizeof(float);
+  const bool lds_ok = nchunk && (size_t)nq * 16 * (ncb / (nchunk ? nchunk : 1)) * 64 <= 150 * 1024;
+  if (!lds_ok) {  // very wide layers: plain VALU kernels
     if (unique_dst) {
       if (R) hipLaunchKernelGGL(k_generic_rules, dim3((unsigned)mm_cdiv(R * Cout, 256)), dim3(256), 0, s, in, ld_in, src, dst,
                                 offsets_dev, K, R, out, ld_out, W, w_kstride, s_ci, s_co, kflip, Cin, Cout);
@@ -340,27 +400,32 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     MM_LAUNCH_CHECK();
     return MM_OK;
   }
+  if (ws_bytes < need) {
+    mm_set_error("spconv_apply: workspace too small (%zu < %zu)", ws_bytes, need);
+    return MM_ERR_WORKSPACE;
+  }
+  MM_CHECK_ARG(((uintptr_t)ws % 16) == 0, "spconv_apply: workspace must be 16-B aligned");
+  float* Wf = (float*)((char*)ws + tmp_bytes);
+  hipLaunchKernelGGL(k_pack_frag, dim3((unsigned)mm_cdiv((int64_t)frag_floats(K, Cin, Cout), 256)), dim3(256), 0, s, W, w_kstride, s_ci,
+                     s_co, kflip, K, Cin, Cout, nq, ncb, Wf);
   KSeg seg;
   int nb = make_seg(offsets_host, K, TR, &seg);
   float* tgt = out;
   int ld_t = ld_out;
   const int32_t* d = dst;
   if (!unique_dst) {
-    if (ws_bytes < (size_t)R * Cout * sizeof(float)) {
-      mm_set_error("spconv_apply: workspace too small (%zu < %zu)", ws_bytes, (size_t)R * Cout * sizeof(float));
-      return MM_ERR_WORKSPACE;
-    }
     tgt = (float*)ws;
     ld_t = Cout;
     d = nullptr;
-    MM_CHECK_ARG(((uintptr_t)ws % 16) == 0, "spconv_apply: workspace must be 16-B aligned");
   }
   if (nb > 0) {
     int rc = MM_OK;
+    const bool e2 = edge || (!unique_dst && (Cout % 4 != 0));
     switch (ncb / nchunk) {
-#define CASE(N)                                                                                                   \
-  case N:                                                                                                         \
-    rc = launch_g<N>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, W, w_kstride, s_ci, s_co, kflip, K, Cin, seg, s); \
+#define CASE(N)                                                                                                          \
+  case N:                                                                                                                \
+    rc = e2 ? launch_g<N, true>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, Cout, seg, s)                  \
+            : launch_g<N, false>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, Cout, seg, s);                \
     break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
@@ -371,8 +436,12 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     if (rc) return rc;
   }
   if (!unique_dst) {
-    hipLaunchKernelGGL(k_csr_reduce, dim3((unsigned)mm_cdiv(n_out * (Cout / 4), 256)), dim3(256), 0, s, tgt, Cout, csr_off,
-                       csr_pos, n_out, out, ld_out, Cout / 4);
+    if (Cout % 4 == 0 && ld_out % 4 == 0 && ((uintptr_t)out % 16) == 0)
+      hipLaunchKernelGGL(k_csr_reduce, dim3((unsigned)mm_cdiv(n_out * (Cout / 4), 256)), dim3(256), 0, s, tgt, Cout, csr_off, csr_pos,
+                         n_out, out, ld_out, Cout / 4);
+    else
+      hipLaunchKernelGGL(k_csr_reduce_scalar, dim3((unsigned)mm_cdiv(n_out * Cout, 256)), dim3(256), 0, s, tgt, Cout, csr_off, csr_pos,
+                         n_out, out, ld_out, Cout);
     MM_LAUNCH_CHECK();
   }
   return MM_OK;
