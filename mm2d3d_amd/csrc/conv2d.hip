@@ -271,6 +271,116 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgP p) {
   }
 }
 
+// Larger-tile weight gradient: TN (64|128) x 128 output tile per workgroup, 64-pixel K'-steps staged by LDS-DMA into
+// double-buffered pixel-major tiles; rows are swizzled (on the DMA source chunk and on the transpose reads) so that
+// ds_read_b64_tr_b16 is bank-conflict free: 256-B rows use chunk ^= ((row&3)<<2)|((row>>2)&3), 128-B rows chunk ^= ((row>>1)&1)<<2.
+template <int TN>
+__global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int YR = TN;          // elements per Ys row
+  u16* Ys = smem;                 // [2][64][TN]
+  u16* Xs = smem + 2 * 64 * TN;   // [2][64][128]
+  constexpr int NTN = TN / 64;    // 32-wide n tiles per wave
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int nkt = (p.Ck + 127) >> 7;
+  const int n0 = (blockIdx.y / nkt) * TN, k0 = (blockIdx.y % nkt) * 128;
+  const int tap = blockIdx.z;
+  const int ty = p.ty[tap], tx = p.tx[tap];
+  const int64_t M = (int64_t)p.B * p.Hg * p.Wg;
+  const int64_t mb = (int64_t)blockIdx.x * p.mchunk;
+  const int64_t me = mb + p.mchunk < M ? mb + p.mchunk : M;
+  f32x16 acc[NTN][2];
+#pragma unroll
+  for (int i = 0; i < NTN; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  auto fy = [](int row) { return TN == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (((row >> 1) & 1) << 2); };
+  auto fx = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+  constexpr int YI = (64 * TN * 2) / (256 * 16);  // DMA instructions per thread for the dY tile (2 or 4)
+  constexpr int YC = TN / 8;                      // 16-B chunks per dY row
+  auto issue = [&](int64_t t0, int buf) {
+#pragma unroll
+    for (int i = 0; i < YI; i++) {
+      const int c = tid + 256 * i, row = c / YC, pc = c % YC;
+      const int64_t m = t0 + row;
+      const u16* g = (m < me) ? p.DY + m * p.ldy + n0 + ((pc ^ fy(row)) << 3) : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Ys + buf * 64 * TN + (wave * 64 + 256 * i) * 8), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + 256 * i, row = c >> 4, pc = c & 15;
+      const int64_t m = t0 + row;
+      const int ch = pc ^ fx(row);
+      const u16* g = (const u16*)g_zero16;
+      if (m < me && k0 + ch * 8 < p.Ck) {
+        int gx = (int)(m % p.Wg);
+        int64_t t = m / p.Wg;
+        int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
+        int sy = gy * p.sa + ty, sx = gx * p.sa + tx;
+        if (sy >= 0 && sx >= 0 && sy < p.Hi && sx < p.Wi) g = p.X + ((int64_t)(b * p.Hi + sy) * p.Wi + sx) * p.ldx + k0 + (ch << 3);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Xs + buf * 64 * 128 + (wave * 64 + 256 * i) * 8), 16, 0, 0);
+    }
+  };
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  if (mb < me) issue(mb, 0);
+  int buf = 0;
+  for (int64_t t0 = mb; t0 < me; t0 += 64, buf ^= 1) {
+    __syncthreads();
+    if (t0 + 64 < me) issue(t0 + 64, buf ^ 1);
+    const u16* Yb = Ys + buf * 64 * TN;
+    const u16* Xb = Xs + buf * 64 * 128;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int prow = kk * 16 + 8 * (g >> 1) + q;
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      bf16x8 af[NTN], bf[2];
+#pragma unroll
+      for (int i = 0; i < NTN; i++) {
+        const int c0 = (wn * (TN / 2) + i * 32 + 16 * (g & 1)) >> 3;
+        const int o0 = prow * YR + (((c0 + (pp >> 1)) ^ fy(prow)) << 3) + 4 * (pp & 1);
+        const int o1 = (prow + 4) * YR + (((c0 + (pp >> 1)) ^ fy(prow + 4)) << 3) + 4 * (pp & 1);
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[o0]);
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[o1]);
+        s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        af[i] = __builtin_bit_cast(bf16x8, av);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int c0 = (wk * 64 + j * 32 + 16 * (g & 1)) >> 3;
+        const int o0 = prow * 128 + (((c0 + (pp >> 1)) ^ fx(prow)) << 3) + 4 * (pp & 1);
+        const int o1 = (prow + 4) * 128 + (((c0 + (pp >> 1)) ^ fx(prow + 4)) << 3) + 4 * (pp & 1);
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xb[o0]);
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xb[o1]);
+        s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        bf[j] = __builtin_bit_cast(bf16x8, bv);
+      }
+#pragma unroll
+      for (int i = 0; i < NTN; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* P = p.partial + (int64_t)blockIdx.x * p.Cn * p.ntaps * p.Ck;
+#pragma unroll
+  for (int i = 0; i < NTN; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) {
+        int n = n0 + wn * (TN / 2) + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        int k = k0 + wk * 64 + j * 32 + (lane & 31);
+        if (n < p.Cn && k < p.Ck) P[((int64_t)n * p.ntaps + tap) * p.Ck + k] = acc[i][j][reg];
+      }
+}
+
 // dW_torch[idx(n,tap,k)] (+)= sum_splits partial[s][n][tap][k];  out strides (sn, st, sk) express the torch layout
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
                                                        float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
@@ -364,7 +474,8 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
 }
 
 static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
-  int64_t tiles = (int64_t)mm_cdiv(Cn, 64) * (Ck / 64) * ntaps;
+  const int tn = (Cn % 128 == 0) ? 128 : 64;
+  int64_t tiles = (int64_t)mm_cdiv(Cn, tn) * mm_cdiv(Ck, 128) * ntaps;
   int64_t want = mm_cdiv(2048, tiles);  // ~2048 workgroups in total
   if (want < 1) want = 1;
   int64_t c = mm_cdiv(mm_cdiv(M, want), 64) * 64;
@@ -398,8 +509,16 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
     return MM_ERR_WORKSPACE;
   }
   p.partial = (float*)ws;
-  if (M > 0)
-    hipLaunchKernelGGL(k_conv_wgrad, dim3(nsplit, (Cn / 64) * (Ck / 64), ntaps), dim3(256), 0, s, p);
+  if (M > 0) {
+    const int nkt = (int)mm_cdiv(Ck, 128);
+    if (Cn % 128 == 0) {
+      const size_t lds = (size_t)(2 * 64 * 128 + 2 * 64 * 128) * 2;
+      hipLaunchKernelGGL(k_conv_wgrad2<128>, dim3(nsplit, (Cn / 128) * nkt, ntaps), dim3(256), lds, s, p);
+    } else {
+      const size_t lds = (size_t)(2 * 64 * 64 + 2 * 64 * 128) * 2;
+      hipLaunchKernelGGL(k_conv_wgrad2<64>, dim3(nsplit, (Cn / 64) * nkt, ntaps), dim3(256), lds, s, p);
+    }
+  }
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 256)), dim3(256), 0, s, p.partial,
                      M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
   MM_LAUNCH_CHECK();

@@ -58,12 +58,12 @@ template <int NCB, bool EDGE>
 __global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ in, int ld_in,
                                                       const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                       float* __restrict__ out, int ld_out, const float* __restrict__ Wf,
-                                                      int ncb_tot, int K, int Cin, int Cout, KSeg seg) {
+                                                      int ncb_tot, int K, int Cin, int Cout, int tr, KSeg seg) {
   extern __shared__ float wl[];  // [nq][NCB][64 lanes][4]
   const int tid = threadIdx.x;
   const int k = find_k(seg, blockIdx.x, K);
-  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * TR;
-  const int r_end = min(seg.rule_off[k + 1], r_begin + TR);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * tr;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + tr);
   const int cb0 = blockIdx.y * NCB;
   const int co_base = cb0 * 16;
   const int nq = (Cin + 15) >> 4;
@@ -339,12 +339,12 @@ int make_seg(const int32_t* offsets_host, int K, int rules_per_block, KSeg* seg)
 
 template <int NCB, bool EDGE>
 int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src, const int32_t* dst, float* out, int ld_out,
-             const float* Wf, int ncb_tot, int K, int Cin, int Cout, const KSeg& seg, hipStream_t s) {
+             const float* Wf, int ncb_tot, int K, int Cin, int Cout, int tr, const KSeg& seg, hipStream_t s) {
   size_t lds = (size_t)((Cin + 15) / 16) * 16 * NCB * 16 * sizeof(float);
   if (lds > 64 * 1024)
     MM_HIP(hipFuncSetAttribute((const void*)k_gather_gemm<NCB, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL((k_gather_gemm<NCB, EDGE>), dim3(nb, nchunk), dim3(256), lds, s, in, ld_in, src, dst, out, ld_out, Wf, ncb_tot, K,
-                     Cin, Cout, seg);
+                     Cin, Cout, tr, seg);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -408,8 +408,12 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
   float* Wf = (float*)((char*)ws + tmp_bytes);
   hipLaunchKernelGGL(k_pack_frag, dim3((unsigned)mm_cdiv((int64_t)frag_floats(K, Cin, Cout), 256)), dim3(256), 0, s, W, w_kstride, s_ci,
                      s_co, kflip, K, Cin, Cout, nq, ncb, Wf);
+  // small layers: fewer rules per workgroup and channel-block splitting so that the grid still covers the 256 CUs
+  int tr = TR;
+  while (tr > 64 && mm_cdiv(R, tr) * nchunk < 1024) tr >>= 1;
+  while (mm_cdiv(R, tr) * nchunk < 512 && (ncb / nchunk) % 2 == 0 && ncb / nchunk >= 2) nchunk *= 2;
   KSeg seg;
-  int nb = make_seg(offsets_host, K, TR, &seg);
+  int nb = make_seg(offsets_host, K, tr, &seg);
   float* tgt = out;
   int ld_t = ld_out;
   const int32_t* d = dst;
@@ -424,8 +428,8 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     switch (ncb / nchunk) {
 #define CASE(N)                                                                                                          \
   case N:                                                                                                                \
-    rc = e2 ? launch_g<N, true>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, Cout, seg, s)                  \
-            : launch_g<N, false>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, Cout, seg, s);                \
+    rc = e2 ? launch_g<N, true>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, Cout, tr, seg, s)              \
+            : launch_g<N, false>(nb, nchunk, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, Cout, tr, seg, s);            \
     break;
       CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8)
 #undef CASE
