@@ -154,6 +154,10 @@ int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
 int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, mm_stream_t stream);
+/* 3x3 stride-1 pad-1 convolution (flip 0) or its data gradient (flip 1, Wp = [ci][tap][co]) from a halo tile staged once
+ * for all 9 taps (EXP/2d_net/backbones.py ResNet34 BasicBlocks; EXP/2d_net/model.py:68-71 decoder convolutions) */
+int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
+                    const float* bias, int flip, mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps);
 /* dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k], base grid = dY pixels */
 int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,

@@ -54,6 +54,7 @@ _PROTOS = {
     "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp]),
     "mm_conv2d_gemm": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp,
                              vp, i32, i64, i32, vp, vp]),
+    "mm_conv2d_3x3s1": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp]),
     "mm_conv2d_wgrad_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_conv2d_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, i64, i32, vp, sz,
                               vp]),

@@ -74,7 +74,11 @@ class Conv2dFn(torch.autograd.Function):
         ty = [kh - padding for kh in range(KH) for _ in range(KW)]
         tx = [kw - padding for _ in range(KH) for kw in range(KW)]
         b = bias.detach().float().contiguous() if bias is not None else None
-        _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b)
+        if (KH, KW, stride, padding) == (3, 3, 1, 1):  # halo-tile kernel: input patch staged once for all 9 taps
+            check(_lib.lib().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, Cin, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0, stream()),
+                  "conv2d_3x3s1")
+        else:
+            _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, bias is not None)
         return y
@@ -92,9 +96,13 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T)  # [ci][t][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
-            ty = [padding - kh for kh in range(KH) for _ in range(KW)]
-            tx = [padding - kw for _ in range(KH) for kw in range(KW)]
-            _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd)
+            if (KH, KW, stride, padding) == (3, 3, 1, 1):
+                check(_lib.lib().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, Cout, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),
+                      "conv2d_3x3s1")
+            else:
+                ty = [padding - kh for kh in range(KH) for _ in range(KW)]
+                tx = [padding - kw for _ in range(KH) for kw in range(KW)]
+                _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]

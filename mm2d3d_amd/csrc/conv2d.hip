@@ -189,6 +189,134 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 stride-1 (halo tile)
+// The bulk of the branch's FLOPs are 3x3 stride-1 pad-1 convolutions (and their data gradients, which are the same
+// operation with flipped taps and transposed weights).  k_conv_gemm re-fetches the input tile for each of the 9 taps;
+// here a workgroup owns an 8 x 16 output patch, stages the (8+2) x (16+2) input halo of one 64-channel chunk ONCE
+// (LDS-DMA, double-buffered across chunks) and serves all 9 taps from it - the MFMA A fragments are simply read at
+// shifted halo rows.  Only the weight tiles stream per tap.  Global->LDS traffic per FLOP drops ~2-4x.
+struct C3P {
+  const u16* A;  // [B,H,W,Ca]
+  int B, H, W, Ca, lda;
+  u16* O;  // [B,H,W,Cn] bf16
+  int Cn, ldo;
+  const u16* Wp;  // [n][9][Ca]
+  const float* bias;
+  int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
+  int tiles_y, tiles_x;
+};
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_conv3x3(C3P p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int HROWS = 10 * 18;            // halo pixels
+  constexpr int HSZ = 184 * 64;             // elements per halo buffer (rounded up to whole 1-KiB DMA pieces)
+  u16* Hs = smem;                           // [2][HSZ]
+  u16* Bs = smem + 2 * HSZ;                 // [2][BN*64]
+  constexpr int NBI = BN / 32;
+  constexpr int TN = BN / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  int t = blockIdx.x;
+  const int tx0 = (t % p.tiles_x) * 16;
+  t /= p.tiles_x;
+  const int ty0 = (t % p.tiles_y) * 8;
+  const int b = t / p.tiles_y;
+  const int n0 = blockIdx.y * BN;
+  const int nchunk = p.Ca >> 6;
+  const int nsteps = nchunk * 9;
+  const int cc = tid & 7, r0 = tid >> 3;
+
+  auto issue_halo = [&](int c, int buf) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int row = r0 + 32 * i;  // halo pixel index (wave-instruction = 8 consecutive halo pixels)
+      if (row < 184) {
+        const int hy = row / 18, hx = row - hy * 18;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const u16* g = (const u16*)g_zero16;
+        if (row < HROWS && y >= 0 && y < p.H && x >= 0 && x < p.W)
+          g = p.A + ((int64_t)(b * p.H + y) * p.W + x) * p.lda + c * 64 + ((cc ^ ((row >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(Hs + buf * HSZ + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+      }
+    }
+  };
+  auto issue_w = [&](int s, int buf) {
+    const int c = s / 9, tap = s - c * 9;
+#pragma unroll
+    for (int i = 0; i < NBI; i++) {
+      const int row = r0 + 32 * i;
+      const int n = n0 + row;
+      const u16* g = n < p.Cn ? p.Wp + ((int64_t)n * 9 + tap) * p.Ca + c * 64 + ((cc ^ ((row >> 1) & 7)) << 3) : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Bs + buf * BN * 64 + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  const int fr_ = lane & 31, fh = lane >> 5;
+  // halo row of this lane's two A-fragment pixels at tap (0,0): pixel (py, px) = (4*wm + 2*i + (fr_>>4), fr_&15)
+  int hbase[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) hbase[i] = (4 * wm + 2 * i + (fr_ >> 4)) * 18 + (fr_ & 15);
+
+  issue_halo(0, 0);
+  issue_w(0, 0);
+  for (int s = 0; s < nsteps; s++) {
+    const int c = s / 9, tap = s - c * 9;
+    __syncthreads();  // vmcnt(0) + barrier: W(s) and halo(c) landed; everyone finished step s-1
+    if (s + 1 < nsteps) issue_w(s + 1, (s + 1) & 1);
+    if (tap == 0 && c + 1 < nchunk) issue_halo(c + 1, (c + 1) & 1);
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int hoff = p.flip ? (2 - kh) * 18 + (2 - kw) : kh * 18 + kw;
+    const u16* Hb = Hs + (c & 1) * HSZ;
+    const u16* Bb = Bs + (s & 1) * BN * 64;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      bf16x8 af[2], bf[TN];
+      const int ch = kk * 2 + fh;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int row = hbase[i] + hoff;
+        af[i] = *(const bf16x8*)&Hb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int row = wn * (BN / 2) + j * 32 + fr_;
+        bf[j] = *(const bf16x8*)&Bb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int r32 = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
+      const int y = ty0 + 4 * wm + 2 * i + (r32 >> 4), x = tx0 + (r32 & 15);
+      if (y >= p.H || x >= p.W) continue;
+      const int64_t orow = (int64_t)(b * p.H + y) * p.W + x;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + fr_;
+        if (n < p.Cn) p.O[orow * p.ldo + n] = f2bf(acc[i][j][reg] + (p.bias ? p.bias[n] : 0.f));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgP {
   const u16* X;   // [B,Hi,Wi,Ck]
@@ -302,6 +430,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
   auto fx = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
   constexpr int YI = (64 * TN * 2) / (256 * 16);  // DMA instructions per thread for the dY tile (2 or 4)
   constexpr int YC = TN / 8;                      // 16-B chunks per dY row
+  // pixel coordinates of this thread's four X rows, advanced by 64 pixels per step (no divisions in the loop)
+  int xb[4], xy[4], xx[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned m = (unsigned)(mb + ((tid + 256 * i) >> 4));
+    const unsigned t = m / (unsigned)p.Wg;
+    xx[i] = (int)(m - t * (unsigned)p.Wg);
+    xb[i] = (int)(t / (unsigned)p.Hg);
+    xy[i] = (int)(t - (unsigned)xb[i] * (unsigned)p.Hg);
+  }
   auto issue = [&](int64_t t0, int buf) {
 #pragma unroll
     for (int i = 0; i < YI; i++) {
@@ -318,14 +456,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
       const int ch = pc ^ fx(row);
       const u16* g = (const u16*)g_zero16;
       if (m < me && k0 + ch * 8 < p.Ck) {
-        int gx = (int)(m % p.Wg);
-        int64_t t = m / p.Wg;
-        int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
-        int sy = gy * p.sa + ty, sx = gx * p.sa + tx;
-        if (sy >= 0 && sx >= 0 && sy < p.Hi && sx < p.Wi) g = p.X + ((int64_t)(b * p.Hi + sy) * p.Wi + sx) * p.ldx + k0 + (ch << 3);
+        int sy = xy[i] * p.sa + ty, sx = xx[i] * p.sa + tx;
+        if (sy >= 0 && sx >= 0 && sy < p.Hi && sx < p.Wi)
+          g = p.X + ((int64_t)(xb[i] * p.Hi + sy) * p.Wi + sx) * p.ldx + k0 + (ch << 3);
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(Xs + buf * 64 * 128 + (wave * 64 + 256 * i) * 8), 16, 0, 0);
+      xx[i] += 64;  // next step's pixel
+      while (xx[i] >= p.Wg) {
+        xx[i] -= p.Wg;
+        if (++xy[i] == p.Hg) {
+          xy[i] = 0;
+          xb[i]++;
+        }
+      }
     }
   };
 
@@ -385,16 +529,26 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
                                                        float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
                                                        int accumulate) {
-  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int64_t ne = (int64_t)Cn * ntaps * Ck;
-  if (e >= ne) return;
+  // block = 32 consecutive elements x 8 split slices; slices combined in a fixed order (bit-stable)
+  __shared__ float red[8][32];
+  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t ne = (int64_t)Cn * ntaps * Ck;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
   float s = 0.f;
-  for (int i = 0; i < nsplit; i++) s += partial[(int64_t)i * ne + e];
-  int k = (int)(e % Ck);
-  int64_t r = e / Ck;
-  int t = (int)(r % ntaps), n = (int)(r / ntaps);
-  float* d = dW + n * sn + t * st + k * sk;
-  *d = accumulate ? *d + s : s;
+  if (e < ne)
+    for (int i = sl; i < nsplit; i += 8) s += partial[(int64_t)i * ne + e];
+  red[sl][el] = s;
+  __syncthreads();
+  if (sl == 0 && e < ne) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t += red[i][el];
+    int k = (int)(e % Ck);
+    int64_t r = e / Ck;
+    int tp = (int)(r % ntaps), n = (int)(r / ntaps);
+    float* d = dW + n * sn + tp * st + k * sk;
+    *d = accumulate ? *d + t : t;
+  }
 }
 
 // packed bf16 weights: out[((z*N + n)*T + t)*K + k] = bf16(in[z*sz + n*sn + t*st + k*sk])
@@ -473,6 +627,31 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
   return MM_OK;
 }
 
+// 3x3, stride 1, pad 1 convolution (flip = 0) or its data gradient (flip = 1; Wp packed as [ci][tap][co]).  NHWC bf16.
+int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp, const float* bias,
+                    int flip, hipStream_t s) {
+  MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0, "conv2d_3x3s1: bad shape");
+  C3P p;
+  p.A = (const u16*)A; p.B = B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O; p.Cn = Cn; p.ldo = ldo;
+  p.Wp = (const u16*)Wp; p.bias = bias; p.flip = flip;
+  p.tiles_y = (int)mm_cdiv(H, 8); p.tiles_x = (int)mm_cdiv(W, 16);
+  const int64_t nt = (int64_t)B * p.tiles_y * p.tiles_x;
+  if (nt == 0) return MM_OK;
+  static bool once = false;
+  const size_t lds64 = (size_t)(2 * 184 * 64 + 2 * 64 * 64) * 2, lds128 = (size_t)(2 * 184 * 64 + 2 * 128 * 64) * 2;
+  if (!once) {
+    MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
+    MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
+    once = true;
+  }
+  if (Cn <= 64)
+    hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
+  else
+    hipLaunchKernelGGL(k_conv3x3<128>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 128)), dim3(256), lds128, s, p);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
 static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
   const int tn = (Cn % 128 == 0) ? 128 : 64;
   int64_t tiles = (int64_t)mm_cdiv(Cn, tn) * mm_cdiv(Ck, 128) * ntaps;
@@ -519,7 +698,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
       hipLaunchKernelGGL(k_conv_wgrad2<64>, dim3(nsplit, (Cn / 64) * nkt, ntaps), dim3(256), lds, s, p);
     }
   }
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 256)), dim3(256), 0, s, p.partial,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 32)), dim3(256), 0, s, p.partial,
                      M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;
