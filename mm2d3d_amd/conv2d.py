@@ -151,3 +151,48 @@ class ConvTranspose2dFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
         return dx, dw, db
+
+
+class StemConvFn(torch.autograd.Function):
+    """7x7, stride 1, pad 3 convolution on a 3- or 1-channel fp32 NCHW image (backbones.py:23-25), bf16 NHWC output.
+
+    The image is rewritten once as a zero-bordered NHWC8 bf16 buffer.  Viewed with a pixel pitch of 8 elements and 64
+    "channels" (8 neighbouring pixels x 8 channel slots), filter row kh is ONE tap of the generic implicit GEMM:
+    K = 7 taps x 64, of which 7 x 7 x Cin carry non-zero weights.  No gradient w.r.t. the image is produced (it is data).
+    """
+
+    @staticmethod
+    def forward(ctx, img, weight):
+        _lib.require_cuda(img, "img")
+        L = _lib.lib()
+        img = img.float().contiguous()
+        Bn, C, H, W = img.shape
+        Cout, _, KH, KW = weight.shape
+        assert (KH, KW) == (7, 7) and C <= 8 and Cout % 64 == 0
+        Hb, Wb = H + 6, W + 6 + 2  # +2: the 8-pixel window of the last output column stays inside the row
+        xb = torch.empty((Bn, Hb, Wb, 8), dtype=BF16, device=img.device)
+        check(L.mm_stem_prep(ptr(img), Bn, C, H, W, 3, Hb, Wb, ptr(xb), stream()), "stem_prep")
+        w = weight.detach().float()
+        wp = torch.zeros((Cout, 7, 8, 8), dtype=torch.float32, device=img.device)  # [co][kh][kw(8)][ci(8)]
+        wp[:, :, :7, :C] = w.permute(0, 2, 3, 1)
+        Wp = wp.to(BF16).contiguous()
+        y = torch.empty((Bn, Cout, H, W), dtype=BF16, device=img.device, memory_format=CL)
+        # virtual activation: pixel pitch (lda) 8, 64 channels, Wi = Wb - 7 valid window starts; output (y,x) reads rows y..y+6 at x
+        check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, 7, _arr(list(range(7))),
+                               _arr([0] * 7), ptr(Wp), 1, 0, 0, None, stream()), "conv2d_gemm(stem)")
+        ctx.save_for_backward(xb)
+        ctx.dims = (Bn, C, H, W, Cout, Hb, Wb, weight.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        (xb,) = ctx.saved_tensors
+        Bn, C, H, W, Cout, Hb, Wb, wshape = ctx.dims
+        dy = as_nhwc_bf16(dy)
+        dwp = torch.empty((Cout, 7, 64), dtype=torch.float32, device=dy.device)
+        ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, 64, 7)), dy.device)
+        check(L.mm_conv2d_wgrad(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(dy), H, W, Cout, Cout, 1, 7, _arr(list(range(7))), _arr([0] * 7),
+                                ptr(dwp), 7 * 64, 64, 1, 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad(stem)")
+        dw = dwp.view(Cout, 7, 8, 8)[:, :, :7, :C].permute(0, 3, 1, 2).contiguous()
+        return None, dw.view(wshape)

@@ -7,8 +7,7 @@ interchange with the reference (and with torchvision's resnet34 keys).  Activati
 
 Kernels: csrc/conv2d.hip (implicit-GEMM MFMA convolutions), csrc/bn2d.hip (BatchNorm + residual + ReLU),
 csrc/misc2d.hip (concat, max-pool, fused segmentation heads).  GPU tensors always take the HIP path; CPU tensors are
-refused (no CPU fallback).  Still on torch ops (interim, listed in DESIGN.md): the 3-/1-channel 7x7 stem convolutions
-and Dropout's mask generation.
+refused (no CPU fallback).  Still on torch ops (interim, listed in DESIGN.md): Dropout's mask generation.
 """
 from __future__ import annotations
 
@@ -38,9 +37,10 @@ class Conv2d(nn.Conv2d):
                              self.groups) and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] \
                 and self.padding_mode == "zeros":
             return _c2d.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
-        # interim: 7x7 stems (Cin 3 / 1); bf16 NHWC in and out so the rest of the branch stays on the HIP kernels
-        x = _c2d.as_nhwc_bf16(x)
-        return F.conv2d(x, self.weight.to(BF16), None if self.bias is None else self.bias.to(BF16), self.stride, self.padding)
+        if k == (7, 7) and self.stride == (1, 1) and self.padding == (3, 3) and self.in_channels <= 8 and self.bias is None \
+                and self.out_channels % 64 == 0 and self.groups == 1:
+            return _c2d.StemConvFn.apply(x, self.weight)  # the two stems (backbones.py:23-25)
+        raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d: shape not on the hot path: {self}")
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

@@ -72,3 +72,24 @@ def test_conv_transpose2d_fwd_bwd(cin, cout, hw):
     assert _rel(xh.grad, xr.grad) < 1e-2
     assert _rel(wh.grad, wr.grad) < 5e-3
     assert _rel(bh.grad, br.grad) < 5e-3
+
+
+@pytest.mark.parametrize("cin", [3, 1])
+def test_stem_conv7x7_fwd_and_weight_grad(cin):
+    from mm2d3d_amd.conv2d import StemConvFn
+
+    dev = _dev()
+    torch.manual_seed(cin)
+    B, H, W = 2, 32, 48
+    img = torch.rand(B, cin, H, W, device=dev)
+    w = torch.randn(64, cin, 7, 7, device=dev) / (cin * 49) ** 0.5
+    xr = img.bfloat16().float()
+    wr = w.bfloat16().float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 1, 3)
+    wh = w.clone().requires_grad_(True)
+    yh = StemConvFn.apply(img, wh)
+    assert yh.shape == yr.shape and _rel(yh, yr) < 1e-2
+    g = torch.randn_like(yr).bfloat16()
+    yr.backward(g.float())
+    yh.backward(g)
+    assert _rel(wh.grad, wr.grad) < 5e-3
