@@ -525,6 +525,115 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
       }
 }
 
+// Weight gradient of a 3x3 stride-1 pad-1 convolution from halo tiles: a workgroup walks 8x16 pixel patches, stages the
+// dY patch [128 px][64 n] and the X halo [10x18 px][64 k] ONCE per patch and accumulates all 9 taps
+// (9 accumulator tiles of 32x32 per wave; the X operand of tap (kh,kw) is the halo read at rows shifted by kh*18+kw).
+// 9x less staging traffic than one workgroup per tap.  Output tile 64 (n) x 64 (k); grid.y enumerates the tiles.
+struct Wg3P {
+  const u16* X;   // [B,H,W,Ck]
+  const u16* DY;  // [B,H,W,Cn]
+  int B, H, W, Ck, ldx, Cn, ldy;
+  int tiles_y, tiles_x;
+  int patches_per_wg;
+  float* partial;  // [gridDim.x][Cn][9][Ck]
+};
+
+__global__ __launch_bounds__(256, 2) void k_wgrad3x3(Wg3P p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int HSZ = 184 * 64;
+  u16* Ys = smem;                // [2][128*64]  pixel-major dY patch
+  u16* Hs = smem + 2 * 128 * 64; // [2][HSZ]     pixel-major X halo
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int nkt = p.Ck >> 6;
+  const int n0 = (blockIdx.y / nkt) * 64, k0 = (blockIdx.y % nkt) * 64;
+  const int npatch = p.B * p.tiles_y * p.tiles_x;
+  const int pb = blockIdx.x * p.patches_per_wg;
+  const int pe = min(npatch, pb + p.patches_per_wg);
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+  const int cc = tid & 7, r0 = tid >> 3;
+  auto fsw = [](int row) { return ((row >> 1) & 1) << 2; };  // 128-B rows: conflict-free transpose reads (see k_conv_wgrad2)
+
+  auto issue = [&](int patch, int buf) {
+    int t = patch;
+    const int tx0 = (t % p.tiles_x) * 16;
+    t /= p.tiles_x;
+    const int ty0 = (t % p.tiles_y) * 8;
+    const int b = t / p.tiles_y;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // dY patch: row = patch pixel py*16+px
+      const int row = r0 + 32 * i;
+      const int y = ty0 + (row >> 4), x = tx0 + (row & 15);
+      const u16* g = (y < p.H && x < p.W) ? p.DY + ((int64_t)(b * p.H + y) * p.W + x) * p.ldy + n0 + ((cc ^ fsw(row)) << 3)
+                                           : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Ys + buf * 128 * 64 + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {  // X halo: row = hy*18+hx
+      const int row = r0 + 32 * i;
+      if (row < 184) {
+        const int hy = row / 18, hx = row - hy * 18;
+        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const u16* g = (const u16*)g_zero16;
+        if (row < 180 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+          g = p.X + ((int64_t)(b * p.H + y) * p.W + x) * p.ldx + k0 + ((cc ^ fsw(row)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(Hs + buf * HSZ + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+      }
+    }
+  };
+
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  if (pb < pe) issue(pb, 0);
+  int buf = 0;
+  for (int patch = pb; patch < pe; patch++, buf ^= 1) {
+    __syncthreads();
+    if (patch + 1 < pe) issue(patch + 1, buf ^ 1);
+    const u16* Yb = Ys + buf * 128 * 64;
+    const u16* Hb = Hs + buf * HSZ;
+#pragma unroll 1
+    for (int py = 0; py < 8; py++) {  // one patch row = 16 pixels = one MFMA K step
+      // A operand: dY[pixel][n]: rows py*16 + 8*(g>>1) + q (+4), channels wn*32 + 16*(g&1) + 4*pp
+      const int prow = py * 16 + 8 * (g >> 1) + q;
+      const int cA = (wn * 32 + 16 * (g & 1)) >> 3;
+      const int a0o = prow * 64 + (((cA + (pp >> 1)) ^ fsw(prow)) << 3) + 4 * (pp & 1);
+      const int a1o = (prow + 4) * 64 + (((cA + (pp >> 1)) ^ fsw(prow + 4)) << 3) + 4 * (pp & 1);
+      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[a0o]);
+      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[a1o]);
+      s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+      const int cB = (wk * 32 + 16 * (g & 1)) >> 3;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const int kh = t / 3, kw = t - kh * 3;
+        // halo rows of the 16 pixels of patch row py at tap (kh,kw): (py+kh)*18 + kw + px
+        const int hrow = (py + kh) * 18 + kw + 8 * (g >> 1) + q;
+        const int b0o = hrow * 64 + (((cB + (pp >> 1)) ^ fsw(hrow)) << 3) + 4 * (pp & 1);
+        const int b1o = (hrow + 4) * 64 + (((cB + (pp >> 1)) ^ fsw(hrow + 4)) << 3) + 4 * (pp & 1);
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hb[b0o]);
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hb[b1o]);
+        s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+      }
+    }
+  }
+  float* P = p.partial + (int64_t)blockIdx.x * p.Cn * 9 * p.Ck;
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      int k = k0 + wk * 32 + (lane & 31);
+      if (n < p.Cn && k < p.Ck) P[((int64_t)n * 9 + t) * p.Ck + k] = acc[t][reg];
+    }
+}
+
 // dW_torch[idx(n,tap,k)] (+)= sum_splits partial[s][n][tap][k];  out strides (sn, st, sk) express the torch layout
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
                                                        float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
@@ -687,7 +796,13 @@ static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
 
 size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps) {
   int64_t c = wgrad_chunk(M, Cn, Ck, ntaps);
-  return mm_align((size_t)mm_cdiv(M, c) * Cn * ntaps * Ck * sizeof(float)) + 256;
+  size_t a = (size_t)mm_cdiv(M, c) * Cn * ntaps * Ck * sizeof(float);
+  if (ntaps == 9) {  // halo variant: at most ceil(1536 / tiles) + 1 pixel splits
+    size_t nsp = (size_t)mm_cdiv(1536, (int64_t)mm_cdiv(Cn, 64) * mm_cdiv(Ck, 64)) + 1;
+    size_t b = nsp * Cn * 9 * Ck * sizeof(float);
+    if (b > a) a = b;
+  }
+  return mm_align(a) + 256;
 }
 
 // dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k];   base grid = dY pixels (B,Hg,Wg), src = (gy*sa+ty, gx*sa+tx)
@@ -704,6 +819,36 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
     p.tx[i] = (short)tx[i];
   }
   const int64_t M = (int64_t)B * Hg * Wg;
+  bool is3x3 = (ntaps == 9 && sa == 1 && Hi == Hg && Wi == Wg);
+  for (int i = 0; i < 9 && is3x3; i++) is3x3 = (ty[i] == i / 3 - 1) && (tx[i] == i % 3 - 1);
+  if (is3x3 && M > 0) {
+    Wg3P q;
+    q.X = (const u16*)X; q.DY = (const u16*)dY; q.B = B; q.H = Hg; q.W = Wg; q.Ck = Ck; q.ldx = ldx; q.Cn = Cn; q.ldy = ldy;
+    q.tiles_y = (int)mm_cdiv(Hg, 8); q.tiles_x = (int)mm_cdiv(Wg, 16);
+    const int64_t npatch = (int64_t)B * q.tiles_y * q.tiles_x;
+    const int ntile = (Cn / 64) * (Ck / 64);
+    int64_t nwg = mm_cdiv(1536, ntile);  // ~1536 workgroups in total
+    if (nwg > npatch) nwg = npatch;
+    if (nwg < 1) nwg = 1;
+    q.patches_per_wg = (int)mm_cdiv(npatch, nwg);
+    const int nsplit3 = (int)mm_cdiv(npatch, q.patches_per_wg);
+    if ((size_t)nsplit3 * Cn * 9 * Ck * sizeof(float) > ws_bytes) {
+      mm_set_error("conv2d_wgrad(3x3): workspace too small");
+      return MM_ERR_WORKSPACE;
+    }
+    q.partial = (float*)ws;
+    const size_t lds = (size_t)(2 * 128 * 64 + 2 * 184 * 64) * 2;
+    static bool once = false;
+    if (!once) {
+      MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      once = true;
+    }
+    hipLaunchKernelGGL(k_wgrad3x3, dim3(nsplit3, ntile), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * 9 * Ck, 32)), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
+                       dW, sn, st, sk, accumulate);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
   p.mchunk = wgrad_chunk(M, Cn, Ck, ntaps);
   const int nsplit = (int)mm_cdiv(M, p.mchunk);
   if ((size_t)nsplit * Cn * ntaps * Ck * sizeof(float) > ws_bytes) {
