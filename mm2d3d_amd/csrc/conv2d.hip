@@ -787,7 +787,9 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
 static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
   const int tn = (Cn % 128 == 0) ? 128 : 64;
   int64_t tiles = (int64_t)mm_cdiv(Cn, tn) * mm_cdiv(Ck, 128) * ntaps;
-  int64_t want = mm_cdiv(2048, tiles);  // ~2048 workgroups in total
+  int64_t want = mm_cdiv(1536, tiles);  // ~1536 workgroups in total, partial slabs capped at 32 MB
+  const int64_t cap = (int64_t)(32u << 20) / ((int64_t)Cn * ntaps * Ck * 4);
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
   int64_t c = mm_cdiv(mm_cdiv(M, want), 64) * 64;
   if (c < 256) c = 256;
@@ -798,7 +800,7 @@ size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps) {
   int64_t c = wgrad_chunk(M, Cn, Ck, ntaps);
   size_t a = (size_t)mm_cdiv(M, c) * Cn * ntaps * Ck * sizeof(float);
   if (ntaps == 9) {  // halo variant: at most ceil(1536 / tiles) + 1 pixel splits
-    size_t nsp = (size_t)mm_cdiv(1536, (int64_t)mm_cdiv(Cn, 64) * mm_cdiv(Ck, 64)) + 1;
+    size_t nsp = (size_t)mm_cdiv(1024, (int64_t)mm_cdiv(Cn, 64) * mm_cdiv(Ck, 64)) + 1;
     size_t b = nsp * Cn * 9 * Ck * sizeof(float);
     if (b > a) a = b;
   }
@@ -827,7 +829,11 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
     q.tiles_y = (int)mm_cdiv(Hg, 8); q.tiles_x = (int)mm_cdiv(Wg, 16);
     const int64_t npatch = (int64_t)B * q.tiles_y * q.tiles_x;
     const int ntile = (Cn / 64) * (Ck / 64);
-    int64_t nwg = mm_cdiv(1536, ntile);  // ~1536 workgroups in total
+    // pixel splits: enough workgroups to fill the chip (~1024 in total), but the fp32 partial slabs (one per split) are
+    // written and re-read, so layers with big weights / few pixels get few splits (<= 32 MB of partials)
+    int64_t nwg = mm_cdiv(1024, ntile);
+    const int64_t cap = (int64_t)(32u << 20) / ((int64_t)Cn * 9 * Ck * 4);
+    if (nwg > cap) nwg = cap;
     if (nwg > npatch) nwg = npatch;
     if (nwg < 1) nwg = 1;
     q.patches_per_wg = (int)mm_cdiv(npatch, nwg);
