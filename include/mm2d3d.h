@@ -180,7 +180,8 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
                      int ld_y, mm_stream_t stream);
 int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N,
                 int C, const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
-                void* dres, int ld_dr, float* dweight, float* dbias, void* ws, size_t ws_bytes, mm_stream_t stream);
+                void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                mm_stream_t stream);
 
 /* ---------------------------------------------------------------- concat, max-pool, fused heads (csrc/misc2d.hip) */
 int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, int64_t N, int C, mm_stream_t stream);

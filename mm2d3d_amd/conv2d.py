@@ -9,7 +9,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, gradsink
 from ._lib import check, ptr, stream
 
 BF16 = torch.bfloat16
@@ -42,11 +42,12 @@ def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz
     )
 
 
-def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk):
+def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk, accumulate=0):
     L = _lib.lib()
     ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * Hg * Wg, Cn, Ck, len(ty))), X.device)
     check(
-        L.mm_conv2d_wgrad(ptr(X), Bn, Hi, Wi, Ck, Ck, ptr(dY), Hg, Wg, Cn, Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(dW), sn, st, sk, 0,
+        L.mm_conv2d_wgrad(ptr(X), Bn, Hi, Wi, Ck, Ck, ptr(dY), Hg, Wg, Cn, Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(dW), sn, st, sk,
+                          accumulate,
                           ptr(ws), ws.numel(), stream()),
         "conv2d_wgrad",
     )
@@ -81,6 +82,7 @@ class Conv2dFn(torch.autograd.Function):
             _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, bias is not None)
+        ctx.wparam = weight if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]) else None
         return y
 
     @staticmethod
@@ -104,10 +106,14 @@ class Conv2dFn(torch.autograd.Function):
                 tx = [padding - kw for _ in range(KH) for kw in range(KW)]
                 _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]
             tx = [kw - padding for _ in range(KH) for kw in range(KW)]
-            _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T)
+            if ctx.wparam is not None:  # accumulate straight into the optimiser's gradient arena
+                _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam._mm_sink, Cin * T, 1, T, accumulate=1)
+                gradsink.done(ctx.wparam)
+            else:
+                dw = torch.empty_like(w)
+                _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T)
         if has_bias and ctx.needs_input_grad[2]:
             db = dy.float().sum((0, 2, 3))
         return dx, dw, db, None, None

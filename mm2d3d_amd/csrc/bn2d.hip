@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restri
 
 __global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
                                                            float* __restrict__ sums /*[2][C]*/, float* __restrict__ dweight,
-                                                           float* __restrict__ dbias) {
+                                                           float* __restrict__ dbias, int accumulate) {
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 64) {
@@ -145,8 +145,8 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restri
   if (threadIdx.x != 0) return;
   sums[c] = (float)s;
   sums[C + c] = (float)q;
-  if (dweight) dweight[c] = (float)q;
-  if (dbias) dbias[c] = (float)s;
+  if (dweight) dweight[c] = accumulate ? dweight[c] + (float)q : (float)q;
+  if (dbias) dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
 }
 
 // Apply kernels: thread = (row slot, 8-channel group); the per-channel scale/shift live in registers and the thread
@@ -283,7 +283,7 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
 // dx (and dres = relu-masked dy when dres != NULL), dweight, dbias
 int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N, int C,
                 const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
-                float* dweight, float* dbias, void* ws, size_t ws_bytes, hipStream_t s) {
+                float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T, "bn2d: C must be a multiple of 8, <= 2048");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
   if (ws_bytes < need + 2 * C * sizeof(float)) {
@@ -295,7 +295,7 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   int nb = stat_blocks(N, C);
   hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y, relu,
                      N, C, save_mean, save_invstd, partial);
-  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sums, dweight, dbias);
+  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sums, dweight, dbias, accumulate);
   if (N > 0)
     hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy,
                        ld_dy, (const u16*)yout, ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres,

@@ -53,6 +53,8 @@ class GradAllReducer:
                         hi, members = lo, []
                 for p in a["params"]:
                     p.register_post_accumulate_grad_hook(self._hook)
+                    if hasattr(p, "_mm_hooks"):  # gradient sinks fire the same hook by hand (gradsink.py)
+                        p._mm_hooks.append(self._hook)
 
     @property
     def grad_scale(self):

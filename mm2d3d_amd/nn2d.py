@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, gradsink
 from . import conv2d as _c2d
 from ._lib import check, ptr, stream
 
@@ -69,6 +69,10 @@ class _BN2dFn(torch.autograd.Function):
                                       momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
                                       stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats)
+            ctx.sinks = None
+            if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[2]):
+                gradsink.claim(ctx, bias, True)
+                ctx.sinks = (weight, bias)
         else:
             check(L.mm_bn2d_fwd_eval(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps,
                                      1 if relu else 0, ptr(y), C, stream()), "bn2d_fwd_eval")
@@ -86,11 +90,20 @@ class _BN2dFn(torch.autograd.Function):
         N = B * H * W
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
-        dw = torch.empty(C, dtype=F32, device=x.device)
-        db = torch.empty(C, dtype=F32, device=x.device)
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
+        if ctx.sinks is not None:  # dgamma / dbeta accumulate straight into the optimiser's gradient arena
+            wp, bp = ctx.sinks
+            dw = db = None
+            dwt, dbt, acc = wp._mm_sink, bp._mm_sink, 1
+        else:
+            dw = dwt = torch.empty(C, dtype=F32, device=x.device)
+            db = dbt = torch.empty(C, dtype=F32, device=x.device)
+            acc = 0
         check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(y), C, 1 if ctx.relu else 0, N, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
-                            ptr(dx), C, ptr(dres), C, ptr(dw), ptr(db), ptr(ws), ws.numel(), stream()), "bn2d_bwd")
+                            ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
+        if ctx.sinks is not None:
+            gradsink.done(wp)
+            gradsink.done(bp)
         return dx, dres, dw, db, None, None, None, None, None, None
 
 

@@ -48,7 +48,14 @@ class FlatAdamW(optim.Optimizer):
             arena = dict(params=ps, p=flat_p, g=flat_g, m=torch.zeros_like(flat_p), v=torch.zeros_like(flat_p), spans=spans,
                          touched=[False] * len(ps))
             for i, p in enumerate(ps):
-                p.register_post_accumulate_grad_hook(self._make_hook(arena, i))
+                hook = self._make_hook(arena, i)
+                p.register_post_accumulate_grad_hook(hook)
+                # gradient sink (mm2d3d_amd/gradsink.py): backward kernels may accumulate straight into the arena slice and
+                # skip autograd's per-parameter add kernels; the same hooks fire when the last contribution has landed
+                lo, hi = spans[i]
+                p._mm_sink = flat_g[lo:hi].view(p.shape)
+                p._mm_pending = 0
+                p._mm_hooks = [hook]
             self._arenas.append(arena)
 
     @staticmethod
@@ -56,7 +63,9 @@ class FlatAdamW(optim.Optimizer):
         def hook(param):
             arena["touched"][i] = True
             lo, hi = arena["spans"][i]
-            if param.grad is not None and param.grad.data_ptr() != arena["g"].data_ptr() + 4 * lo:
+            if param.grad is None:  # contribution(s) arrived through the gradient sink
+                param.grad = arena["g"][lo:hi].view(param.shape)
+            elif param.grad.data_ptr() != arena["g"].data_ptr() + 4 * lo:
                 # autograd replaced .grad (it was None): fold it back into the arena
                 arena["g"][lo:hi].copy_(param.grad.reshape(-1))
                 param.grad = arena["g"][lo:hi].view(param.shape)
@@ -74,6 +83,7 @@ class FlatAdamW(optim.Optimizer):
             a["g"].zero_()
             a["touched"] = [False] * len(a["params"])
             for (lo, hi), p in zip(a["spans"], a["params"]):
+                p._mm_pending = 0
                 if p.grad is None or p.grad.data_ptr() != a["g"].data_ptr() + 4 * lo:
                     p.grad = a["g"][lo:hi].view(p.shape)
 

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import torch
 
-from .. import _lib
+from .. import _lib, gradsink
 from .._lib import check, ptr, stream
 
 F32 = torch.float32
@@ -51,13 +51,14 @@ def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_
     return out
 
 
-def _dw(x, dout, rb, src, dst, cin, cout):
+def _dw(x, dout, rb, src, dst, cin, cout, sink=None):
+    """dW [K, cin, cout]; with ``sink`` (the parameter's slice of the gradient arena) the kernel accumulates into it."""
     L = _lib.lib()
-    dW = torch.empty((rb.K, cin, cout), dtype=F32, device=x.device)
+    dW = sink if sink is not None else torch.empty((rb.K, cin, cout), dtype=F32, device=x.device)
     ws = _lib.workspace.get(int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), x.device)
     check(
         L.mm_spconv_dw(ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
-                       ptr(dW), 0, ptr(ws), ws.numel(), stream()),
+                       ptr(dW), 0 if sink is None else 1, ptr(ws), ws.numel(), stream()),
         "spconv_dw",
     )
     return dW
@@ -81,6 +82,8 @@ class SparseConvFunction(torch.autograd.Function):
             raise ValueError(mode)
         ctx.save_for_backward(x, w)
         ctx.rb, ctx.mode, ctx.n_in, ctx.wshape = rb, mode, n_in, weight.shape
+        ctx.wparam = weight if (weight.dtype == F32 and weight.is_contiguous()
+                                and gradsink.claim(ctx, weight, ctx.needs_input_grad[1])) else None
         return out
 
     @staticmethod
@@ -98,11 +101,16 @@ class SparseConvFunction(torch.autograd.Function):
             else:
                 dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False))
         if ctx.needs_input_grad[1]:
+            sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
             if mode == "up":
-                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rout, rb.rin, cin, cout))
+                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rout, rb.rin, cin, cout, sink))
             else:
-                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rin, rb.rout, cin, cout))
-            dw = dw.reshape(ctx.wshape)
+                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rin, rb.rout, cin, cout, sink))
+            if sink is not None:
+                gradsink.done(ctx.wparam)
+                dw = None
+            else:
+                dw = dw.reshape(ctx.wshape)
         return dx, dw, None, None, None, None
 
 
@@ -124,6 +132,10 @@ class BatchNormActFunction(torch.autograd.Function):
             )
             ctx.save_for_backward(x, weight, bias, stats)
             ctx.leak = leak
+            ctx.sinks = None
+            if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[1]):
+                gradsink.claim(ctx, bias, True)
+                ctx.sinks = (weight, bias)
         else:
             check(
                 L.mm_bn_fwd_eval(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, leak,
@@ -143,14 +155,23 @@ class BatchNormActFunction(torch.autograd.Function):
         dy = _c(dy.to(F32))
         N, C = x.shape
         dx = torch.empty_like(x)
-        dw = torch.empty(C, dtype=F32, device=x.device) if weight is not None else None
-        db = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
         ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
+        if ctx.sinks is not None:
+            wp, bp = ctx.sinks
+            dw = db = None
+            dwt, dbt, acc = wp._mm_sink, bp._mm_sink, 1
+        else:
+            dw = dwt = torch.empty(C, dtype=F32, device=x.device) if weight is not None else None
+            db = dbt = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
+            acc = 0
         check(
             L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
-                        ptr(dw), ptr(db), 0, ptr(ws), ws.numel(), stream()),
+                        ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
             "bn_bwd",
         )
+        if ctx.sinks is not None:
+            gradsink.done(wp)
+            gradsink.done(bp)
         return dx, dw, db, None, None, None, None, None, None
 
 

@@ -153,3 +153,50 @@ def test_full_step_losses_and_gradients_vs_oracle():
         # test_gpu_conv2d.py / test_gpu_net2d.py; here the composed gradient must point the same way as the fp32 oracle's
         cos = torch.nn.functional.cosine_similarity(p.grad.cpu().flatten().double(), t.flatten().double(), dim=0).item()
         assert cos > 0.6 or t.norm() < 1e-2, (name, cos)  # tiny early-layer gradients are the noisiest in bf16
+
+
+def test_gradient_sinks_equal_autograd_accumulation():
+    """With FlatAdamW installed, weight-gradient kernels accumulate straight into the flat arena (gradsink.py); the arena
+    after backward must equal what plain autograd accumulation produces for the same step."""
+    import copy
+
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = _dev()
+    torch.manual_seed(0)
+    kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+    W = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]
+    n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+    for m in n2.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+    mk = lambda: {"source": make_batch(5, 1, "nuscenes", (48, 64), device=dev), "target": make_batch(6, 1, "nuscenes", (48, 64), device=dev)}
+    loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
+    plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
+    plain.training_step(mk()).backward()
+    opts = {k: Optimizer("adamw", lr=1e-3) for k in ("2d_net", "3d_net")}
+    sunk = TrainModel({"2d_net": n2, "3d_net": n3}, opts, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
+    sunk.configure_optimizers()
+    for o in sunk.optimizers:
+        o.zero_grad()
+    sunk.training_step(mk()).backward()
+    n_sink = 0
+    for (name, p), (_, q) in zip(list(n2.named_parameters()) + list(n3.named_parameters()),
+                                 list(n2b.named_parameters()) + list(n3b.named_parameters())):
+        if q.grad is None:
+            assert p._mm_pending == 0 and float(p._mm_sink.abs().max()) == 0.0, name
+            continue
+        n_sink += hasattr(p, "_mm_sink")
+        assert p._mm_pending == 0, name
+        ref = q.grad.float()
+        assert torch.allclose(p._mm_sink, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max()) + 1e-7), name
+    assert n_sink > 300
+    for o in sunk.optimizers:  # every parameter that received a gradient is marked for the update
+        for a in o._arenas:
+            assert sum(a["touched"]) >= len(a["params"]) - 6
