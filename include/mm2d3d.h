@@ -142,6 +142,9 @@ int mm_lift_gather(const float* seg, int64_t chan_stride, const int64_t* pix_off
                    mm_stream_t stream);
 int mm_lift_scatter(const float* dout, int C, const int64_t* upix_off, const int32_t* csr_off,
                     const int32_t* csr_pts, int64_t n_unique, int64_t chan_stride, float* dseg, mm_stream_t stream);
+/* backward of the lifting without compaction: order = stable argsort of the pixel keys, first[e] marks run starts */
+int mm_lift_scatter_runs(const float* dout, int C, const int64_t* order, const unsigned char* first,
+                         const int64_t* sorted_off, int64_t N, int64_t chan_stride, float* dseg, mm_stream_t stream);
 /* torch.optim.AdamW update over flat fp32 arenas (EXP/train.py:627-636); step counts from 1; g is multiplied by grad_scale */
 int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int64_t step, double grad_scale, mm_stream_t stream);

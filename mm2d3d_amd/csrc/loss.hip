@@ -168,6 +168,25 @@ __global__ __launch_bounds__(T) void k_lift_scatter(const float* __restrict__ do
   dseg[upix_off[u] + c * sc] = s;
 }
 
+// runs of equal pixel keys in the key-sorted point order: the first element of each run sums the run (ascending point
+// order inside a run because the sort is stable) - no compaction, so the host never needs the number of unique pixels
+__global__ __launch_bounds__(T) void k_lift_scatter_runs(const float* __restrict__ dout, int C, const int64_t* __restrict__ order,
+                                                          const unsigned char* __restrict__ first,
+                                                          const int64_t* __restrict__ sorted_off, int64_t N, int64_t sc,
+                                                          float* __restrict__ dseg) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t e = gid / C;
+  int c = (int)(gid - e * C);
+  if (e >= N || !first[e]) return;
+  float s = 0.f;
+  int64_t j = e;
+  do {
+    s += dout[order[j] * C + c];
+    j++;
+  } while (j < N && !first[j]);
+  dseg[sorted_off[e] + c * sc] = s;
+}
+
 // ---- AdamW over flat fp32 arenas (torch.optim.AdamW semantics, amsgrad off; same op order as torch's
 // single-tensor path: p*=1-lr*wd; m.lerp_(g,1-b1); v=b2*v+(1-b2)*g*g; p-=step_size*m/(sqrt(v)/sqrt(bc2)+eps))
 __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -259,6 +278,17 @@ int mm_lift_scatter(const float* dout, int C, const int64_t* upix_off, const int
   if (n_unique == 0) return MM_OK;
   hipLaunchKernelGGL(k_lift_scatter, dim3((unsigned)mm_cdiv(n_unique * C, T)), dim3(T), 0, s, dout, C, upix_off, csr_off, csr_pts,
                      n_unique, chan_stride, dseg);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// same as mm_lift_scatter without compaction: order = stable argsort of the pixel keys, first[e] = 1 at run starts,
+// sorted_off[e] = element offset of channel 0 of the pixel of sorted element e
+int mm_lift_scatter_runs(const float* dout, int C, const int64_t* order, const unsigned char* first, const int64_t* sorted_off,
+                         int64_t N, int64_t chan_stride, float* dseg, hipStream_t s) {
+  if (N == 0) return MM_OK;
+  hipLaunchKernelGGL(k_lift_scatter_runs, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, dout, C, order, first, sorted_off, N,
+                     chan_stride, dseg);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -2,8 +2,9 @@
 
 Reference: ``segm.permute(0,2,3,1)[i][img_indices[i][:,0], img_indices[i][:,1]]`` per sample + ``cat``
 (2d_net/model.py:131-137, 166-173); backward = ``index_put_(accumulate=True)`` (duplicate pixels add up).
-Here one gather kernel serves the whole batch; the backward is a segmented sum over a pixel->points CSR
-prepared once per batch on the host from the (numpy) ``img_indices`` - no float atomics, bit-stable.
+Here one gather kernel serves the whole batch; the backward is a segmented sum over runs of equal pixels in a
+stable key-sorted point order - no float atomics, bit-stable.  The index (one stable sort of the pixel keys) is built
+on the GPU once per batch; the host only concatenates the numpy ``img_indices`` and never needs a device->host sync.
 """
 from __future__ import annotations
 
@@ -20,35 +21,33 @@ class PixelIndex:
     """Batch-level index built from ``img_indices`` (list of numpy int64 [n_i, 2] = (row, col))."""
 
     def __init__(self, img_indices, H, W, device):
-        rows = [np.asarray(ix, dtype=np.int64) for ix in img_indices]
+        rows = [np.asarray(ix, dtype=np.int64).reshape(-1, 2) for ix in img_indices]
         for ix in rows:  # the reference asserts these bounds in the loader (nuscenes_dataloader.py:280-283)
             if len(ix) and (ix.min() < 0 or ix[:, 0].max() >= H or ix[:, 1].max() >= W):
                 raise IndexError("img_indices out of the image bounds")
-        b = np.concatenate([np.full(len(ix), i, np.int64) for i, ix in enumerate(rows)]) if rows else np.zeros(0, np.int64)
+        counts = [len(ix) for ix in rows]
+        self.n = int(sum(counts))
+        self.H, self.W, self.device = H, W, device
         rc = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int64)
-        self.n = len(b)
-        self.H, self.W = H, W
-        self.key = (b * H + rc[:, 0]) * W + rc[:, 1]  # flat pixel id b*H*W + r*W + c
-        order = np.argsort(self.key, kind="stable")   # stable: ascending point order inside a pixel
-        sk = self.key[order]
-        first = np.ones(len(sk), bool)
-        first[1:] = sk[1:] != sk[:-1]
-        self.ukey = sk[first]
-        off = np.flatnonzero(first)
-        self.csr_off = torch.from_numpy(np.concatenate([off, [len(sk)]]).astype(np.int32)).to(device)
-        self.csr_pts = torch.from_numpy(order.astype(np.int32)).to(device)
-        self.device = device
+        rc_d = torch.from_numpy(np.ascontiguousarray(rc)).to(device, non_blocking=True)
+        b = torch.repeat_interleave(torch.arange(len(rows), device=device),
+                                    torch.tensor(counts, device=device), output_size=self.n)
+        self.b, self.r, self.c = b, rc_d[:, 0], rc_d[:, 1]
+        key = (b * H + self.r) * W + self.c                   # flat pixel id b*H*W + r*W + c
+        self.skey, self.order = torch.sort(key, stable=True)  # stable: ascending point order inside a pixel
+        first = torch.ones(self.n, dtype=torch.bool, device=device)
+        if self.n > 1:
+            first[1:] = self.skey[1:] != self.skey[:-1]
+        self.first = first.to(torch.uint8)
         self._cache = {}
 
-    def offsets(self, sb, sy, sx, unique=False):
-        """Element offset of channel 0 of every point's (or unique pixel's) pixel in a [B,C,H,W] map with strides
-        (sb, *, sy, sx) - NCHW and NHWC maps (and channel slices of either) are both served without a copy."""
-        k = (int(sb), int(sy), int(sx), unique)
+    def offsets(self, sb, sy, sx, sorted_order=False):
+        """Element offset of channel 0 of every point's pixel in a [B,C,H,W] map with strides (sb, *, sy, sx); with
+        ``sorted_order`` the offsets follow the key-sorted order (for the backward)."""
+        k = (int(sb), int(sy), int(sx), sorted_order)
         if k not in self._cache:
-            HW = self.H * self.W
-            key = self.ukey if unique else self.key
-            b, r = key // HW, key % HW
-            self._cache[k] = torch.from_numpy(b * int(sb) + (r // self.W) * int(sy) + (r % self.W) * int(sx)).to(self.device)
+            off = self.b * int(sb) + self.r * int(sy) + self.c * int(sx)
+            self._cache[k] = off.index_select(0, self.order).contiguous() if sorted_order else off.contiguous()
         return self._cache[k]
 
 
@@ -74,12 +73,12 @@ class _LiftFn(torch.autograd.Function):
         dout = dout.to(F32).contiguous()
         # gradient map in NHWC (what the fused heads' backward reads coalesced); logical shape stays [B,C,H,W]
         dseg = torch.zeros((B, H, W, C), dtype=F32, device=dout.device).permute(0, 3, 1, 2)
-        upix = index.offsets(dseg.stride(0), dseg.stride(2), dseg.stride(3), unique=True)
-        check(L.mm_lift_scatter(ptr(dout), C, ptr(upix), ptr(index.csr_off), ptr(index.csr_pts), len(index.ukey), dseg.stride(1),
-                                ptr(dseg), stream()), "lift_scatter")
+        soff = index.offsets(dseg.stride(0), dseg.stride(2), dseg.stride(3), sorted_order=True)
+        check(L.mm_lift_scatter_runs(ptr(dout), C, ptr(index.order), ptr(index.first), ptr(soff), index.n, dseg.stride(1), ptr(dseg),
+                                     stream()), "lift_scatter_runs")
         return dseg, None
 
 
 def lift(seg, index: PixelIndex):
-    """seg [B,C,H,W] -> [N_points, C] in the concatenated point order of the batch."""
+    """seg [B,C,H,W] (any strides) -> [N_points, C] in the concatenated point order of the batch."""
     return _LiftFn.apply(seg, index)
