@@ -145,6 +145,9 @@ int mm_lift_scatter(const float* dout, int C, const int64_t* upix_off, const int
 /* backward of the lifting without compaction: order = stable argsort of the pixel keys, first[e] marks run starts */
 int mm_lift_scatter_runs(const float* dout, int C, const int64_t* order, const unsigned char* first,
                          const int64_t* sorted_off, int64_t N, int64_t chan_stride, float* dseg, mm_stream_t stream);
+/* evaluation (EXP/train.py:297-339): confusion matrices [3][C][C] int64 of argmax(2D), argmax(3D), argmax(softmax mean) */
+int mm_eval_confusion(const float* logits2d, int ld2, const float* logits3d, int ld3, const int64_t* labels, int64_t N,
+                      int C, int64_t ignore_index, int64_t* cm, mm_stream_t stream);
 /* torch.optim.AdamW update over flat fp32 arenas (EXP/train.py:627-636); step counts from 1; g is multiplied by grad_scale */
 int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int64_t step, double grad_scale, mm_stream_t stream);

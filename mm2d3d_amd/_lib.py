@@ -52,6 +52,7 @@ _PROTOS = {
     "mm_lift_gather": (i32, [vp, i64, vp, i64, i32, vp, vp]),
     "mm_lift_scatter": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp]),
     "mm_lift_scatter_runs": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp]),
+    "mm_eval_confusion": (i32, [vp, i32, vp, i32, vp, i64, i32, i64, vp, vp]),
     "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp]),
     "mm_conv2d_gemm": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp,
                              vp, i32, i64, i32, vp, vp]),

@@ -187,6 +187,45 @@ __global__ __launch_bounds__(T) void k_lift_scatter_runs(const float* __restrict
   dseg[sorted_off[e] + c * sc] = s;
 }
 
+// ---- evaluation (train.py:297-339): argmax of the 2D logits, of the 3D logits and of the softmax average, three
+// confusion matrices [target][pred] over the rows whose label != ignore.  Integer counts: order independent.
+__global__ __launch_bounds__(T) void k_eval_confusion(const float* __restrict__ l2, int ld2, const float* __restrict__ l3, int ld3,
+                                                       const int64_t* __restrict__ labels, int64_t N, int C, int64_t ignore,
+                                                       unsigned long long* __restrict__ cm /*[3][C][C]*/) {
+  extern __shared__ unsigned int hist[];  // [3][C][C]
+  for (int i = threadIdx.x; i < 3 * C * C; i += T) hist[i] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * T + threadIdx.x; i < N; i += (int64_t)gridDim.x * T) {
+    int64_t y = labels[i];
+    if (y == ignore || y < 0 || y >= C) continue;
+    const float* a = l2 + i * ld2;
+    const float* b = l3 + i * ld3;
+    float ma = a[0], mb = b[0];
+    int ia = 0, ib = 0;
+    for (int c = 1; c < C; c++) {
+      if (a[c] > ma) { ma = a[c]; ia = c; }
+      if (b[c] > mb) { mb = b[c]; ib = c; }
+    }
+    float sa = 0.f, sb = 0.f;
+    for (int c = 0; c < C; c++) {
+      sa += expf(a[c] - ma);
+      sb += expf(b[c] - mb);
+    }
+    float best = -1.f;
+    int ie = 0;
+    for (int c = 0; c < C; c++) {
+      float e = 0.5f * (expf(a[c] - ma) / sa + expf(b[c] - mb) / sb);
+      if (e > best) { best = e; ie = c; }
+    }
+    atomicAdd(&hist[(0 * C + (int)y) * C + ia], 1u);
+    atomicAdd(&hist[(1 * C + (int)y) * C + ib], 1u);
+    atomicAdd(&hist[(2 * C + (int)y) * C + ie], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C * C; i += T)
+    if (hist[i]) atomicAdd(&cm[i], (unsigned long long)hist[i]);
+}
+
 // ---- AdamW over flat fp32 arenas (torch.optim.AdamW semantics, amsgrad off; same op order as torch's
 // single-tensor path: p*=1-lr*wd; m.lerp_(g,1-b1); v=b2*v+(1-b2)*g*g; p-=step_size*m/(sqrt(v)/sqrt(bc2)+eps))
 __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -289,6 +328,19 @@ int mm_lift_scatter_runs(const float* dout, int C, const int64_t* order, const u
   if (N == 0) return MM_OK;
   hipLaunchKernelGGL(k_lift_scatter_runs, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, dout, C, order, first, sorted_off, N,
                      chan_stride, dseg);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// cm int64 [3][C][C] (2D, 3D, softmax-average ensemble), accumulated (caller zeroes it at the start of an epoch)
+int mm_eval_confusion(const float* logits2d, int ld2, const float* logits3d, int ld3, const int64_t* labels, int64_t N, int C,
+                      int64_t ignore_index, int64_t* cm, hipStream_t s) {
+  MM_CHECK_ARG(C > 0 && C <= MAXC, "eval_confusion: bad C");
+  if (N == 0) return MM_OK;
+  int nb = (int)mm_cdiv(N, (int64_t)T * 8);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(k_eval_confusion, dim3(nb), dim3(T), (size_t)3 * C * C * sizeof(unsigned int), s, logits2d, ld2, logits3d, ld3,
+                     labels, N, C, ignore_index, (unsigned long long*)cm);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

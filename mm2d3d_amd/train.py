@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from .ddp import GradAllReducer
 from .losses import Loss, cross_modal_loss
+from .metrics import SegIoU
 
 
 class TrainModel(nn.Module):
@@ -30,6 +31,12 @@ class TrainModel(nn.Module):
         self.reducer = None
         self.global_step = 0
         self.last_logs = {}
+        self.class_names = list(train_kwargs.get("class_names", []))
+        self.num_classes = train_kwargs.get("num_classes", len(self.class_names) or None)
+        self._ious = {}
+        # best_* trackers are part of the checkpoint (train.py:475-489)
+        self.best = {k: 0.0 for k in ("best_source_iou", "best_target_iou", "best_source_iou_3d", "best_target_iou_3d",
+                                      "best_source_iou_avg", "best_target_iou_avg")}
 
     # ------------------------------------------------------------------ Lightning-shaped hooks
     def configure_optimizers(self):
@@ -69,6 +76,67 @@ class TrainModel(nn.Module):
 
     def training_step(self, batch, batch_idx=0):
         return self._generic_step(batch, "train")
+
+    # ------------------------------------------------------------------ validation / test (train.py:297-365, 374-458)
+    def _iou(self, stage, device, num_classes):
+        if stage not in self._ious:
+            self._ious[stage] = SegIoU(num_classes, device)
+        return self._ious[stage]
+
+    @torch.no_grad()
+    def _generic_step_val(self, batch, stage):
+        self.model.eval()
+        p2d, _, _, _ = self(batch, model_name=self.modules_name[0])
+        p3d, _, _ = self(batch, model_name=self.modules_name[1])
+        loss_2d = self.loss("segmentation", pred=p2d["seg_logit"], gt=batch["seg_label"])
+        loss_3d = self.loss("segmentation", pred=p3d["seg_logit"], gt=batch["seg_label"])
+        C = p2d["seg_logit"].shape[1]
+        self._iou(stage, p2d["seg_logit"].device, C).update(p2d["seg_logit"], p3d["seg_logit"], batch["seg_label"])
+        self.last_logs = {f"{stage}/loss_segmentation": loss_2d, f"{stage}/loss_segmentation_3d": loss_3d}
+        return self.last_logs
+
+    def validation_step(self, batch, batch_idx=0, dataloader_idx=0):
+        return self._generic_step_val(batch, "val/target" if dataloader_idx == 0 else "test/target")
+
+    def test_step(self, batch, batch_idx=0):
+        return self._generic_step_val(batch, "test/target")
+
+    def evaluation_end(self, stage):
+        """Epoch end: sync the confusion matrices over ranks, mean IoU of 2D / 3D / ensemble, best-metric tracking."""
+        m = self._ious[stage]
+        m.sync()
+        per_class = m.compute()
+        out = {f"{stage}/iou": per_class["2d"].mean().item(), f"{stage}/iou_3d": per_class["3d"].mean().item(),
+               f"{stage}/iou_avg": per_class["avg"].mean().item()}
+        dom = "source" if stage == "val/source" else "target" if stage == "val/target" else None
+        if dom:
+            for suffix, key in (("", "iou"), ("_3d", "iou_3d"), ("_avg", "iou_avg")):
+                k = f"best_{dom}_iou{suffix}"
+                if out[f"{stage}/{key}"] > self.best[k]:
+                    self.best[k] = out[f"{stage}/{key}"]
+        out["per_class"] = {n: v.tolist() for n, v in per_class.items()}
+        m.reset()
+        self.model.train()
+        return out
+
+    # ------------------------------------------------------------------ checkpoints (run.py:166-182, train.py:475-489)
+    def checkpoint(self):
+        """state_dict keys ``model.<net>.*`` as under the reference's ModuleDict; optimisers as a list (HybridOptim)."""
+        return {"state_dict": {f"model.{k}": v for k, v in self.model.state_dict().items()},
+                "optimizer_states": [o.state_dict() for o in self.optimizers],
+                "lr_schedulers": [s.state_dict() if s is not None else None for s in self.schedulers],
+                "global_step": self.global_step, **self.best}
+
+    def load_checkpoint(self, ckpt):
+        self.model.load_state_dict({k[len("model."):]: v for k, v in ckpt["state_dict"].items()})
+        for o, sd in zip(self.optimizers, ckpt.get("optimizer_states", [])):
+            o.load_state_dict(sd)
+        for s, sd in zip(self.schedulers, ckpt.get("lr_schedulers", [])):
+            if s is not None and sd is not None:
+                s.load_state_dict(sd)
+        self.global_step = ckpt.get("global_step", 0)
+        for k in self.best:
+            self.best[k] = ckpt.get(k, self.best[k])
 
     # ------------------------------------------------------------------ what Lightning's loop does around it
     def fit_step(self, batch):

@@ -200,3 +200,45 @@ def test_gradient_sinks_equal_autograd_accumulation():
     for o in sunk.optimizers:  # every parameter that received a gradient is marked for the update
         for a in o._arenas:
             assert sum(a["touched"]) >= len(a["params"]) - 6
+
+
+def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
+    from mm2d3d_amd.metrics import SegIoU
+
+    dev = _dev()
+    torch.manual_seed(3)
+    N, C = 5000, 6
+    a, b = torch.randn(N, C) * 2, torch.randn(N, C) * 2
+    y = torch.randint(0, C, (N,))
+    y[::7] = -100
+    m = SegIoU(C, dev)
+    m.update(a[:3000].to(dev), b[:3000].to(dev), y[:3000].to(dev))
+    m.update(a[3000:].to(dev), b[3000:].to(dev), y[3000:].to(dev))
+    keep = y != -100
+    ens = (F.softmax(a, 1) + F.softmax(b, 1)) / 2
+    for i, pred in enumerate((a.argmax(1), b.argmax(1), ens.argmax(1))):
+        cm = torch.zeros(C, C, dtype=torch.int64)
+        cm.index_put_((y[keep], pred[keep]), torch.ones(int(keep.sum()), dtype=torch.int64), accumulate=True)
+        assert torch.equal(m.cm[i].cpu(), cm)
+        tp = cm.diag().double()
+        iou = tp / (cm.sum(0) + cm.sum(1) - cm.diag()).double()
+        assert torch.allclose(m.compute()[SegIoU.NAMES[i]].cpu().double(), iou, atol=1e-6)
+    # checkpoint round trip of a tiny trainer (keys follow the reference: model.<net>.*)
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.train import TrainModel
+
+    kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=3)
+    mk = lambda: TrainModel({"2d_net": torch.nn.Linear(2, 2).to(dev), "3d_net": Net3DSeg(6, True, kw).to(dev)},
+                            {k: Optimizer("adamw", lr=1e-3) for k in ("2d_net", "3d_net")}, Loss("cross_entropy"), {})
+    t1, t2 = mk(), mk()
+    t1.configure_optimizers(), t2.configure_optimizers()
+    t1.best["best_target_iou"] = 0.5
+    ck = t1.checkpoint()
+    assert any(k.startswith("model.3d_net.net_3d.layer2.weight") for k in ck["state_dict"])
+    torch.save(ck, tmp_path / "last.ckpt")
+    t2.load_checkpoint(torch.load(tmp_path / "last.ckpt", weights_only=False))
+    for (k1, v1), (k2, v2) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    assert t2.best["best_target_iou"] == 0.5
