@@ -85,6 +85,10 @@ def conv_roofline(tm, batch, dev):
         k[1] += r["e0"].elapsed_time(r["e1"])
         k[2] += 1
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None  # PMC bytes per step, measured offline with rocprofv3 --pmc (profiles/r01/traffic_3d.json) for this workload
+    tpath = os.path.join(ROOT, "profiles", "r01", "traffic_3d.json")
+    if os.path.exists(tpath) and abs(alg_bytes / 17936522196 - 1.0) < 0.02:
+        traffic = json.load(open(tpath))["bytes_per_step"]
     if os.environ.get("MM_BENCH_LAYERS"):
         for r in rec[: len(rec) // 2 if os.environ["MM_BENCH_LAYERS"] == "half" else len(rec)]:
             t = r["e0"].elapsed_time(r["e1"])
@@ -92,7 +96,7 @@ def conv_roofline(tm, batch, dev):
                   f"{r['bytes']/t/1e6:8.1f} GB/s  {2*r['R']*r['cin']*r['cout']/t/1e9:6.1f} TF/s", file=sys.stderr)
     return {
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-        "traffic": None,
+        "traffic": traffic,
         "kernel": "sparse-conv engines: k_gather_gemm<*> + k_csr_reduce (fwd, dX), k_dw_direct<*> + k_dw_reduce (dW)",
         "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
         "by_pass": {k: {"GB/s": round(v[0] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else 0.0, "ms": round(v[1], 3), "calls": v[2]}

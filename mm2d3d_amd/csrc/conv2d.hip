@@ -776,7 +776,7 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
     MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
     once = true;
   }
-  if (Cn <= 64)
+  if (Cn % 128 != 0)  // 64, 192, ...: 64-wide blocks waste no MFMA columns (the halo re-read per block is cheap)
     hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
   else
     hipLaunchKernelGGL(k_conv3x3<128>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 128)), dim3(256), lds128, s, p);
