@@ -32,7 +32,7 @@ NET3D_KW = dict(in_channels=3, m=16, block_reps=1, residual_blocks=False, full_s
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_trainer(dev, total_steps=49047):
+def build_trainer(dev, total_steps=49047, num_classes=6, class_weights=None):
     from mm2d3d_amd.losses import Loss
     from mm2d3d_amd.net2d import Net2DSeg
     from mm2d3d_amd.net3d import Net3DSeg
@@ -40,13 +40,14 @@ def build_trainer(dev, total_steps=49047):
     from mm2d3d_amd.train import TrainModel
 
     torch.manual_seed(42)
-    nets = {"2d_net": Net2DSeg(6, pretrained=True).to(dev), "3d_net": Net3DSeg(6, True, NET3D_KW).to(dev)}
+    nets = {"2d_net": Net2DSeg(num_classes, pretrained=True).to(dev), "3d_net": Net3DSeg(num_classes, True, NET3D_KW).to(dev)}
     opts = {}
     for k in nets:
         o = Optimizer("adamw", lr=0.001)
         o.set_scheduler("one_cycle", max_lr=0.005, total_steps=total_steps)
         opts[k] = o
-    loss = Loss([{"name": "cross_entropy", "weight": 1.0, "target": "segmentation", "args": {"weight": CLASS_WEIGHTS}}])
+    loss = Loss([{"name": "cross_entropy", "weight": 1.0, "target": "segmentation",
+                  "args": {"weight": class_weights if class_weights is not None else CLASS_WEIGHTS}}])
     tm = TrainModel(nets, opts, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
     tm.configure_optimizers()
     return tm
@@ -135,6 +136,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes", type=int, default=8, help="scenes per domain per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
+                    help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,11 +159,15 @@ def main():
 
     from mm2d3d_amd.synthetic import make_batch
 
-    tm = build_trainer(dev)
-    B = a.scenes
+    if a.workload == "c4":
+        shape, ncls, B = "kitti", 10, (a.scenes if a.scenes != 8 else 4)
+        tm = build_trainer(dev, num_classes=10, class_weights=[1.0] * 10)
+    else:
+        shape, ncls, B = "nuscenes", 6, a.scenes
+        tm = build_trainer(dev)
     batch = {
-        "source": make_batch(2, B, "nuscenes", (302, 480), rank=rank, device=dev, augment=True),
-        "target": make_batch(3, B, "nuscenes", (302, 480), rank=rank, device=dev, augment=True),
+        "source": make_batch(2 if a.workload == "c2" else 4, B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True),
+        "target": make_batch(3 if a.workload == "c2" else 5, B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True),
     }
     n_pts = batch["source"]["x"][0].shape[0] + batch["target"]["x"][0].shape[0]
 
@@ -192,7 +199,9 @@ def main():
                                "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
                    "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
     }
-    if rank == 0 and world == 1 and not a.no_extras:
+    if a.workload != "c2":
+        out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
+    if rank == 0 and world == 1 and not a.no_extras and a.workload == "c2":
         print(f"[bench] timed region done: {ms:.2f} ms/step; roofline leg ...", file=sys.stderr, flush=True)
         out["roofline"] = conv_roofline(tm, batch, dev)
         print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
