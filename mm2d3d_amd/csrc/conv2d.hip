@@ -776,7 +776,9 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
     MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
     once = true;
   }
-  if (Cn % 128 != 0)  // 64, 192, ...: 64-wide blocks waste no MFMA columns (the halo re-read per block is cheap)
+  // 64-wide blocks when Cout is not a multiple of 128 (no wasted MFMA columns; the halo re-read per block is cheap)
+  // or when 128-wide blocks would leave most of the 256 CUs without a workgroup (low-resolution layers)
+  if (Cn % 128 != 0 || nt * (Cn / 128) < 256)
     hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
   else
     hipLaunchKernelGGL(k_conv3x3<128>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 128)), dim3(256), lds128, s, p);
