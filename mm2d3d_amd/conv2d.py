@@ -28,9 +28,24 @@ def as_nhwc_bf16(x):
     return x
 
 
-def _pack(w, Z, N, T, K, sz, sn, st, sk):
+PARAM_EPOCH = [0]  # bumped by FlatAdamW.step(): packed bf16 copies of the fp32 master weights are valid for one epoch
+
+
+def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
+    """bf16 kernel-layout copy of a weight.  With ``owner`` (the nn.Parameter) the copy is cached until the weight changes
+    (torch in-place ops bump ``_version``; the fused AdamW kernel bumps PARAM_EPOCH): both forward passes of a step and
+    both backward passes share one pack."""
+    key = None
+    if owner is not None:
+        key = (owner._version, PARAM_EPOCH[0], owner.data_ptr())
+        cache = owner.__dict__.setdefault("_mm_packs", {})
+        hit = cache.get(kind)
+        if hit is not None and hit[0] == key:
+            return hit[1]
     out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
     check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
+    if key is not None:
+        cache[kind] = (key, out)
     return out
 
 
@@ -70,7 +85,7 @@ class Conv2dFn(torch.autograd.Function):
         Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
         w = weight.detach().float().contiguous()
         T = KH * KW
-        Wp = _pack(w, 1, Cout, T, Cin, 0, Cin * T, 1, T)  # [co][t][ci]
+        Wp = _pack(w, 1, Cout, T, Cin, 0, Cin * T, 1, T, weight, "fwd")  # [co][t][ci]
         y = torch.empty((Bn, Cout, Ho, Wo), dtype=BF16, device=x.device, memory_format=CL)
         ty = [kh - padding for kh in range(KH) for _ in range(KW)]
         tx = [kw - padding for _ in range(KH) for kw in range(KW)]
@@ -82,6 +97,7 @@ class Conv2dFn(torch.autograd.Function):
             _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b)
         ctx.save_for_backward(x, w)
         ctx.cfg = (stride, padding, bias is not None)
+        ctx.wowner = weight
         ctx.wparam = weight if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]) else None
         return y
 
@@ -96,7 +112,7 @@ class Conv2dFn(torch.autograd.Function):
         T = KH * KW
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T)  # [ci][t][co]
+            Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T, ctx.wowner, "dgrad")  # [ci][t][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
             if (KH, KW, stride, padding) == (3, 3, 1, 1):
                 check(_lib.lib().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, Cout, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),

@@ -30,19 +30,21 @@ __global__ __launch_bounds__(T) void k_copy_rows(const u16* __restrict__ src, in
   *(uint4*)(dst + r * ld_d + c * 8) = *(const uint4*)(src + r * ld_s + c * 8);
 }
 
-// ---- max-pool 3x3 stride 2 pad 1, NHWC bf16; idx = winning tap (kh*3+kw), first maximum in scan order (torch)
+// ---- max-pool 3x3 stride 2 pad 1, NHWC bf16; idx = winning tap (kh*3+kw), first maximum in scan order (torch).
+// thread = 8 consecutive channels of one pixel (16-B loads/stores, 8-B index vectors)
 __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, int B, int H, int W, int C, u16* __restrict__ y,
                                                     unsigned char* __restrict__ idx, int Ho, int Wo) {
+  const int C8 = C >> 3;
   int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * Ho * Wo * C;
+  int64_t total = (int64_t)B * Ho * Wo * C8;
   if (gid >= total) return;
-  int c = (int)(gid % C);
-  int64_t pix = gid / C;
+  int c8 = (int)(gid % C8);
+  int64_t pix = gid / C8;
   int ox = (int)(pix % Wo);
   int64_t t = pix / Wo;
   int oy = (int)(t % Ho), b = (int)(t / Ho);
-  float best = -INFINITY;
-  int bi = 0;
+  float best[8];
+  unsigned char bi[8];
   bool any = false;
   for (int kh = 0; kh < 3; kh++) {
     int iy = oy * 2 - 1 + kh;
@@ -50,42 +52,65 @@ __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, in
     for (int kw = 0; kw < 3; kw++) {
       int ix = ox * 2 - 1 + kw;
       if (ix < 0 || ix >= W) continue;
-      float v = bf2f(x[((int64_t)(b * H + iy) * W + ix) * C + c]);
-      if (!any || v > best) {
-        best = v;
-        bi = kh * 3 + kw;
-        any = true;
+      uint4 v = *(const uint4*)(x + ((int64_t)(b * H + iy) * W + ix) * C + c8 * 8);
+      unsigned wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        float f = __uint_as_float((i & 1) ? (wv[i >> 1] & 0xFFFF0000u) : (wv[i >> 1] << 16));
+        if (!any || f > best[i]) {
+          best[i] = f;
+          bi[i] = (unsigned char)(kh * 3 + kw);
+        }
       }
+      any = true;
     }
   }
-  y[gid] = f2bf(best);
-  idx[gid] = (unsigned char)bi;
+  unsigned ow[4];
+  unsigned long long iw = 0ull;
+#pragma unroll
+  for (int i = 0; i < 4; i++) ow[i] = (unsigned)f2bf(best[2 * i]) | ((unsigned)f2bf(best[2 * i + 1]) << 16);
+#pragma unroll
+  for (int i = 0; i < 8; i++) iw |= (unsigned long long)bi[i] << (8 * i);
+  *(uint4*)(y + pix * C + c8 * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  *(unsigned long long*)(idx + pix * C + c8 * 8) = iw;
 }
 
 __global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, const unsigned char* __restrict__ idx, int B, int H,
                                                     int W, int C, int Ho, int Wo, u16* __restrict__ dx) {
+  const int C8 = C >> 3;
   int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * H * W * C;
+  int64_t total = (int64_t)B * H * W * C8;
   if (gid >= total) return;
-  int c = (int)(gid % C);
-  int64_t pix = gid / C;
+  int c8 = (int)(gid % C8);
+  int64_t pix = gid / C8;
   int ix = (int)(pix % W);
   int64_t t = pix / W;
   int iy = (int)(t % H), b = (int)(t / H);
-  float s = 0.f;
-  for (int oy = (iy) / 2; oy <= (iy + 1) / 2; oy++) {  // windows with oy*2-1 <= iy <= oy*2+1
-    if (oy < 0 || oy >= Ho) continue;
+  float s[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) s[i] = 0.f;
+  for (int oy = iy / 2; oy <= (iy + 1) / 2; oy++) {  // windows with oy*2-1 <= iy <= oy*2+1
+    if (oy >= Ho) continue;
     int kh = iy - (oy * 2 - 1);
     if (kh < 0 || kh > 2) continue;
-    for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ox++) {
-      if (ox < 0 || ox >= Wo) continue;
+    for (int ox = ix / 2; ox <= (ix + 1) / 2; ox++) {
+      if (ox >= Wo) continue;
       int kw = ix - (ox * 2 - 1);
       if (kw < 0 || kw > 2) continue;
-      int64_t o = ((int64_t)(b * Ho + oy) * Wo + ox) * C + c;
-      if (idx[o] == kh * 3 + kw) s += bf2f(dy[o]);
+      int64_t o = ((int64_t)(b * Ho + oy) * Wo + ox) * C + c8 * 8;
+      unsigned long long iw = *(const unsigned long long*)(idx + o);
+      uint4 v = *(const uint4*)(dy + o);
+      unsigned wv[4] = {v.x, v.y, v.z, v.w};
+      const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (((iw >> (8 * i)) & 0xFFull) == tap) s[i] += __uint_as_float((i & 1) ? (wv[i >> 1] & 0xFFFF0000u) : (wv[i >> 1] << 16));
     }
   }
-  dx[gid] = f2bf(s);
+  unsigned ow[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) ow[i] = (unsigned)f2bf(s[2 * i]) | ((unsigned)f2bf(s[2 * i + 1]) << 16);
+  *(uint4*)(dx + pix * C + c8 * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
 // ---- heads: z[pix][j] = sum_c x[pix][c] * Wj[j][c]   (x NHWC bf16 with row pitch; region h x w of an Hp x Wp map)
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B,
 // dx[pix][c] = sum_j dz[pix][j] * Wj[j][c]  (bf16, zero outside the h x w region), partial dW[j][c] = sum_pix dz*x
 __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w, int C,
                                                  const float* __restrict__ Wj, int NJ, const float* __restrict__ dz,
-                                                 u16* __restrict__ dx, double* __restrict__ partial, int64_t pix_per_block) {
+                                                 u16* __restrict__ dx, float* __restrict__ partial, int64_t pix_per_block) {
   extern __shared__ float sm[];  // [4][NJ][C] reduction buffer
   const int c = threadIdx.x % C, slot = threadIdx.x / C;  // C = 64 -> 4 pixel slots
   const int nslot = T / C;
@@ -187,18 +212,20 @@ __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int H
   for (int j = 0; j < NJ; j++) sm[(slot * NJ + j) * C + c] = acc[j];
   __syncthreads();
   for (int e = threadIdx.x; e < NJ * C; e += T) {
-    double s = 0.0;
-    for (int sl = 0; sl < nslot; sl++) s += (double)sm[sl * NJ * C + e];
+    float s = 0.f;
+    for (int sl = 0; sl < nslot; sl++) s += sm[sl * NJ * C + e];
     partial[(int64_t)blockIdx.x * NJ * C + e] = s;
   }
 }
 
-__global__ void k_sum_dbl_partials(const double* __restrict__ partial, int nblk, int ne, float* __restrict__ out) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= ne) return;
+// one wave per output element: lanes stride over the block partials (fp64), fixed shuffle tree
+__global__ __launch_bounds__(64) void k_sum_partials_f(const float* __restrict__ partial, int nblk, int ne, float* __restrict__ out) {
+  const int e = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nblk; b++) s += partial[(int64_t)b * ne + e];
-  out[e] = (float)s;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += (double)partial[(int64_t)b * ne + e];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
+  if (threadIdx.x == 0) out[e] = (float)s;
 }
 }  // namespace
 
@@ -216,7 +243,8 @@ int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, in
 
 int mm_maxpool3x3s2_fwd(const void* x, int B, int H, int W, int C, void* y, void* idx, hipStream_t s) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  int64_t total = (int64_t)B * Ho * Wo * C;
+  MM_CHECK_ARG(C % 8 == 0, "maxpool: C must be a multiple of 8");
+  int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   if (total == 0) return MM_OK;
   hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)x, B, H, W, C, (u16*)y,
                      (unsigned char*)idx, Ho, Wo);
@@ -226,7 +254,8 @@ int mm_maxpool3x3s2_fwd(const void* x, int B, int H, int W, int C, void* y, void
 
 int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, hipStream_t s) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  int64_t total = (int64_t)B * H * W * C;
+  MM_CHECK_ARG(C % 8 == 0, "maxpool: C must be a multiple of 8");
+  int64_t total = (int64_t)B * H * W * (C / 8);
   if (total == 0) return MM_OK;
   hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)dy, (const unsigned char*)idx, B, H, W,
                      C, Ho, Wo, (u16*)dx);
@@ -236,7 +265,7 @@ int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, in
 
 size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ) {
   size_t z = mm_align((size_t)B * h * w * NJ * sizeof(float));
-  size_t part = mm_align((size_t)2048 * NJ * C * sizeof(double));
+  size_t part = mm_align((size_t)8192 * NJ * C * sizeof(float));
   return z + part + 256;
 }
 
@@ -265,21 +294,21 @@ int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C == 64, "head_bwd: C must be 64");
   size_t zb = mm_align((size_t)B * h * w * NJ * sizeof(float));
   const int64_t total = (int64_t)B * Hp * Wp;
-  int nblk = (int)mm_cdiv(total, 1024);
-  if (nblk > 2048) nblk = 2048;
+  int nblk = (int)mm_cdiv(total, 128);
+  if (nblk > 8192) nblk = 8192;
   if (nblk < 1) nblk = 1;
   const int64_t ppb = mm_cdiv(total, nblk);
-  if (ws_bytes < zb + (size_t)nblk * NJ * C * sizeof(double)) {
+  if (ws_bytes < zb + (size_t)nblk * NJ * C * sizeof(float)) {
     mm_set_error("head_bwd: workspace too small");
     return MM_ERR_WORKSPACE;
   }
   float* dz = (float*)ws;
-  double* partial = (double*)((char*)ws + zb);
+  float* partial = (float*)((char*)ws + zb);
   int64_t npix = (int64_t)B * h * w;
   if (npix) hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, dout, B, h, w, NJ, nullptr, dz);
   hipLaunchKernelGGL(k_head_bwd, dim3(nblk), dim3(T), (size_t)(T / C) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, NJ, dz,
                      (u16*)dx, partial, ppb);
-  hipLaunchKernelGGL(k_sum_dbl_partials, dim3((unsigned)mm_cdiv(NJ * C, 64)), dim3(64), 0, s, partial, nblk, NJ * C, dWj);
+  hipLaunchKernelGGL(k_sum_partials_f, dim3(NJ * C), dim3(64), 0, s, partial, nblk, NJ * C, dWj);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

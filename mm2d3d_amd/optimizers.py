@@ -99,6 +99,9 @@ class FlatAdamW(optim.Optimizer):
             raise RuntimeError("FlatAdamW.step: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
         L = _lib.lib()
         self._step += 1
+        from . import conv2d as _c2d
+
+        _c2d.PARAM_EPOCH[0] += 1  # packed bf16 weight copies are stale after this update
         for group, a in zip(self.param_groups, self._arenas):
             if a is None:
                 continue
