@@ -53,9 +53,9 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
   const int rs = T / CV;  // row slots per block
   const int tid = threadIdx.x;
   const int slot = tid / CV, cv = tid - slot * CV;
-  double a[VEC], b[VEC];
+  float a[VEC], b[VEC];  // per-thread partials cover <= ~100 rows; block / grid combination is fp64
 #pragma unroll
-  for (int i = 0; i < VEC; i++) a[i] = b[i] = 0.0;
+  for (int i = 0; i < VEC; i++) a[i] = b[i] = 0.f;
   float m[VEC], is[VEC], w[VEC], bs[VEC];
   if (MODE == 1 && slot < rs) {
 #pragma unroll
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
-          a[i] += (double)xv[i];
-          b[i] += (double)xv[i] * (double)xv[i];
+          a[i] += xv[i];
+          b[i] = fmaf(xv[i], xv[i], b[i]);
         }
       } else {
         float dv[VEC];
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
           float xh = (xv[i] - m[i]) * is[i];
           float y = xh * w[i] + bs[i];
           float g = y > 0.f ? dv[i] : dv[i] * leak;
-          a[i] += (double)g;
-          b[i] += (double)g * (double)xh;
+          a[i] += g;
+          b[i] = fmaf(g, xh, b[i]);
         }
       }
     }
@@ -97,8 +97,8 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
     __syncthreads();
-    red[tid] = a[i];
-    red[T + tid] = b[i];
+    red[tid] = (double)a[i];
+    red[T + tid] = (double)b[i];
     __syncthreads();
     if (tid < CV) {
       double sa = 0.0, sb = 0.0;
@@ -163,6 +163,8 @@ __global__ __launch_bounds__(64) void k_bn_finalize_bwd(const double* __restrict
   if (dbias) dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
 }
 
+constexpr int APPLY_ROWS = 8;  // rows per thread in the apply kernels (parameters live in registers)
+
 // y = act((x - mean) * invstd * w + b)
 template <int VEC>
 __global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int ld_x, int64_t N, int C,
@@ -171,20 +173,32 @@ __global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int
                                                  const float* __restrict__ bias, float leak, float* __restrict__ y,
                                                  int ld_y) {
   const int CV = C / VEC;
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t r = gid / CV;
-  int cv = (int)(gid - r * CV);
-  if (r >= N) return;
-  float xv[VEC], yv[VEC];
-  ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+  const int rs = T / CV;
+  const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
+  if (slot >= rs) return;
+  float m[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
     int c = cv * VEC + i;
     float is = invstd_is_var ? 1.f / sqrtf(invstd[c] + eps) : invstd[c];
-    float v = (xv[i] - mean[c]) * is * (weight ? weight[c] : 1.f) + (bias ? bias[c] : 0.f);
-    yv[i] = v > 0.f ? v : v * leak;
+    m[i] = mean[c];
+    sc[i] = is * (weight ? weight[c] : 1.f);
+    sh[i] = bias ? bias[c] : 0.f;
   }
-  stv<VEC>(y + r * ld_y + cv * VEC, yv);
+  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+#pragma unroll 4
+  for (int k = 0; k < APPLY_ROWS; k++) {
+    const int64_t r = r0 + (int64_t)k * rs;
+    if (r >= N) break;
+    float xv[VEC], yv[VEC];
+    ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      float v = (xv[i] - m[i]) * sc[i] + sh[i];
+      yv[i] = v > 0.f ? v : v * leak;
+    }
+    stv<VEC>(y + r * ld_y + cv * VEC, yv);
+  }
 }
 
 // dx = w*invstd * (dy' - sum_dy/N - xhat * sum_dy_xhat/N)
@@ -197,29 +211,48 @@ __global__ __launch_bounds__(T) void k_bn_bwd_apply(const float* __restrict__ x,
                                                      const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
                                                      int ld_dx) {
   const int CV = C / VEC;
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t r = gid / CV;
-  int cv = (int)(gid - r * CV);
-  if (r >= N) return;
-  float xv[VEC], dv[VEC], ov[VEC];
-  ldv<VEC>(x + r * ld_x + cv * VEC, xv);
-  ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
+  const int rs = T / CV;
+  const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
+  if (slot >= rs) return;
   const float invN = 1.f / (float)N;
+  float m[VEC], is[VEC], w[VEC], b[VEC], s1[VEC], s2[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
     int c = cv * VEC + i;
-    float w = weight ? weight[c] : 1.f, b = bias ? bias[c] : 0.f;
-    float xh = (xv[i] - mean[c]) * invstd[c];
-    float yy = xh * w + b;
-    float g = yy > 0.f ? dv[i] : dv[i] * leak;
-    ov[i] = w * invstd[c] * (g - sum_dy[c] * invN - xh * sum_dy_xhat[c] * invN);
+    m[i] = mean[c];
+    is[i] = invstd[c];
+    w[i] = weight ? weight[c] : 1.f;
+    b[i] = bias ? bias[c] : 0.f;
+    s1[i] = sum_dy[c] * invN;
+    s2[i] = sum_dy_xhat[c] * invN;
   }
-  stv<VEC>(dx + r * ld_dx + cv * VEC, ov);
+  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+#pragma unroll 4
+  for (int k = 0; k < APPLY_ROWS; k++) {
+    const int64_t r = r0 + (int64_t)k * rs;
+    if (r >= N) break;
+    float xv[VEC], dv[VEC], ov[VEC];
+    ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+    ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
+#pragma unroll
+    for (int i = 0; i < VEC; i++) {
+      float xh = (xv[i] - m[i]) * is[i];
+      float yy = xh * w[i] + b[i];
+      float g = yy > 0.f ? dv[i] : dv[i] * leak;
+      ov[i] = w[i] * is[i] * (g - s1[i] - xh * s2[i]);
+    }
+    stv<VEC>(dx + r * ld_dx + cv * VEC, ov);
+  }
+}
+
+inline unsigned apply_blocks(int64_t N, int C, int VEC) {
+  int rs = T / (C / VEC);
+  return (unsigned)mm_cdiv(N, (int64_t)rs * APPLY_ROWS);
 }
 
 inline int stat_blocks(int64_t N, int C, int VEC) {
   int rs = T / (C / VEC);
-  int64_t nb = mm_cdiv(N, (int64_t)rs * 8);
+  int64_t nb = mm_cdiv(N, (int64_t)rs * 32);
   if (nb < 1) nb = 1;
   if (nb > MAX_PART) nb = MAX_PART;
   return (int)nb;
@@ -252,10 +285,10 @@ int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int C, const float* wei
                      running_mean, running_var, save_mean, save_invstd);
   if (N > 0) {
     if (v4)
-      hipLaunchKernelGGL(k_bn_apply<4>, dim3((unsigned)mm_cdiv(N * (C / 4), T)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
+      hipLaunchKernelGGL(k_bn_apply<4>, dim3(apply_blocks(N, C, 4)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
                          save_invstd, 0, eps, weight, bias, leak, y, ld_y);
     else
-      hipLaunchKernelGGL(k_bn_apply<1>, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
+      hipLaunchKernelGGL(k_bn_apply<1>, dim3(apply_blocks(N, C, 1)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
                          save_invstd, 0, eps, weight, bias, leak, y, ld_y);
   }
   MM_LAUNCH_CHECK();
@@ -269,10 +302,10 @@ int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weig
   if (N == 0) return MM_OK;
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
   if (v4)
-    hipLaunchKernelGGL(k_bn_apply<4>, dim3((unsigned)mm_cdiv(N * (C / 4), T)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
+    hipLaunchKernelGGL(k_bn_apply<4>, dim3(apply_blocks(N, C, 4)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
                        running_var, 1, eps, weight, bias, leak, y, ld_y);
   else
-    hipLaunchKernelGGL(k_bn_apply<1>, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
+    hipLaunchKernelGGL(k_bn_apply<1>, dim3(apply_blocks(N, C, 1)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
                        running_var, 1, eps, weight, bias, leak, y, ld_y);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -304,10 +337,10 @@ int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, i
                      dweight, dbias, accumulate);
   if (N > 0) {
     if (v4)
-      hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3((unsigned)mm_cdiv(N * (C / 4), T)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
+      hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(apply_blocks(N, C, 4)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
                          save_mean, save_invstd, weight, bias, leak, sum_dy, sum_dy_xhat, dx, ld_dx);
     else
-      hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
+      hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(apply_blocks(N, C, 1)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
                          save_mean, save_invstd, weight, bias, leak, sum_dy, sum_dy_xhat, dx, ld_dx);
   }
   MM_LAUNCH_CHECK();
