@@ -207,12 +207,12 @@ struct C3P {
 };
 
 template <int BN>
-__global__ __launch_bounds__(256, 2) void k_conv3x3(C3P p) {
+__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void k_conv3x3(C3P p) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
   constexpr int HROWS = 10 * 18;            // halo pixels
   constexpr int HSZ = 184 * 64;             // elements per halo buffer (rounded up to whole 1-KiB DMA pieces)
-  u16* Hs = smem;                           // [2][HSZ]
-  u16* Bs = smem + 2 * HSZ;                 // [2][BN*64]
+  u16* Hs = smem;                           // [HSZ]        one halo buffer: more resident workgroups hide the DMA latency
+  u16* Bs = smem + HSZ;                     // [2][BN*64]
   constexpr int NBI = BN / 32;
   constexpr int TN = BN / 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -272,12 +272,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3(C3P p) {
   issue_w(0, 0);
   for (int s = 0; s < nsteps; s++) {
     const int c = s / 9, tap = s - c * 9;
+    if (tap == 0 && c > 0) {  // chunk switch: everyone is done with the previous chunk's halo, restage it
+      __syncthreads();
+      issue_halo(c, 0);
+    }
     __syncthreads();  // vmcnt(0) + barrier: W(s) and halo(c) landed; everyone finished step s-1
     if (s + 1 < nsteps) issue_w(s + 1, (s + 1) & 1);
-    if (tap == 0 && c + 1 < nchunk) issue_halo(c + 1, (c + 1) & 1);
     const int kh = tap / 3, kw = tap - kh * 3;
     const int hoff = p.flip ? (2 - kh) * 18 + (2 - kw) : kh * 18 + kw;
-    const u16* Hb = Hs + (c & 1) * HSZ;
+    const u16* Hb = Hs;
     const u16* Bb = Bs + (s & 1) * BN * 64;
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) {
@@ -770,18 +773,14 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
   const int64_t nt = (int64_t)B * p.tiles_y * p.tiles_x;
   if (nt == 0) return MM_OK;
   static bool once = false;
-  const size_t lds64 = (size_t)(2 * 184 * 64 + 2 * 64 * 64) * 2, lds128 = (size_t)(2 * 184 * 64 + 2 * 128 * 64) * 2;
+  const size_t lds64 = (size_t)(184 * 64 + 2 * 64 * 64) * 2;
   if (!once) {
     MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
-    MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128));
     once = true;
   }
-  // 64-wide blocks when Cout is not a multiple of 128 (no wasted MFMA columns; the halo re-read per block is cheap)
-  // or when 128-wide blocks would leave most of the 256 CUs without a workgroup (low-resolution layers)
-  if (Cn % 128 != 0 || nt * (Cn / 128) < 256)
-    hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
-  else
-    hipLaunchKernelGGL(k_conv3x3<128>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 128)), dim3(256), lds128, s, p);
+  // 64-wide output-channel blocks everywhere: 39 KB of LDS per workgroup -> 4 workgroups per CU.  Measured: resident
+  // workgroups (DMA-latency hiding) matter more than the halved B-fragment traffic of 128-wide blocks (tools/bench_conv.py).
+  hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
