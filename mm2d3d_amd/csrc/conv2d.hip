@@ -541,27 +541,30 @@ struct Wg3P {
   float* partial;  // [gridDim.x][Cn][9][Ck]
 };
 
-__global__ __launch_bounds__(256, 2) void k_wgrad3x3(Wg3P p) {
+__global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
+  // blockIdx.z = filter row kh: the workgroup accumulates the three taps (kh, 0..2) -> 48 accumulator registers and
+  // 34 KB of LDS (dY patch 16 KB + the 8 halo rows this kh needs, 18 KB), i.e. 4 workgroups per CU to hide the DMA latency.
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
-  constexpr int HSZ = 184 * 64;
-  u16* Ys = smem;                // [2][128*64]  pixel-major dY patch
-  u16* Hs = smem + 2 * 128 * 64; // [2][HSZ]     pixel-major X halo
+  constexpr int HROW = 8 * 18;              // halo pixels used by one filter row
+  u16* Ys = smem;                           // [128*64]  pixel-major dY patch
+  u16* Hs = smem + 128 * 64;                // [144*64]  pixel-major X halo rows kh .. kh+7
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 1, wk = wave & 1;
   const int nkt = p.Ck >> 6;
   const int n0 = (blockIdx.y / nkt) * 64, k0 = (blockIdx.y % nkt) * 64;
+  const int kh = blockIdx.z;
   const int npatch = p.B * p.tiles_y * p.tiles_x;
   const int pb = blockIdx.x * p.patches_per_wg;
   const int pe = min(npatch, pb + p.patches_per_wg);
-  f32x16 acc[9];
+  f32x16 acc[3];
 #pragma unroll
-  for (int t = 0; t < 9; t++)
+  for (int t = 0; t < 3; t++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
   const int cc = tid & 7, r0 = tid >> 3;
   auto fsw = [](int row) { return ((row >> 1) & 1) << 2; };  // 128-B rows: conflict-free transpose reads (see k_conv_wgrad2)
 
-  auto issue = [&](int patch, int buf) {
+  auto issue = [&](int patch) {
     int t = patch;
     const int tx0 = (t % p.tiles_x) * 16;
     t /= p.tiles_x;
@@ -574,66 +577,60 @@ __global__ __launch_bounds__(256, 2) void k_wgrad3x3(Wg3P p) {
       const u16* g = (y < p.H && x < p.W) ? p.DY + ((int64_t)(b * p.H + y) * p.W + x) * p.ldy + n0 + ((cc ^ fsw(row)) << 3)
                                            : (const u16*)g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(Ys + buf * 128 * 64 + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(Ys + (wave * 8 + 32 * i) * 64), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 6; i++) {  // X halo: row = hy*18+hx
+    for (int i = 0; i < 5; i++) {  // X halo rows: row = hy*18 + hx, hy = 0..7 <-> image row ty0 + hy + kh - 1
       const int row = r0 + 32 * i;
-      if (row < 184) {
+      if (row < HROW) {
         const int hy = row / 18, hx = row - hy * 18;
-        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+        const int y = ty0 + hy + kh - 1, x = tx0 + hx - 1;
         const u16* g = (const u16*)g_zero16;
-        if (row < 180 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+        if (y >= 0 && y < p.H && x >= 0 && x < p.W)
           g = p.X + ((int64_t)(b * p.H + y) * p.W + x) * p.ldx + k0 + ((cc ^ fsw(row)) << 3);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(Hs + buf * HSZ + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(Hs + (wave * 8 + 32 * i) * 64), 16, 0, 0);
       }
     }
   };
 
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   typedef short s16x8 __attribute__((ext_vector_type(8)));
-  if (pb < pe) issue(pb, 0);
-  int buf = 0;
-  for (int patch = pb; patch < pe; patch++, buf ^= 1) {
-    __syncthreads();
-    if (patch + 1 < pe) issue(patch + 1, buf ^ 1);
-    const u16* Yb = Ys + buf * 128 * 64;
-    const u16* Hb = Hs + buf * HSZ;
-#pragma unroll 1
+  for (int patch = pb; patch < pe; patch++) {
+    __syncthreads();  // everyone finished reading the previous patch
+    issue(patch);
+    __syncthreads();  // vmcnt(0) + barrier: patch landed
+#pragma unroll 2
     for (int py = 0; py < 8; py++) {  // one patch row = 16 pixels = one MFMA K step
-      // A operand: dY[pixel][n]: rows py*16 + 8*(g>>1) + q (+4), channels wn*32 + 16*(g&1) + 4*pp
       const int prow = py * 16 + 8 * (g >> 1) + q;
       const int cA = (wn * 32 + 16 * (g & 1)) >> 3;
       const int a0o = prow * 64 + (((cA + (pp >> 1)) ^ fsw(prow)) << 3) + 4 * (pp & 1);
       const int a1o = (prow + 4) * 64 + (((cA + (pp >> 1)) ^ fsw(prow + 4)) << 3) + 4 * (pp & 1);
-      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[a0o]);
-      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[a1o]);
+      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[a0o]);
+      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[a1o]);
       s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
       const bf16x8 af = __builtin_bit_cast(bf16x8, av);
       const int cB = (wk * 32 + 16 * (g & 1)) >> 3;
 #pragma unroll
-      for (int t = 0; t < 9; t++) {
-        const int kh = t / 3, kw = t - kh * 3;
-        // halo rows of the 16 pixels of patch row py at tap (kh,kw): (py+kh)*18 + kw + px
-        const int hrow = (py + kh) * 18 + kw + 8 * (g >> 1) + q;
+      for (int kw = 0; kw < 3; kw++) {
+        const int hrow = py * 18 + kw + 8 * (g >> 1) + q;  // halo rows of the 16 pixels of patch row py at tap (kh,kw)
         const int b0o = hrow * 64 + (((cB + (pp >> 1)) ^ fsw(hrow)) << 3) + 4 * (pp & 1);
         const int b1o = (hrow + 4) * 64 + (((cB + (pp >> 1)) ^ fsw(hrow + 4)) << 3) + 4 * (pp & 1);
-        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hb[b0o]);
-        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hb[b1o]);
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hs[b0o]);
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hs[b1o]);
         s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+        acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[kw], 0, 0, 0);
       }
     }
   }
   float* P = p.partial + (int64_t)blockIdx.x * p.Cn * 9 * p.Ck;
 #pragma unroll
-  for (int t = 0; t < 9; t++)
+  for (int kw = 0; kw < 3; kw++)
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
       int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
       int k = k0 + wk * 32 + (lane & 31);
-      if (n < p.Cn && k < p.Ck) P[((int64_t)n * 9 + t) * p.Ck + k] = acc[t][reg];
+      if (n < p.Cn && k < p.Ck) P[((int64_t)n * 9 + kh * 3 + kw) * p.Ck + k] = acc[kw][reg];
     }
 }
 
@@ -844,13 +841,13 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
       return MM_ERR_WORKSPACE;
     }
     q.partial = (float*)ws;
-    const size_t lds = (size_t)(2 * 128 * 64 + 2 * 184 * 64) * 2;
+    const size_t lds = (size_t)(128 * 64 + 160 * 64) * 2;
     static bool once = false;
     if (!once) {
       MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       once = true;
     }
-    hipLaunchKernelGGL(k_wgrad3x3, dim3(nsplit3, ntile), dim3(256), lds, s, q);
+    hipLaunchKernelGGL(k_wgrad3x3, dim3(nsplit3, ntile, 3), dim3(256), lds, s, q);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * 9 * Ck, 32)), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
                        dW, sn, st, sk, accumulate);
     MM_LAUNCH_CHECK();
