@@ -12,6 +12,8 @@
 //                      slabs per block + ordered reduce (deterministic).
 // Arithmetic is exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain (no reduced precision).
 // Generic VALU kernels cover channel counts that are not multiples of 16 (the 3-channel stem).
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -121,6 +123,87 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ i
       }
     }
   }
+}
+
+// Small rulebooks (coarse levels): staging W[k] per workgroup costs more than the rows it multiplies.  Here every wave owns
+// one 16-rule group and reads the packed fragments straight from L2 (1 KiB coalesced per wave-instruction): no LDS, no
+// barrier, one group per wave -> thousands of independent waves even at a few thousand rules.
+template <int NCB>
+__global__ __launch_bounds__(256) void k_gather_gemm_direct(const float* __restrict__ in, int ld_in,
+                                                             const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                             float* __restrict__ out, int ld_out, const float* __restrict__ Wf,
+                                                             int ncb_tot, int K, int Cin, KSeg seg) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int g = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * 64 + wave * 16;
+  const int r_end = seg.rule_off[k + 1];
+  if (g >= r_end) return;
+  const int cb0 = blockIdx.y * NCB;
+  const int nq = Cin >> 4;
+  const int r = g + rl;
+  const bool valid = r < r_end;
+  const int sidx = valid ? src[r] : 0;
+  const float* row = in + (int64_t)sidx * ld_in + sl * 4;
+  const f32x4* Wk = (const f32x4*)Wf + ((int64_t)k * nq * ncb_tot + cb0) * 64 + lane;
+  f32x4 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < nq; q++) {
+    f32x4 x = valid ? *(const f32x4*)(row + q * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 w[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) w[cb] = Wk[((int64_t)q * ncb_tot + cb) * 64];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].x, x.x, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].y, x.y, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].z, x.z, acc[cb], 0, 0, 0);
+      acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb].w, x.w, acc[cb], 0, 0, 0);
+    }
+  }
+  if (valid) {
+    const int64_t orow = dst ? (int64_t)dst[r] : (int64_t)r;
+    float* o = out + orow * ld_out + cb0 * 16 + sl * 4;
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) *(f32x4*)(o + cb * 16) = acc[cb];
+  }
+}
+
+// Narrow inputs (the 3-channel stem, Cin <= 4): output-stationary, thread = one output row with all Cout (<= 32)
+// accumulators; the rules of the row come from the CSR in ascending k; W (K*Cin*Cout floats) sits in LDS.
+__global__ __launch_bounds__(256) void k_rows_narrow(const float* __restrict__ in, int ld_in, const int32_t* __restrict__ src,
+                                                      KSeg seg, int K, const int32_t* __restrict__ csr_off,
+                                                      const int32_t* __restrict__ csr_pos, int64_t n_out, float* __restrict__ out,
+                                                      int ld_out, const float* __restrict__ W, int64_t w_kstride, int s_ci, int s_co,
+                                                      int kflip, int Cin, int Cout) {
+  extern __shared__ float wsm[];  // [K][Cin][Cout]
+  for (int e = threadIdx.x; e < K * Cin * Cout; e += 256) {
+    int co = e % Cout, t = e / Cout, ci = t % Cin, k = t / Cin;
+    wsm[e] = W[(int64_t)(kflip ? K - 1 - k : k) * w_kstride + (int64_t)ci * s_ci + (int64_t)co * s_co];
+  }
+  __syncthreads();
+  int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_out) return;
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; c++) acc[c] = 0.f;
+  for (int e = csr_off[row]; e < csr_off[row + 1]; e++) {
+    const int pos = csr_pos[e];
+    int k = 0;
+    while (k + 1 < K && pos >= seg.rule_off[k + 1]) k++;
+    const float* x = in + (int64_t)src[pos] * ld_in;
+    for (int ci = 0; ci < Cin; ci++) {
+      const float xv = x[ci];
+      const float* wr = wsm + (k * Cin + ci) * Cout;
+#pragma unroll
+      for (int c = 0; c < 32; c++)
+        if (c < Cout) acc[c] = fmaf(xv, wr[c], acc[c]);
+    }
+  }
+  float* o = out + row * ld_out;
+#pragma unroll
+  for (int c = 0; c < 32; c++)
+    if (c < Cout) o[c] = acc[c];
 }
 
 // ------------------------------------------------------------------------------------------------ engine R
@@ -400,6 +483,14 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     MM_LAUNCH_CHECK();
     return MM_OK;
   }
+  if (!unique_dst && Cin <= 4 && Cout <= 32 && (size_t)K * Cin * Cout * 4 <= 48 * 1024 && !getenv("MM_NO_NARROW")) {  // the stem: no tmp, one pass
+    KSeg sg;
+    make_seg(offsets_host, K, TR, &sg);
+    hipLaunchKernelGGL(k_rows_narrow, dim3((unsigned)mm_cdiv(n_out, 256)), dim3(256), (size_t)K * Cin * Cout * 4, s, in, ld_in, src, sg, K,
+                       csr_off, csr_pos, n_out, out, ld_out, W, w_kstride, s_ci, s_co, kflip, Cin, Cout);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
   if (ws_bytes < need) {
     mm_set_error("spconv_apply: workspace too small (%zu < %zu)", ws_bytes, need);
     return MM_ERR_WORKSPACE;
@@ -422,9 +513,21 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     ld_t = Cout;
     d = nullptr;
   }
-  if (nb > 0) {
+  const bool e2 = edge || (!unique_dst && (Cout % 4 != 0));
+  if (!e2 && R > 0 && R < 200000 && ncb <= 8 && !getenv("MM_NO_DIRECT")) {  // coarse levels: direct-from-L2 weights, one 16-rule group per wave
+    KSeg sg;
+    const int nbd = make_seg(offsets_host, K, 64, &sg);
+    switch (ncb) {
+#define DCASE(N)                                                                                                         \
+  case N:                                                                                                                \
+    hipLaunchKernelGGL(k_gather_gemm_direct<N>, dim3(nbd, 1), dim3(256), 0, s, in, ld_in, src, d, tgt, ld_t, Wf, ncb, K, Cin, sg); \
+    break;
+      DCASE(1) DCASE(2) DCASE(3) DCASE(4) DCASE(5) DCASE(6) DCASE(7) DCASE(8)
+#undef DCASE
+    }
+    MM_LAUNCH_CHECK();
+  } else if (nb > 0) {
     int rc = MM_OK;
-    const bool e2 = edge || (!unique_dst && (Cout % 4 != 0));
     switch (ncb / nchunk) {
 #define CASE(N)                                                                                                          \
   case N:                                                                                                                \
