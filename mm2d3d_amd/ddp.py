@@ -90,12 +90,25 @@ class GradAllReducer:
             b.pending, b.launched, b.work = b.n_params, False, None
 
     def broadcast_buffers(self, modules, src=0):
-        """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win."""
+        """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a
+        dtype travel in ONE coalesced broadcast (≈0.15 MB), as DDP does."""
         if self.world == 1:
             return
+        by_dtype = {}
         for m in modules:
             for buf in m.buffers():
-                dist.broadcast(buf, src=src, group=self.group)
+                by_dtype.setdefault(buf.dtype, []).append(buf)
+        pg = self.group if self.group is not None else dist.group.WORLD
+        for bufs in by_dtype.values():
+            if hasattr(dist, "_broadcast_coalesced"):
+                dist._broadcast_coalesced(pg, bufs, 256 << 20, src)
+            else:  # pragma: no cover
+                flat = torch.cat([b.reshape(-1) for b in bufs])
+                dist.broadcast(flat, src=src, group=self.group)
+                off = 0
+                for b in bufs:
+                    b.copy_(flat[off : off + b.numel()].view_as(b))
+                    off += b.numel()
 
 
 def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):

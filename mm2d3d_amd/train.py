@@ -26,6 +26,7 @@ class TrainModel(nn.Module):
         self.loss = loss
         self.lambda_xm_src = train_kwargs.get("lambda_xm_src", 1.0)
         self.lambda_xm_trg = train_kwargs.get("lambda_xm_trg", 0.1)
+        self.broadcast_buffers = train_kwargs.get("broadcast_buffers", True)  # torch DDP default (run.py:264-268)
         self._opt_factories = optimizer or {}
         self.optimizers, self.schedulers = [], []
         self.reducer = None
@@ -144,6 +145,8 @@ class TrainModel(nn.Module):
             self.configure_optimizers()
         for o in self.optimizers:
             o.zero_grad()
+        if self.broadcast_buffers and self.reducer.world > 1:
+            self.reducer.broadcast_buffers(self.model.values())  # DDP syncs module buffers from rank 0 before each forward
         loss = self.training_step(batch, self.global_step)
         loss.backward()
         self.reducer.finish()

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build artefact (git-ignored): compile it once if this checkout has not built it yet
+    from mm2d3d_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
 
 
 def pytest_collection_modifyitems(config, items):
