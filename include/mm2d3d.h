@@ -178,9 +178,9 @@ int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K,
 /* ---------------------------------------------------------------- BatchNorm2d (+residual) (+ReLU), NHWC bf16 (csrc/bn2d.hip) */
 size_t mm_bn2d_ws_bytes(int C);
 int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
-                      const float* bias, float* running_mean, float* running_var, float eps, float momentum, int relu,
-                      void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
-                      mm_stream_t stream);
+                      const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                      float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
+                      size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);

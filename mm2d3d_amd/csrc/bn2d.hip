@@ -109,8 +109,9 @@ __device__ inline double wave_sum(double v) {
 __global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C, float eps,
                                                            float momentum, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ save_mean,
-                                                           float* __restrict__ save_invstd) {
+                                                           float* __restrict__ save_invstd, int64_t* __restrict__ num_batches) {
   const int c = blockIdx.x;
+  if (c == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;  // nn.BatchNorm2d.num_batches_tracked
   double s = 0.0, q = 0.0;
   for (int b = threadIdx.x; b < nblk; b += 64) {
     s += partial[((int64_t)b * 2 + 0) * C + c];
@@ -250,8 +251,8 @@ size_t mm_bn2d_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * size
 
 // y = act(BN_train(x) + res); x,res,y NHWC bf16 [N rows, C]; save_* fp32 [C]; momentum = torch's (0.1)
 int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
-                      float* running_mean, float* running_var, float eps, float momentum, int relu, void* y, int ld_y,
-                      float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps, float momentum, int relu,
+                      void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_y % 8 == 0, "bn2d: C must be a multiple of 8, <= 2048");
   if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
     mm_set_error("bn2d: workspace too small");
@@ -262,7 +263,7 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
   hipLaunchKernelGGL(k_bn2d_reduce<0>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr, nullptr,
                      partial);
   hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb, N, C, eps, momentum, running_mean, running_var,
-                     save_mean, save_invstd);
+                     save_mean, save_invstd, num_batches_tracked);
   if (N > 0)
     hipLaunchKernelGGL(k_bn2d_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r,
                        N, C, save_mean, save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y);

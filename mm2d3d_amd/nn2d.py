@@ -54,7 +54,7 @@ class ConvTranspose2d(nn.ConvTranspose2d):
 
 class _BN2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None):
         L = _lib.lib()
         x = _c2d.as_nhwc_bf16(x)
         B, C, H, W = x.shape
@@ -65,8 +65,8 @@ class _BN2dFn(torch.autograd.Function):
         if training:
             stats = torch.empty((2, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
-            check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps,
-                                      momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
+            check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                      ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
                                       stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats)
             ctx.sinks = None
@@ -104,7 +104,7 @@ class _BN2dFn(torch.autograd.Function):
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
-        return dx, dres, dw, db, None, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -117,11 +117,10 @@ class BatchNorm2d(nn.BatchNorm2d):
 
     def forward(self, x, residual=None):
         _need_gpu(x, "BatchNorm2d")
-        if self.training and self.track_running_stats and self.num_batches_tracked is not None:
-            self.num_batches_tracked.add_(1)
         use_batch = self.training or not self.track_running_stats
+        nbt = self.num_batches_tracked if (self.training and self.track_running_stats) else None  # incremented in the kernel
         return _BN2dFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, use_batch, float(self.eps),
-                             float(self.momentum if self.momentum is not None else 0.1), bool(self.relu))
+                             float(self.momentum if self.momentum is not None else 0.1), bool(self.relu), nbt)
 
 
 class FusedAway(nn.Module):

@@ -94,3 +94,38 @@ if __name__ == "__main__":
     loss_cases()
     optimizer_cases()
     print("golden fixtures written to", HERE)
+
+
+def wiring_case():
+    """The reference's OWN composition (3d_net/scn_unet.py: UNet recursion, channel plan, join order) executed over the
+    oracle's primitives registered as ``sparseconvnet``: pins layer order / state_dict naming / return value of the
+    composition against the reference's source.  Arithmetic inside the primitives is pinned by test_oracle_dense.py."""
+    import importlib.util
+
+    from oracle import scn_ref
+
+    sys.modules["sparseconvnet"] = scn_ref
+    spec = importlib.util.spec_from_file_location(
+        "ref_scn_unet", "/root/reference/experiments_USA_SING/rgbd_rgbxyz_sigmoid_for_rgb/3d_net/scn_unet.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for tag, kw in (("vgg", dict(residual_blocks=False)), ("res", dict(residual_blocks=True))):
+        torch.manual_seed(11)
+        net = mod.UNetSCN(in_channels=3, m=4, block_reps=1, full_scale=64, num_planes=4, **kw)
+        g = np.random.default_rng(5)
+        coords = np.concatenate([g.integers(0, 64, (300, 3)), g.integers(0, 2, (300, 1))], 1).astype(np.int64)
+        coords = np.concatenate([coords, coords[:40]], 0)  # duplicates
+        feats = g.standard_normal((len(coords), 3)).astype(np.float32)
+        net.train()
+        y = net([torch.from_numpy(coords), torch.from_numpy(feats)])
+        out[f"{tag}/coords"], out[f"{tag}/feats"], out[f"{tag}/out"] = coords, feats, y.detach().numpy()
+        for k, v in net.state_dict().items():
+            out[f"{tag}/sd/{k}"] = v.numpy()  # AFTER the forward: running stats included
+    np.savez_compressed(os.path.join(HERE, "wiring_unet.npz"), **out)
+    del sys.modules["sparseconvnet"]
+
+
+if __name__ == "__main__":
+    wiring_case()
+    print("wiring fixture written")

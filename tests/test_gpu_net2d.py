@@ -49,6 +49,7 @@ def test_bn2d_train_eval_backward(C, relu, with_res):
         yr = F.relu(yr)
     assert _rel(yh, yr) < 1e-2
     assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-4) and torch.allclose(bn.running_var, ref.running_var, atol=1e-3)
+    assert int(bn.num_batches_tracked) == 1  # incremented inside the finalize kernel
     g = torch.randn_like(yr).bfloat16()
     # reference gradient with the bf16-rounded forward output deciding the ReLU mask, as the kernel does
     yr.backward(g.float())
