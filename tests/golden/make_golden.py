@@ -126,6 +126,125 @@ def wiring_case():
     del sys.modules["sparseconvnet"]
 
 
+def _torchvision_standin():
+    """torchvision is absent from this image: a minimal stand-in (the published ResNet34 topology over plain torch.nn,
+    torchvision's attribute / state_dict names) registered in sys.modules IN THIS CONTAINER ONLY so that the reference's
+    2d_net imports unchanged.  The stand-in's arithmetic is torch CPU's."""
+    import types
+
+    import torch.nn as nn
+
+    class BasicBlock(nn.Module):
+        def __init__(self, inpl, planes, stride, down, norm):
+            super().__init__()
+            self.conv1 = nn.Conv2d(inpl, planes, 3, stride, 1, bias=False)
+            self.bn1 = norm(planes)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.bn2 = norm(planes)
+            self.downsample = down
+
+        def forward(self, x):
+            idt = x if self.downsample is None else self.downsample(x)
+            y = self.relu(self.bn1(self.conv1(x)))
+            return self.relu(self.bn2(self.conv2(y)) + idt)
+
+    class ResNet34(nn.Module):
+        def __init__(self, norm):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+            self.bn1 = norm(64)
+            self.relu = nn.ReLU(inplace=True)
+            self.maxpool = nn.MaxPool2d(3, 2, 1)
+            inpl = 64
+            for li, (planes, n, stride) in enumerate(((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)), 1):
+                blocks = []
+                for b in range(n):
+                    s = stride if b == 0 else 1
+                    down = None
+                    if s != 1 or inpl != planes:
+                        down = nn.Sequential(nn.Conv2d(inpl, planes, 1, s, bias=False), norm(planes))
+                    blocks.append(BasicBlock(inpl, planes, s, down, norm))
+                    inpl = planes
+                setattr(self, f"layer{li}", nn.Sequential(*blocks))
+
+    class FrozenBatchNorm2d(nn.Module):
+        def __init__(self, n, eps=1e-5):
+            super().__init__()
+            self.eps = eps
+            for k, v in (("weight", torch.ones(n)), ("bias", torch.zeros(n)), ("running_mean", torch.zeros(n)),
+                         ("running_var", torch.ones(n))):
+                self.register_buffer(k, v)
+
+        def forward(self, x):
+            sc = self.weight * (self.running_var + self.eps).rsqrt()
+            return x * sc.view(1, -1, 1, 1) + (self.bias - self.running_mean * sc).view(1, -1, 1, 1)
+
+    def resnet34(pretrained=False, norm_layer=None, **_):
+        return ResNet34(norm_layer or nn.BatchNorm2d)  # no network: never pretrained
+
+    tv = types.ModuleType("torchvision")
+    tv.__version__ = "0.0+standin"
+    tv.ops = types.ModuleType("torchvision.ops")
+    tv.ops.FrozenBatchNorm2d = FrozenBatchNorm2d
+    tv.models = types.ModuleType("torchvision.models")
+    tv.models.resnet = types.ModuleType("torchvision.models.resnet")
+    tv.models.resnet.resnet34 = resnet34
+    return {"torchvision": tv, "torchvision.ops": tv.ops, "torchvision.models": tv.models,
+            "torchvision.models.resnet": tv.models.resnet}
+
+
+def wiring_case_2d():
+    """The reference's OWN 2d_net (model.py + backbones.py, imported unchanged by bare name as train.py:522 does) on a
+    tiny padded batch in eval mode, weights regenerated from key names (tests/golden/fill.py).  Pins the decoder wiring
+    (concat order [depth, up, rgb], stage channel plan, pad-to-16/crop, heads, per-sample lifting, return tuple)."""
+    import importlib
+
+    from fill import fill_state_dict
+
+    mods = _torchvision_standin()
+    sys.modules.update(mods)
+    exp = "/root/reference/experiments_USA_SING/rgbd_rgbxyz_sigmoid_for_rgb"
+    sys.path.insert(0, exp)
+    try:
+        ref = importlib.import_module("2d_net")
+        out = {}
+        for tag, frozen in (("bn", False), ("frozen", True)):
+            net = ref.Model(num_classes=6, pretrained=False, frozen_batch_norm=frozen)
+            net.load_state_dict(fill_state_dict(net.state_dict()))
+            net.eval()
+            g = np.random.default_rng(21)
+            B, H, W = 2, 40, 52
+            img = g.random((B, 3, H, W), dtype=np.float32)
+            depth = np.zeros((B, 1, H, W), np.float32)
+            idx = []
+            for b in range(B):
+                n = 57 + 13 * b
+                ix = np.stack([g.integers(0, H, n), g.integers(0, W, n)], 1).astype(np.int64)
+                depth[b, 0, ix[:, 0], ix[:, 1]] = g.uniform(1, 50, n).astype(np.float32)
+                idx.append(ix)
+            with torch.no_grad():
+                preds, segm_last, _, aux = net({"img": torch.from_numpy(img), "depth": torch.from_numpy(depth),
+                                                "img_indices": idx})
+            out[f"{tag}/img"], out[f"{tag}/depth"] = img, depth
+            for b in range(B):
+                out[f"{tag}/idx{b}"] = idx[b]
+            out[f"{tag}/seg_logit"] = preds["seg_logit"].numpy()
+            out[f"{tag}/seg_logit_avg"] = aux["seg_logit_avg"].numpy()
+            if not frozen:  # dense maps once (fixture size)
+                out[f"{tag}/seg_logit_2d"] = preds["seg_logit_2d"].numpy()
+                out[f"{tag}/segm_last"] = segm_last.numpy()
+                out[f"{tag}/seg_logit_avg_2d"] = aux["seg_logit_avg_2d"].numpy()
+            out[f"{tag}/keys"] = np.array(sorted(net.state_dict().keys()))
+            out[f"{tag}/shapes"] = np.array([str(tuple(net.state_dict()[k].shape)) for k in sorted(net.state_dict())])
+        np.savez_compressed(os.path.join(HERE, "wiring_net2d.npz"), **out)
+    finally:
+        sys.path.remove(exp)
+        for k in mods:
+            sys.modules.pop(k, None)
+
+
 if __name__ == "__main__":
     wiring_case()
-    print("wiring fixture written")
+    wiring_case_2d()
+    print("wiring fixtures written")
