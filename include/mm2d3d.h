@@ -174,6 +174,10 @@ int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, i
 /* out[((z*N+n)*T+t)*K+k] = bf16(in[z*sz + n*sn + t*st + k*sk]) : fp32 master weights -> kernel layouts */
 int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st,
                          int64_t sk, mm_stream_t stream);
+/* One launch for a table of weights (every conv layer of a model after an optimiser step).  desc (device memory):
+ * ndesc rows of 11 int64 {in, out, Z, N, T, K, sz, sn, st, sk, first_block}; first_block = running sum of
+ * ceil(Z*N*T*K / 256) over the preceding rows, total_blocks = the sum over all rows. */
+int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- BatchNorm2d (+residual) (+ReLU), NHWC bf16 (csrc/bn2d.hip) */
 size_t mm_bn2d_ws_bytes(int C);
@@ -188,6 +192,11 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
                 int C, const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
                 void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                 mm_stream_t stream);
+
+/* out[c] (+)= sum_rows x[row][c]: the conv bias gradient, torch's dy.sum((0,2,3)) (2d_net/model.py:68-81 convs with bias).
+ * ws >= mm_bn2d_ws_bytes(C). */
+int mm_colsum_bf16(const void* x, int ld_x, int64_t N, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
+                   mm_stream_t stream);
 
 /* ---------------------------------------------------------------- concat, max-pool, fused heads (csrc/misc2d.hip) */
 int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, int64_t N, int C, mm_stream_t stream);

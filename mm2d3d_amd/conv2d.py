@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import weakref
+
 import torch
 
 from . import _lib, gradsink
@@ -31,21 +33,103 @@ def as_nhwc_bf16(x):
 PARAM_EPOCH = [0]  # bumped by FlatAdamW.step(): packed bf16 copies of the fp32 master weights are valid for one epoch
 
 
+class _PackEntry:
+    __slots__ = ("owner", "kind", "out", "key", "in_ptr", "args", "nblk")
+
+
+class _PackRegistry:
+    """All cached packs of one device.  The first stale hit after an optimiser step repacks EVERY registered weight in
+    one launch (mm_pack_weights_bf16_batch) instead of one small launch per layer."""
+
+    def __init__(self):
+        self.entries = []
+        self.table = None  # device int64 [n, 11]
+        self.table_n = 0
+        self.total_blocks = 0
+
+    def _alive(self):
+        ok = True
+        for e in self.entries:
+            o = e.owner()
+            if o is None or o.data_ptr() != e.in_ptr[1]:
+                ok = False
+                break
+        if ok:
+            return
+        keep = []
+        for e in self.entries:
+            o = e.owner()
+            if o is None:
+                continue
+            if o.data_ptr() != e.in_ptr[1]:  # parameter moved: forget the pack, it re-registers on its next use
+                o.__dict__.get("_mm_packs", {}).pop(e.kind, None)
+                continue
+            keep.append(e)
+        self.entries = keep
+        self.table = None
+
+    def repack_all(self, device):
+        self._alive()
+        if not self.entries:
+            return
+        if self.table is None or self.table_n != len(self.entries):
+            rows, blk = [], 0
+            for e in self.entries:
+                rows.append([e.in_ptr[0], e.out.data_ptr(), *e.args, blk])
+                blk += e.nblk
+            self.table = torch.tensor(rows, dtype=torch.int64).to(device)
+            self.table_n, self.total_blocks = len(rows), blk
+        check(_lib.lib().mm_pack_weights_bf16_batch(ptr(self.table), self.table_n, self.total_blocks, stream()), "pack_weights_batch")
+        ep = PARAM_EPOCH[0]
+        for e in self.entries:
+            o = e.owner()
+            e.key = (o._version, ep, o.data_ptr())
+
+
+_REGISTRIES = {}
+
+
 def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
     """bf16 kernel-layout copy of a weight.  With ``owner`` (the nn.Parameter) the copy is cached until the weight changes
     (torch in-place ops bump ``_version``; the fused AdamW kernel bumps PARAM_EPOCH): both forward passes of a step and
-    both backward passes share one pack."""
-    key = None
-    if owner is not None:
-        key = (owner._version, PARAM_EPOCH[0], owner.data_ptr())
-        cache = owner.__dict__.setdefault("_mm_packs", {})
-        hit = cache.get(kind)
-        if hit is not None and hit[0] == key:
-            return hit[1]
-    out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
-    check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
-    if key is not None:
-        cache[kind] = (key, out)
+    both backward passes share one pack, and all stale packs of a device are refreshed together."""
+    if owner is None:
+        out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
+        check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
+        return out
+    key = (owner._version, PARAM_EPOCH[0], owner.data_ptr())
+    cache = owner.__dict__.setdefault("_mm_packs", {})
+    e = cache.get(kind)
+    if e is not None:
+        if e.key == key:
+            return e.out
+        reg = _REGISTRIES[w.device.index]
+        reg.repack_all(w.device)
+        e = cache.get(kind)
+        if e is not None and e.key == key:
+            return e.out
+    # first use (or the parameter moved): pack this one and register it
+    e = _PackEntry()
+    e.owner, e.kind = weakref.ref(owner), kind
+    e.out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
+    e.in_ptr = (w.data_ptr(), owner.data_ptr())
+    e.args = (Z, N, T, K, sz, sn, st, sk)
+    e.nblk = (Z * N * T * K + 255) // 256
+    check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(e.out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
+    e.key = key
+    cache[kind] = e
+    _REGISTRIES.setdefault(w.device.index, _PackRegistry()).entries.append(e)
+    return e.out
+
+
+def _bias_grad(dy):
+    """dy.sum((0, 2, 3)) of an NHWC bf16 gradient in one pass (fp64 combination), fp32 result."""
+    L = _lib.lib()
+    Bn, C, H, W = dy.shape
+    out = torch.empty(C, dtype=torch.float32, device=dy.device)
+    ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), dy.device)
+    check(L.mm_colsum_bf16(ptr(dy), C, Bn * H * W, C, ptr(out), 0, ptr(ws), ws.numel(), stream()),
+          "colsum")
     return out
 
 
@@ -131,7 +215,7 @@ class Conv2dFn(torch.autograd.Function):
                 dw = torch.empty_like(w)
                 _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T)
         if has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum((0, 2, 3))
+            db = _bias_grad(dy)
         return dx, dw, db, None, None
 
 
@@ -146,7 +230,8 @@ class ConvTranspose2dFn(torch.autograd.Function):
         _, Cout, KH, KW = weight.shape
         assert (KH, KW) == (2, 2)
         w = weight.detach().float().contiguous()  # [ci][co][a][b]
-        Wp = _pack(w, 4, Cout, 1, Cin, 1, 4, 0, Cout * 4)  # [z=(a,b)][co][ci]
+        Wp = _pack(w, 4, Cout, 1, Cin, 1, 4, 0, Cout * 4, weight, "tfwd")  # [z=(a,b)][co][ci]
+        ctx.wowner = weight
         y = torch.empty((Bn, Cout, 2 * H, 2 * W), dtype=BF16, device=x.device, memory_format=CL)
         b = bias.detach().float().contiguous() if bias is not None else None
         _gemm(x, Bn, H, W, Cin, y, 2 * H, 2 * W, Cout, H, W, 2, 1, 1, [0], [0], Wp, nz=4, wz=Cout * Cin, zpar=1, bias=b)
@@ -163,7 +248,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         dx = dw = db = None
         ty, tx = [0, 0, 1, 1], [0, 1, 0, 1]
         if ctx.needs_input_grad[0]:
-            Wd = _pack(w, 1, Cin, 4, Cout, 0, Cout * 4, 1, 4)  # [ci][t=(a,b)][co]
+            Wd = _pack(w, 1, Cin, 4, Cout, 0, Cout * 4, 1, 4, ctx.wowner, "tdgrad")  # [ci][t=(a,b)][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
             _gemm(dy, Bn, 2 * H, 2 * W, Cout, dx, H, W, Cin, H, W, 1, 2, 1, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
@@ -171,7 +256,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             # roles: "dY" := x (base grid H x W, n = ci), "X" := dy (source pixel (2y+a, 2x+b), k = co)
             _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, dw, Cout * 4, 1, 4)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum((0, 2, 3))
+            db = _bias_grad(dy)
         return dx, dw, db
 
 

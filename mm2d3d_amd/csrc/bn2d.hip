@@ -33,7 +33,7 @@ __device__ inline void st8(u16* p, const float (&v)[8]) {
   *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * (yout > 0 if relu)
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * (yout > 0 if relu).  MODE 2: sum x only
 template <int MODE>
 __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
                                                     const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
@@ -61,7 +61,10 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
     for (int64_t r = r0 + slot; r < r1; r += rs) {
       float xv[8];
       ld8(x + r * ld_x + cv * 8, xv);
-      if (MODE == 0) {
+      if (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] += xv[i];
+      } else if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           a[i] += xv[i];
@@ -148,6 +151,15 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restri
   sums[C + c] = (float)q;
   if (dweight) dweight[c] = accumulate ? dweight[c] + (float)q : (float)q;
   if (dbias) dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+}
+
+__global__ __launch_bounds__(64) void k_colsum_finalize(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out,
+                                                         int accumulate) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblk; b += 64) s += partial[((int64_t)b * 2 + 0) * C + c];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // Apply kernels: thread = (row slot, 8-channel group); the per-channel scale/shift live in registers and the thread
@@ -301,6 +313,21 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
     hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy,
                        ld_dy, (const u16*)yout, ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres,
                        ld_dr);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// out[c] (+)= sum over the N rows of x[:, c]  (conv bias gradient: torch's dy.sum((0, 2, 3)))
+int mm_colsum_bf16(const void* x, int ld_x, int64_t N, int C, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0, "colsum: C must be a multiple of 8, <= 2048");
+  if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
+    mm_set_error("colsum: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  int nb = stat_blocks(N, C);
+  hipLaunchKernelGGL(k_bn2d_reduce<2>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr, nullptr,
+                     (double*)ws);
+  hipLaunchKernelGGL(k_colsum_finalize, dim3(C), dim3(64), 0, s, (const double*)ws, nb, C, out, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -674,6 +674,31 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
   out[e] = f2bf(in[z * sz + n * sn + t * st + k * sk]);
 }
 
+// The same for a table of weights in one launch (all conv layers of a model after an optimiser step).  desc = 11 x
+// int64: in, out, Z, N, T, K, sz, sn, st, sk, first block; block -> desc by binary search over the first-block column.
+__global__ __launch_bounds__(256) void k_pack_weights_batch(const int64_t* __restrict__ desc, int ndesc) {
+  int lo = 0, hi = ndesc - 1;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (desc[(int64_t)mid * 11 + 10] <= (int64_t)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const int64_t* d = desc + (int64_t)lo * 11;
+  const float* in = (const float*)d[0];
+  u16* out = (u16*)d[1];
+  const int Z = (int)d[2], N = (int)d[3], T = (int)d[4], K = (int)d[5];
+  const int64_t sz = d[6], sn = d[7], st = d[8], sk = d[9];
+  int64_t e = ((int64_t)blockIdx.x - d[10]) * 256 + threadIdx.x;
+  int64_t ne = (int64_t)Z * N * T * K;
+  if (e >= ne) return;
+  int k = (int)(e % K);
+  int64_t r = e / K;
+  int t = (int)(r % T);
+  r /= T;
+  int n = (int)(r % N), z = (int)(r / N);
+  out[e] = f2bf(in[z * sz + n * sn + t * st + k * sk]);
+}
+
 // NCHW fp32 -> NHWC bf16 and back (model boundary)
 __global__ __launch_bounds__(256) void k_nchw_to_nhwc_bf16(const float* __restrict__ in, u16* __restrict__ out, int B, int C, int H,
                                                             int W, int ldo) {
@@ -890,6 +915,16 @@ int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K,
   int64_t ne = (int64_t)Z * N * T * K;
   if (ne == 0) return MM_OK;
   hipLaunchKernelGGL(k_pack_weights, dim3((unsigned)mm_cdiv(ne, 256)), dim3(256), 0, s, in, (u16*)out, Z, N, T, K, sz, sn, st, sk);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// desc (device): ndesc rows of 11 int64 {in, out, Z, N, T, K, sz, sn, st, sk, first_block}, first_block = prefix sum of
+// ceil(Z*N*T*K / 256) over the preceding rows; total_blocks = the sum over all rows.
+int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, hipStream_t s) {
+  MM_CHECK_ARG(ndesc >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "pack_weights_batch: bad table");
+  if (ndesc == 0 || total_blocks == 0) return MM_OK;
+  hipLaunchKernelGGL(k_pack_weights_batch, dim3((unsigned)total_blocks), dim3(256), 0, s, desc, ndesc);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -114,21 +114,20 @@ __global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, c
 }
 
 // ---- heads: z[pix][j] = sum_c x[pix][c] * Wj[j][c]   (x NHWC bf16 with row pitch; region h x w of an Hp x Wp map)
+template <int MJ>
 __global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w, int C,
                                                   const float* __restrict__ Wj, int NJ, float* __restrict__ z) {
   extern __shared__ float ws[];  // [NJ][C]
   for (int i = threadIdx.x; i < NJ * C; i += T) ws[i] = Wj[i];
   __syncthreads();
-  int64_t pix = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * h * w;
-  if (pix >= total) return;
-  int xx = (int)(pix % w);
-  int64_t t = pix / w;
-  int yy = (int)(t % h), b = (int)(t / h);
+  const unsigned pix = blockIdx.x * (unsigned)T + threadIdx.x;  // host guarantees B*h*w < 2^31
+  if (pix >= (unsigned)B * h * w) return;
+  const unsigned t = pix / (unsigned)w;
+  const int xx = (int)(pix - t * w), b = (int)(t / (unsigned)h), yy = (int)(t - (unsigned)b * h);
   const u16* row = x + ((int64_t)(b * Hp + yy) * Wp + xx) * ld;
-  float acc[MAXJ];
+  float acc[MJ];
 #pragma unroll
-  for (int j = 0; j < MAXJ; j++) acc[j] = 0.f;
+  for (int j = 0; j < MJ; j++) acc[j] = 0.f;
   for (int c0 = 0; c0 < C; c0 += 8) {
     uint4 v = *(const uint4*)(row + c0);
     unsigned wv[4] = {v.x, v.y, v.z, v.w};
@@ -139,15 +138,15 @@ __global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int 
       xv[2 * i + 1] = __uint_as_float(wv[i] & 0xFFFF0000u);
     }
 #pragma unroll
-    for (int j = 0; j < MAXJ; j++)
+    for (int j = 0; j < MJ; j++)
       if (j < NJ) {
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[j] = fmaf(xv[i], ws[j * C + c0 + i], acc[j]);
       }
   }
 #pragma unroll
-  for (int j = 0; j < MAXJ; j++)
-    if (j < NJ) z[pix * NJ + j] = acc[j];
+  for (int j = 0; j < MJ; j++)
+    if (j < NJ) z[(int64_t)pix * NJ + j] = acc[j];
 }
 
 // 5x5 box / 25 with zero padding on NHWC fp32 maps [B,h,w,NJ] (+ bias): thread = (pixel, j), j fastest, so both the
@@ -175,45 +174,100 @@ __global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B,
   out[gid] = s * (1.f / 25.f) + (bias ? bias[j] : 0.f);
 }
 
-// dx[pix][c] = sum_j dz[pix][j] * Wj[j][c]  (bf16, zero outside the h x w region), partial dW[j][c] = sum_pix dz*x
+// same, 4 maps per thread (NJ % 4 == 0): 16-byte reads, a quarter of the load instructions
+__global__ __launch_bounds__(T) void k_box5_v4(const float* __restrict__ in, int B, int h, int w, int NJ4, const float* __restrict__ bias,
+                                                float* __restrict__ out) {
+  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
+  int64_t total = (int64_t)B * h * w * NJ4;
+  if (gid >= total) return;
+  int j4 = (int)(gid % NJ4);
+  int64_t t = gid / NJ4;
+  int xx = (int)(t % w);
+  t /= w;
+  int yy = (int)(t % h), b = (int)(t / h);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int x0 = xx - 2 < 0 ? 0 : xx - 2, x1 = xx + 2 >= w ? w - 1 : xx + 2;
+  for (int dy = -2; dy <= 2; dy++) {
+    int y2 = yy + dy;
+    if (y2 < 0 || y2 >= h) continue;
+    const float4* rowp = (const float4*)in + ((int64_t)(b * h + y2) * w) * NJ4 + j4;
+    for (int x2 = x0; x2 <= x1; x2++) {
+      float4 v = rowp[(int64_t)x2 * NJ4];
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  }
+  float4 bb = bias ? *(const float4*)(bias + 4 * j4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 r = make_float4(s.x * (1.f / 25.f) + bb.x, s.y * (1.f / 25.f) + bb.y, s.z * (1.f / 25.f) + bb.z, s.w * (1.f / 25.f) + bb.w);
+  ((float4*)out)[gid] = r;
+}
+
+// dx[pix][c] = sum_j dz[pix][j] * Wj[j][c]  (bf16, zero outside the h x w region), partial dW[j][c] = sum_pix dz*x.
+// C = 64: a thread owns 4 channels of one pixel (8-byte loads/stores), 16 threads per pixel, 4 pixels per wave; the
+// per-block dW partial is folded over the wave's 4 pixel slots with two shuffles and over the 4 waves through LDS.
+template <int MJ>
 __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w, int C,
                                                  const float* __restrict__ Wj, int NJ, const float* __restrict__ dz,
                                                  u16* __restrict__ dx, float* __restrict__ partial, int64_t pix_per_block) {
-  extern __shared__ float sm[];  // [4][NJ][C] reduction buffer
-  const int c = threadIdx.x % C, slot = threadIdx.x / C;  // C = 64 -> 4 pixel slots
-  const int nslot = T / C;
-  float wc[MAXJ], acc[MAXJ];
+  extern __shared__ float sm[];  // [T/64][NJ][C]
+  const int c4 = (threadIdx.x & 15) * 4, slot = threadIdx.x >> 4;
+  constexpr int NSLOT = T / 16;
+  float wc[MJ][4], acc[MJ][4];
 #pragma unroll
-  for (int j = 0; j < MAXJ; j++) {
-    wc[j] = j < NJ ? Wj[j * C + c] : 0.f;
-    acc[j] = 0.f;
-  }
+  for (int j = 0; j < MJ; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      wc[j][i] = j < NJ ? Wj[j * C + c4 + i] : 0.f;
+      acc[j][i] = 0.f;
+    }
   const int64_t total = (int64_t)B * Hp * Wp;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
   const int64_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
-  for (int64_t pp = p0 + slot; pp < p1; pp += nslot) {
-    int xx = (int)(pp % Wp);
-    int64_t t = pp / Wp;
-    int yy = (int)(t % Hp), b = (int)(t / Hp);
-    float o = 0.f;
+  int xx, yy, b;
+  {
+    const int64_t pp = p0 + slot, t = pp / Wp;
+    xx = (int)(pp - t * Wp), b = (int)(t / Hp), yy = (int)(t - (int64_t)b * Hp);
+  }
+  for (int64_t pp = p0 + slot; pp < p1; pp += NSLOT, xx += NSLOT) {
+    while (xx >= Wp) {
+      xx -= Wp;
+      if (++yy == Hp) yy = 0, b++;
+    }
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
     if (yy < h && xx < w) {
       const float* g = dz + ((int64_t)(b * h + yy) * w + xx) * NJ;
-      float xv = bf2f(x[pp * ld + c]);
+      uint2 v = *(const uint2*)(x + pp * ld + c4);
+      float xv[4] = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+                     __uint_as_float(v.y & 0xFFFF0000u)};
 #pragma unroll
-      for (int j = 0; j < MAXJ; j++)
+      for (int j = 0; j < MJ; j++)
         if (j < NJ) {
           float gj = g[j];
-          o = fmaf(gj, wc[j], o);
-          acc[j] = fmaf(gj, xv, acc[j]);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            o[i] = fmaf(gj, wc[j][i], o[i]);
+            acc[j][i] = fmaf(gj, xv[i], acc[j][i]);
+          }
         }
     }
-    dx[pp * ld + c] = f2bf(o);
+    uint2 r;
+    r.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+    r.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+    *(uint2*)(dx + pp * ld + c4) = r;
   }
-  for (int j = 0; j < NJ; j++) sm[(slot * NJ + j) * C + c] = acc[j];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int j = 0; j < MJ; j++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float a = acc[j][i];
+      a += __shfl_xor(a, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      if (j < NJ && lane < 16) sm[(wave * NJ + j) * C + c4 + i] = a;
+    }
   __syncthreads();
   for (int e = threadIdx.x; e < NJ * C; e += T) {
     float s = 0.f;
-    for (int sl = 0; sl < nslot; sl++) s += sm[sl * NJ * C + e];
+    for (int wv = 0; wv < T / 64; wv++) s += sm[wv * NJ * C + e];
     partial[(int64_t)blockIdx.x * NJ * C + e] = s;
   }
 }
@@ -228,6 +282,14 @@ __global__ __launch_bounds__(64) void k_sum_partials_f(const float* __restrict__
   if (threadIdx.x == 0) out[e] = (float)s;
 }
 }  // namespace
+
+static void launch_box5(const float* in, int B, int h, int w, int NJ, const float* bias, float* out, hipStream_t s) {
+  int64_t npix = (int64_t)B * h * w;
+  if (NJ % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0))
+    hipLaunchKernelGGL(k_box5_v4, dim3((unsigned)mm_cdiv(npix * (NJ / 4), T)), dim3(T), 0, s, in, B, h, w, NJ / 4, bias, out);
+  else
+    hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, in, B, h, w, NJ, bias, out);
+}
 
 extern "C" {
 
@@ -281,9 +343,16 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   float* z = (float*)ws;
   int64_t npix = (int64_t)B * h * w;
   if (npix == 0) return MM_OK;
-  hipLaunchKernelGGL(k_head_proj, dim3((unsigned)mm_cdiv(npix, T)), dim3(T), (size_t)NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C,
-                     Wj, NJ, z);
-  hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, z, B, h, w, NJ, bias, out);
+  MM_CHECK_ARG(npix < (1ll << 31), "head: too many pixels");
+#define MM_HEAD_PROJ(MJ)                                                                                                          \
+  hipLaunchKernelGGL(k_head_proj<MJ>, dim3((unsigned)mm_cdiv(npix, T)), dim3(T), (size_t)NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, \
+                     w, C, Wj, NJ, z)
+  if (NJ <= 8) MM_HEAD_PROJ(8);
+  else if (NJ <= 12) MM_HEAD_PROJ(12);
+  else if (NJ <= 20) MM_HEAD_PROJ(20);
+  else MM_HEAD_PROJ(32);
+#undef MM_HEAD_PROJ
+  launch_box5(z, B, h, w, NJ, bias, out, s);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -295,7 +364,7 @@ int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   size_t zb = mm_align((size_t)B * h * w * NJ * sizeof(float));
   const int64_t total = (int64_t)B * Hp * Wp;
   int nblk = (int)mm_cdiv(total, 128);
-  if (nblk > 8192) nblk = 8192;
+  if (nblk > 2048) nblk = 2048;
   if (nblk < 1) nblk = 1;
   const int64_t ppb = mm_cdiv(total, nblk);
   if (ws_bytes < zb + (size_t)nblk * NJ * C * sizeof(float)) {
@@ -305,9 +374,15 @@ int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   float* dz = (float*)ws;
   float* partial = (float*)((char*)ws + zb);
   int64_t npix = (int64_t)B * h * w;
-  if (npix) hipLaunchKernelGGL(k_box5, dim3((unsigned)mm_cdiv(npix * NJ, T)), dim3(T), 0, s, dout, B, h, w, NJ, nullptr, dz);
-  hipLaunchKernelGGL(k_head_bwd, dim3(nblk), dim3(T), (size_t)(T / C) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, NJ, dz,
-                     (u16*)dx, partial, ppb);
+  if (npix) launch_box5(dout, B, h, w, NJ, nullptr, dz, s);
+#define MM_HEAD_BWD(MJ)                                                                                                          \
+  hipLaunchKernelGGL(k_head_bwd<MJ>, dim3(nblk), dim3(T), (size_t)(T / 64) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, \
+                     NJ, dz, (u16*)dx, partial, ppb)
+  if (NJ <= 8) MM_HEAD_BWD(8);
+  else if (NJ <= 12) MM_HEAD_BWD(12);
+  else if (NJ <= 20) MM_HEAD_BWD(20);
+  else MM_HEAD_BWD(32);
+#undef MM_HEAD_BWD
   hipLaunchKernelGGL(k_sum_partials_f, dim3(NJ * C), dim3(64), 0, s, partial, nblk, NJ * C, dWj);
   MM_LAUNCH_CHECK();
   return MM_OK;

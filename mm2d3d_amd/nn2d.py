@@ -66,8 +66,7 @@ class _BN2dFn(torch.autograd.Function):
             stats = torch.empty((2, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
             check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
-                                      ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
-                                      stream()), "bn2d_fwd_train")
+                                      ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats)
             ctx.sinks = None
             if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[2]):
@@ -100,7 +99,8 @@ class _BN2dFn(torch.autograd.Function):
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
         check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(y), C, 1 if ctx.relu else 0, N, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
-                            ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
+                            ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
+                            stream()), "bn2d_bwd")
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
