@@ -59,6 +59,10 @@ int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, cons
                     size_t ws_bytes, mm_stream_t stream);
 
 /* nbr[k*n + o] = id of the active site at coord(o) + offset(k), k = ((dx+1)*3 + (dy+1))*3 + (dz+1), or -1 */
+/* out[0] = number of active rows with batch index < split.  Rows are in first-occurrence order of a batch-sorted point
+ * list (collate_scn_base, lib/dataset/__init__.py:63-67), so those are rows 0 .. out[0]-1: the statistics-group boundary
+ * of the batch-norm layers when source and target scenes share one pass. */
+int mm_batch_lower_bound(const int32_t* vox_coords, const int32_t* n_dev, int32_t split, int32_t* out, mm_stream_t stream);
 int mm_subm_neighbors(const int32_t* vox_coords, int64_t n, int32_t spatial_size, const uint64_t* tkeys,
                       const int32_t* tvals, int64_t cap, int32_t* nbr, mm_stream_t stream);
 
@@ -92,13 +96,16 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
 /* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
  * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */
 size_t mm_bn_ws_bytes(int C);
-int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+/* Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step;
+ * train.py:186-292 calls the net once per domain) are normalised with their OWN batch statistics and the running
+ * buffers are updated group 0 first, then group 1.  Ns = N (or 0): single batch.  save_mean/save_invstd: [G][C]. */
+int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
                    const float* running_mean, const float* running_var, float eps, float leak, float* y, int ld_y,
                    mm_stream_t stream);
-int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int C, const float* weight,
+int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 
@@ -181,7 +188,10 @@ int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blo
 
 /* ---------------------------------------------------------------- BatchNorm2d (+residual) (+ReLU), NHWC bf16 (csrc/bn2d.hip) */
 size_t mm_bn2d_ws_bytes(int C);
-int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
+/* Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source / target halves of a jointly
+ * batched step; train.py:186-292 calls each net once per domain) and the running buffers are updated group 0 first,
+ * then group 1, as two consecutive calls would.  Ns = N (or 0): ordinary single batch.  save_mean/save_invstd: [G][C]. */
+int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
@@ -189,8 +199,8 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);
 int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N,
-                int C, const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx,
-                void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                int64_t Ns, int C, const float* weight, const float* save_mean, const float* save_invstd, void* dx,
+                int ld_dx, void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                 mm_stream_t stream);
 
 /* out[c] (+)= sum_rows x[row][c]: the conv bias gradient, torch's dy.sum((0,2,3)) (2d_net/model.py:68-81 convs with bias).

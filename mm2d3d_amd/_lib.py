@@ -25,6 +25,7 @@ _PROTOS = {
     "mm_hash_capacity": (i64, [i64]),
     "mm_dedupe_ws_bytes": (sz, [i64]),
     "mm_voxel_dedupe": (i32, [vp, i32, i64, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_batch_lower_bound": (i32, [vp, vp, i32, vp, vp]),
     "mm_subm_neighbors": (i32, [vp, i64, i32, vp, vp, i64, vp, vp]),
     "mm_down_neighbors": (i32, [vp, i64, vp, i64, vp, vp]),
     "mm_rulebook_ws_bytes": (sz, [i64, i32]),
@@ -34,9 +35,9 @@ _PROTOS = {
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
     "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
     "mm_bn_ws_bytes": (sz, [i32]),
-    "mm_bn_fwd_train": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn_fwd_train": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
-    "mm_bn_bwd": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn_bwd": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_point_ws_bytes": (sz, [i32, i32]),
     "mm_gate_fwd": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "mm_gate_bwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
@@ -64,9 +65,9 @@ _PROTOS = {
     "mm_pack_weights_bf16_batch": (i32, [vp, i32, i64, vp]),
     "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_bn2d_ws_bytes": (sz, [i32]),
-    "mm_bn2d_fwd_train": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn2d_fwd_train": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
-    "mm_bn2d_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i64, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn2d_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_colsum_bf16": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
     "mm_copy_rows_bf16": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "mm_maxpool3x3s2_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),

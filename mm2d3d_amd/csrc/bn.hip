@@ -47,8 +47,14 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
                                                   int ld_dy, int64_t N, int C, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ weight,
                                                   const float* __restrict__ bias, float leak,
-                                                  double* __restrict__ partial) {
-  __shared__ double red[2 * T];  // reused once per vector lane below
+                                                  double* __restrict__ partial, int64_t Ns, int nb0) {
+  // rows [0, Ns) are statistics group 0 (blocks [0, nb0)), rows [Ns, N) group 1 (the other blocks): the two domains of a
+  // jointly batched training step keep their own batch statistics.  Ns == N: one group.
+  __shared__ double red[2 * T];
+  const int grp = (int)blockIdx.x >= nb0;
+  const int lb = grp ? blockIdx.x - nb0 : blockIdx.x, nbg = grp ? gridDim.x - nb0 : nb0;
+  const int64_t gbase = grp ? Ns : 0, Ng = grp ? N - Ns : Ns;
+  if (MODE == 1) mean += grp * C, invstd += grp * C;  // reused once per vector lane below
   const int CV = C / VEC;
   const int rs = T / CV;  // row slots per block
   const int tid = threadIdx.x;
@@ -66,9 +72,9 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, in
       bs[i] = bias ? bias[cv * VEC + i] : 0.f;
     }
   }
-  const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  const int64_t rows_per_block = (Ng + nbg - 1) / nbg;
+  const int64_t r0 = gbase + (int64_t)lb * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < gbase + Ng ? r0 + rows_per_block : gbase + Ng;
   if (slot < rs) {
     for (int64_t r = r0 + slot; r < r1; r += rs) {
       float xv[VEC];
@@ -118,49 +124,64 @@ __device__ inline double wave_sum(double v) {
   return v;  // lane 0 holds the sum; fixed tree order -> bit-stable
 }
 
-// one wave per channel: lane l sums partials l, l+64, ... then a fixed shuffle tree
-__global__ __launch_bounds__(64) void k_bn_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C,
-                                                         float eps, float momentum, float* __restrict__ running_mean,
+// one wave per channel: lane l sums partials l, l+64, ... then a fixed shuffle tree.  With two statistics groups the
+// running buffers are updated group 0 first, then group 1 - what two consecutive forward calls do.
+__global__ __launch_bounds__(64) void k_bn_finalize_fwd(const double* __restrict__ partial, int nb0, int nb1, int64_t Ns, int64_t N,
+                                                         int C, float eps, float momentum, float* __restrict__ running_mean,
                                                          float* __restrict__ running_var, float* __restrict__ save_mean,
                                                          float* __restrict__ save_invstd) {
   const int c = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) {
-    s += partial[((int64_t)b * 2 + 0) * C + c];
-    q += partial[((int64_t)b * 2 + 1) * C + c];
-  }
-  s = wave_sum(s);
-  q = wave_sum(q);
-  if (threadIdx.x != 0) return;
-  double mean = N > 0 ? s / (double)N : 0.0;
-  double var = N > 0 ? q / (double)N - mean * mean : 0.0;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
-    running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * (float)mean;
-    running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)unbiased;
+  const int G = nb1 > 0 ? 2 : 1;
+  for (int g = 0; g < G; g++) {
+    const int b0 = g ? nb0 : 0, b1 = g ? nb0 + nb1 : nb0;
+    const int64_t Ng = g ? N - Ns : Ns;
+    double s = 0.0, q = 0.0;
+    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
+      s += partial[((int64_t)b * 2 + 0) * C + c];
+      q += partial[((int64_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+      double mean = Ng > 0 ? s / (double)Ng : 0.0;
+      double var = Ng > 0 ? q / (double)Ng - mean * mean : 0.0;
+      if (var < 0.0) var = 0.0;
+      save_mean[g * C + c] = (float)mean;
+      save_invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        double unbiased = Ng > 1 ? var * (double)Ng / (double)(Ng - 1) : var;
+        running_mean[c] = momentum * running_mean[c] + (1.f - momentum) * (float)mean;
+        running_var[c] = momentum * running_var[c] + (1.f - momentum) * (float)unbiased;
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void k_bn_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
-                                                         float* __restrict__ sum_dy, float* __restrict__ sum_dy_xhat,
-                                                         float* __restrict__ dweight, float* __restrict__ dbias,
-                                                         int accumulate) {
+// sums[g][0][C] = sum dy', sums[g][1][C] = sum dy'*xhat per group; dweight / dbias are the totals over the groups
+__global__ __launch_bounds__(64) void k_bn_finalize_bwd(const double* __restrict__ partial, int nb0, int nb1, int C,
+                                                         float* __restrict__ sums, float* __restrict__ dweight,
+                                                         float* __restrict__ dbias, int accumulate) {
   const int c = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) {
-    s += partial[((int64_t)b * 2 + 0) * C + c];
-    q += partial[((int64_t)b * 2 + 1) * C + c];
+  const int G = nb1 > 0 ? 2 : 1;
+  float ts = 0.f, tq = 0.f;
+  for (int g = 0; g < G; g++) {
+    const int b0 = g ? nb0 : 0, b1 = g ? nb0 + nb1 : nb0;
+    double s = 0.0, q = 0.0;
+    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
+      s += partial[((int64_t)b * 2 + 0) * C + c];
+      q += partial[((int64_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+      sums[(g * 2 + 0) * C + c] = (float)s;
+      sums[(g * 2 + 1) * C + c] = (float)q;
+      ts += (float)s, tq += (float)q;
+    }
   }
-  s = wave_sum(s);
-  q = wave_sum(q);
   if (threadIdx.x != 0) return;
-  sum_dy[c] = (float)s;
-  sum_dy_xhat[c] = (float)q;
-  if (dweight) dweight[c] = accumulate ? dweight[c] + (float)q : (float)q;
-  if (dbias) dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+  if (dweight) dweight[c] = accumulate ? dweight[c] + tq : tq;
+  if (dbias) dbias[c] = accumulate ? dbias[c] + ts : ts;
 }
 
 constexpr int APPLY_ROWS = 8;  // rows per thread in the apply kernels (parameters live in registers)
@@ -171,11 +192,14 @@ __global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int
                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                  int invstd_is_var, float eps, const float* __restrict__ weight,
                                                  const float* __restrict__ bias, float leak, float* __restrict__ y,
-                                                 int ld_y) {
+                                                 int ld_y, int64_t Ns, int ab0) {
   const int CV = C / VEC;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
   if (slot >= rs) return;
+  const int grp = (int)blockIdx.x >= ab0;  // statistics group of this block's rows (see k_bn_reduce)
+  const int64_t gbase = grp ? Ns : 0, gend = grp ? N : Ns;
+  mean += grp * C, invstd += grp * C;
   float m[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
@@ -185,11 +209,11 @@ __global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int
     sc[i] = is * (weight ? weight[c] : 1.f);
     sh[i] = bias ? bias[c] : 0.f;
   }
-  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+  const int64_t r0 = gbase + (int64_t)(grp ? blockIdx.x - ab0 : blockIdx.x) * rs * APPLY_ROWS + slot;
 #pragma unroll 4
   for (int k = 0; k < APPLY_ROWS; k++) {
     const int64_t r = r0 + (int64_t)k * rs;
-    if (r >= N) break;
+    if (r >= gend) break;
     float xv[VEC], yv[VEC];
     ldv<VEC>(x + r * ld_x + cv * VEC, xv);
 #pragma unroll
@@ -207,14 +231,18 @@ __global__ __launch_bounds__(T) void k_bn_bwd_apply(const float* __restrict__ x,
                                                      int ld_dy, int64_t N, int C, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, const float* __restrict__ weight,
                                                      const float* __restrict__ bias, float leak,
-                                                     const float* __restrict__ sum_dy,
-                                                     const float* __restrict__ sum_dy_xhat, float* __restrict__ dx,
-                                                     int ld_dx) {
+                                                     const float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dx,
+                                                     int ld_dx, int64_t Ns, int ab0) {
   const int CV = C / VEC;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
   if (slot >= rs) return;
-  const float invN = 1.f / (float)N;
+  const int grp = (int)blockIdx.x >= ab0;
+  const int64_t gbase = grp ? Ns : 0, gend = grp ? N : Ns;
+  mean += grp * C, invstd += grp * C;
+  const float* sum_dy = sums + grp * 2 * C;
+  const float* sum_dy_xhat = sum_dy + C;
+  const float invN = 1.f / (float)(gend - gbase);
   float m[VEC], is[VEC], w[VEC], b[VEC], s1[VEC], s2[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; i++) {
@@ -226,11 +254,11 @@ __global__ __launch_bounds__(T) void k_bn_bwd_apply(const float* __restrict__ x,
     s1[i] = sum_dy[c] * invN;
     s2[i] = sum_dy_xhat[c] * invN;
   }
-  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+  const int64_t r0 = gbase + (int64_t)(grp ? blockIdx.x - ab0 : blockIdx.x) * rs * APPLY_ROWS + slot;
 #pragma unroll 4
   for (int k = 0; k < APPLY_ROWS; k++) {
     const int64_t r = r0 + (int64_t)k * rs;
-    if (r >= N) break;
+    if (r >= gend) break;
     float xv[VEC], dv[VEC], ov[VEC];
     ldv<VEC>(x + r * ld_x + cv * VEC, xv);
     ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
@@ -261,35 +289,54 @@ inline int stat_blocks(int64_t N, int C, int VEC) {
 
 extern "C" {
 
-size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + 256; }
+size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 
-// training forward: batch statistics over N rows; running stats updated in place (scn "momentum" = keep fraction)
-int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+static void split_blocks(int64_t N, int64_t& Ns, int C, int VEC, bool stats, int& b0, int& b1) {
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  if (stats) {
+    b0 = stat_blocks(Ns, C, VEC);
+    b1 = Ns < N ? stat_blocks(N - Ns, C, VEC) : 0;
+    if (b1 > 0) {  // both groups share the MAX_PART partial slots
+      if (b0 > MAX_PART / 2) b0 = MAX_PART / 2;
+      if (b1 > MAX_PART / 2) b1 = MAX_PART / 2;
+    }
+  } else {
+    b0 = (int)apply_blocks(Ns, C, VEC);
+    b1 = Ns < N ? (int)apply_blocks(N - Ns, C, VEC) : 0;
+  }
+}
+
+// training forward: batch statistics over the N rows; running stats updated in place (scn "momentum" = keep fraction).
+// Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step) are
+// normalised with their OWN statistics; Ns = N (or 0): ordinary single batch.  save_mean / save_invstd: [G][C].
+int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_y >= C, "bn_fwd: bad shape C=%d", C);
-  if (ws_bytes < mm_bn_ws_bytes(C) - 256) {
+  if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
     mm_set_error("bn_fwd: workspace too small");
     return MM_ERR_WORKSPACE;
   }
   double* partial = (double*)ws;
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
-  int nb = stat_blocks(N, C, v4 ? 4 : 1);
+  int nb0, nb1, ab0, ab1;
+  split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
-    hipLaunchKernelGGL((k_bn_reduce<4, 0>), dim3(nb), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
-                       nullptr, 0.f, partial);
+    hipLaunchKernelGGL((k_bn_reduce<4, 0>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
+                       nullptr, 0.f, partial, Ns, nb0);
   else
-    hipLaunchKernelGGL((k_bn_reduce<1, 0>), dim3(nb), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
-                       nullptr, 0.f, partial);
-  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb, N, C, eps, momentum,
-                     running_mean, running_var, save_mean, save_invstd);
+    hipLaunchKernelGGL((k_bn_reduce<1, 0>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
+                       nullptr, 0.f, partial, Ns, nb0);
+  hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
+                     save_mean, save_invstd);
   if (N > 0) {
+    split_blocks(N, Ns, C, v4 ? 4 : 1, false, ab0, ab1);
     if (v4)
-      hipLaunchKernelGGL(k_bn_apply<4>, dim3(apply_blocks(N, C, 4)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
-                         save_invstd, 0, eps, weight, bias, leak, y, ld_y);
+      hipLaunchKernelGGL(k_bn_apply<4>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, N, C, save_mean, save_invstd, 0, eps, weight, bias,
+                         leak, y, ld_y, Ns, ab0);
     else
-      hipLaunchKernelGGL(k_bn_apply<1>, dim3(apply_blocks(N, C, 1)), dim3(T), 0, s, x, ld_x, N, C, save_mean,
-                         save_invstd, 0, eps, weight, bias, leak, y, ld_y);
+      hipLaunchKernelGGL(k_bn_apply<1>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, N, C, save_mean, save_invstd, 0, eps, weight, bias,
+                         leak, y, ld_y, Ns, ab0);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -301,47 +348,48 @@ int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weig
   MM_CHECK_ARG(C > 0 && ld_x >= C && ld_y >= C, "bn_eval: bad shape");
   if (N == 0) return MM_OK;
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  const int ab = (int)apply_blocks(N, C, v4 ? 4 : 1);
   if (v4)
-    hipLaunchKernelGGL(k_bn_apply<4>, dim3(apply_blocks(N, C, 4)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
-                       running_var, 1, eps, weight, bias, leak, y, ld_y);
+    hipLaunchKernelGGL(k_bn_apply<4>, dim3(ab), dim3(T), 0, s, x, ld_x, N, C, running_mean, running_var, 1, eps, weight, bias, leak, y,
+                       ld_y, N, ab);
   else
-    hipLaunchKernelGGL(k_bn_apply<1>, dim3(apply_blocks(N, C, 1)), dim3(T), 0, s, x, ld_x, N, C, running_mean,
-                       running_var, 1, eps, weight, bias, leak, y, ld_y);
+    hipLaunchKernelGGL(k_bn_apply<1>, dim3(ab), dim3(T), 0, s, x, ld_x, N, C, running_mean, running_var, 1, eps, weight, bias, leak, y,
+                       ld_y, N, ab);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-// training backward; dweight/dbias may be null; accumulate != 0 adds into them
-int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int C, const float* weight,
+// training backward; dweight/dbias may be null; accumulate != 0 adds into them; Ns and [G][C] statistics as in the forward
+int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_dy >= C && ld_dx >= C, "bn_bwd: bad shape");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
-  if (ws_bytes < need + 2 * C * sizeof(float)) {
+  if (ws_bytes < need + 4 * C * sizeof(float)) {
     mm_set_error("bn_bwd: workspace too small");
     return MM_ERR_WORKSPACE;
   }
   double* partial = (double*)ws;
-  float* sum_dy = (float*)((char*)ws + need);
-  float* sum_dy_xhat = sum_dy + C;
+  float* sums = (float*)((char*)ws + need);
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) &&
                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0);
-  int nb = stat_blocks(N, C, v4 ? 4 : 1);
+  int nb0, nb1, ab0, ab1;
+  split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
-    hipLaunchKernelGGL((k_bn_reduce<4, 1>), dim3(nb), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd,
-                       weight, bias, leak, partial);
+    hipLaunchKernelGGL((k_bn_reduce<4, 1>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+                       bias, leak, partial, Ns, nb0);
   else
-    hipLaunchKernelGGL((k_bn_reduce<1, 1>), dim3(nb), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd,
-                       weight, bias, leak, partial);
-  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sum_dy, sum_dy_xhat,
-                     dweight, dbias, accumulate);
+    hipLaunchKernelGGL((k_bn_reduce<1, 1>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+                       bias, leak, partial, Ns, nb0);
+  hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   if (N > 0) {
+    split_blocks(N, Ns, C, v4 ? 4 : 1, false, ab0, ab1);
     if (v4)
-      hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(apply_blocks(N, C, 4)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
-                         save_mean, save_invstd, weight, bias, leak, sum_dy, sum_dy_xhat, dx, ld_dx);
+      hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+                         bias, leak, sums, dx, ld_dx, Ns, ab0);
     else
-      hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(apply_blocks(N, C, 1)), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C,
-                         save_mean, save_invstd, weight, bias, leak, sum_dy, sum_dy_xhat, dx, ld_dx);
+      hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+                         bias, leak, sums, dx, ld_dx, Ns, ab0);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;

@@ -38,8 +38,14 @@ template <int MODE>
 __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
                                                     const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                    double* __restrict__ partial) {
+                                                    double* __restrict__ partial, int64_t Ns, int nb0) {
+  // rows [0, Ns) are statistics group 0 (blocks [0, nb0)), rows [Ns, N) group 1 (the other blocks): the two domains of a
+  // jointly batched training step keep their own batch statistics.  Ns == N: one group.
   __shared__ float red[2][T];
+  const int grp = (int)blockIdx.x >= nb0;
+  const int lb = grp ? blockIdx.x - nb0 : blockIdx.x, nbg = grp ? gridDim.x - nb0 : nb0;
+  const int64_t gbase = grp ? Ns : 0, Ng = grp ? N - Ns : Ns;
+  if (MODE == 1) mean += grp * C, invstd += grp * C;
   const int CV = C >> 3;
   const int rs = T / CV;
   const int tid = threadIdx.x;
@@ -54,9 +60,9 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
       is[i] = invstd[cv * 8 + i];
     }
   }
-  const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  const int64_t rows_per_block = (Ng + nbg - 1) / nbg;
+  const int64_t r0 = gbase + (int64_t)lb * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < gbase + Ng ? r0 + rows_per_block : gbase + Ng;
   if (slot < rs) {
     for (int64_t r = r0 + slot; r < r1; r += rs) {
       float xv[8];
@@ -108,49 +114,65 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
-// torch semantics: running = (1-momentum)*running + momentum*batch (unbiased variance)
-__global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restrict__ partial, int nblk, int64_t N, int C, float eps,
-                                                           float momentum, float* __restrict__ running_mean,
+// torch semantics: running = (1-momentum)*running + momentum*batch (unbiased variance); with two statistics groups the
+// running buffers are updated group 0 first, then group 1 - exactly what two consecutive forward calls do.
+__global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restrict__ partial, int nb0, int nb1, int64_t Ns, int64_t N,
+                                                           int C, float eps, float momentum, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, int64_t* __restrict__ num_batches) {
   const int c = blockIdx.x;
-  if (c == 0 && threadIdx.x == 0 && num_batches) *num_batches += 1;  // nn.BatchNorm2d.num_batches_tracked
-  double s = 0.0, q = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) {
-    s += partial[((int64_t)b * 2 + 0) * C + c];
-    q += partial[((int64_t)b * 2 + 1) * C + c];
-  }
-  s = wave_sum(s);
-  q = wave_sum(q);
-  if (threadIdx.x != 0) return;
-  double mean = N > 0 ? s / (double)N : 0.0;
-  double var = N > 0 ? q / (double)N - mean * mean : 0.0;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    double unbiased = N > 1 ? var * (double)N / (double)(N - 1) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  const int G = nb1 > 0 ? 2 : 1;
+  if (c == 0 && threadIdx.x == 0 && num_batches) *num_batches += G;  // nn.BatchNorm2d.num_batches_tracked
+  for (int g = 0; g < G; g++) {
+    const int b0 = g ? nb0 : 0, b1 = g ? nb0 + nb1 : nb0;
+    const int64_t Ng = g ? N - Ns : Ns;
+    double s = 0.0, q = 0.0;
+    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
+      s += partial[((int64_t)b * 2 + 0) * C + c];
+      q += partial[((int64_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+      double mean = Ng > 0 ? s / (double)Ng : 0.0;
+      double var = Ng > 0 ? q / (double)Ng - mean * mean : 0.0;
+      if (var < 0.0) var = 0.0;
+      save_mean[g * C + c] = (float)mean;
+      save_invstd[g * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+      if (running_mean) {
+        double unbiased = Ng > 1 ? var * (double)Ng / (double)(Ng - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nblk, int C,
-                                                           float* __restrict__ sums /*[2][C]*/, float* __restrict__ dweight,
+// sums[g][0][C] = sum g, sums[g][1][C] = sum g*xhat per statistics group; dweight / dbias are the totals over the groups
+__global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nb0, int nb1, int C,
+                                                           float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dweight,
                                                            float* __restrict__ dbias, int accumulate) {
   const int c = blockIdx.x;
-  double s = 0.0, q = 0.0;
-  for (int b = threadIdx.x; b < nblk; b += 64) {
-    s += partial[((int64_t)b * 2 + 0) * C + c];
-    q += partial[((int64_t)b * 2 + 1) * C + c];
+  const int G = nb1 > 0 ? 2 : 1;
+  float ts = 0.f, tq = 0.f;
+  for (int g = 0; g < G; g++) {
+    const int b0 = g ? nb0 : 0, b1 = g ? nb0 + nb1 : nb0;
+    double s = 0.0, q = 0.0;
+    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
+      s += partial[((int64_t)b * 2 + 0) * C + c];
+      q += partial[((int64_t)b * 2 + 1) * C + c];
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (threadIdx.x == 0) {
+      sums[(g * 2 + 0) * C + c] = (float)s;
+      sums[(g * 2 + 1) * C + c] = (float)q;
+      ts += (float)s, tq += (float)q;  // the order two consecutive backward calls accumulate in
+    }
   }
-  s = wave_sum(s);
-  q = wave_sum(q);
   if (threadIdx.x != 0) return;
-  sums[c] = (float)s;
-  sums[C + c] = (float)q;
-  if (dweight) dweight[c] = accumulate ? dweight[c] + (float)q : (float)q;
-  if (dbias) dbias[c] = accumulate ? dbias[c] + (float)s : (float)s;
+  if (dweight) dweight[c] = accumulate ? dweight[c] + tq : tq;
+  if (dbias) dbias[c] = accumulate ? dbias[c] + ts : ts;
 }
 
 __global__ __launch_bounds__(64) void k_colsum_finalize(const double* __restrict__ partial, int nblk, int C, float* __restrict__ out,
@@ -171,11 +193,14 @@ __global__ __launch_bounds__(T) void k_bn2d_apply(const u16* __restrict__ x, int
                                                    int64_t N, int C, const float* __restrict__ mean,
                                                    const float* __restrict__ invstd, int stat_is_var, float eps,
                                                    const float* __restrict__ weight, const float* __restrict__ bias, int relu,
-                                                   u16* __restrict__ y, int ld_y) {
+                                                   u16* __restrict__ y, int ld_y, int64_t Ns, int ab0) {
   const int CV = C >> 3;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
   if (slot >= rs) return;
+  const int grp = (int)blockIdx.x >= ab0;  // statistics group of this block's rows (see k_bn2d_reduce)
+  const int64_t gbase = grp ? Ns : 0, gend = grp ? N : Ns;
+  mean += grp * C, invstd += grp * C;
   float sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -184,11 +209,11 @@ __global__ __launch_bounds__(T) void k_bn2d_apply(const u16* __restrict__ x, int
     sc[i] = is * (weight ? weight[c] : 1.f);
     sh[i] = (bias ? bias[c] : 0.f) - mean[c] * sc[i];
   }
-  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+  const int64_t r0 = gbase + (int64_t)(grp ? blockIdx.x - ab0 : blockIdx.x) * rs * APPLY_ROWS + slot;
 #pragma unroll 4
   for (int k = 0; k < APPLY_ROWS; k++) {
     const int64_t r = r0 + (int64_t)k * rs;
-    if (r >= N) break;
+    if (r >= gend) break;
     float xv[8], rv[8], yv[8];
     ld8(x + r * ld_x + cv * 8, xv);
     if (res) ld8(res + r * ld_r + cv * 8, rv);
@@ -207,14 +232,18 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
                                                        const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ sums,
-                                                       u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr) {
+                                                       u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr, int64_t Ns,
+                                                       int ab0) {
   const int CV = C >> 3;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
   if (slot >= rs) return;
-  // dx = a*g + b*x + c0 with a = w*is, b = -w*is^2*sgx/N, c0 = -a*sg/N - b*mean
+  const int grp = (int)blockIdx.x >= ab0;
+  const int64_t gbase = grp ? Ns : 0, gend = grp ? N : Ns;
+  mean += grp * C, invstd += grp * C, sums += grp * 2 * C;
+  // dx = a*g + b*x + c0 with a = w*is, b = -w*is^2*sgx/N, c0 = -a*sg/N - b*mean   (N = rows of this statistics group)
   float ka[8], kb[8], kc[8];
-  const float invN = 1.f / (float)N;
+  const float invN = 1.f / (float)(gend - gbase);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     int c = cv * 8 + i;
@@ -223,11 +252,11 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
     kb[i] = -w * is * is * sums[C + c] * invN;
     kc[i] = -ka[i] * sums[c] * invN - kb[i] * mean[c];
   }
-  const int64_t r0 = (int64_t)blockIdx.x * rs * APPLY_ROWS + slot;
+  const int64_t r0 = gbase + (int64_t)(grp ? blockIdx.x - ab0 : blockIdx.x) * rs * APPLY_ROWS + slot;
 #pragma unroll 4
   for (int k = 0; k < APPLY_ROWS; k++) {
     const int64_t r = r0 + (int64_t)k * rs;
-    if (r >= N) break;
+    if (r >= gend) break;
     float xv[8], dv[8], yv[8], ov[8], gv[8];
     ld8(x + r * ld_x + cv * 8, xv);
     ld8(dy + r * ld_dy + cv * 8, dv);
@@ -259,26 +288,49 @@ inline int stat_blocks(int64_t N, int C) {
 
 extern "C" {
 
-size_t mm_bn2d_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(2 * C * sizeof(float)) + 256; }
+size_t mm_bn2d_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 
-// y = act(BN_train(x) + res); x,res,y NHWC bf16 [N rows, C]; save_* fp32 [C]; momentum = torch's (0.1)
-int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
-                      float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps, float momentum, int relu,
-                      void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+// block counts of the two statistics groups (rows [0,Ns) and [Ns,N)); Ns == N or Ns == 0: a single group
+static void split_blocks(int64_t N, int64_t& Ns, int C, bool stats, int& b0, int& b1) {
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  if (stats) {
+    b0 = stat_blocks(Ns, C);
+    b1 = Ns < N ? stat_blocks(N - Ns, C) : 0;
+    if (b1 > 0) {  // both groups share the MAX_PART partial slots
+      if (b0 > MAX_PART / 2) b0 = MAX_PART / 2;
+      if (b1 > MAX_PART / 2) b1 = MAX_PART / 2;
+    }
+  } else {
+    b0 = (int)apply_blocks(Ns, C);
+    b1 = Ns < N ? (int)apply_blocks(N - Ns, C) : 0;
+  }
+}
+
+// y = act(BN_train(x) + res); x,res,y NHWC bf16 [N rows, C]; momentum = torch's (0.1).
+// Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source and target halves of a jointly
+// batched step, train.py:186-292 calls the net once per domain); Ns = N (or 0) is the ordinary single-batch case.
+// save_mean / save_invstd: fp32 [G][C], G = 2 when split.
+int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+                      const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                      float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                      hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_y % 8 == 0, "bn2d: C must be a multiple of 8, <= 2048");
   if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
     mm_set_error("bn2d: workspace too small");
     return MM_ERR_WORKSPACE;
   }
   double* partial = (double*)ws;
-  int nb = stat_blocks(N, C);
-  hipLaunchKernelGGL(k_bn2d_reduce<0>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr, nullptr,
-                     partial);
-  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb, N, C, eps, momentum, running_mean, running_var,
+  int nb0, nb1, ab0, ab1;
+  split_blocks(N, Ns, C, true, nb0, nb1);
+  hipLaunchKernelGGL(k_bn2d_reduce<0>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr,
+                     nullptr, partial, Ns, nb0);
+  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
                      save_mean, save_invstd, num_batches_tracked);
-  if (N > 0)
-    hipLaunchKernelGGL(k_bn2d_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r,
-                       N, C, save_mean, save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y);
+  if (N > 0) {
+    split_blocks(N, Ns, C, false, ab0, ab1);
+    hipLaunchKernelGGL(k_bn2d_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N, C, save_mean,
+                       save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y, Ns, ab0);
+  }
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -287,32 +339,35 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
                      const float* running_mean, const float* running_var, float eps, int relu, void* y, int ld_y, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0, "bn2d: C must be a multiple of 8");
   if (N == 0) return MM_OK;
-  hipLaunchKernelGGL(k_bn2d_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N,
-                     C, running_mean, running_var, 1, eps, weight, bias, relu, (u16*)y, ld_y);
+  const int ab = (int)apply_blocks(N, C);
+  hipLaunchKernelGGL(k_bn2d_apply, dim3(ab), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N, C, running_mean, running_var,
+                     1, eps, weight, bias, relu, (u16*)y, ld_y, N, ab);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-// dx (and dres = relu-masked dy when dres != NULL), dweight, dbias
-int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N, int C,
+// dx (and dres = relu-masked dy when dres != NULL), dweight, dbias; Ns and the [G][C] statistics as in mm_bn2d_fwd_train
+int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N, int64_t Ns, int C,
                 const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
                 float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T, "bn2d: C must be a multiple of 8, <= 2048");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
-  if (ws_bytes < need + 2 * C * sizeof(float)) {
+  if (ws_bytes < need + 4 * C * sizeof(float)) {
     mm_set_error("bn2d_bwd: workspace too small");
     return MM_ERR_WORKSPACE;
   }
   double* partial = (double*)ws;
   float* sums = (float*)((char*)ws + need);
-  int nb = stat_blocks(N, C);
-  hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y, relu,
-                     N, C, save_mean, save_invstd, partial);
-  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb, C, sums, dweight, dbias, accumulate);
-  if (N > 0)
-    hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(apply_blocks(N, C)), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy,
-                       ld_dy, (const u16*)yout, ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres,
-                       ld_dr);
+  int nb0, nb1, ab0, ab1;
+  split_blocks(N, Ns, C, true, nb0, nb1);
+  hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y,
+                     relu, N, C, save_mean, save_invstd, partial, Ns, nb0);
+  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
+  if (N > 0) {
+    split_blocks(N, Ns, C, false, ab0, ab1);
+    hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout,
+                       ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres, ld_dr, Ns, ab0);
+  }
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -326,7 +381,7 @@ int mm_colsum_bf16(const void* x, int ld_x, int64_t N, int C, float* out, int ac
   }
   int nb = stat_blocks(N, C);
   hipLaunchKernelGGL(k_bn2d_reduce<2>, dim3(nb), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr, nullptr,
-                     (double*)ws);
+                     (double*)ws, N, nb);
   hipLaunchKernelGGL(k_colsum_finalize, dim3(C), dim3(64), 0, s, (const double*)ws, nb, C, out, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;

@@ -228,6 +228,18 @@ __global__ void k_fill_i32(int32_t* p, int64_t n, int32_t v) {
 
 inline unsigned nblk(int64_t n) { return (unsigned)mm_cdiv(n > 0 ? n : 1, T); }
 
+// first row whose batch index (column 3 of the [n,4] voxel coordinates) is >= split; rows are in first-occurrence order of a
+// batch-sorted point list, hence batch-sorted themselves.  One thread: a 20-step binary search.
+__global__ void k_batch_lower_bound(const int32_t* __restrict__ coords, const int32_t* __restrict__ n_dev, int32_t split,
+                                    int32_t* __restrict__ out) {
+  int lo = 0, hi = *n_dev;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (coords[(int64_t)mid * 4 + 3] < split) lo = mid + 1;
+    else hi = mid;
+  }
+  *out = lo;
+}
 }  // namespace
 
 extern "C" {
@@ -345,6 +357,14 @@ int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, 
   rc = mm_exclusive_scan_i32(cnt, csr_off, n_out, csr_off + n_out, scan_ws, sws, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_row_fill, dim3(nblk(n_out)), dim3(T), 0, s, nbr, pos, n_out, K, csr_off, csr_pos);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// out[0] = number of active rows whose batch index < split (their row ids are 0 .. out[0]-1); n_dev: device row count
+int mm_batch_lower_bound(const int32_t* vox_coords, const int32_t* n_dev, int32_t split, int32_t* out, hipStream_t s) {
+  MM_CHECK_ARG(vox_coords && n_dev && out, "batch_lower_bound: null pointer");
+  hipLaunchKernelGGL(k_batch_lower_bound, dim3(1), dim3(1), 0, s, vox_coords, n_dev, split, out);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib, gradsink
+from . import _lib, domains, gradsink
 from . import conv2d as _c2d
 from ._lib import check, ptr, stream
 
@@ -63,9 +63,12 @@ class _BN2dFn(torch.autograd.Function):
             res = _c2d.as_nhwc_bf16(res)
         y = torch.empty_like(x)
         if training:
-            stats = torch.empty((2, C), dtype=F32, device=x.device)
+            nf = domains.current()  # jointly batched domains keep their own batch statistics
+            Ns = nf * H * W if (nf is not None and 0 < nf < B) else N
+            stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
-            check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+            ctx.Ns = Ns
+            check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
                                       ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats)
             ctx.sinks = None
@@ -98,7 +101,7 @@ class _BN2dFn(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device)
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
-        check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(y), C, 1 if ctx.relu else 0, N, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
+        check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(y), C, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
                             ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
                             stream()), "bn2d_bwd")
         if ctx.sinks is not None:

@@ -229,7 +229,8 @@ class BatchNormalization(nn.Module):
 
     def forward(self, x):
         f = ops.BatchNormActFunction.apply(x.features, self.weight, self.bias, self.running_mean, self.running_var,
-                                           self.training, float(self.eps), float(self.momentum), float(self.leakiness))
+                                           self.training, float(self.eps), float(self.momentum), float(self.leakiness),
+                                           getattr(x.level, "seg_rows", None))
         return x._with(f)
 
     def __repr__(self):

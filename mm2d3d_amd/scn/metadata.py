@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .. import _lib
+from .. import _lib, domains
 from .._lib import check, ptr, stream
 
 I32 = torch.int32
@@ -42,6 +42,7 @@ class Level:
         self.csr_off = None    # site -> items (ascending)
         self.csr_items = None
         self.n_items = 0
+        self.seg_rows = None   # rows [0, seg_rows) belong to the first statistics group (mm2d3d_amd/domains.py)
         self.subm = None
         self.down = None       # Rulebook (K=8) to self.coarse
         self.coarse = None
@@ -63,8 +64,9 @@ class Metadata:
         dev = self.device
         n_pts = coords_i64.shape[0]
         nlev = max(1, min(self.prebuild_levels, max(1, int(np.log2(max(self.spatial_size, 2))))))
-        counts = torch.zeros(nlev + 1, dtype=I32, device=dev)  # [n_0..n_{L-1}, err]
-        err = counts[nlev:]
+        counts = torch.zeros(2 * nlev + 1, dtype=I32, device=dev)  # [n_0..n_{L-1}, err, seg_0..seg_{L-1}]
+        err = counts[nlev : nlev + 1]
+        split = self.split = domains.current()  # scenes [0, split) / [split, B) keep their own batch-norm statistics
         cap = int(L.mm_hash_capacity(n_pts))
         ws = _lib.workspace.get(int(L.mm_dedupe_ws_bytes(n_pts)), dev)
         S = self.spatial_size
@@ -88,6 +90,9 @@ class Metadata:
                                   ptr(counts[l : l + 1]), ptr(err), ptr(ws), ws.numel(), stream()),
                 "voxel_dedupe",
             )
+            if split is not None:
+                check(L.mm_batch_lower_bound(ptr(lv.coords), ptr(counts[l : l + 1]), split, ptr(counts[nlev + 1 + l : nlev + 2 + l]),
+                                             stream()), "batch_lower_bound")
             if prev is not None:
                 prev.coarse, lv.fine = lv, prev
             self.levels.append(lv)
@@ -99,6 +104,7 @@ class Metadata:
         n_items = n_pts
         for l, lv in enumerate(self.levels):
             lv.n = int(host[l])
+            lv.seg_rows = int(host[nlev + 1 + l]) if split is not None else None
             lv.n_items = n_items
             lv.coords = lv.coords[: lv.n]
             lv.item2vox = lv.item2vox[:n_items]
@@ -120,7 +126,7 @@ class Metadata:
         lv.coords = torch.empty((max(n, 1), 4), dtype=I32, device=dev)
         lv.csr_off = torch.empty(n + 1, dtype=I32, device=dev)
         lv.csr_items = torch.empty(max(n, 1), dtype=I32, device=dev)
-        cnt = torch.zeros(2, dtype=I32, device=dev)
+        cnt = torch.zeros(3, dtype=I32, device=dev)
         ws = _lib.workspace.get(int(L.mm_dedupe_ws_bytes(n)), dev)
         check(
             L.mm_voxel_dedupe(ptr(fine.coords), 0, n, None, 1, ptr(lv.tkeys), ptr(lv.tvals), lv.cap, ptr(lv.item2vox),
@@ -128,7 +134,11 @@ class Metadata:
                               ws.numel(), stream()),
             "voxel_dedupe",
         )
-        lv.n = int(cnt[0].item())
+        if fine.seg_rows is not None:
+            check(L.mm_batch_lower_bound(ptr(lv.coords), ptr(cnt[0:1]), self.split, ptr(cnt[2:3]), stream()), "batch_lower_bound")
+        hc = cnt.cpu().numpy()
+        lv.n = int(hc[0])
+        lv.seg_rows = int(hc[2]) if fine.seg_rows is not None else None
         lv.n_items = n
         lv.coords = lv.coords[: lv.n]
         lv.csr_off = lv.csr_off[: lv.n + 1]

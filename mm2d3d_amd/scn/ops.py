@@ -116,17 +116,19 @@ class SparseConvFunction(torch.autograd.Function):
 
 class BatchNormActFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, momentum, leak):
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, momentum, leak, seg_rows=None):
         _lib.require_cuda(x, "features")
         L = _lib.lib()
         x = _c(x.to(F32))
         N, C = x.shape
         y = torch.empty_like(x)
         if training:
-            stats = torch.empty((2, C), dtype=F32, device=x.device)
+            Ns = seg_rows if (seg_rows is not None and 0 < seg_rows < N) else N  # per-domain statistics of a joint batch
+            ctx.Ns = Ns
+            stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
             check(
-                L.mm_bn_fwd_train(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
+                L.mm_bn_fwd_train(ptr(x), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
                                   leak, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()),
                 "bn_fwd_train",
             )
@@ -165,14 +167,14 @@ class BatchNormActFunction(torch.autograd.Function):
             db = dbt = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
             acc = 0
         check(
-            L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
+            L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
                         ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
             "bn_bwd",
         )
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class InputMeanFunction(torch.autograd.Function):

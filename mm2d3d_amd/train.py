@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import domains
 from .ddp import GradAllReducer
 from .losses import Loss, cross_modal_loss
 from .metrics import SegIoU
@@ -27,6 +28,10 @@ class TrainModel(nn.Module):
         self.lambda_xm_src = train_kwargs.get("lambda_xm_src", 1.0)
         self.lambda_xm_trg = train_kwargs.get("lambda_xm_trg", 0.1)
         self.broadcast_buffers = train_kwargs.get("broadcast_buffers", True)  # torch DDP default (run.py:264-268)
+        # One pass per network over [source scenes | target scenes] instead of one per domain: half the launches, twice
+        # the rows per launch.  The batch-norm layers keep per-domain statistics (mm2d3d_amd/domains.py), so the
+        # arithmetic is that of the reference's two calls.  False: the literal two-call sequence.
+        self.joint_domains = train_kwargs.get("joint_domains", True)
         self._opt_factories = optimizer or {}
         self.optimizers, self.schedulers = [], []
         self.reducer = None
@@ -53,19 +58,48 @@ class TrainModel(nn.Module):
 
     cross_modal_loss = staticmethod(cross_modal_loss)
 
+    @staticmethod
+    def _join(src, trg):
+        """[source | target] batch dict: scene / image indices of the target follow the source's."""
+        B = src["img"].shape[0]
+        locs_t = trg["x"][0].clone()
+        locs_t[:, -1] += B
+        return {
+            "x": [torch.cat([src["x"][0], locs_t], 0), torch.cat([src["x"][1], trg["x"][1]], 0)],
+            "img": torch.cat([src["img"], trg["img"]], 0),
+            "depth": torch.cat([src["depth"], trg["depth"]], 0),
+            "img_indices": list(src["img_indices"]) + list(trg["img_indices"]),
+        }, B
+
+    def _can_join(self, src, trg):
+        return (self.joint_domains and self.training and src["img"].is_cuda and src["img"].shape[1:] == trg["img"].shape[1:]
+                and src["depth"].shape[1:] == trg["depth"].shape[1:])
+
     def _generic_step(self, batch, stage):
         src, trg = batch["source"], batch["target"]
         n2d, n3d = self.modules_name[0], self.modules_name[1]
-        p2d, _, _, aux2d = self(src, model_name=n2d)
-        p3d, _, aux3d = self(src, model_name=n3d)
-        seg2d = self.loss("segmentation", pred=p2d["seg_logit"], gt=src["seg_label"])
-        seg3d = self.loss("segmentation", pred=p3d["seg_logit"], gt=src["seg_label"])
-        xs2d, xs3d = self.cross_modal_loss(p3d["seg_logit"], aux2d["seg_logit_avg"], p2d["seg_logit"],
-                                           aux3d["seg_logit_point"])
-        p2d, _, _, aux2d = self(trg, model_name=n2d)
-        p3d, _, aux3d = self(trg, model_name=n3d)
-        xt2d, xt3d = self.cross_modal_loss(p3d["seg_logit"], aux2d["seg_logit_avg"], p2d["seg_logit"],
-                                           aux3d["seg_logit_point"])
+        if self._can_join(src, trg):
+            both, B = self._join(src, trg)
+            P = src["x"][0].shape[0]  # point rows [0, P) are the source's
+            with domains.split(B):
+                p2d, _, _, aux2d = self(both, model_name=n2d)
+                p3d, _, aux3d = self(both, model_name=n3d)
+            l2d, a2d, l3d, a3d = p2d["seg_logit"], aux2d["seg_logit_avg"], p3d["seg_logit"], aux3d["seg_logit_point"]
+            seg2d = self.loss("segmentation", pred=l2d[:P], gt=src["seg_label"])
+            seg3d = self.loss("segmentation", pred=l3d[:P], gt=src["seg_label"])
+            xs2d, xs3d = self.cross_modal_loss(l3d[:P], a2d[:P], l2d[:P], a3d[:P])
+            xt2d, xt3d = self.cross_modal_loss(l3d[P:], a2d[P:], l2d[P:], a3d[P:])
+        else:
+            p2d, _, _, aux2d = self(src, model_name=n2d)
+            p3d, _, aux3d = self(src, model_name=n3d)
+            seg2d = self.loss("segmentation", pred=p2d["seg_logit"], gt=src["seg_label"])
+            seg3d = self.loss("segmentation", pred=p3d["seg_logit"], gt=src["seg_label"])
+            xs2d, xs3d = self.cross_modal_loss(p3d["seg_logit"], aux2d["seg_logit_avg"], p2d["seg_logit"],
+                                               aux3d["seg_logit_point"])
+            p2d, _, _, aux2d = self(trg, model_name=n2d)
+            p3d, _, aux3d = self(trg, model_name=n3d)
+            xt2d, xt3d = self.cross_modal_loss(p3d["seg_logit"], aux2d["seg_logit_avg"], p2d["seg_logit"],
+                                               aux3d["seg_logit_point"])
         self.last_logs = {
             f"{stage}/loss_segmentation": seg2d, f"{stage}/loss_segmentation_3d": seg3d,
             f"{stage}/xm_loss_src_2d": xs2d, f"{stage}/xm_loss_tgt_2d": xt2d,
