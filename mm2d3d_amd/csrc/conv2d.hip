@@ -320,6 +320,219 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void k_conv3x3(C3P p) {
   }
 }
 
+// Persistent variant (the one that runs).  At these layer sizes a 128 px x 64 cout workgroup's MFMA work is ~1 us while
+// its fixed costs (first halo from HBM, output stores, dispatch) are several, and every workgroup re-streams the whole
+// weight tensor of its cout block from L2: measured with MFMAs and all streaming switched off, the kernel above still
+// takes 2/3 of its time, and the L2->LDS weight traffic (pixels/128 x |W|) is 3-20x the activation bytes.
+// Here ONE 8-wave workgroup per CU stays resident and walks a list of (256-pixel tile, BN-cout block) items - half the
+// weight traffic per FLOP, half the LDS-DMA issues per MFMA - with everything software-pipelined ACROSS items and LDS-DMA
+// kept in flight over raw barriers (counted s_waitcnt vmcnt, cdna_hip_programming.md "Pipelining across barriers"):
+//   halo ring of 2: the halo of the next (item, 64-channel chunk) is requested while the current chunk is multiplied
+//   W ring of 3   : weight tiles are requested two taps ahead
+//   the bf16 output stores of item t drain while item t+1 is already computing.
+// MFMA operands are swapped (D = W x X^T) so that a lane owns 4 consecutive output channels of one pixel: 8-byte stores.
+// Every DMA / store instruction is issued unconditionally (padding reads come from g_zero16, out-of-image stores go to
+// g_dump) so the per-wave VMEM instruction counts the waits rely on are exact (checked in the disassembly: the
+// global_load_lds sit outside the exec-masked address selection, NST global_store_dwordx2 per item).
+// TW = 16: 16 x 16 pixel tiles (large maps); TW = 32: 8 x 32 (low-resolution maps waste fewer out-of-image pixels).
+__device__ __attribute__((aligned(16))) unsigned int g_dump[256];  // sink for the stores of out-of-image pixels
+
+template <int N>
+__device__ inline void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BN, int TW>
+__global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
+  constexpr int HSZ = 384 * 64;   // elements per halo buffer: 6 DMA rounds of 64 rows
+  constexpr int BSZ = BN * 64;
+  constexpr int NB = BN / 64;     // W DMA instructions per thread and tile
+  constexpr int TN = BN / 64;     // 32-cout fragments per wave
+  constexpr int NST = 2 * TN * 4; // store instructions per wave and item
+  static_assert(HROWS <= 384, "halo does not fit its 6 DMA rounds");
+  u16* Hs = smem;                 // [2][HSZ]
+  u16* Bs = smem + 2 * HSZ;       // [3][BSZ]
+  float* biasl = (float*)(Bs + 3 * BSZ);  // [Cn <= 1024] when p.bias
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;  // 4 (pixels) x 2 (couts)
+  const int cc = tid & 7, r0 = tid >> 3;
+  const int nchunk = p.Ca >> 6, ncb = p.Cn / BN;
+  if (p.bias) {  // staged once by DMA: an ordinary global load inside the pipeline would make hipcc drain it (vmcnt(0))
+    for (int k0 = 0; k0 < p.Cn; k0 += 512) {
+      const int k = k0 + tid < p.Cn ? k0 + tid : p.Cn - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + k),
+                                       (__attribute__((address_space(3))) void*)(biasl + k0 + wave * 64), 4, 0, 0);
+    }
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+  }
+  const int nitems = p.B * p.tiles_y * p.tiles_x * ncb;
+  // item schedule: the 8 XCDs own contiguous item ranges (blockIdx round-robins over XCDs), so the workgroups that share
+  // a tile's halo (its cout blocks are consecutive items) run on one XCD at the same time and share its L2
+  const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int it_begin = xcd * per + local;
+  const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
+  if (it_begin >= it_end) return;
+  const int my_items = (it_end - it_begin + G8 - 1) / G8;
+  const int nseg = my_items * nchunk;
+
+  auto decode = [&](int item, int& b, int& ty0, int& tx0, int& n0) {
+    n0 = (item % ncb) * BN;
+    int t = item / ncb;
+    tx0 = (t % p.tiles_x) * TW;
+    t /= p.tiles_x;
+    ty0 = (t % p.tiles_y) * TH;
+    b = t / p.tiles_y;
+  };
+  // Producer cursors advance incrementally (no per-step divisions between the barrier and the MFMAs).
+  // halo cursor: one step = one (item, chunk) segment
+  int h_item = it_begin, h_c = 0, h_b, h_ty0, h_tx0, h_n0;
+  decode(h_item, h_b, h_ty0, h_tx0, h_n0);
+  int hyx[6];  // this thread's 6 halo pixels (hy << 8 | hx), 0xFFFF = beyond the halo
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    const int row = r0 + 64 * i, hy = row / HC;
+    hyx[i] = row < HROWS ? (hy << 8) | (row - hy * HC) : 0xFFFF;
+  }
+  auto issue_halo = [&](int buf) {  // 6 DMA instructions, always; then advance the cursor
+    const bool live = h_item < it_end;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const int row = r0 + 64 * i;  // halo pixel index (wave-instruction = 8 consecutive halo pixels)
+      const int y = h_ty0 + (hyx[i] >> 8) - 1, x = h_tx0 + (hyx[i] & 255) - 1;
+      const u16* g = (const u16*)g_zero16;
+      if (live && hyx[i] != 0xFFFF && y >= 0 && y < p.H && x >= 0 && x < p.W)
+        g = p.A + ((int64_t)(h_b * p.H + y) * p.W + x) * p.lda + h_c * 64 + ((cc ^ ((row >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Hs + buf * HSZ + (wave * 8 + 64 * i) * 64), 16, 0, 0);
+    }
+    if (++h_c == nchunk) {
+      h_c = 0;
+      h_item += G8;
+      if (h_item < it_end) decode(h_item, h_b, h_ty0, h_tx0, h_n0);
+    }
+  };
+  // W cursor: one step = one (item, chunk, tap)
+  int w_item = it_begin, w_c = 0, w_tap = 0, w_n0 = (it_begin % ncb) * BN;
+  auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
+    const bool live = w_item < it_end;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int row = r0 + 64 * i;
+      const u16* g_ = live ? p.Wp + ((int64_t)(w_n0 + row) * 9 + w_tap) * p.Ca + w_c * 64 + ((cc ^ ((row >> 1) & 7)) << 3) : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,
+                                       (__attribute__((address_space(3))) void*)(Bs + buf * BSZ + (wave * 8 + 64 * i) * 64), 16, 0, 0);
+    }
+    if (++w_tap == 9) {
+      w_tap = 0;
+      if (++w_c == nchunk) {
+        w_c = 0;
+        w_item += G8;
+        w_n0 = (w_item % ncb) * BN;
+      }
+    }
+  };
+
+  f32x16 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int fr_ = lane & 31, fh = lane >> 5;
+  int hbase[2], ppy[2], ppx[2];  // this lane's two pixels p = 64*wm + 32*i + fr_ -> (p / TW, p % TW); halo row at tap (0,0)
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int pix = 64 * wm + 32 * i + fr_;
+    ppy[i] = pix / TW, ppx[i] = pix % TW;
+    hbase[i] = ppy[i] * HC + ppx[i];
+  }
+
+  issue_halo(0);
+  issue_w(0);
+  issue_w(1);
+  int wb = 0;          // W ring slot of the current step
+  int st_age = 2;      // steps since the last item's stores were issued (they sit in the VMEM queue behind W(g+1))
+  int c_item = it_begin, c_c = 0;  // consumer cursor
+  for (int seg = 0; seg < nseg; seg++) {
+    const u16* Hb = Hs + (seg & 1) * HSZ;
+#pragma unroll 1
+    for (int tap = 0; tap < 9; tap++) {
+      // W(g) [and, at tap 0, this segment's halo, which is older] must have landed.  Younger than W(g) in the queue:
+      // W(g+1) (NB); the next halo (6) when the previous step was a tap 0; the previous item's stores (NST) for two steps.
+      const bool h = tap == 1, st = st_age < 2;
+      if (!h && !st) wait_vm<NB>();
+      else if (h && !st) wait_vm<NB + 6>();
+      else if (!h && st) wait_vm<NB + NST>();
+      else wait_vm<NB + 6 + NST>();
+      __builtin_amdgcn_s_barrier();  // everyone finished step g-1: ring slots (g+2)%3 and (seg+1)&1 are free
+      if (tap == 0) issue_halo((seg + 1) & 1);
+      int wb2 = wb + 2;
+      if (wb2 >= 3) wb2 -= 3;
+      issue_w(wb2);
+      st_age++;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int hoff = p.flip ? (2 - kh) * HC + (2 - kw) : kh * HC + kw;
+      const u16* Bb = Bs + wb * BSZ;
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        bf16x8 af[2], bf[TN];
+        const int ch = kk * 2 + fh;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const int row = hbase[i] + hoff;
+          af[i] = *(const bf16x8*)&Hb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
+        }
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          const int row = wn * (BN / 2) + j * 32 + fr_;
+          bf[j] = *(const bf16x8*)&Bb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);  // D[cout][pixel]
+      }
+      if (++wb == 3) wb = 0;
+    }
+    if (++c_c == nchunk) {  // item finished: D row (reg&3) + 8*(reg>>2) + 4*fh = output channel, column fr_ = pixel
+      int b, ty0, tx0, n0;
+      decode(c_item, b, ty0, tx0, n0);
+      c_c = 0;
+      c_item += G8;
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const int y = ty0 + ppy[i], x = tx0 + ppx[i];
+        const bool inside = y < p.H && x < p.W;
+        u16* orow = p.O + ((int64_t)(b * p.H + y) * p.W + x) * p.ldo + n0 + wn * (BN / 2) + 4 * fh;
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              v[e] = acc[i][j][4 * q + e];
+              if (p.bias) v[e] += biasl[n0 + wn * (BN / 2) + 32 * j + 8 * q + 4 * fh + e];
+              acc[i][j][4 * q + e] = 0.f;
+            }
+            uint2 o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *(uint2*)(inside ? orow + 32 * j + 8 * q : (u16*)g_dump + lane * 4) = o;
+          }
+      }
+      st_age = 0;
+    }
+  }
+  wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgP {
   const u16* X;   // [B,Hi,Wi,Ck]
@@ -802,7 +1015,34 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
   }
   // 64-wide output-channel blocks everywhere: 39 KB of LDS per workgroup -> 4 workgroups per CU.  Measured: resident
   // workgroups (DMA-latency hiding) matter more than the halved B-fragment traffic of 128-wide blocks (tools/bench_conv.py).
-  hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
+  static const bool old_kernel = getenv("MM_C3_OLD") != nullptr;  // tools/bench_c3.py A/B switch
+  if (old_kernel || Cn % 64 != 0 || Cn > 1024 || ldo % 4 != 0 || ((uintptr_t)O % 8) != 0) {
+    hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
+  } else {
+    // 16 x 16 tiles on large maps, 8 x 32 where that wastes fewer out-of-image pixels; 128-cout blocks when Cn allows
+    const int64_t px16 = mm_cdiv(H, 16) * mm_cdiv(W, 16), px32 = mm_cdiv(H, 8) * mm_cdiv(W, 32);
+    const int tw = px32 < px16 ? 32 : 16;
+    const int bn = Cn % 128 == 0 ? 128 : 64;
+    p.tiles_y = (int)mm_cdiv(H, 256 / tw); p.tiles_x = (int)mm_cdiv(W, tw);
+    const int64_t nitems = (int64_t)B * p.tiles_y * p.tiles_x * (Cn / bn);
+    MM_CHECK_ARG(nitems < (1ll << 30), "conv2d_3x3s1: too many tiles");
+    const size_t ldsw = (size_t)(2 * 384 * 64 + 3 * bn * 64) * 2 + (bias ? (size_t)mm_cdiv(Cn, 512) * 512 * 4 : 0);
+    int64_t grid = mm_cdiv(nitems, 8) * 8;  // a multiple of the 8 XCDs
+    if (grid > 256) grid = 256;             // one resident 8-wave workgroup per CU
+    static bool once_w = false;
+    if (!once_w) {
+      const int mx = (2 * 384 * 64 + 3 * 128 * 64) * 2 + 4096;
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      once_w = true;
+    }
+    if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv3x3w<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+    else if (tw == 16) hipLaunchKernelGGL((k_conv3x3w<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+    else hipLaunchKernelGGL((k_conv3x3w<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+  }
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

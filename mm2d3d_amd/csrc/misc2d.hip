@@ -30,6 +30,38 @@ __global__ __launch_bounds__(T) void k_copy_rows(const u16* __restrict__ src, in
   *(uint4*)(dst + r * ld_d + c * 8) = *(const uint4*)(src + r * ld_s + c * 8);
 }
 
+// Channel concat / split of up to 4 NHWC bf16 maps in ONE launch: dst[r] = [src0[r] | src1[r] | ...] (SPLIT: the reverse).
+// A thread owns one 16-B chunk column of the wide row and walks ROWS rows, so the wide rows are written (read) as whole
+// contiguous lines and there is no per-element division.
+struct CatP {
+  const u16* src[4];  // SPLIT: destinations (cast away const at the store)
+  int c8[4];          // chunks (8 channels) per part
+  int n;
+  u16* wide;
+  int ct8;            // chunks per wide row
+  int64_t N;
+};
+template <bool SPLIT>
+__global__ __launch_bounds__(T) void k_concat(CatP p) {
+  constexpr int ROWS = 8;
+  const int rows_per_pass = T / p.ct8;  // host guarantees ct8 <= T
+  const int rl = threadIdx.x / p.ct8, c = threadIdx.x - rl * p.ct8;
+  if (rl >= rows_per_pass) return;
+  int part = 0, cc = c;
+  while (part < p.n - 1 && cc >= p.c8[part]) cc -= p.c8[part], part++;
+  u16* narrow = (u16*)p.src[part];
+  const int ldn = p.c8[part] * 8;
+  int64_t r = (int64_t)blockIdx.x * rows_per_pass * ROWS + rl;
+#pragma unroll
+  for (int k = 0; k < ROWS; k++, r += rows_per_pass) {
+    if (r >= p.N) break;
+    uint4* w = (uint4*)(p.wide + (r * p.ct8 + c) * 8);
+    uint4* q = (uint4*)(narrow + r * ldn + cc * 8);
+    if (SPLIT) *q = *w;
+    else *w = *q;
+  }
+}
+
 // ---- max-pool 3x3 stride 2 pad 1, NHWC bf16; idx = winning tap (kh*3+kw), first maximum in scan order (torch).
 // thread = 8 consecutive channels of one pixel (16-B loads/stores, 8-B index vectors)
 __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, int B, int H, int W, int C, u16* __restrict__ y,
@@ -299,6 +331,29 @@ int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, in
                "copy_rows: C and pitches must be multiples of 8 elements");
   if (N == 0) return MM_OK;
   hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)src, ld_s, (u16*)dst, ld_d, N, C / 8);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// wide[r] = [parts[0][r] | parts[1][r] | ...] (split != 0: parts[i][r] = the i-th channel slice of wide[r]); all maps are
+// dense NHWC bf16 rows, channel counts multiples of 8, 1 <= nparts <= 4
+int mm_concat_bf16(void* const* parts, const int* channels, int nparts, void* wide, int64_t N, int split, hipStream_t s) {
+  MM_CHECK_ARG(nparts >= 1 && nparts <= 4 && parts && channels && wide, "concat: 1..4 parts");
+  CatP p = {};
+  int ct = 0;
+  for (int i = 0; i < nparts; i++) {
+    MM_CHECK_ARG(channels[i] > 0 && channels[i] % 8 == 0 && ((uintptr_t)parts[i] % 16) == 0, "concat: channels must be multiples of 8");
+    p.src[i] = (const u16*)parts[i];
+    p.c8[i] = channels[i] / 8;
+    ct += channels[i];
+  }
+  MM_CHECK_ARG(ct / 8 <= T && ((uintptr_t)wide % 16) == 0, "concat: at most 2048 channels");
+  p.n = nparts, p.wide = (u16*)wide, p.ct8 = ct / 8, p.N = N;
+  if (N == 0) return MM_OK;
+  const int rows_per_block = (T / p.ct8) * 8;
+  const unsigned nb = (unsigned)mm_cdiv(N, rows_per_block);
+  if (split) hipLaunchKernelGGL(k_concat<true>, dim3(nb), dim3(T), 0, s, p);
+  else hipLaunchKernelGGL(k_concat<false>, dim3(nb), dim3(T), 0, s, p);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -11,6 +11,8 @@ refused (no CPU fallback).  Still on torch ops (interim, listed in DESIGN.md): D
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -187,10 +189,9 @@ class _CatFn(torch.autograd.Function):
         cs = [x.shape[1] for x in xs]
         Ct = sum(cs)
         out = torch.empty((B, Ct, H, W), dtype=BF16, device=xs[0].device, memory_format=CL)
-        N, off = B * H * W, 0
-        for x, c in zip(xs, cs):
-            check(L.mm_copy_rows_bf16(ptr(x), c, out.data_ptr() + 2 * off, Ct, N, c, stream()), "copy_rows")
-            off += c
+        n = len(xs)
+        check(L.mm_concat_bf16((ctypes.c_void_p * n)(*[x.data_ptr() for x in xs]), (ctypes.c_int * n)(*cs), n, ptr(out), B * H * W, 0,
+                               stream()), "concat")
         ctx.cs = cs
         return out
 
@@ -199,12 +200,10 @@ class _CatFn(torch.autograd.Function):
         L = _lib.lib()
         dy = _c2d.as_nhwc_bf16(dy)
         B, Ct, H, W = dy.shape
-        N, off, outs = B * H * W, 0, []
-        for c in ctx.cs:
-            g = torch.empty((B, c, H, W), dtype=BF16, device=dy.device, memory_format=CL)
-            check(L.mm_copy_rows_bf16(dy.data_ptr() + 2 * off, Ct, ptr(g), c, N, c, stream()), "copy_rows")
-            outs.append(g)
-            off += c
+        outs = [torch.empty((B, c, H, W), dtype=BF16, device=dy.device, memory_format=CL) for c in ctx.cs]
+        n = len(outs)
+        check(L.mm_concat_bf16((ctypes.c_void_p * n)(*[g.data_ptr() for g in outs]), (ctypes.c_int * n)(*ctx.cs), n, ptr(dy), B * H * W, 1,
+                               stream()), "split")
         return tuple(outs)
 
 
