@@ -344,17 +344,18 @@ __device__ inline void wait_vm() {
 
 template <int BN, int TW>
 __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
-  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  extern __shared__ __attribute__((aligned(16))) char smemc[];
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
-  constexpr int HSZ = 384 * 64;   // elements per halo buffer: 6 DMA rounds of 64 rows
-  constexpr int BSZ = BN * 64;
-  constexpr int NB = BN / 64;     // W DMA instructions per thread and tile
-  constexpr int TN = BN / 64;     // 32-cout fragments per wave
-  constexpr int NST = 2 * TN * 4; // store instructions per wave and item
+  constexpr int HSZB = 384 * 128;  // bytes per halo buffer: 6 DMA rounds of 64 rows of 128 B
+  constexpr int BSZB = BN * 128;   // bytes per W buffer
+  constexpr int NB = BN / 64;      // W DMA instructions per thread and tile
+  constexpr int TN = BN / 64;      // 32-cout fragments per wave
+  constexpr int NST = 2 * TN * 4;  // store instructions per wave and item
   static_assert(HROWS <= 384, "halo does not fit its 6 DMA rounds");
-  u16* Hs = smem;                 // [2][HSZ]
-  u16* Bs = smem + 2 * HSZ;       // [3][BSZ]
-  float* biasl = (float*)(Bs + 3 * BSZ);  // [Cn <= 1024] when p.bias
+  // LDS map (bytes): W ring [3][BSZB] at 0 (so the ring slot fits the 16-bit ds_read offset), halo ring [2][HSZB], bias
+  constexpr int HS0 = 3 * BSZB;
+  char* const lds = smemc;
+  float* biasl = (float*)(lds + HS0 + 2 * HSZB);  // [Cn <= 1024] when p.bias
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;  // 4 (pixels) x 2 (couts)
   const int cc = tid & 7, r0 = tid >> 3;
@@ -387,27 +388,66 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
     ty0 = (t % p.tiles_y) * TH;
     b = t / p.tiles_y;
   };
-  // Producer cursors advance incrementally (no per-step divisions between the barrier and the MFMAs).
-  // halo cursor: one step = one (item, chunk) segment
-  int h_item = it_begin, h_c = 0, h_b, h_ty0, h_tx0, h_n0;
-  decode(h_item, h_b, h_ty0, h_tx0, h_n0);
-  int hyx[6];  // this thread's 6 halo pixels (hy << 8 | hx), 0xFFFF = beyond the halo
+  // ---- everything lane-constant is computed once: the per-step instruction stream is what bounds this kernel
+  // (measured: 2/3 of the wave cycles were non-MFMA issue and waits before this was hoisted).
+  // halo DMA: source = A + hu (uniform, per segment) + hl[i] (per lane); rows beyond the halo re-read the tile origin
+  int hl[6], hyx[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    const int row = r0 + 64 * i, hy = row / HC;
-    hyx[i] = row < HROWS ? (hy << 8) | (row - hy * HC) : 0xFFFF;
+    const int row = r0 + 64 * i, hy = row / HC, hx = row - hy * HC;
+    const bool used = row < HROWS;
+    hyx[i] = used ? ((hy - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;  // (dy, dx) relative to the tile origin; unused rows: origin
+    hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ ((row >> 1) & 7)) << 3);
   }
+  int wl[NB];  // W DMA: source = Wp + wu (uniform, per step) + wl[i]
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int row = r0 + 64 * i;
+    wl[i] = row * 9 * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3);
+  }
+  const int fr_ = lane & 31, fh = lane >> 5;
+  int ppy[2], ppx[2];  // this lane's two pixels p = 64*wm + 32*i + fr_ -> (p / TW, p % TW)
+  int aoff[2][9];      // LDS byte offset of pixel i's fragment at tap t, kk = 0, inside a halo buffer
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int pix = 64 * wm + 32 * i + fr_;
+    ppy[i] = pix / TW, ppx[i] = pix % TW;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int kh = t / 3, kw = t % 3;
+      const int row = ppy[i] * HC + ppx[i] + (p.flip ? (2 - kh) * HC + (2 - kw) : kh * HC + kw);
+      aoff[i][t] = HS0 + row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+    }
+  }
+  int boff[TN];        // LDS byte offset of cout fragment j, kk = 0, inside a W buffer
+#pragma unroll
+  for (int j = 0; j < TN; j++) {
+    const int row = wn * (BN / 2) + j * 32 + fr_;
+    boff[j] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+  }
+
+  // producer cursors advance incrementally: no divisions between a barrier and the MFMAs
+  int h_item = it_begin, h_c = 0, h_b, h_ty0, h_tx0, h_n0;
+  decode(h_item, h_b, h_ty0, h_tx0, h_n0);
   auto issue_halo = [&](int buf) {  // 6 DMA instructions, always; then advance the cursor
     const bool live = h_item < it_end;
+    const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
+    const u16* base = p.A + ((int64_t)(h_b * p.H + h_ty0) * p.W + h_tx0) * p.lda + h_c * 64;
+    char* dst = lds + HS0 + buf * HSZB + wave * 1024;
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int row = r0 + 64 * i;  // halo pixel index (wave-instruction = 8 consecutive halo pixels)
-      const int y = h_ty0 + (hyx[i] >> 8) - 1, x = h_tx0 + (hyx[i] & 255) - 1;
-      const u16* g = (const u16*)g_zero16;
-      if (live && hyx[i] != 0xFFFF && y >= 0 && y < p.H && x >= 0 && x < p.W)
-        g = p.A + ((int64_t)(h_b * p.H + y) * p.W + x) * p.lda + h_c * 64 + ((cc ^ ((row >> 1) & 7)) << 3);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(Hs + buf * HSZ + (wave * 8 + 64 * i) * 64), 16, 0, 0);
+      for (int i = 0; i < 6; i++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int y = h_ty0 + (hyx[i] >> 16), x = h_tx0 + (short)(hyx[i] & 0xFFFF);
+        const bool ok = live && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const u16* g = ok ? base + hl[i] : (const u16*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+      }
     }
     if (++h_c == nchunk) {
       h_c = 0;
@@ -415,17 +455,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
       if (h_item < it_end) decode(h_item, h_b, h_ty0, h_tx0, h_n0);
     }
   };
-  // W cursor: one step = one (item, chunk, tap)
   int w_item = it_begin, w_c = 0, w_tap = 0, w_n0 = (it_begin % ncb) * BN;
   auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
     const bool live = w_item < it_end;
+    const u16* base = live ? p.Wp + ((int64_t)w_n0 * 9 + w_tap) * p.Ca + w_c * 64 : (const u16*)g_zero16;
+    char* dst = lds + buf * BSZB + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < NB; i++) {
-      const int row = r0 + 64 * i;
-      const u16* g_ = live ? p.Wp + ((int64_t)(w_n0 + row) * 9 + w_tap) * p.Ca + w_c * 64 + ((cc ^ ((row >> 1) & 7)) << 3) : (const u16*)g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g_,
-                                       (__attribute__((address_space(3))) void*)(Bs + buf * BSZ + (wave * 8 + 64 * i) * 64), 16, 0, 0);
-    }
+    for (int i = 0; i < NB; i++)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (live ? wl[i] : 0)),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
     if (++w_tap == 9) {
       w_tap = 0;
       if (++w_c == nchunk) {
@@ -443,63 +481,46 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
     for (int j = 0; j < TN; j++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  const int fr_ = lane & 31, fh = lane >> 5;
-  int hbase[2], ppy[2], ppx[2];  // this lane's two pixels p = 64*wm + 32*i + fr_ -> (p / TW, p % TW); halo row at tap (0,0)
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int pix = 64 * wm + 32 * i + fr_;
-    ppy[i] = pix / TW, ppx[i] = pix % TW;
-    hbase[i] = ppy[i] * HC + ppx[i];
-  }
 
   issue_halo(0);
   issue_w(0);
   issue_w(1);
-  int wb = 0;          // W ring slot of the current step
-  int st_age = 2;      // steps since the last item's stores were issued (they sit in the VMEM queue behind W(g+1))
+  bool st = false;                 // the previous segment ended an item: its NST stores sit in the VMEM queue behind W(g+1)
   int c_item = it_begin, c_c = 0;  // consumer cursor
   for (int seg = 0; seg < nseg; seg++) {
-    const u16* Hb = Hs + (seg & 1) * HSZ;
-#pragma unroll 1
-    for (int tap = 0; tap < 9; tap++) {
+    const int hb = (seg & 1) * HSZB;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {  // unrolled: the W ring slot is tap % 3 (9 taps per segment) and aoff[][tap] is static
       // W(g) [and, at tap 0, this segment's halo, which is older] must have landed.  Younger than W(g) in the queue:
       // W(g+1) (NB); the next halo (6) when the previous step was a tap 0; the previous item's stores (NST) for two steps.
-      const bool h = tap == 1, st = st_age < 2;
-      if (!h && !st) wait_vm<NB>();
-      else if (h && !st) wait_vm<NB + 6>();
-      else if (!h && st) wait_vm<NB + NST>();
-      else wait_vm<NB + 6 + NST>();
+      if (tap == 0) {
+        if (st) wait_vm<NB + NST>();
+        else wait_vm<NB>();
+      } else if (tap == 1) {
+        if (st) wait_vm<NB + 6 + NST>();
+        else wait_vm<NB + 6>();
+      } else {
+        wait_vm<NB>();
+      }
       __builtin_amdgcn_s_barrier();  // everyone finished step g-1: ring slots (g+2)%3 and (seg+1)&1 are free
       if (tap == 0) issue_halo((seg + 1) & 1);
-      int wb2 = wb + 2;
-      if (wb2 >= 3) wb2 -= 3;
-      issue_w(wb2);
-      st_age++;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      const int hoff = p.flip ? (2 - kh) * HC + (2 - kw) : kh * HC + kw;
-      const u16* Bb = Bs + wb * BSZ;
+      issue_w((tap + 2) % 3);
+      const int slot = (tap % 3) * BSZB;
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         bf16x8 af[2], bf[TN];
-        const int ch = kk * 2 + fh;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-          const int row = hbase[i] + hoff;
-          af[i] = *(const bf16x8*)&Hb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
-        }
+        for (int i = 0; i < 2; i++) af[i] = *(const bf16x8*)(lds + (((aoff[i][tap] + hb)) ^ (kk << 5)));
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-          const int row = wn * (BN / 2) + j * 32 + fr_;
-          bf[j] = *(const bf16x8*)&Bb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
-        }
+        for (int j = 0; j < TN; j++) bf[j] = *(const bf16x8*)(lds + ((boff[j] ^ (kk << 5)) + slot));
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);  // D[cout][pixel]
       }
-      if (++wb == 3) wb = 0;
     }
+    st = false;
     if (++c_c == nchunk) {  // item finished: D row (reg&3) + 8*(reg>>2) + 4*fh = output channel, column fr_ = pixel
       int b, ty0, tx0, n0;
       decode(c_item, b, ty0, tx0, n0);
@@ -527,7 +548,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
             *(uint2*)(inside ? orow + 32 * j + 8 * q : (u16*)g_dump + lane * 4) = o;
           }
       }
-      st_age = 0;
+      st = true;
     }
   }
   wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
