@@ -213,7 +213,7 @@ int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, in
 /* torch.cat(parts, dim=1) of NHWC bf16 maps in one launch (decoder concat [depth, up, rgb], 2d_net/model.py:104-123);
  * split != 0 is its backward: parts[i] = channel slice i of wide.  Channel counts multiples of 8, 1..4 parts. */
 int mm_concat_bf16(void* const* parts, const int* channels, int nparts, void* wide, int64_t N, int split, mm_stream_t stream);
-int mm_maxpool3x3s2_fwd(const void* x, int B, int H, int W, int C, void* y, void* idx, mm_stream_t stream);
+int mm_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, mm_stream_t stream);
 int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, mm_stream_t stream);
 size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ);
 /* AvgPool2d(5,1,2) + Conv2d 1x1 of both heads (EXP/2d_net/model.py:59-60,129-130,158,163-164): out NHWC fp32 [B,h,w,NJ] */

@@ -71,7 +71,7 @@ _PROTOS = {
     "mm_colsum_bf16": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
     "mm_copy_rows_bf16": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "mm_concat_bf16": (i32, [vp, vp, i32, vp, i64, i32, vp]),
-    "mm_maxpool3x3s2_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    "mm_maxpool3x3s2_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "mm_maxpool3x3s2_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
     "mm_head_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "mm_head_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),

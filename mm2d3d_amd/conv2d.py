@@ -18,6 +18,18 @@ BF16 = torch.bfloat16
 CL = torch.channels_last
 
 
+def nhwc_pitch(x):
+    """(tensor, pitch in elements) of an NHWC bf16 map that may be a channel slice of a wider NHWC buffer (pitch > C):
+    the decoder's concat buffers are filled in place by their producers and read through such views."""
+    if x.dtype != BF16:
+        x = x.to(BF16)
+    B, C, H, W = x.shape
+    s0, s1, s2, s3 = x.stride()
+    if s1 == 1 and s3 >= C and s3 % 8 == 0 and s2 == W * s3 and s0 == H * W * s3 and x.data_ptr() % 16 == 0:
+        return x, s3
+    return x.contiguous(memory_format=CL), C
+
+
 def _arr(v):
     return (C.c_int * len(v))(*v)
 
@@ -133,19 +145,19 @@ def _bias_grad(dy):
     return out
 
 
-def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None):
+def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None, lda=None):
     check(
-        _lib.lib().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
+        _lib.lib().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, lda or Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
                                   Hg, Wg, so, 0, 0, sa, fr, len(ty), _arr(ty), _arr(tx), ptr(Wp), nz, wz, zpar, ptr(bias), stream()),
         "conv2d_gemm",
     )
 
 
-def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk, accumulate=0):
+def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk, accumulate=0, ldx=None, ldy=None):
     L = _lib.lib()
     ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * Hg * Wg, Cn, Ck, len(ty))), X.device)
     check(
-        L.mm_conv2d_wgrad(ptr(X), Bn, Hi, Wi, Ck, Ck, ptr(dY), Hg, Wg, Cn, Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(dW), sn, st, sk,
+        L.mm_conv2d_wgrad(ptr(X), Bn, Hi, Wi, Ck, ldx or Ck, ptr(dY), Hg, Wg, Cn, ldy or Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(dW), sn, st, sk,
                           accumulate,
                           ptr(ws), ws.numel(), stream()),
         "conv2d_wgrad",
@@ -163,7 +175,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding):
         _lib.require_cuda(x, "x")
-        x = as_nhwc_bf16(x)
+        x, ldx = nhwc_pitch(x)
         Bn, Cin, H, W = x.shape
         Cout, _, KH, KW = weight.shape
         Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
@@ -175,11 +187,12 @@ class Conv2dFn(torch.autograd.Function):
         tx = [kw - padding for _ in range(KH) for kw in range(KW)]
         b = bias.detach().float().contiguous() if bias is not None else None
         if (KH, KW, stride, padding) == (3, 3, 1, 1):  # halo-tile kernel: input patch staged once for all 9 taps
-            check(_lib.lib().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, Cin, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0, stream()),
+            check(_lib.lib().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0, stream()),
                   "conv2d_3x3s1")
         else:
-            _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b)
+            _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b, lda=ldx)
         ctx.save_for_backward(x, w)
+        ctx.ldx = ldx
         ctx.cfg = (stride, padding, bias is not None)
         ctx.wowner = weight
         ctx.wparam = weight if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]) else None
@@ -189,7 +202,8 @@ class Conv2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         stride, padding, has_bias = ctx.cfg
-        dy = as_nhwc_bf16(dy)
+        dy, ldy = nhwc_pitch(dy)
+        ldx = ctx.ldx
         Bn, Cin, H, W = x.shape
         Cout, _, KH, KW = w.shape
         Ho, Wo = dy.shape[2], dy.shape[3]
@@ -199,23 +213,24 @@ class Conv2dFn(torch.autograd.Function):
             Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T, ctx.wowner, "dgrad")  # [ci][t][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
             if (KH, KW, stride, padding) == (3, 3, 1, 1):
-                check(_lib.lib().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, Cout, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),
+                check(_lib.lib().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),
                       "conv2d_3x3s1")
             else:
                 ty = [padding - kh for kh in range(KH) for _ in range(KW)]
                 tx = [padding - kw for _ in range(KH) for kw in range(KW)]
-                _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd)
+                _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd, lda=ldy)
         if ctx.needs_input_grad[1]:
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]
             tx = [kw - padding for _ in range(KH) for kw in range(KW)]
             if ctx.wparam is not None:  # accumulate straight into the optimiser's gradient arena
-                _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam._mm_sink, Cin * T, 1, T, accumulate=1)
+                _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam._mm_sink, Cin * T, 1, T, accumulate=1, ldx=ldx,
+                       ldy=ldy)
                 gradsink.done(ctx.wparam)
             else:
                 dw = torch.empty_like(w)
-                _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T)
+                _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T, ldx=ldx, ldy=ldy)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _bias_grad(dy)
+            db = _bias_grad(as_nhwc_bf16(dy))
         return dx, dw, db, None, None
 
 

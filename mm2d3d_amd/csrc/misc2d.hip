@@ -64,7 +64,7 @@ __global__ __launch_bounds__(T) void k_concat(CatP p) {
 
 // ---- max-pool 3x3 stride 2 pad 1, NHWC bf16; idx = winning tap (kh*3+kw), first maximum in scan order (torch).
 // thread = 8 consecutive channels of one pixel (16-B loads/stores, 8-B index vectors)
-__global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, int B, int H, int W, int C, u16* __restrict__ y,
+__global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, int ldx, int B, int H, int W, int C, u16* __restrict__ y,
                                                     unsigned char* __restrict__ idx, int Ho, int Wo) {
   const int C8 = C >> 3;
   int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, in
     for (int kw = 0; kw < 3; kw++) {
       int ix = ox * 2 - 1 + kw;
       if (ix < 0 || ix >= W) continue;
-      uint4 v = *(const uint4*)(x + ((int64_t)(b * H + iy) * W + ix) * C + c8 * 8);
+      uint4 v = *(const uint4*)(x + ((int64_t)(b * H + iy) * W + ix) * ldx + c8 * 8);
       unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -358,12 +358,12 @@ int mm_concat_bf16(void* const* parts, const int* channels, int nparts, void* wi
   return MM_OK;
 }
 
-int mm_maxpool3x3s2_fwd(const void* x, int B, int H, int W, int C, void* y, void* idx, hipStream_t s) {
+int mm_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, hipStream_t s) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  MM_CHECK_ARG(C % 8 == 0, "maxpool: C must be a multiple of 8");
+  MM_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, "maxpool: C and the input pitch must be multiples of 8");
   int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   if (total == 0) return MM_OK;
-  hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)x, B, H, W, C, (u16*)y,
+  hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)x, ldx, B, H, W, C, (u16*)y,
                      (unsigned char*)idx, Ho, Wo);
   MM_LAUNCH_CHECK();
   return MM_OK;

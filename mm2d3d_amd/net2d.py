@@ -59,11 +59,12 @@ class BasicBlock(nn.Module):
             self.bn1.relu = True
             self.bn2.relu = True
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """``out``: optional NHWC channel slice the block's result is written into (see nn2d.CatBuffer)."""
         identity = x if self.downsample is None else self.downsample(x)
         if self._fused:
-            out = self.bn1(self.conv1(x))
-            return self.bn2(self.conv2(out), identity)
+            y = self.bn1(self.conv1(x))
+            return self.bn2(self.conv2(y), identity, out=out)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         return self.relu(out + identity)
@@ -110,13 +111,25 @@ class Backbone(nn.Module):
     def channels(self):
         return 64, 64, 128, 256, 512
 
-    def forward(self, x):
+    @staticmethod
+    def _run(layer, x, out):
+        for blk in list(layer)[:-1]:
+            x = blk(x)
+        last = layer[-1]
+        return last(x, out=out) if (out is not None and getattr(last, "_fused", False)) else last(x)
+
+    def forward(self, x, outs=None):
+        """``outs``: optional destinations (channel slices of the decoder's concat buffers) for feats 0..2."""
         feats = []
-        x = self.bn1(self.conv1(x)) if self._fused else self.relu(self.bn1(self.conv1(x)))
+        o = (list(outs) + [None] * 3)[:3] if outs is not None else [None] * 3
+        if self._fused:
+            x = self.bn1(self.conv1(x), out=o[0])
+        else:
+            x = self.relu(self.bn1(self.conv1(x)))
         feats.append(x)
-        x = self.layer1(self.maxpool(x))
+        x = self._run(self.layer1, self.maxpool(x), o[1])
         feats.append(x)
-        x = self.layer2(x)
+        x = self._run(self.layer2, x, o[2])
         feats.append(x)
         x = self.dropout(self.layer3(x))
         feats.append(x)
@@ -181,18 +194,37 @@ class Net2DSeg(nn.Module):
         if pad_h or pad_w:
             img = F.pad(img, [0, pad_w, 0, pad_h])
             hints = F.pad(hints, [0, pad_w, 0, pad_h])
-        r = self.rgb_backbone(img)
-        d = self.depth_backbone(hints)
+        # The three full-resolution decoder concats [depth | up | rgb] are never copied: their buffers exist up front and
+        # the producing BatchNorm layers (stem / layer1 / layer2 of both backbones, the transposed-conv stages) write
+        # straight into their channel slices; the backbones keep reading those slices as pitched NHWC maps.
+        Bn, Hp, Wp = img.shape[0], img.shape[2], img.shape[3]
+        cb = [nn2d.CatBuffer(Bn, (c, c, c), Hp >> l, Wp >> l, img.device) for l, c in enumerate(self.rgb_backbone.channels[:3])]
+        r = self.rgb_backbone(img, outs=[b.slot(2) for b in cb])
+        d = self.depth_backbone(hints, outs=[b.slot(0) for b in cb])
+        for l in range(3):
+            cb[l].put(0, d[l])
+            cb[l].put(2, r[l])
         cat = nn2d.cat_channels
+
+        def up(stage, x, buf):  # ConvTranspose2d + BatchNorm(+ReLU) writing into the middle slice of the next concat
+            bn = stage[1]
+            if isinstance(bn, nn2d.BatchNorm2d):
+                y = bn(stage[0](x), out=buf.slot(1))
+                for m in list(stage)[2:]:
+                    y = m(y)
+                buf.put(1, y)
+                return y
+            return stage(x)
+
         # decoder: concat order is [depth, upsampled, rgb] (model.py:107,112,117,122)
         x = self.dec_t_conv_stage5(cat([d[4], r[4]]))
         x = self.dec_conv_stage4(cat([d[3], x, r[3]]))
-        x = self.dec_t_conv_stage4(x)
-        x = self.dec_conv_stage3(cat([d[2], x, r[2]]))
-        x = self.dec_t_conv_stage3(x)
-        x = self.dec_conv_stage2(cat([d[1], x, r[1]]))
-        x = self.dec_t_conv_stage2(x)
-        x = self.dec_conv_stage1(cat([d[0], x, r[0]]))
+        x = up(self.dec_t_conv_stage4, x, cb[2])
+        x = self.dec_conv_stage3(cb[2].cat([d[2], x, r[2]]))
+        x = up(self.dec_t_conv_stage3, x, cb[1])
+        x = self.dec_conv_stage2(cb[1].cat([d[1], x, r[1]]))
+        x = up(self.dec_t_conv_stage2, x, cb[0])
+        x = self.dec_conv_stage1(cb[0].cat([d[0], x, r[0]]))
         segm_last = x[:, :, 0:h, 0:w]  # crop of the padding (a view; the heads read the padded map with bounds h, w)
         segm, avg = nn2d.fused_heads(x, h, w, self.con1_1_avg, self.aux.con1_1_avg)
         pix = _pixel_index(data_batch, h, w, segm.device)

@@ -56,31 +56,41 @@ class ConvTranspose2d(nn.ConvTranspose2d):
 
 class _BN2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None, out=None):
         L = _lib.lib()
-        x = _c2d.as_nhwc_bf16(x)
+        x, ldx = _c2d.nhwc_pitch(x)
         B, C, H, W = x.shape
         N = B * H * W
+        ldr = C
         if res is not None:
-            res = _c2d.as_nhwc_bf16(res)
-        y = torch.empty_like(x)
+            res, ldr = _c2d.nhwc_pitch(res)
+        # ``out`` = [view]: a channel slice of a wider NHWC buffer (the decoder's concat input) that this layer fills in
+        # place.  It travels in a list so that autograd sees a fresh output, not an in-place modified input view.
+        if out is not None:
+            dst = out[0].detach()
+            y, ldy = _c2d.nhwc_pitch(dst)
+            if y.data_ptr() != dst.data_ptr() or tuple(y.shape) != tuple(x.shape) or y.dtype != BF16:
+                raise ValueError("BatchNorm2d(out=): destination must be an NHWC bf16 channel slice of the output's shape")
+        else:
+            y, ldy = torch.empty((B, C, H, W), dtype=BF16, device=x.device, memory_format=CL), C
         if training:
             nf = domains.current()  # jointly batched domains keep their own batch statistics
             Ns = nf * H * W if (nf is not None and 0 < nf < B) else N
             stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
             ctx.Ns = Ns
-            check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(res), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
-                                      ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
+            check(L.mm_bn2d_fwd_train(ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                      ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), ldy, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats)
             ctx.sinks = None
             if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[2]):
                 gradsink.claim(ctx, bias, True)
                 ctx.sinks = (weight, bias)
         else:
-            check(L.mm_bn2d_fwd_eval(ptr(x), C, ptr(res), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps,
-                                     1 if relu else 0, ptr(y), C, stream()), "bn2d_fwd_eval")
+            check(L.mm_bn2d_fwd_eval(ptr(x), ldx, ptr(res), ldr, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps,
+                                     1 if relu else 0, ptr(y), ldy, stream()), "bn2d_fwd_eval")
         ctx.training, ctx.relu, ctx.has_res = training, relu, res is not None
+        ctx.lds = (ldx, ldy)
         return y
 
     @staticmethod
@@ -89,11 +99,12 @@ class _BN2dFn(torch.autograd.Function):
             raise RuntimeError("BatchNorm2d backward in eval mode is not part of the hot path")
         L = _lib.lib()
         x, y, weight, stats = ctx.saved_tensors
-        dy = _c2d.as_nhwc_bf16(dy)
+        dy, lddy = _c2d.nhwc_pitch(dy)
+        ldx, ldy = ctx.lds
         B, C, H, W = x.shape
         N = B * H * W
-        dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
+        dx = torch.empty((B, C, H, W), dtype=BF16, device=x.device, memory_format=CL)
+        dres = torch.empty_like(dx) if ctx.has_res else None
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
         if ctx.sinks is not None:  # dgamma / dbeta accumulate straight into the optimiser's gradient arena
             wp, bp = ctx.sinks
@@ -103,13 +114,13 @@ class _BN2dFn(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device)
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
-        check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(y), C, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
+        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), lddy, ptr(y), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
                             ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
                             stream()), "bn2d_bwd")
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
-        return dx, dres, dw, db, None, None, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -120,12 +131,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.relu = relu
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out=None):
         _need_gpu(x, "BatchNorm2d")
         use_batch = self.training or not self.track_running_stats
         nbt = self.num_batches_tracked if (self.training and self.track_running_stats) else None  # incremented in the kernel
         return _BN2dFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, use_batch, float(self.eps),
-                             float(self.momentum if self.momentum is not None else 0.1), bool(self.relu), nbt)
+                             float(self.momentum if self.momentum is not None else 0.1), bool(self.relu), nbt,
+                             [out] if out is not None else None)
 
 
 class FusedAway(nn.Module):
@@ -143,12 +155,12 @@ class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         L = _lib.lib()
-        x = _c2d.as_nhwc_bf16(x)
+        x, ldx = _c2d.nhwc_pitch(x)
         B, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty((B, C, Ho, Wo), dtype=BF16, device=x.device, memory_format=CL)
         idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
-        check(L.mm_maxpool3x3s2_fwd(ptr(x), B, H, W, C, ptr(y), ptr(idx), stream()), "maxpool_fwd")
+        check(L.mm_maxpool3x3s2_fwd(ptr(x), ldx, B, H, W, C, ptr(y), ptr(idx), stream()), "maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.shape = (B, C, H, W)
         return y
@@ -205,6 +217,57 @@ class _CatFn(torch.autograd.Function):
         check(L.mm_concat_bf16((ctypes.c_void_p * n)(*[g.data_ptr() for g in outs]), (ctypes.c_int * n)(*ctx.cs), n, ptr(dy), B * H * W, 1,
                                stream()), "split")
         return tuple(outs)
+
+
+class _CatFilledFn(torch.autograd.Function):
+    """torch.cat(parts, 1) where every part already IS its channel slice of ``holder[0]`` (each producer wrote it in
+    place through BatchNorm2d(out=)): no copy forward; backward hands out the channel slices of the gradient as views."""
+
+    @staticmethod
+    def forward(ctx, holder, *parts):
+        buf = holder[0]
+        off = 0
+        for q in parts:
+            if q.data_ptr() != buf.data_ptr() + 2 * off or q.stride(3) != buf.shape[1]:
+                raise ValueError("cat_filled: part is not the expected slice of the buffer")
+            off += q.shape[1]
+        ctx.cs = [q.shape[1] for q in parts]
+        return buf.detach()
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c2d.as_nhwc_bf16(dy)
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(dy[:, off:off + c])
+            off += c
+        return (None, *outs)
+
+
+class CatBuffer:
+    """Pre-allocated NHWC bf16 concat buffer whose channel slices are handed to the producers as destinations."""
+
+    def __init__(self, B, channels, H, W, device):
+        self.buf = torch.empty((B, sum(channels), H, W), dtype=BF16, device=device, memory_format=CL)
+        self.channels = list(channels)
+        self.parts = [None] * len(channels)
+
+    def slot(self, i):
+        off = sum(self.channels[:i])
+        return self.buf[:, off:off + self.channels[i]]
+
+    def put(self, i, t):
+        """Record producer output ``t`` for slot i; copies only if the producer could not write in place."""
+        v = self.slot(i)
+        if t.data_ptr() != v.data_ptr() or t.stride(3) != self.buf.shape[1]:
+            return False
+        self.parts[i] = t
+        return True
+
+    def cat(self, fallback):
+        if all(q is not None for q in self.parts):
+            return _CatFilledFn.apply([self.buf], *self.parts)
+        return cat_channels(fallback)
 
 
 def cat_channels(xs):
