@@ -98,7 +98,7 @@ def conv_roofline(tm, batch, dev):
     return {
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "traffic": traffic,
-        "kernel": "sparse-conv engines: k_gather_gemm<*> + k_csr_reduce (fwd, dX), k_dw_direct<*> + k_dw_reduce (dW)",
+        "kernel": "sparse-conv engines: k_gather_gemm<*> / k_gather_gemm_s3<*> + k_csr_reduce (fwd, dX), k_dw_direct<*> / k_dw_direct_s3<*> + k_dw_reduce (dW)",
         "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
         "by_pass": {k: {"GB/s": round(v[0] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else 0.0, "ms": round(v[1], 3), "calls": v[2]}
                     for k, v in by_kind.items()},
@@ -192,7 +192,7 @@ def main():
     out = {
         "metric": "LiDAR scenes/sec fwd+bwd (NuScenes ~35k pts, 5cm voxel)", "value": round(2 * B * world / (ms * 1e-3), 3),
         "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP) + f32 MFMA (3D sparse branch, fp32 as in the reference)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP) + f32 (3D sparse branch, fp32 as in the reference: f32 MFMA below 64 input channels, fp32-faithful 3-term split-bf16 products with fp32 accumulation from 64 up)",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: NuScenes-shaped (32x1090 sweep, 34,880 pts/scene), 5 cm voxels, 480x302 RGB + "
                                "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "

@@ -169,6 +169,131 @@ __global__ __launch_bounds__(256) void k_gather_gemm_direct(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------- engine G, split-bf16 products
+// For Cin >= 64 the gather-GEMM is bound by the fp32 matrix rate (v_mfma_f32_16x16x4_f32: 256 FLOP/clk/CU; the layers
+// measure 46-55 TFLOP/s), not by HBM.  Here every fp32 operand is split in registers into NT bf16 terms,
+// x = x1 + x2 (+ x3), x1 = bf16_rne(x), x2 = bf16_rne(x - x1), x3 = bf16_rne(x - x1 - x2); the weights are pre-split by
+// k_pack_frag_s3, and x.w is accumulated in fp32 on v_mfma_f32_16x16x32_bf16 from the partial products whose magnitude
+// reaches the target precision:
+//   NT = 3 (default): x1w1 + x1w2 + x2w1 + x2w2 + x1w3 + x3w1   - everything down to 2^-18 |x.w|; the three 8-bit terms
+//            carry the whole 24-bit significand, the dropped products are <= 2^-26 |x.w|: fp32-faithful (6 x 16 cycles
+//            per 16x16x32 block instead of 8 x 32 on the fp32 matrix instruction: 2.7x the rate)
+//   NT = 2 (MM_SPCONV_SPLIT=2): x1w1 + x1w2 + x2w1, product error <= ~2^-16 |x.w| (3 x 16 cycles: 5.3x the rate)
+// MM_SPCONV_FP32=1 keeps the plain fp32 engine.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NT>
+__device__ inline void split8(const f32x4& a, const f32x4& b, bf16x8 (&t)[NT]) {
+  float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    float r = v[i];
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+      const __bf16 h = (__bf16)r;
+      t[n][i] = h;
+      r -= (float)h;
+    }
+  }
+}
+
+// acc += x . w from the split terms (a: MFMA A operand, b: MFMA B operand), largest products last is not needed: fp32 adds
+template <int NT>
+__device__ inline f32x4 mfma_split(const bf16x8 (&a)[NT], const bf16x8 (&b)[NT], f32x4 acc) {
+  if (NT == 3) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+  }
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  return acc;
+}
+
+// Wf3[k][q][cb][lane][term][0..7] = bf16 terms of W[kk][ci = 32q + 8(lane>>4) + j][co = 16cb + (lane&15)]  (0 beyond Cin)
+template <int NT>
+__global__ __launch_bounds__(256) void k_pack_frag_s3(const float* __restrict__ W, int64_t w_kstride, int s_ci, int s_co, int kflip,
+                                                       int K, int Cin, int Cout, int nq, int ncb, __bf16* __restrict__ Wf) {
+  int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = (int64_t)K * nq * ncb * 64 * 8;
+  if (e >= total) return;
+  int j = (int)(e & 7), lane = (int)((e >> 3) & 63);
+  int64_t t = e >> 9;
+  int cb = (int)(t % ncb);
+  t /= ncb;
+  int q = (int)(t % nq), k = (int)(t / nq);
+  int ci = 32 * q + 8 * (lane >> 4) + j, co = 16 * cb + (lane & 15);
+  float r = 0.f;
+  if (ci < Cin && co < Cout) r = W[(int64_t)(kflip ? K - 1 - k : k) * w_kstride + (int64_t)ci * s_ci + (int64_t)co * s_co];
+  const int64_t base = (e >> 3) * (8 * NT);
+#pragma unroll
+  for (int n = 0; n < NT; n++) {
+    const __bf16 h = (__bf16)r;
+    Wf[base + 8 * n + j] = h;
+    r -= (float)h;
+  }
+}
+
+// LDSW: W[k] (the NT term fragments of the NCB cout blocks) staged in LDS once per workgroup and reused over its `tr`
+// rules; !LDSW (small rulebooks): one 16-rule group per wave, fragments straight from L2, no barrier.
+// Cin, Cout multiples of 16; D[co][rule] as in k_gather_gemm.
+template <int NCB, bool LDSW, int NT>
+__global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict__ in, int ld_in, const int32_t* __restrict__ src,
+                                                         const int32_t* __restrict__ dst, float* __restrict__ out, int ld_out,
+                                                         const __bf16* __restrict__ Wf, int ncb_tot, int K, int Cin, int tr,
+                                                         KSeg seg) {
+  extern __shared__ __attribute__((aligned(16))) char wlds[];  // [nq][NCB][64 lanes][NT][16 B]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * tr;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + tr);
+  const int cb0 = blockIdx.y * NCB;
+  const int nq = (Cin + 31) >> 5;
+  const bf16x8* Wk = (const bf16x8*)Wf + ((int64_t)k * nq * ncb_tot + cb0) * 64 * NT;
+  if (LDSW) {
+    bf16x8* w8 = (bf16x8*)wlds;
+    for (int e = tid; e < nq * NCB * 64 * NT; e += 256) {
+      const int q = e / (NCB * 64 * NT), r = e - q * (NCB * 64 * NT);
+      w8[e] = Wk[(int64_t)q * ncb_tot * 64 * NT + r];
+    }
+    __syncthreads();
+  }
+  for (int g = r_begin + wave * 16; g < r_end; g += 64) {
+    const int r = g + rl;
+    const bool valid = r < r_end;
+    const int sidx = valid ? src[r] : 0;
+    const float* row = in + (int64_t)sidx * ld_in + sl * 8;
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < nq; q++) {
+      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+      if (valid && q * 32 + sl * 8 < Cin) {  // Cin % 16 == 0: the 8 channels are inside or outside together
+        x0 = *(const f32x4*)(row + q * 32);
+        x1 = *(const f32x4*)(row + q * 32 + 4);
+      }
+      bf16x8 xt[NT];
+      split8<NT>(x0, x1, xt);
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+        const bf16x8* w8 = LDSW ? (const bf16x8*)wlds + ((q * NCB + cb) * 64 + lane) * NT
+                                : Wk + (((int64_t)q * ncb_tot + cb) * 64 + lane) * NT;
+        bf16x8 wt[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) wt[n] = w8[n];
+        acc[cb] = mfma_split<NT>(wt, xt, acc[cb]);
+      }
+    }
+    if (valid) {
+      const int64_t orow = dst ? (int64_t)dst[r] : (int64_t)r;
+      float* o = out + orow * ld_out + cb0 * 16 + sl * 4;
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) *(f32x4*)(o + cb * 16) = acc[cb];
+    }
+  }
+}
+
 // Narrow inputs (the 3-channel stem, Cin <= 4): output-stationary, thread = one output row with all Cout (<= 32)
 // accumulators; the rules of the row come from the CSR in ascending k; W (K*Cin*Cout floats) sits in LDS.
 __global__ __launch_bounds__(256) void k_rows_narrow(const float* __restrict__ in, int ld_in, const int32_t* __restrict__ src,
@@ -349,6 +474,87 @@ __global__ __launch_bounds__(256) void k_dw_direct(const float* __restrict__ in,
   }
 }
 
+// Split-bf16 variant (see engine G): 32 rules per v_mfma_f32_16x16x32_bf16; lane (rl = channel, sl) gathers the 8 rules
+// 8*sl .. 8*sl+7 of the group for its channel of every block, splits them into NT terms, and each (ci block, co block)
+// pair accumulates the partial products of mfma_split.
+template <int TI, int TJ, int NT>
+__global__ __launch_bounds__(256) void k_dw_direct_s3(const float* __restrict__ in, int ld_in, const float* __restrict__ dout,
+                                                       int ld_do, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
+                                                       int Cin, int Cout, int K, KSeg seg, int chunk, float* __restrict__ partial) {
+  extern __shared__ float red[];  // [3 waves][TI*TJ][64 lanes] f32x4
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * chunk;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + chunk);
+  const int ncib = Cin >> 4, ncob = Cout >> 4;
+  const int nrj = (ncob + TJ - 1) / TJ;
+  const int ci0 = (blockIdx.y / nrj) * TI, co0 = (blockIdx.y % nrj) * TJ;
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r0 = r_begin + wave * 32; r0 < r_end; r0 += 128) {
+    int si[8], di[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const int r = r0 + 8 * sl + t;
+      const bool valid = r < r_end;
+      si[t] = valid ? src[r] : -1;
+      di[t] = valid ? dst[r] : 0;
+    }
+    bf16x8 at[TI][NT], bt[TJ][NT];
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      f32x4 v0, v1;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const float x = (si[t] >= 0 && ci0 + i < ncib) ? in[(int64_t)si[t] * ld_in + (ci0 + i) * 16 + rl] : 0.f;
+        if (t < 4) v0[t] = x;
+        else v1[t - 4] = x;
+      }
+      split8<NT>(v0, v1, at[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+      f32x4 v0, v1;
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const float x = (si[t] >= 0 && co0 + j < ncob) ? dout[(int64_t)di[t] * ld_do + (co0 + j) * 16 + rl] : 0.f;
+        if (t < 4) v0[t] = x;
+        else v1[t - 4] = x;
+      }
+      split8<NT>(v0, v1, bt[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) acc[i][j] = mfma_split<NT>(at[i], bt[j], acc[i][j]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) *(f32x4*)&red[(((wave - 1) * TI * TJ + i * TJ + j) * 64 + lane) * 4] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* P = partial + (int64_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) {
+        f32x4 v = acc[i][j];
+#pragma unroll
+        for (int w = 0; w < 3; w++) v += *(const f32x4*)&red[((w * TI * TJ + i * TJ + j) * 64 + lane) * 4];
+        if (ci0 + i < ncib && co0 + j < ncob) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) P[(int64_t)((ci0 + i) * 16 + sl * 4 + r) * Cout + (co0 + j) * 16 + rl] = v[r];
+        }
+      }
+  }
+}
+
 // generic dW: thread = (ci, co) pairs strided over the block; rules staged in LDS 64 at a time
 __global__ __launch_bounds__(256) void k_dw_generic(const float* __restrict__ in, int ld_in,
                                                      const float* __restrict__ dout, int ld_do,
@@ -434,6 +640,30 @@ int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src,
 
 }  // namespace
 
+// bf16 terms per fp32 operand in the split-product engines: 3 (fp32-faithful, default), 2 (MM_SPCONV_SPLIT=2), 0 = plain fp32
+static int split_terms() {
+  static const int nt = [] {
+    if (getenv("MM_SPCONV_FP32")) return 0;
+    const char* e = getenv("MM_SPCONV_SPLIT");
+    return (e && atoi(e) == 2) ? 2 : 3;
+  }();
+  return nt;
+}
+
+template <int N, int NT>
+static int launch_s3(bool small, int nb, int nch, size_t lds, const float* in, int ld_in, const int32_t* src, const int32_t* d, float* tgt,
+                     int ld_t, const __bf16* Wf3, int ncb, int K, int Cin, int tr, const KSeg& sg, hipStream_t s) {
+  if (small) {
+    hipLaunchKernelGGL((k_gather_gemm_s3<N, false, NT>), dim3(nb, nch), dim3(256), 0, s, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr,
+                       sg);
+  } else {
+    if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)k_gather_gemm_s3<N, true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_gather_gemm_s3<N, true, NT>), dim3(nb, nch), dim3(256), lds, s, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr,
+                       sg);
+  }
+  return MM_OK;
+}
+
 extern "C" {
 
 static inline size_t frag_floats(int K, int Cin, int Cout) {
@@ -442,7 +672,10 @@ static inline size_t frag_floats(int K, int Cin, int Cout) {
 
 // bytes of the workspace (tmp rows + packed weight fragments) one mm_spconv_apply call needs
 size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K) {
-  return mm_align((size_t)n_rules * Cout * sizeof(float)) + mm_align(frag_floats(K, Cin, Cout) * sizeof(float)) + 512;
+  const size_t frag3 = (size_t)K * ((Cin + 31) / 32) * ((Cout + 15) / 16) * 64 * 48;  // split-bf16 fragments (3 terms, Cin padded to 32)
+  size_t frag = frag_floats(K, Cin, Cout) * sizeof(float);
+  if (frag3 > frag) frag = frag3;
+  return mm_align((size_t)n_rules * Cout * sizeof(float)) + mm_align(frag) + 512;
 }
 
 // out[dst] (+)= in[src] . W[k]   over a k-major rulebook.
@@ -497,6 +730,49 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
   }
   MM_CHECK_ARG(((uintptr_t)ws % 16) == 0, "spconv_apply: workspace must be 16-B aligned");
   float* Wf = (float*)((char*)ws + tmp_bytes);
+  const int nt = split_terms();
+  if (nt && !edge && Cin >= 64 && (unique_dst || Cout % 4 == 0) && R > 0) {  // matrix-rate-bound widths: split-bf16 products
+    const int nq3 = (Cin + 31) / 32;
+    MM_CHECK_ARG(ws_bytes >= tmp_bytes + (size_t)K * nq3 * ncb * 64 * 16 * nt, "spconv_apply: workspace too small for the split fragments");
+    __bf16* Wf3 = (__bf16*)Wf;
+    if (nt == 3)
+      hipLaunchKernelGGL(k_pack_frag_s3<3>, dim3((unsigned)mm_cdiv((int64_t)K * nq3 * ncb * 512, 256)), dim3(256), 0, s, W, w_kstride,
+                         s_ci, s_co, kflip, K, Cin, Cout, nq3, ncb, Wf3);
+    else
+      hipLaunchKernelGGL(k_pack_frag_s3<2>, dim3((unsigned)mm_cdiv((int64_t)K * nq3 * ncb * 512, 256)), dim3(256), 0, s, W, w_kstride,
+                         s_ci, s_co, kflip, K, Cin, Cout, nq3, ncb, Wf3);
+    float* tgt = out;
+    int ld_t = ld_out;
+    const int32_t* d = dst;
+    if (!unique_dst) tgt = (float*)ws, ld_t = Cout, d = nullptr;
+    int nch = 1;  // cout blocks per workgroup <= 8 and the staged W[k] slice <= 80 KiB (two workgroups per CU)
+    while (ncb % nch != 0 || ncb / nch > 8 || (size_t)nq3 * (ncb / nch) * 64 * 16 * nt > 80 * 1024) nch++;
+    const int ncbw = ncb / nch;
+    const bool small = R < 200000;
+    int tr = small ? 64 : TR;
+    while (!small && tr > 64 && mm_cdiv(R, tr) * nch < 1024) tr >>= 1;
+    KSeg sg;
+    const int nb = make_seg(offsets_host, K, tr, &sg);
+    const size_t lds = small ? 0 : (size_t)nq3 * ncbw * 64 * 16 * nt;
+    int rc = MM_OK;
+    switch (ncbw) {
+#define SCASE(N)                                                                                                          \
+  case N:                                                                                                                 \
+    rc = nt == 3 ? launch_s3<N, 3>(small, nb, nch, lds, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr, sg, s)          \
+                 : launch_s3<N, 2>(small, nb, nch, lds, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr, sg, s);         \
+    break;
+      SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8)
+#undef SCASE
+    }
+    if (rc) return rc;
+    MM_LAUNCH_CHECK();
+    if (!unique_dst) {
+      hipLaunchKernelGGL(k_csr_reduce, dim3((unsigned)mm_cdiv(n_out * (Cout / 4), 256)), dim3(256), 0, s, tgt, Cout, csr_off, csr_pos,
+                         n_out, out, ld_out, Cout / 4);
+      MM_LAUNCH_CHECK();
+    }
+    return MM_OK;
+  }
   hipLaunchKernelGGL(k_pack_frag, dim3((unsigned)mm_cdiv((int64_t)frag_floats(K, Cin, Cout), 256)), dim3(256), 0, s, W, w_kstride, s_ci,
                      s_co, kflip, K, Cin, Cout, nq, ncb, Wf);
   // small layers: fewer rules per workgroup and channel-block splitting so that the grid still covers the 256 CUs
@@ -594,10 +870,19 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
       const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
       const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
       const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
+      const int nt = Cin >= 64 ? split_terms() : 0;  // matrix-rate-bound widths, as in mm_spconv_apply
 #define DWCASE(I, J)                                                                                                  \
-  if (ti == I && tj == J)                                                                                             \
-    hipLaunchKernelGGL((k_dw_direct<I, J>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, \
-                       K, seg, chunk, partial);
+  if (ti == I && tj == J) {                                                                                           \
+    if (nt == 3)                                                                                                      \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 3>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, \
+                         Cout, K, seg, chunk, partial);                                                               \
+    else if (nt == 2)                                                                                                 \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 2>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, \
+                         Cout, K, seg, chunk, partial);                                                               \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_dw_direct<I, J>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, \
+                         K, seg, chunk, partial);                                                                     \
+  }
       DWCASE(1, 1) DWCASE(1, 2) DWCASE(1, 3) DWCASE(1, 4) DWCASE(2, 1) DWCASE(2, 2) DWCASE(2, 3) DWCASE(2, 4)
       DWCASE(3, 1) DWCASE(3, 2) DWCASE(3, 3) DWCASE(3, 4) DWCASE(4, 1) DWCASE(4, 2) DWCASE(4, 3) DWCASE(4, 4)
 #undef DWCASE
