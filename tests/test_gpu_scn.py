@@ -96,7 +96,7 @@ def _pair(mod_ref, mod_hip):
     return mod_ref, mod_hip.cuda()
 
 
-@pytest.mark.parametrize("cin,cout", [(3, 16), (16, 16), (32, 16), (16, 32), (48, 48), (5, 7), (64, 192), (192, 96)])
+@pytest.mark.parametrize("cin,cout", [(3, 16), (16, 16), (32, 16), (16, 32), (48, 48), (5, 7), (64, 192), (192, 96), (80, 80), (112, 48)])
 def test_conv_ops_forward_backward(cin, cout):
     from mm2d3d_amd import scn
 
