@@ -38,7 +38,8 @@ template <int MODE>
 __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
                                                     const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                    double* __restrict__ partial, int64_t Ns, int nb0) {
+                                                    double* __restrict__ partial, int64_t Ns, int nb0,
+                                                    const float* __restrict__ weight = nullptr, const float* __restrict__ bias = nullptr) {
   // rows [0, Ns) are statistics group 0 (blocks [0, nb0)), rows [Ns, N) group 1 (the other blocks): the two domains of a
   // jointly batched training step keep their own batch statistics.  Ns == N: one group.
   __shared__ float red[2][T];
@@ -50,14 +51,19 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
   const int rs = T / CV;
   const int tid = threadIdx.x;
   const int slot = tid / CV, cv = tid - slot * CV;
-  float a[8], b[8], m[8], is[8];
+  float a[8], b[8], m[8], is[8], sc[8], sh[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) a[i] = b[i] = 0.f;
+  // relu without yout: the mask is recomputed from x exactly as the forward decided it (v = fma(x, sc, sh) > 0 in fp32),
+  // which saves reading the output map back (layers without a residual input)
+  const bool remask = MODE == 1 && relu && yout == nullptr;
   if (MODE == 1 && slot < rs) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       m[i] = mean[cv * 8 + i];
       is[i] = invstd[cv * 8 + i];
+      sc[i] = is[i] * (weight ? weight[cv * 8 + i] : 1.f);
+      sh[i] = (bias ? bias[cv * 8 + i] : 0.f) - m[i] * sc[i];
     }
   }
   const int64_t rows_per_block = (Ng + nbg - 1) / nbg;
@@ -79,9 +85,10 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
       } else {
         float dv[8], yv[8];
         ld8(dy + r * ld_dy + cv * 8, dv);
-        if (relu) ld8(yout + r * ld_y + cv * 8, yv);
+        if (relu && !remask) ld8(yout + r * ld_y + cv * 8, yv);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
+          if (remask) yv[i] = fmaf(xv[i], sc[i], sh[i]);
           float g = (relu && !(yv[i] > 0.f)) ? 0.f : dv[i];
           a[i] += g;
           b[i] = fmaf(g, (xv[i] - m[i]) * is[i], b[i]);
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ sums,
                                                        u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr, int64_t Ns,
-                                                       int ab0) {
+                                                       int ab0, const float* __restrict__ bias) {
   const int CV = C >> 3;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
@@ -242,12 +249,15 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
   const int64_t gbase = grp ? Ns : 0, gend = grp ? N : Ns;
   mean += grp * C, invstd += grp * C, sums += grp * 2 * C;
   // dx = a*g + b*x + c0 with a = w*is, b = -w*is^2*sgx/N, c0 = -a*sg/N - b*mean   (N = rows of this statistics group)
-  float ka[8], kb[8], kc[8];
+  float ka[8], kb[8], kc[8], sc[8], sh[8];
   const float invN = 1.f / (float)(gend - gbase);
+  const bool remask = relu && yout == nullptr;  // see k_bn2d_reduce
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     int c = cv * 8 + i;
     float is = invstd[c], w = weight ? weight[c] : 1.f;
+    sc[i] = is * w;
+    sh[i] = (bias ? bias[c] : 0.f) - mean[c] * sc[i];
     ka[i] = w * is;
     kb[i] = -w * is * is * sums[C + c] * invN;
     kc[i] = -ka[i] * sums[c] * invN - kb[i] * mean[c];
@@ -260,9 +270,10 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
     float xv[8], dv[8], yv[8], ov[8], gv[8];
     ld8(x + r * ld_x + cv * 8, xv);
     ld8(dy + r * ld_dy + cv * 8, dv);
-    if (relu) ld8(yout + r * ld_y + cv * 8, yv);
+    if (relu && !remask) ld8(yout + r * ld_y + cv * 8, yv);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+      if (remask) yv[i] = fmaf(xv[i], sc[i], sh[i]);
       float g = (relu && !(yv[i] > 0.f)) ? 0.f : dv[i];
       gv[i] = g;
       ov[i] = fmaf(ka[i], g, fmaf(kb[i], xv[i], kc[i]));
@@ -346,9 +357,11 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
   return MM_OK;
 }
 
-// dx (and dres = relu-masked dy when dres != NULL), dweight, dbias; Ns and the [G][C] statistics as in mm_bn2d_fwd_train
+// dx (and dres = relu-masked dy when dres != NULL), dweight, dbias; Ns and the [G][C] statistics as in mm_bn2d_fwd_train.
+// yout == NULL with relu != 0 (only valid when the forward had no residual input): the ReLU mask is recomputed from x,
+// weight, bias and the saved statistics instead of reading the output map.
 int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N, int64_t Ns, int C,
-                const float* weight, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
+                const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
                 float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T, "bn2d: C must be a multiple of 8, <= 2048");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
@@ -361,12 +374,12 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, true, nb0, nb1);
   hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y,
-                     relu, N, C, save_mean, save_invstd, partial, Ns, nb0);
+                     relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias);
   hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   if (N > 0) {
     split_blocks(N, Ns, C, false, ab0, ab1);
     hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout,
-                       ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres, ld_dr, Ns, ab0);
+                       ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres, ld_dr, Ns, ab0, bias);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;

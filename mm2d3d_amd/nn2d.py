@@ -81,7 +81,7 @@ class _BN2dFn(torch.autograd.Function):
             ctx.Ns = Ns
             check(L.mm_bn2d_fwd_train(ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
                                       ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), ldy, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
-            ctx.save_for_backward(x, y, weight, stats)
+            ctx.save_for_backward(x, y, weight, stats, bias)
             ctx.sinks = None
             if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[2]):
                 gradsink.claim(ctx, bias, True)
@@ -98,8 +98,9 @@ class _BN2dFn(torch.autograd.Function):
         if not ctx.training:
             raise RuntimeError("BatchNorm2d backward in eval mode is not part of the hot path")
         L = _lib.lib()
-        x, y, weight, stats = ctx.saved_tensors
+        x, y, weight, stats, bias = ctx.saved_tensors
         dy, lddy = _c2d.nhwc_pitch(dy)
+        ymask = y if (ctx.has_res or not ctx.relu or weight is None) else None  # no residual: mask recomputed from x
         ldx, ldy = ctx.lds
         B, C, H, W = x.shape
         N = B * H * W
@@ -114,7 +115,8 @@ class _BN2dFn(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device)
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
-        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), lddy, ptr(y), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight), ptr(stats[0]), ptr(stats[1]),
+        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), lddy, ptr(ymask), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight), ptr(bias),
+                            ptr(stats[0]), ptr(stats[1]),
                             ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
                             stream()), "bn2d_bwd")
         if ctx.sinks is not None:
