@@ -10,7 +10,7 @@
 //       128 x BN x 64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16_bf16, double-buffered LDS with register prefetch
 //       (global loads of tile s+1 are in flight while tile s is multiplied), XOR-swizzled 128-B LDS rows so the
 //       ds_read_b128 fragment reads are bank-conflict free.
-//   G2  k_conv_wgrad dW[n][tap][k] = sum_m dY[m][n] * X[src(m,tap)][k]
+//   G2  k_conv_wgrad2 / k_wgrad3x3  dW[n][tap][k] = sum_m dY[m][n] * X[src(m,tap)][k]
 //       reduction over pixels: both MFMA operands are read from pixel-major LDS tiles with the hardware transpose
 //       read ds_read_b64_tr_b16; split over pixel chunks into fp32 partial slabs, reduced in a fixed order.
 #include <hip/hip_bf16.h>
@@ -565,77 +565,6 @@ struct WgP {
   int64_t mchunk;  // pixels per split
 };
 
-// tile: 64 (n) x 64 (k), 4 waves 2x2 of one 32x32 MFMA tile; K' = pixels in steps of 64
-__global__ __launch_bounds__(256) void k_conv_wgrad(WgP p) {
-  __shared__ __attribute__((aligned(16))) u16 Ys[64 * 64];  // [pixel][n]  128-B rows
-  __shared__ __attribute__((aligned(16))) u16 Xs[64 * 64];  // [pixel][k]
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wn = wave >> 1, wk = wave & 1;
-  const int nkt = p.Ck >> 6;
-  const int n0 = (blockIdx.y / nkt) * 64, k0 = (blockIdx.y % nkt) * 64;
-  const int tap = blockIdx.z;
-  const int ty = p.ty[tap], tx = p.tx[tap];
-  const int64_t M = (int64_t)p.B * p.Hg * p.Wg;
-  const int64_t mb = (int64_t)blockIdx.x * p.mchunk;
-  const int64_t me = mb + p.mchunk < M ? mb + p.mchunk : M;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; r++) acc[r] = 0.f;
-  // staging: 64 rows x 8 chunks = 512 chunks per tile -> 2 per thread
-  const int cc = tid & 7, r0 = tid >> 3;  // rows r0, r0+32
-  // transpose-read lane roles
-  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  for (int64_t t0 = mb; t0 < me; t0 += 64) {
-    uint4 vy[2], vx[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      int64_t m = t0 + r0 + 32 * i;
-      vy[i] = vx[i] = make_uint4(0, 0, 0, 0);
-      if (m < me) {
-        int gx = (int)(m % p.Wg);
-        int64_t t = m / p.Wg;
-        int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
-        vy[i] = *(const uint4*)(p.DY + m * p.ldy + n0 + cc * 8);
-        int sy = gy * p.sa + ty, sx = gx * p.sa + tx;
-        if (sy >= 0 && sx >= 0 && sy < p.Hi && sx < p.Wi)
-          vx[i] = *(const uint4*)(p.X + ((int64_t)(b * p.Hi + sy) * p.Wi + sx) * p.ldx + k0 + cc * 8);
-      }
-    }
-    __syncthreads();  // previous tile fully consumed
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      int row = r0 + 32 * i;
-      *(uint4*)&Ys[row * 64 + cc * 8] = vy[i];
-      *(uint4*)&Xs[row * 64 + cc * 8] = vx[i];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {  // 16 pixels per MFMA
-      // operand A[i = n (32)][k = pixel (16)], lane (r = lane&31, h = lane>>5) holds pixels 8h..8h+7 of channel r.
-      // tr read: 16-lane group gq covers channels 16*(gq&1).., pixel rows 8*(gq>>1) + {0..3} then +4
-      const int prow = kk * 16 + 8 * (g >> 1) + q;
-      const int ncol = wn * 32 + 16 * (g & 1) + 4 * pp;
-      const int kcol = wk * 32 + 16 * (g & 1) + 4 * pp;
-      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[prow * 64 + ncol]);
-      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[(prow + 4) * 64 + ncol]);
-      s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xs[prow * 64 + kcol]);
-      s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xs[(prow + 4) * 64 + kcol]);
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
-    }
-  }
-  // acc: row i = n: (reg&3) + 8*(reg>>2) + 4*(lane>>5); col j = k: lane&31
-  float* P = p.partial + (int64_t)blockIdx.x * p.Cn * p.ntaps * p.Ck;
-#pragma unroll
-  for (int reg = 0; reg < 16; reg++) {
-    int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-    int k = k0 + wk * 32 + (lane & 31);
-    if (n < p.Cn) P[((int64_t)n * p.ntaps + tap) * p.Ck + k] = acc[reg];
-  }
-}
-
 // Larger-tile weight gradient: TN (64|128) x 128 output tile per workgroup, 64-pixel K'-steps staged by LDS-DMA into
 // double-buffered pixel-major tiles; rows are swizzled (on the DMA source chunk and on the transpose reads) so that
 // ds_read_b64_tr_b16 is bank-conflict free: 256-B rows use chunk ^= ((row&3)<<2)|((row>>2)&3), 128-B rows chunk ^= ((row>>1)&1)<<2.
@@ -1036,8 +965,7 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
   }
   // 64-wide output-channel blocks everywhere: 39 KB of LDS per workgroup -> 4 workgroups per CU.  Measured: resident
   // workgroups (DMA-latency hiding) matter more than the halved B-fragment traffic of 128-wide blocks (tools/bench_conv.py).
-  static const bool old_kernel = getenv("MM_C3_OLD") != nullptr;  // tools/bench_c3.py A/B switch
-  if (old_kernel || Cn % 64 != 0 || Cn > 1024 || ldo % 4 != 0 || ((uintptr_t)O % 8) != 0) {
+  if (Cn % 64 != 0 || Cn > 1024 || ldo % 4 != 0 || ((uintptr_t)O % 8) != 0) {
     hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
   } else {
     // 16 x 16 tiles on large maps, 8 x 32 where that wastes fewer out-of-image pixels; 128-cout blocks when Cn allows

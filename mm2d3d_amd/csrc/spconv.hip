@@ -716,7 +716,7 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     MM_LAUNCH_CHECK();
     return MM_OK;
   }
-  if (!unique_dst && Cin <= 4 && Cout <= 32 && (size_t)K * Cin * Cout * 4 <= 48 * 1024 && !getenv("MM_NO_NARROW")) {  // the stem: no tmp, one pass
+  if (!unique_dst && Cin <= 4 && Cout <= 32 && (size_t)K * Cin * Cout * 4 <= 48 * 1024) {  // the stem: no tmp, one pass
     KSeg sg;
     make_seg(offsets_host, K, TR, &sg);
     hipLaunchKernelGGL(k_rows_narrow, dim3((unsigned)mm_cdiv(n_out, 256)), dim3(256), (size_t)K * Cin * Cout * 4, s, in, ld_in, src, sg, K,
@@ -790,7 +790,7 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     d = nullptr;
   }
   const bool e2 = edge || (!unique_dst && (Cout % 4 != 0));
-  if (!e2 && R > 0 && R < 200000 && ncb <= 8 && !getenv("MM_NO_DIRECT")) {  // coarse levels: direct-from-L2 weights, one 16-rule group per wave
+  if (!e2 && R > 0 && R < 200000 && ncb <= 8) {  // coarse levels: direct-from-L2 weights, one 16-rule group per wave
     KSeg sg;
     const int nbd = make_seg(offsets_host, K, 64, &sg);
     switch (ncb) {
