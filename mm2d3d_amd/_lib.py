@@ -5,6 +5,7 @@ operator raises.  PyTorch is used only for device memory and the current HIP str
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -130,9 +131,10 @@ class _Workspace:
 
     def __init__(self):
         self.bufs = {}
+        self.default_slot = "main"
 
-    def get(self, nbytes: int, device, slot: str = "main"):
-        key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    def get(self, nbytes: int, device, slot: str = None):
+        key = (device.index if device.index is not None else torch.cuda.current_device(), slot or self.default_slot)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)
@@ -141,6 +143,18 @@ class _Workspace:
 
 
 workspace = _Workspace()
+
+
+@contextlib.contextmanager
+def workspace_slot(name):
+    """Kernels enqueued on another stream must not share the scratch buffer of the main stream: inside this context
+    ``workspace.get`` hands out the buffer ``name``."""
+    old = workspace.default_slot
+    workspace.default_slot = name
+    try:
+        yield
+    finally:
+        workspace.default_slot = old
 
 
 def require_cuda(t, name="tensor"):

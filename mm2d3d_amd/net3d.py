@@ -105,6 +105,12 @@ class Net3DSeg(nn.Module):
         self.dual_head = dual_head
         self.aux = L2G_classifier_3D(16, num_classes)
 
+    def prepare(self, data_batch, side_stream=None, after=None):
+        """Optional: build the sparse metadata of ``data_batch`` ahead of the forward (TrainModel overlaps it with the 2D
+        branch on a side stream).  ``forward`` finds it on the coordinate tensor."""
+        layer = self.net_3d.layer1  # scn.InputLayer
+        return scn.prebuild_metadata(data_batch["x"][0], layer.spatial_size, side_stream, after, layer.prebuild_levels)
+
     def forward(self, data_batch):
         coords, feats = data_batch["x"][0], data_batch["x"][1]
         gated, mask_rgb = ops.GateFunction.apply(feats, self.linear_rgb_mask.weight, self.linear_rgb_mask.bias)

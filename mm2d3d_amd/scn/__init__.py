@@ -116,8 +116,14 @@ class InputLayer(nn.Module):
             coords = torch.cat([coords, coords.new_zeros((coords.shape[0], 1))], 1)
         coords = coords.contiguous()
         S = int(self.spatial_size if not torch.is_tensor(self.spatial_size) else self.spatial_size.max())
-        md = Metadata(dev, S, self.prebuild_levels)
-        lv0 = md.build_levels(coords)
+        md = getattr(x[0], "_mm_metadata", None)  # built ahead of time by prebuild_metadata (possibly on a side stream)
+        if md is not None and md.n_points == coords.shape[0] and md.spatial_size == S and md.device == dev:
+            if md.ready is not None:
+                torch.cuda.current_stream(dev).wait_event(md.ready)
+            lv0 = md.levels[0]
+        else:
+            md = Metadata(dev, S, self.prebuild_levels)
+            lv0 = md.build_levels(coords)
         if self.mode in (3, 4):
             f = ops.InputMeanFunction.apply(feats, lv0, self.mode == 4)
         elif self.mode in (0, 2):  # first occurrence: the smallest point index of each list
@@ -127,6 +133,22 @@ class InputLayer(nn.Module):
         else:
             raise ValueError(f"InputLayer mode {self.mode}")
         return SparseConvNetTensor(f, md, self.spatial_size, lv0)
+
+
+def prebuild_metadata(coords, spatial_size, side_stream=None, after=None, prebuild_levels=7):
+    """Builds the voxel hash / active sets / rulebooks of ``coords`` ([N, 3+1] int64 on the GPU) now and attaches them to
+    the tensor object; the InputLayer that later receives this very tensor uses them instead of building its own.  With
+    ``side_stream`` the build (about 60 small kernels and two host read-backs) overlaps the work already queued on the
+    current stream."""
+    if not coords.is_cuda:
+        raise RuntimeError("mm2d3d_amd.scn.prebuild_metadata: coordinates must be on the GPU")
+    c = coords if coords.dtype == torch.int64 and coords.is_contiguous() else coords.to(torch.int64).contiguous()
+    if c.shape[1] == 3:
+        c = torch.cat([c, c.new_zeros((c.shape[0], 1))], 1).contiguous()
+    md = Metadata.prebuild(c, int(spatial_size), prebuild_levels, side_stream, after)
+    md._coords_keepalive = c
+    coords._mm_metadata = md
+    return md
 
 
 class OutputLayer(nn.Module):

@@ -56,13 +56,55 @@ class Metadata:
         self.prebuild_levels = prebuild_levels
         self.levels = []
         self._rulebooks_built = False
+        self.ready = None   # event of the stream that built it (prebuild on a side stream)
+        self.n_points = 0
+        self.split = None
 
     # ------------------------------------------------------------------ active sets
+    @classmethod
+    def prebuild(cls, coords_i64, spatial_size, prebuild_levels=7, side_stream=None, after=None):
+        """Active sets and every rulebook of the level chain for ``coords``, optionally on ``side_stream`` (its kernels
+        and its two small host read-backs then overlap whatever the caller already queued on the current stream, e.g. the
+        2D branch).  ``after``: event the side stream waits for first (so that it cannot run ahead into memory the previous
+        step still uses).  The result carries ``ready``: consumers on another stream wait for it (InputLayer does)."""
+        md = cls(coords_i64.device, spatial_size, prebuild_levels)
+        if side_stream is None:
+            md.build_levels(coords_i64)
+            md.build_rulebooks()
+            return md
+        cur = torch.cuda.current_stream(coords_i64.device)
+        if after is not None:
+            side_stream.wait_event(after)
+        with torch.cuda.stream(side_stream), _lib.workspace_slot("meta"):
+            md.build_levels(coords_i64)
+            md.build_rulebooks()
+            md.ready = side_stream.record_event()
+        # the tensors were allocated on the side stream and are consumed on ``cur``: tell the caching allocator
+        for t in md.tensors():
+            t.record_stream(cur)
+        return md
+
+    def tensors(self):
+        for lv in self.levels:
+            for t in (lv.coords, lv.tkeys, lv.tvals, lv.item2vox, lv.csr_off, lv.csr_items):
+                if t is not None:
+                    yield t
+            for rb in (lv.subm, lv.down):
+                if rb is not None:
+                    for name in Rulebook.__slots__:
+                        t = getattr(rb, name, None)
+                        if torch.is_tensor(t):
+                            yield t
+                        elif isinstance(t, (list, tuple)):
+                            for u in t:
+                                if torch.is_tensor(u):
+                                    yield u
+
     def build_levels(self, coords_i64: torch.Tensor):
         """Dedupe chain: points -> level 0 -> level 1 ... (A.8 i, ii).  One host sync at the end."""
         L = _lib.lib()
         dev = self.device
-        n_pts = coords_i64.shape[0]
+        n_pts = self.n_points = coords_i64.shape[0]
         nlev = max(1, min(self.prebuild_levels, max(1, int(np.log2(max(self.spatial_size, 2))))))
         counts = torch.zeros(2 * nlev + 1, dtype=I32, device=dev)  # [n_0..n_{L-1}, err, seg_0..seg_{L-1}]
         err = counts[nlev : nlev + 1]

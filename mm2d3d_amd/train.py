@@ -32,6 +32,10 @@ class TrainModel(nn.Module):
         # the rows per launch.  The batch-norm layers keep per-domain statistics (mm2d3d_amd/domains.py), so the
         # arithmetic is that of the reference's two calls.  False: the literal two-call sequence.
         self.joint_domains = train_kwargs.get("joint_domains", True)
+        # building the 3D metadata on a side stream during the 2D branch measured SLOWER (55.1-57.5 vs 53.7-54.0 ms/step:
+        # its small kernels queue behind the persistent conv workgroups and the host waits longer at the read-backs): off
+        self.overlap_metadata = train_kwargs.get("overlap_metadata", False)
+        self._side = None
         self._opt_factories = optimizer or {}
         self.optimizers, self.schedulers = [], []
         self.reducer = None
@@ -82,7 +86,16 @@ class TrainModel(nn.Module):
             both, B = self._join(src, trg)
             P = src["x"][0].shape[0]  # point rows [0, P) are the source's
             with domains.split(B):
+                dev = both["img"].device
+                step_start = torch.cuda.current_stream(dev).record_event()
                 p2d, _, _, aux2d = self(both, model_name=n2d)
+                # the 2D branch is queued: build the voxel hash / rulebooks of the 3D branch on a side stream while the GPU
+                # works through it (the build's two host read-backs would otherwise drain the queue)
+                prep = getattr(self.model[n3d], "prepare", None)
+                if prep is not None and self.overlap_metadata:
+                    if self._side is None:
+                        self._side = torch.cuda.Stream(dev)
+                    prep(both, self._side, step_start)
                 p3d, _, aux3d = self(both, model_name=n3d)
             l2d, a2d, l3d, a3d = p2d["seg_logit"], aux2d["seg_logit_avg"], p3d["seg_logit"], aux3d["seg_logit_point"]
             seg2d = self.loss("segmentation", pred=l2d[:P], gt=src["seg_label"])
