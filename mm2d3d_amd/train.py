@@ -88,10 +88,10 @@ class TrainModel(nn.Module):
             with domains.split(B):
                 dev = both["img"].device
                 step_start = torch.cuda.current_stream(dev).record_event()
+                prep = getattr(self.model[n3d], "prepare", None)
                 p2d, _, _, aux2d = self(both, model_name=n2d)
                 # the 2D branch is queued: build the voxel hash / rulebooks of the 3D branch on a side stream while the GPU
                 # works through it (the build's two host read-backs would otherwise drain the queue)
-                prep = getattr(self.model[n3d], "prepare", None)
                 if prep is not None and self.overlap_metadata:
                     if self._side is None:
                         self._side = torch.cuda.Stream(dev)
