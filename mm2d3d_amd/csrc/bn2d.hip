@@ -121,9 +121,27 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+// sums partial[b][0][c] and partial[b][1][c] over b in [b0, b1) with the 256 threads of the block (fixed tree: lanes stride
+// the blocks, shuffle tree per wave, the 4 wave results added in wave order); result valid in thread 0
+__device__ inline void block_sum2(const double* __restrict__ partial, int b0, int b1, int C, int c, double& s, double& q) {
+  __shared__ double red[2][4];
+  double ls = 0.0, lq = 0.0;
+  for (int b = b0 + threadIdx.x; b < b1; b += 256) {
+    ls += partial[((int64_t)b * 2 + 0) * C + c];
+    lq += partial[((int64_t)b * 2 + 1) * C + c];
+  }
+  ls = wave_sum(ls);
+  lq = wave_sum(lq);
+  __syncthreads();  // red[] may still be read by the previous call
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = ls, red[1][threadIdx.x >> 6] = lq;
+  __syncthreads();
+  s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+  q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+}
+
 // torch semantics: running = (1-momentum)*running + momentum*batch (unbiased variance); with two statistics groups the
 // running buffers are updated group 0 first, then group 1 - exactly what two consecutive forward calls do.
-__global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restrict__ partial, int nb0, int nb1, int64_t Ns, int64_t N,
+__global__ __launch_bounds__(256) void k_bn2d_finalize_fwd(const double* __restrict__ partial, int nb0, int nb1, int64_t Ns, int64_t N,
                                                            int C, float eps, float momentum, float* __restrict__ running_mean,
                                                            float* __restrict__ running_var, float* __restrict__ save_mean,
                                                            float* __restrict__ save_invstd, int64_t* __restrict__ num_batches) {
@@ -133,13 +151,8 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restri
   for (int g = 0; g < G; g++) {
     const int b0 = g ? nb0 : 0, b1 = g ? nb0 + nb1 : nb0;
     const int64_t Ng = g ? N - Ns : Ns;
-    double s = 0.0, q = 0.0;
-    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
-      s += partial[((int64_t)b * 2 + 0) * C + c];
-      q += partial[((int64_t)b * 2 + 1) * C + c];
-    }
-    s = wave_sum(s);
-    q = wave_sum(q);
+    double s, q;
+    block_sum2(partial, b0, b1, C, c, s, q);
     if (threadIdx.x == 0) {
       double mean = Ng > 0 ? s / (double)Ng : 0.0;
       double var = Ng > 0 ? q / (double)Ng - mean * mean : 0.0;
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_fwd(const double* __restri
 }
 
 // sums[g][0][C] = sum g, sums[g][1][C] = sum g*xhat per statistics group; dweight / dbias are the totals over the groups
-__global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nb0, int nb1, int C,
+__global__ __launch_bounds__(256) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nb0, int nb1, int C,
                                                            float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dweight,
                                                            float* __restrict__ dbias, int accumulate) {
   const int c = blockIdx.x;
@@ -164,13 +177,8 @@ __global__ __launch_bounds__(64) void k_bn2d_finalize_bwd(const double* __restri
   float ts = 0.f, tq = 0.f;
   for (int g = 0; g < G; g++) {
     const int b0 = g ? nb0 : 0, b1 = g ? nb0 + nb1 : nb0;
-    double s = 0.0, q = 0.0;
-    for (int b = b0 + threadIdx.x; b < b1; b += 64) {
-      s += partial[((int64_t)b * 2 + 0) * C + c];
-      q += partial[((int64_t)b * 2 + 1) * C + c];
-    }
-    s = wave_sum(s);
-    q = wave_sum(q);
+    double s, q;
+    block_sum2(partial, b0, b1, C, c, s, q);
     if (threadIdx.x == 0) {
       sums[(g * 2 + 0) * C + c] = (float)s;
       sums[(g * 2 + 1) * C + c] = (float)q;
@@ -335,7 +343,7 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
   split_blocks(N, Ns, C, true, nb0, nb1);
   hipLaunchKernelGGL(k_bn2d_reduce<0>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr,
                      nullptr, partial, Ns, nb0);
-  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
+  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
                      save_mean, save_invstd, num_batches_tracked);
   if (N > 0) {
     split_blocks(N, Ns, C, false, ab0, ab1);
@@ -375,7 +383,7 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   split_blocks(N, Ns, C, true, nb0, nb1);
   hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y,
                      relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias);
-  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
+  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   if (N > 0) {
     split_blocks(N, Ns, C, false, ab0, ab1);
     hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout,
