@@ -181,6 +181,53 @@ __global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int 
     if (j < NJ) z[(int64_t)pix * NJ + j] = acc[j];
 }
 
+// MFMA version for C = 64, NJ <= 16 (the model's heads): D[j][pixel] = W[j][:] . x[pixel][:] on v_mfma_f32_16x16x32_bf16;
+// x is bf16 already, the fp32 weights enter as two bf16 terms (hi + lo: 2^-17 relative), so this is the fp32-weight
+// product to fp32 accumulation noise.  A lane loads 16 B of one pixel row per MFMA (whole 128-B rows per 4 lanes) and
+// stores 4 consecutive outputs of its pixel (16 B): a pure streaming kernel.
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef float hf32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(T) void k_head_proj_mfma(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w,
+                                                       const float* __restrict__ Wj, int NJ, float* __restrict__ z, int groups) {
+  const int lane = threadIdx.x & 63, jl = lane & 15, sl = lane >> 4;
+  hbf16x8 wh[2], wl[2];  // A operand: W[j = jl][c = 32*half + 8*sl + t]
+#pragma unroll
+  for (int half = 0; half < 2; half++)
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+      const float v = jl < NJ ? Wj[jl * 64 + 32 * half + 8 * sl + t] : 0.f;
+      const __bf16 hh = (__bf16)v;
+      wh[half][t] = hh;
+      wl[half][t] = (__bf16)(v - (float)hh);
+    }
+  const unsigned total = (unsigned)B * h * w;
+  const int gw = (blockIdx.x * (T / 64) + (threadIdx.x >> 6));  // global wave index
+  const int nw = gridDim.x * (T / 64);
+  for (int g = gw; g < groups; g += nw) {
+    const unsigned pix = (unsigned)g * 16 + jl;  // this lane's pixel (B operand column / D column)
+    const bool ok = pix < total;
+    const unsigned t = pix / (unsigned)w;
+    const int xx = (int)(pix - t * w), b = (int)(t / (unsigned)h), yy = (int)(t - (unsigned)b * h);
+    const u16* row = x + ((int64_t)(b * Hp + yy) * Wp + xx) * ld + 8 * sl;
+    uint4 v0 = make_uint4(0u, 0u, 0u, 0u), v1 = v0;
+    if (ok) v0 = *(const uint4*)row, v1 = *(const uint4*)(row + 32);
+    const hbf16x8 x0 = __builtin_bit_cast(hbf16x8, v0), x1 = __builtin_bit_cast(hbf16x8, v1);
+    hf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[0], x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[1], x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0], x0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[1], x1, acc, 0, 0, 0);
+    if (ok) {  // D row 4*sl + r = output j, column jl = pixel
+      float* o = z + (int64_t)pix * NJ + 4 * sl;
+      if (4 * sl + 3 < NJ && (NJ & 3) == 0) *(hf32x4*)o = acc;
+      else
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (4 * sl + r < NJ) o[r] = acc[r];
+    }
+  }
+}
+
 // 5x5 box / 25 with zero padding on NHWC fp32 maps [B,h,w,NJ] (+ bias): thread = (pixel, j), j fastest, so both the
 // 25 reads and the write are coalesced across the wave
 __global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B, int h, int w, int NJ, const float* __restrict__ bias,
@@ -254,37 +301,49 @@ __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int H
   const int64_t total = (int64_t)B * Hp * Wp;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
   const int64_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
-  int xx, yy, b;
-  {
-    const int64_t pp = p0 + slot, t = pp / Wp;
-    xx = (int)(pp - t * Wp), b = (int)(t / Hp), yy = (int)(t - (int64_t)b * Hp);
-  }
-  for (int64_t pp = p0 + slot; pp < p1; pp += NSLOT, xx += NSLOT) {
-    while (xx >= Wp) {
-      xx -= Wp;
-      if (++yy == Hp) yy = 0, b++;
+  // UN pixels per thread and iteration, all loads issued before the arithmetic (the loop is latency-bound otherwise)
+  constexpr int UN = 4;
+  for (int64_t pb = p0 + slot; pb < p1; pb += NSLOT * UN) {
+    uint2 xv2[UN];
+    float gj[UN][MJ];
+    bool in[UN];
+#pragma unroll
+    for (int u = 0; u < UN; u++) {
+      const int64_t pp = pb + (int64_t)u * NSLOT;
+      const unsigned t = (unsigned)pp / (unsigned)Wp;  // host guarantees B*Hp*Wp < 2^31
+      const int xx = (int)((unsigned)pp - t * (unsigned)Wp), b = (int)(t / (unsigned)Hp), yy = (int)(t - (unsigned)b * (unsigned)Hp);
+      in[u] = pp < p1 && yy < h && xx < w;
+      xv2[u] = make_uint2(0u, 0u);
+      if (in[u]) {
+        xv2[u] = *(const uint2*)(x + pp * ld + c4);
+        const float* g = dz + ((int64_t)(b * h + yy) * w + xx) * NJ;
+#pragma unroll
+        for (int j = 0; j < MJ; j++) gj[u][j] = j < NJ ? g[j] : 0.f;
+      }
     }
-    float o[4] = {0.f, 0.f, 0.f, 0.f};
-    if (yy < h && xx < w) {
-      const float* g = dz + ((int64_t)(b * h + yy) * w + xx) * NJ;
-      uint2 v = *(const uint2*)(x + pp * ld + c4);
-      float xv[4] = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
-                     __uint_as_float(v.y & 0xFFFF0000u)};
 #pragma unroll
-      for (int j = 0; j < MJ; j++)
-        if (j < NJ) {
-          float gj = g[j];
+    for (int u = 0; u < UN; u++) {
+      const int64_t pp = pb + (int64_t)u * NSLOT;
+      if (pp >= p1) break;
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      if (in[u]) {
+        const float xv[4] = {__uint_as_float(xv2[u].x << 16), __uint_as_float(xv2[u].x & 0xFFFF0000u), __uint_as_float(xv2[u].y << 16),
+                             __uint_as_float(xv2[u].y & 0xFFFF0000u)};
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
-            o[i] = fmaf(gj, wc[j][i], o[i]);
-            acc[j][i] = fmaf(gj, xv[i], acc[j][i]);
+        for (int j = 0; j < MJ; j++)
+          if (j < NJ) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              o[i] = fmaf(gj[u][j], wc[j][i], o[i]);
+              acc[j][i] = fmaf(gj[u][j], xv[i], acc[j][i]);
+            }
           }
-        }
+      }
+      uint2 r;
+      r.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+      r.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+      *(uint2*)(dx + pp * ld + c4) = r;
     }
-    uint2 r;
-    r.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-    r.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-    *(uint2*)(dx + pp * ld + c4) = r;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -402,7 +461,12 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
 #define MM_HEAD_PROJ(MJ)                                                                                                          \
   hipLaunchKernelGGL(k_head_proj<MJ>, dim3((unsigned)mm_cdiv(npix, T)), dim3(T), (size_t)NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, \
                      w, C, Wj, NJ, z)
-  if (NJ <= 8) MM_HEAD_PROJ(8);
+  if (C == 64 && NJ <= 16 && ld % 8 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)z % 16) == 0) {
+    const int groups = (int)mm_cdiv(npix, 16);
+    int nb = (int)mm_cdiv(groups, (T / 64) * 4);  // ~4 pixel groups per wave
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(k_head_proj_mfma, dim3(nb), dim3(T), 0, s, (const u16*)x, Hp, Wp, ld, B, h, w, Wj, NJ, z, groups);
+  } else if (NJ <= 8) MM_HEAD_PROJ(8);
   else if (NJ <= 12) MM_HEAD_PROJ(12);
   else if (NJ <= 20) MM_HEAD_PROJ(20);
   else MM_HEAD_PROJ(32);
@@ -416,6 +480,7 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
 int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ, const float* dout,
                 void* dx, float* dWj, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C == 64, "head_bwd: C must be 64");
+  MM_CHECK_ARG((int64_t)B * Hp * Wp < (1ll << 31), "head_bwd: too many pixels");
   size_t zb = mm_align((size_t)B * h * w * NJ * sizeof(float));
   const int64_t total = (int64_t)B * Hp * Wp;
   int nblk = (int)mm_cdiv(total, 128);
