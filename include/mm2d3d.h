@@ -177,7 +177,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
                     int64_t sk, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 /* stem input (EXP/2d_net/backbones.py:23-25, 7x7 stride-1 conv on 3 / 1 channels): NCHW fp32 -> zero-bordered NHWC8 bf16 */
-int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, void* out, mm_stream_t stream);
+int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, mm_stream_t stream);
 /* out[((z*N+n)*T+t)*K+k] = bf16(in[z*sz + n*sn + t*st + k*sk]) : fp32 master weights -> kernel layouts */
 int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st,
                          int64_t sk, mm_stream_t stream);

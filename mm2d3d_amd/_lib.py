@@ -64,7 +64,7 @@ _PROTOS = {
                               vp]),
     "mm_pack_weights_bf16": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp]),
     "mm_pack_weights_bf16_batch": (i32, [vp, i32, i64, vp]),
-    "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_bn2d_ws_bytes": (sz, [i32]),
     "mm_bn2d_fwd_train": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),

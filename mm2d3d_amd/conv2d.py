@@ -275,12 +275,39 @@ class ConvTranspose2dFn(torch.autograd.Function):
         return dx, dw, db
 
 
+_STEM_IDX = {}
+
+
+def _stem_index(C, device):
+    """Index table of the stem's packed weight: packed[co][t][kw8][slot] = W[co][c][kh][kw] with slot = r*C + c,
+    kh = t*R + r, R = 8 // C rows per tap; entries outside the 7x7xC filter point at a zero column."""
+    key = (C, device)
+    hit = _STEM_IDX.get(key)
+    if hit is None:
+        R = 8 // C
+        T = (7 + R - 1) // R
+        idx = torch.full((T, 8, 8), C * 49, dtype=torch.int64)  # C*49 = the appended zero column
+        for t in range(T):
+            for r in range(R):
+                kh = t * R + r
+                if kh >= 7:
+                    continue
+                for kw in range(7):
+                    for c in range(C):
+                        idx[t, kw, r * C + c] = (c * 7 + kh) * 7 + kw
+        flat = idx.reshape(-1)
+        valid = (flat < C * 49).nonzero().reshape(-1)
+        hit = _STEM_IDX[key] = (R, T, flat.to(device), valid.to(device), flat[valid].to(device))
+    return hit
+
+
 class StemConvFn(torch.autograd.Function):
     """7x7, stride 1, pad 3 convolution on a 3- or 1-channel fp32 NCHW image (backbones.py:23-25), bf16 NHWC output.
 
-    The image is rewritten once as a zero-bordered NHWC8 bf16 buffer.  Viewed with a pixel pitch of 8 elements and 64
-    "channels" (8 neighbouring pixels x 8 channel slots), filter row kh is ONE tap of the generic implicit GEMM:
-    K = 7 taps x 64, of which 7 x 7 x Cin carry non-zero weights.  No gradient w.r.t. the image is produced (it is data).
+    The image is rewritten once as a zero-bordered bf16 buffer with 8 slots per pixel holding R = 8 // C vertically
+    stacked rows of the C channels.  Viewed with a pixel pitch of 8 elements and 64 "channels" (8 neighbouring pixels x 8
+    slots), R filter rows are ONE tap of the generic implicit GEMM: K = 64 for the depth image (1 tap), 256 for RGB
+    (4 taps).  No gradient w.r.t. the image is produced (it is data).
     """
 
     @staticmethod
@@ -291,17 +318,17 @@ class StemConvFn(torch.autograd.Function):
         Bn, C, H, W = img.shape
         Cout, _, KH, KW = weight.shape
         assert (KH, KW) == (7, 7) and C <= 8 and Cout % 64 == 0
-        Hb, Wb = H + 6, W + 6 + 2  # +2: the 8-pixel window of the last output column stays inside the row
+        R, T, flat, valid, src = _stem_index(C, img.device)
+        Hb, Wb = H + 6 + 8, W + 6 + 2  # rows: taps reach R*T - 1 <= 7 rows further; cols: the 8-pixel window of the last column
         xb = torch.empty((Bn, Hb, Wb, 8), dtype=BF16, device=img.device)
-        check(L.mm_stem_prep(ptr(img), Bn, C, H, W, 3, Hb, Wb, ptr(xb), stream()), "stem_prep")
-        w = weight.detach().float()
-        wp = torch.zeros((Cout, 7, 8, 8), dtype=torch.float32, device=img.device)  # [co][kh][kw(8)][ci(8)]
-        wp[:, :, :7, :C] = w.permute(0, 2, 3, 1)
-        Wp = wp.to(BF16).contiguous()
+        check(L.mm_stem_prep(ptr(img), Bn, C, H, W, 3, Hb, Wb, R, ptr(xb), stream()), "stem_prep")
+        w = weight.detach().float().reshape(Cout, C * 49)
+        Wp = torch.cat([w, w.new_zeros((Cout, 1))], 1).index_select(1, flat).to(BF16).contiguous()  # [co][t][kw8][slot]
         y = torch.empty((Bn, Cout, H, W), dtype=BF16, device=img.device, memory_format=CL)
-        # virtual activation: pixel pitch (lda) 8, 64 channels, Wi = Wb - 7 valid window starts; output (y,x) reads rows y..y+6 at x
-        check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, 7, _arr(list(range(7))),
-                               _arr([0] * 7), ptr(Wp), 1, 0, 0, None, stream()), "conv2d_gemm(stem)")
+        ty = [t * R for t in range(T)]
+        # virtual activation: pixel pitch (lda) 8, 64 channels, Wi = Wb - 7 valid window starts; output (y,x) reads row y + t*R at x
+        check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, T, _arr(ty),
+                               _arr([0] * T), ptr(Wp), 1, 0, 0, None, stream()), "conv2d_gemm(stem)")
         ctx.save_for_backward(xb)
         ctx.dims = (Bn, C, H, W, Cout, Hb, Wb, weight.shape)
         return y
@@ -311,10 +338,15 @@ class StemConvFn(torch.autograd.Function):
         L = _lib.lib()
         (xb,) = ctx.saved_tensors
         Bn, C, H, W, Cout, Hb, Wb, wshape = ctx.dims
+        R, T, flat, valid, src = _stem_index(C, dy.device)
         dy = as_nhwc_bf16(dy)
-        dwp = torch.empty((Cout, 7, 64), dtype=torch.float32, device=dy.device)
-        ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, 64, 7)), dy.device)
-        check(L.mm_conv2d_wgrad(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(dy), H, W, Cout, Cout, 1, 7, _arr(list(range(7))), _arr([0] * 7),
-                                ptr(dwp), 7 * 64, 64, 1, 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad(stem)")
-        dw = dwp.view(Cout, 7, 8, 8)[:, :, :7, :C].permute(0, 3, 1, 2).contiguous()
+        dwp = torch.empty((Cout, T * 64), dtype=torch.float32, device=dy.device)
+        ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, 64, T)), dy.device)
+        ty = [t * R for t in range(T)]
+        check(L.mm_conv2d_wgrad(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(dy), H, W, Cout, Cout, 1, T, _arr(ty), _arr([0] * T),
+                                ptr(dwp), T * 64, 64, 1, 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad(stem)")
+        dw = torch.zeros((Cout, C * 49), dtype=torch.float32, device=dy.device)
+        dw.index_copy_(1, src, dwp.index_select(1, valid))
         return None, dw.view(wshape)
+
+

@@ -876,26 +876,28 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_bf16(const float* __restri
   out[pix * ldo + c] = f2bf(in[((int64_t)b * C + c) * hw + r]);
 }
 
-// Stem input: NCHW fp32 [B,C,H,W] (C <= 8) -> zero-bordered NHWC8 bf16 [B, Hb, Wb, 8] with the image at (pad, pad).
-// Viewed with a pixel pitch of 8 elements and 64 "channels" (8 neighbouring pixels x 8), one row of the 7x7 stem filter
-// becomes a single 128-B tap of the implicit GEMM (conv2d.py StemConvFn).
+// Stem input: NCHW fp32 [B,C,H,W] (C <= 8) -> zero-bordered bf16 buffer [B, Hb, Wb, 8] whose 8 slots per pixel hold
+// R = 8 / C vertically stacked rows of the C channels: slot r*C + c of buffer pixel (yb, xb) = img[c][yb + r - pad][xb - pad].
+// Viewed with a pixel pitch of 8 elements and 64 "channels" (8 neighbouring pixels x 8 slots), R rows of the 7x7 stem
+// filter become ONE 128-B tap of the implicit GEMM (conv2d.py StemConvFn): 1 tap for the depth image, 4 for RGB.
 __global__ __launch_bounds__(256) void k_stem_prep(const float* __restrict__ in, int B, int C, int H, int W, int pad, int Hb, int Wb,
-                                                    u16* __restrict__ out) {
+                                                    int R, u16* __restrict__ out) {
   int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int64_t total = (int64_t)B * Hb * Wb;
   if (gid >= total) return;
   int x = (int)(gid % Wb);
   int64_t t = gid / Wb;
   int y = (int)(t % Hb), b = (int)(t / Hb);
-  unsigned w[4] = {0u, 0u, 0u, 0u};
-  int sy = y - pad, sx = x - pad;
-  if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
-    u16 v[8];
+  u16 v[8];
 #pragma unroll
-    for (int c = 0; c < 8; c++) v[c] = c < C ? f2bf(in[((int64_t)(b * C + c) * H + sy) * W + sx]) : (u16)0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = (unsigned)v[2 * i] | ((unsigned)v[2 * i + 1] << 16);
+  for (int sl = 0; sl < 8; sl++) {
+    const int r = sl / C, c = sl - r * C;
+    const int sy = y + r - pad, sx = x - pad;
+    v[sl] = (r < R && sy >= 0 && sy < H && sx >= 0 && sx < W) ? f2bf(in[((int64_t)(b * C + c) * H + sy) * W + sx]) : (u16)0;
   }
+  unsigned w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) w[i] = (unsigned)v[2 * i] | ((unsigned)v[2 * i + 1] << 16);
   *(uint4*)(out + gid * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
@@ -1090,11 +1092,11 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
   return MM_OK;
 }
 
-int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, void* out, hipStream_t s) {
-  MM_CHECK_ARG(C >= 1 && C <= 8 && Hb >= H + pad && Wb >= W + pad, "stem_prep: bad shape");
+int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, hipStream_t s) {
+  MM_CHECK_ARG(C >= 1 && C <= 8 && R >= 1 && R * C <= 8 && Hb >= H + pad && Wb >= W + pad, "stem_prep: bad shape");
   int64_t total = (int64_t)B * Hb * Wb;
   if (total == 0) return MM_OK;
-  hipLaunchKernelGGL(k_stem_prep, dim3((unsigned)mm_cdiv(total, 256)), dim3(256), 0, s, in, B, C, H, W, pad, Hb, Wb, (u16*)out);
+  hipLaunchKernelGGL(k_stem_prep, dim3((unsigned)mm_cdiv(total, 256)), dim3(256), 0, s, in, B, C, H, W, pad, Hb, Wb, R, (u16*)out);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
