@@ -198,9 +198,10 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
 int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);
-/* yout == NULL with relu != 0 (forward without residual): the ReLU mask is recomputed from x and the saved statistics. */
-int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N,
-                int64_t Ns, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
+/* yout == NULL with relu != 0 (forward without residual): the ReLU mask is recomputed from x and the saved statistics.
+ * dy2 != NULL: the incoming gradient is dy + dy2 (a map with two consumers: residual / concat), summed in the kernel. */
+int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y,
+                int relu, int64_t N, int64_t Ns, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
                 int ld_dx, void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                 mm_stream_t stream);
 

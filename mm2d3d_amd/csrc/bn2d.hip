@@ -39,7 +39,8 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
                                                     const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     double* __restrict__ partial, int64_t Ns, int nb0,
-                                                    const float* __restrict__ weight = nullptr, const float* __restrict__ bias = nullptr) {
+                                                    const float* __restrict__ weight = nullptr, const float* __restrict__ bias = nullptr,
+                                                    const u16* __restrict__ dy2 = nullptr, int ld_dy2 = 0) {
   // rows [0, Ns) are statistics group 0 (blocks [0, nb0)), rows [Ns, N) group 1 (the other blocks): the two domains of a
   // jointly batched training step keep their own batch statistics.  Ns == N: one group.
   __shared__ float red[2][T];
@@ -85,6 +86,12 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
       } else {
         float dv[8], yv[8];
         ld8(dy + r * ld_dy + cv * 8, dv);
+        if (dy2) {  // second gradient contribution of this map (residual / concat consumer), summed here instead of by an add kernel
+          float d2[8];
+          ld8(dy2 + r * ld_dy2 + cv * 8, d2);
+#pragma unroll
+          for (int i = 0; i < 8; i++) dv[i] += d2[i];
+        }
         if (relu && !remask) ld8(yout + r * ld_y + cv * 8, yv);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ sums,
                                                        u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr, int64_t Ns,
-                                                       int ab0, const float* __restrict__ bias) {
+                                                       int ab0, const float* __restrict__ bias, const u16* __restrict__ dy2, int ld_dy2) {
   const int CV = C >> 3;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
@@ -278,6 +285,12 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
     float xv[8], dv[8], yv[8], ov[8], gv[8];
     ld8(x + r * ld_x + cv * 8, xv);
     ld8(dy + r * ld_dy + cv * 8, dv);
+    if (dy2) {
+      float d2[8];
+      ld8(dy2 + r * ld_dy2 + cv * 8, d2);
+#pragma unroll
+      for (int i = 0; i < 8; i++) dv[i] += d2[i];
+    }
     if (relu && !remask) ld8(yout + r * ld_y + cv * 8, yv);
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -366,9 +379,11 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
 }
 
 // dx (and dres = relu-masked dy when dres != NULL), dweight, dbias; Ns and the [G][C] statistics as in mm_bn2d_fwd_train.
+// dy2 != NULL: the incoming gradient is dy + dy2 (the map had two consumers; summed here in fp32 instead of by an add kernel).
 // yout == NULL with relu != 0 (only valid when the forward had no residual input): the ReLU mask is recomputed from x,
 // weight, bias and the saved statistics instead of reading the output map.
-int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* yout, int ld_y, int relu, int64_t N, int64_t Ns, int C,
+int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y, int relu,
+                int64_t N, int64_t Ns, int C,
                 const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
                 float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T, "bn2d: C must be a multiple of 8, <= 2048");
@@ -382,12 +397,13 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, true, nb0, nb1);
   hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y,
-                     relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias);
+                     relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias, (const u16*)dy2, ld_dy2);
   hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   if (N > 0) {
     split_blocks(N, Ns, C, false, ab0, ab1);
     hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout,
-                       ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres, ld_dr, Ns, ab0, bias);
+                       ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres, ld_dr, Ns, ab0, bias, (const u16*)dy2,
+                       ld_dy2);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;

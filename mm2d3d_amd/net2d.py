@@ -64,7 +64,7 @@ class BasicBlock(nn.Module):
         identity = x if self.downsample is None else self.downsample(x)
         if self._fused:
             y = self.bn1(self.conv1(x))
-            return self.bn2(self.conv2(y), identity, out=out)
+            return self.bn2(self.conv2(y), identity, out=out, residual_shared=self.downsample is None)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
         return self.relu(out + identity)
@@ -202,8 +202,8 @@ class Net2DSeg(nn.Module):
         r = self.rgb_backbone(img, outs=[b.slot(2) for b in cb])
         d = self.depth_backbone(hints, outs=[b.slot(0) for b in cb])
         for l in range(3):
-            cb[l].put(0, d[l])
-            cb[l].put(2, r[l])
+            cb[l].put(0, d[l], shared=True)  # the backbones keep consuming these maps
+            cb[l].put(2, r[l], shared=True)
         cat = nn2d.cat_channels
 
         def up(stage, x, buf):  # ConvTranspose2d + BatchNorm(+ReLU) writing into the middle slice of the next concat

@@ -54,10 +54,24 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         return _c2d.ConvTranspose2dFn.apply(x, self.weight, self.bias)
 
 
+class GradHandoff:
+    """A map with two consumers (block output -> next conv + next residual add; backbone feature -> next stage + decoder
+    concat) would have its two gradient contributions summed by an autograd add kernel.  Instead the second consumer's
+    backward leaves its contribution here and returns None, and the producing BatchNorm's backward kernels read both
+    (``dy + extra`` in fp32).  The producer node runs after both consumers (graph dependency), so the slot is filled."""
+
+    __slots__ = ("extra",)
+
+    def __init__(self):
+        self.extra = []
+
+
 class _BN2dFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None, out=None):
+    def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None, out=None, handoff=None,
+                res_handoff=None):
         L = _lib.lib()
+        ctx.handoff, ctx.res_handoff = handoff, res_handoff
         x, ldx = _c2d.nhwc_pitch(x)
         B, C, H, W = x.shape
         N = B * H * W
@@ -100,6 +114,13 @@ class _BN2dFn(torch.autograd.Function):
         L = _lib.lib()
         x, y, weight, stats, bias = ctx.saved_tensors
         dy, lddy = _c2d.nhwc_pitch(dy)
+        dy2, lddy2 = None, 0
+        if ctx.handoff is not None and ctx.handoff.extra:
+            extra, ctx.handoff.extra = ctx.handoff.extra, []
+            for e in extra[1:]:  # never more than one in this model; kept general
+                dy = dy + e
+                dy, lddy = _c2d.nhwc_pitch(dy)
+            dy2, lddy2 = _c2d.nhwc_pitch(extra[0])
         ymask = y if (ctx.has_res or not ctx.relu or weight is None) else None  # no residual: mask recomputed from x
         ldx, ldy = ctx.lds
         B, C, H, W = x.shape
@@ -115,14 +136,18 @@ class _BN2dFn(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device)
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
-        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), lddy, ptr(ymask), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight), ptr(bias),
+        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), lddy, ptr(dy2), lddy2, ptr(ymask), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight),
+                            ptr(bias),
                             ptr(stats[0]), ptr(stats[1]),
                             ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
                             stream()), "bn2d_bwd")
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
-        return dx, dres, dw, db, None, None, None, None, None, None, None, None
+        if dres is not None and ctx.res_handoff is not None:  # the residual's producer sums it in its own backward kernels
+            ctx.res_handoff.extra.append(dres)
+            dres = None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -133,13 +158,21 @@ class BatchNorm2d(nn.BatchNorm2d):
         super().__init__(num_features, eps, momentum, affine, track_running_stats)
         self.relu = relu
 
-    def forward(self, x, residual=None, out=None):
+    def forward(self, x, residual=None, out=None, residual_shared=False):
+        """``residual_shared``: the residual map has another consumer (it is the block input, also read by conv1), so its
+        gradient contribution from here is handed to its producer (GradHandoff) instead of being summed by autograd."""
         _need_gpu(x, "BatchNorm2d")
         use_batch = self.training or not self.track_running_stats
         nbt = self.num_batches_tracked if (self.training and self.track_running_stats) else None  # incremented in the kernel
-        return _BN2dFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, use_batch, float(self.eps),
-                             float(self.momentum if self.momentum is not None else 0.1), bool(self.relu), nbt,
-                             [out] if out is not None else None)
+        track = use_batch and torch.is_grad_enabled() and x.requires_grad
+        handoff = GradHandoff() if track else None
+        res_handoff = getattr(residual, "_mm_handoff", None) if (track and residual is not None and residual_shared) else None
+        y = _BN2dFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, use_batch, float(self.eps),
+                          float(self.momentum if self.momentum is not None else 0.1), bool(self.relu), nbt,
+                          [out] if out is not None else None, handoff, res_handoff)
+        if handoff is not None:
+            y._mm_handoff = handoff
+        return y
 
 
 class FusedAway(nn.Module):
@@ -226,7 +259,7 @@ class _CatFilledFn(torch.autograd.Function):
     place through BatchNorm2d(out=)): no copy forward; backward hands out the channel slices of the gradient as views."""
 
     @staticmethod
-    def forward(ctx, holder, *parts):
+    def forward(ctx, holder, handoffs, *parts):
         buf = holder[0]
         off = 0
         for q in parts:
@@ -234,16 +267,21 @@ class _CatFilledFn(torch.autograd.Function):
                 raise ValueError("cat_filled: part is not the expected slice of the buffer")
             off += q.shape[1]
         ctx.cs = [q.shape[1] for q in parts]
+        ctx.handoffs = handoffs
         return buf.detach()
 
     @staticmethod
     def backward(ctx, dy):
         dy = _c2d.as_nhwc_bf16(dy)
         outs, off = [], 0
-        for c in ctx.cs:
-            outs.append(dy[:, off:off + c])
+        for c, h in zip(ctx.cs, ctx.handoffs):
+            g = dy[:, off:off + c]
+            if h is not None:  # the part has another consumer: its producer adds this slice in its backward kernels
+                h.extra.append(g)
+                g = None
+            outs.append(g)
             off += c
-        return (None, *outs)
+        return (None, None, *outs)
 
 
 class CatBuffer:
@@ -253,22 +291,25 @@ class CatBuffer:
         self.buf = torch.empty((B, sum(channels), H, W), dtype=BF16, device=device, memory_format=CL)
         self.channels = list(channels)
         self.parts = [None] * len(channels)
+        self.shared = [False] * len(channels)
 
     def slot(self, i):
         off = sum(self.channels[:i])
         return self.buf[:, off:off + self.channels[i]]
 
-    def put(self, i, t):
-        """Record producer output ``t`` for slot i; copies only if the producer could not write in place."""
+    def put(self, i, t, shared=False):
+        """Record producer output ``t`` for slot i (False if the producer could not write in place: ``cat`` then copies).
+        ``shared``: the map has another consumer besides the concat (its gradient slice is handed to the producer)."""
         v = self.slot(i)
         if t.data_ptr() != v.data_ptr() or t.stride(3) != self.buf.shape[1]:
             return False
-        self.parts[i] = t
+        self.parts[i], self.shared[i] = t, shared
         return True
 
     def cat(self, fallback):
         if all(q is not None for q in self.parts):
-            return _CatFilledFn.apply([self.buf], *self.parts)
+            handoffs = [getattr(q, "_mm_handoff", None) if sh else None for q, sh in zip(self.parts, self.shared)]
+            return _CatFilledFn.apply([self.buf], handoffs, *self.parts)
         return cat_channels(fallback)
 
 
