@@ -801,25 +801,30 @@ __global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
                                                        float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
                                                        int accumulate) {
-  // block = 32 consecutive elements x 8 split slices; slices combined in a fixed order (bit-stable)
-  __shared__ float red[8][32];
-  const int el = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  // block = 32 float4 columns (128 consecutive elements) x 8 split slices; slices combined in a fixed order (bit-stable).
+  // ne is a multiple of 4 (Ck % 64 == 0), so the 16-byte loads never straddle the end.
+  __shared__ float4 red[8][32];
+  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int64_t ne = (int64_t)Cn * ntaps * Ck;
-  const int64_t e = (int64_t)blockIdx.x * 32 + el;
-  float s = 0.f;
+  const int64_t e = ((int64_t)blockIdx.x * 32 + col) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < ne)
-    for (int i = sl; i < nsplit; i += 8) s += partial[(int64_t)i * ne + e];
-  red[sl][el] = s;
+    for (int i = sl; i < nsplit; i += 8) {
+      const float4 v = *(const float4*)(partial + (int64_t)i * ne + e);
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+  red[sl][col] = s;
   __syncthreads();
   if (sl == 0 && e < ne) {
-    float t = 0.f;
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; i++) t += red[i][el];
-    int k = (int)(e % Ck);
-    int64_t r = e / Ck;
-    int tp = (int)(r % ntaps), n = (int)(r / ntaps);
+    for (int i = 0; i < 8; i++) t[0] += red[i][col].x, t[1] += red[i][col].y, t[2] += red[i][col].z, t[3] += red[i][col].w;
+    const int k = (int)(e % Ck);  // the 4 elements share n and tap (Ck % 4 == 0)
+    const int64_t r = e / Ck;
+    const int tp = (int)(r % ntaps), n = (int)(r / ntaps);
     float* d = dW + n * sn + tp * st + k * sk;
-    *d = accumulate ? *d + t : t;
+#pragma unroll
+    for (int j = 0; j < 4; j++) d[j * sk] = accumulate ? d[j * sk] + t[j] : t[j];
   }
 }
 
@@ -1064,7 +1069,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
       once = true;
     }
     hipLaunchKernelGGL(k_wgrad3x3, dim3(nsplit3, ntile, 3), dim3(256), lds, s, q);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * 9 * Ck, 32)), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * 9 * Ck, 128)), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
                        dW, sn, st, sk, accumulate);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -1086,7 +1091,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
       hipLaunchKernelGGL(k_conv_wgrad2<64>, dim3(nsplit, (Cn / 64) * nkt, ntaps), dim3(256), lds, s, p);
     }
   }
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 32)), dim3(256), 0, s, p.partial,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 128)), dim3(256), 0, s, p.partial,
                      M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;
