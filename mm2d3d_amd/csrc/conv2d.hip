@@ -88,35 +88,67 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   const int kcn = p.Ca >> 6;
   const int nsteps = p.ntaps * kcn;
 
+  // Lane-constant parts of the staging addresses, computed once (the per-step instruction stream between the barrier
+  // and the MFMAs is what bounds these short-K kernels): for fr == 1 the source pixel of (row, tap) is
+  // (ay*sa + ty, ax*sa + tx), i.e. a per-row base pointer plus a uniform tap offset, and its validity is one bit of a
+  // per-row tap mask.
+  const u16* abase[4];
+  unsigned amask[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = r0 + 32 * i;
+    abase[i] = p.A + ((int64_t)((ab[i] < 0 ? 0 : ab[i]) * p.Hi + ay[i] * p.sa) * p.Wi + ax[i] * p.sa) * p.lda + ((cc ^ ((row >> 1) & 7)) << 3);
+    unsigned mk = 0;
+    if (ab[i] >= 0 && p.fr == 1)
+      for (int t = 0; t < p.ntaps; t++) {
+        const int sy = ay[i] * p.sa + p.ty[t], sx = ax[i] * p.sa + p.tx[t];
+        if (sy >= 0 && sx >= 0 && sy < p.Hi && sx < p.Wi) mk |= 1u << t;
+      }
+    amask[i] = mk;
+  }
+  const u16* wbase[NBI];
+#pragma unroll
+  for (int i = 0; i < NBI; i++) {
+    const int row = r0 + 32 * i;
+    wbase[i] = n0 + row < p.Cn ? Wz + (int64_t)(n0 + row) * p.ntaps * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3) : nullptr;
+  }
+
   // Stage tile s into LDS buffer `buf` with LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.
   // One wave-instruction writes 1 KiB = 8 consecutive 128-B rows linearly, so the bank swizzle is applied to the
   // SOURCE chunk (lane (row, pc) fetches chunk pc ^ ((row>>1)&7)) and again on the fragment reads below.
   auto issue = [&](int s, int buf) {
     const int tap = s / kcn, kc = s - tap * kcn;
     const int ty = p.ty[tap], tx = p.tx[tap];
+    if (p.fr == 1) {
+      const int64_t toff = ((int64_t)ty * p.Wi + tx) * p.lda + kc * 64;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int row = r0 + 32 * i;
-      int sy = ay[i] * p.sa + ty, sx = ax[i] * p.sa + tx;
-      bool ok = ab[i] >= 0 && sy >= 0 && sx >= 0;
-      if (p.fr == 2) {
+      for (int i = 0; i < 4; i++) {
+        const u16* g = (amask[i] >> tap) & 1u ? abase[i] + toff : (const u16*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(As + buf * 128 * 64 + (wave * 8 + 32 * i) * 64), 16,
+                                         0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int row = r0 + 32 * i;
+        int sy = ay[i] * p.sa + ty, sx = ax[i] * p.sa + tx;
+        bool ok = ab[i] >= 0 && sy >= 0 && sx >= 0;
         ok = ok && !((sy | sx) & 1);
         sy >>= 1;
         sx >>= 1;
+        ok = ok && sy < p.Hi && sx < p.Wi;
+        const u16* g = ok ? p.A + ((int64_t)(ab[i] * p.Hi + sy) * p.Wi + sx) * p.lda + kc * 64 + ((cc ^ ((row >> 1) & 7)) << 3)
+                          : (const u16*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(As + buf * 128 * 64 + (wave * 8 + 32 * i) * 64), 16,
+                                         0, 0);
       }
-      ok = ok && sy < p.Hi && sx < p.Wi;
-      const u16* g = ok ? p.A + ((int64_t)(ab[i] * p.Hi + sy) * p.Wi + sx) * p.lda + kc * 64 + ((cc ^ ((row >> 1) & 7)) << 3)
-                        : (const u16*)g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(As + buf * 128 * 64 + (wave * 8 + 32 * i) * 64), 16, 0,
-                                       0);
     }
+    const int woff = tap * p.Ca + kc * 64;
 #pragma unroll
     for (int i = 0; i < NBI; i++) {
-      const int row = r0 + 32 * i;
-      const int n = n0 + row;
-      const u16* g = n < p.Cn ? Wz + ((int64_t)n * p.ntaps + tap) * p.Ca + kc * 64 + ((cc ^ ((row >> 1) & 7)) << 3)
-                              : (const u16*)g_zero16;
+      const u16* g = wbase[i] ? wbase[i] + woff : (const u16*)g_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(Bs + buf * BN * 64 + (wave * 8 + 32 * i) * 64), 16, 0,
                                        0);
