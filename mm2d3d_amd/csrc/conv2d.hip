@@ -738,11 +738,12 @@ struct Wg3P {
 
 __global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
   // blockIdx.z = filter row kh: the workgroup accumulates the three taps (kh, 0..2) -> 48 accumulator registers and
-  // 34 KB of LDS (dY patch 16 KB + the 8 halo rows this kh needs, 18 KB), i.e. 4 workgroups per CU to hide the DMA latency.
-  extern __shared__ __attribute__((aligned(16))) u16 smem[];
-  constexpr int HROW = 8 * 18;              // halo pixels used by one filter row
-  u16* Ys = smem;                           // [128*64]  pixel-major dY patch
-  u16* Hs = smem + 128 * 64;                // [144*64]  pixel-major X halo rows kh .. kh+7
+  // 36 KB of LDS (dY patch 16 KB + the 8 halo rows this kh needs, 20 KB), i.e. 4 workgroups per CU to hide the DMA latency.
+  // Everything lane-constant (DMA source offsets, the transpose-read addresses of the dY rows and of the three taps) is
+  // computed once; the patch row only enters through immediate offsets (dY rows advance by 16 pixels, halo rows by 18:
+  // the swizzle bit of a halo row flips with the row parity, which is one XOR of 64 bytes).
+  extern __shared__ __attribute__((aligned(16))) char smw[];
+  constexpr int YB = 128 * 128;  // bytes of a dY patch [128 px][64 n]; the halo rows follow
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 1, wk = wave & 1;
   const int nkt = p.Ck >> 6;
@@ -759,61 +760,91 @@ __global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
   const int cc = tid & 7, r0 = tid >> 3;
   auto fsw = [](int row) { return ((row >> 1) & 1) << 2; };  // 128-B rows: conflict-free transpose reads (see k_conv_wgrad2)
 
-  auto issue = [&](int patch) {
+  // DMA sources: patch origin (uniform) + lane-constant offsets; bounds are checked per lane only on edge patches
+  int yoff[4], yyx[4], xoff[5], xyx[5];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int row = r0 + 32 * i;
+    yyx[i] = ((row >> 4) << 16) | (row & 15);
+    yoff[i] = ((row >> 4) * p.W + (row & 15)) * p.ldy + n0 + ((cc ^ fsw(row)) << 3);
+  }
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const int row = r0 + 32 * i, hy = row / 18, hx = row - hy * 18;
+    const bool used = row < 144;
+    xyx[i] = used ? ((hy + kh - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
+    xoff[i] = (used ? ((hy + kh - 1) * p.W + (hx - 1)) * p.ldx : 0) + k0 + ((cc ^ fsw(row)) << 3);
+  }
+  auto issue = [&](int patch) {  // 9 DMA instructions
     int t = patch;
     const int tx0 = (t % p.tiles_x) * 16;
     t /= p.tiles_x;
     const int ty0 = (t % p.tiles_y) * 8;
     const int b = t / p.tiles_y;
+    const int64_t origin = (int64_t)(b * p.H + ty0) * p.W + tx0;
+    const u16* yb = p.DY + origin * p.ldy;
+    const u16* xb = p.X + origin * p.ldx;
+    char* dst = smw + wave * 1024;
+    const bool interior = ty0 + kh >= 1 && ty0 + kh + 7 <= p.H && ty0 + 8 <= p.H && tx0 >= 1 && tx0 + 17 <= p.W;
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {  // dY patch: row = patch pixel py*16+px
-      const int row = r0 + 32 * i;
-      const int y = ty0 + (row >> 4), x = tx0 + (row & 15);
-      const u16* g = (y < p.H && x < p.W) ? p.DY + ((int64_t)(b * p.H + y) * p.W + x) * p.ldy + n0 + ((cc ^ fsw(row)) << 3)
-                                           : (const u16*)g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(Ys + (wave * 8 + 32 * i) * 64), 16, 0, 0);
-    }
+      for (int i = 0; i < 4; i++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(yb + yoff[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 5; i++) {  // X halo rows: row = hy*18 + hx, hy = 0..7 <-> image row ty0 + hy + kh - 1
-      const int row = r0 + 32 * i;
-      if (row < HROW) {
-        const int hy = row / 18, hx = row - hy * 18;
-        const int y = ty0 + hy + kh - 1, x = tx0 + hx - 1;
-        const u16* g = (const u16*)g_zero16;
-        if (y >= 0 && y < p.H && x >= 0 && x < p.W)
-          g = p.X + ((int64_t)(b * p.H + y) * p.W + x) * p.ldx + k0 + ((cc ^ fsw(row)) << 3);
+      for (int i = 0; i < 5; i++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
+                                         (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int y = ty0 + (yyx[i] >> 16), x = tx0 + (yyx[i] & 0xFFFF);
+        const u16* g = (y < p.H && x < p.W) ? yb + yoff[i] : (const u16*)g_zero16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(Hs + (wave * 8 + 32 * i) * 64), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        const int y = ty0 + (xyx[i] >> 16), x = tx0 + (short)(xyx[i] & 0xFFFF);
+        const u16* g = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? xb + xoff[i] : (const u16*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
       }
     }
   };
 
+  // transpose-read addresses (bytes, patch row 0): lane (g, q, pp)
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int c0 = 8 * (g >> 1) + q;
+  const int cA = (wn * 32 + 16 * (g & 1)) >> 3, cB = (wk * 32 + 16 * (g & 1)) >> 3;
+  const int a0 = (c0 * 64 + (((cA + (pp >> 1)) ^ fsw(c0)) << 3) + 4 * (pp & 1)) * 2;
+  const int a1 = ((c0 + 4) * 64 + (((cA + (pp >> 1)) ^ fsw(c0 + 4)) << 3) + 4 * (pp & 1)) * 2;
+  int b0[3], b1[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; kw++) {
+    const int hr = kw + c0;
+    b0[kw] = YB + (hr * 64 + (((cB + (pp >> 1)) ^ fsw(hr)) << 3) + 4 * (pp & 1)) * 2;
+    b1[kw] = YB + ((hr + 4) * 64 + (((cB + (pp >> 1)) ^ fsw(hr + 4)) << 3) + 4 * (pp & 1)) * 2;
+  }
   typedef short s16x8 __attribute__((ext_vector_type(8)));
+  auto rd = [&](int byte_off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smw + byte_off));
+  };
+
   for (int patch = pb; patch < pe; patch++) {
     __syncthreads();  // everyone finished reading the previous patch
     issue(patch);
     __syncthreads();  // vmcnt(0) + barrier: patch landed
-#pragma unroll 2
+#pragma unroll
     for (int py = 0; py < 8; py++) {  // one patch row = 16 pixels = one MFMA K step
-      const int prow = py * 16 + 8 * (g >> 1) + q;
-      const int cA = (wn * 32 + 16 * (g & 1)) >> 3;
-      const int a0o = prow * 64 + (((cA + (pp >> 1)) ^ fsw(prow)) << 3) + 4 * (pp & 1);
-      const int a1o = (prow + 4) * 64 + (((cA + (pp >> 1)) ^ fsw(prow + 4)) << 3) + 4 * (pp & 1);
-      s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[a0o]);
-      s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Ys[a1o]);
-      s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const s16x4 x0 = rd(a0 + py * 16 * 128), x1 = rd(a1 + py * 16 * 128);
+      const s16x8 av = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       const bf16x8 af = __builtin_bit_cast(bf16x8, av);
-      const int cB = (wk * 32 + 16 * (g & 1)) >> 3;
+      const int flip = (py & 1) << 6;  // halo rows advance by 18 pixels: their swizzle bit alternates with the row parity
 #pragma unroll
       for (int kw = 0; kw < 3; kw++) {
-        const int hrow = py * 18 + kw + 8 * (g >> 1) + q;  // halo rows of the 16 pixels of patch row py at tap (kh,kw)
-        const int b0o = hrow * 64 + (((cB + (pp >> 1)) ^ fsw(hrow)) << 3) + 4 * (pp & 1);
-        const int b1o = (hrow + 4) * 64 + (((cB + (pp >> 1)) ^ fsw(hrow + 4)) << 3) + 4 * (pp & 1);
-        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hs[b0o]);
-        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Hs[b1o]);
-        s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const s16x4 y0 = rd((b0[kw] ^ flip) + py * 18 * 128), y1 = rd((b1[kw] ^ flip) + py * 18 * 128);
+        const s16x8 bv = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
         acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[kw], 0, 0, 0);
       }
     }
