@@ -105,6 +105,32 @@ def conv_roofline(tm, batch, dev):
     }
 
 
+def branch_rates(tm, batch, dev, iters=5):
+    """SURVEY.md section 8d "also reported": each branch alone, fwd+bwd with the CE loss on the B source scenes (no optimiser
+    step), scenes/s from HIP events."""
+    src = batch["source"]
+    B = src["img"].shape[0]
+    out = {}
+    for name in tm.modules_name:
+        def one():
+            for o in tm.optimizers:
+                o.zero_grad()
+            b = fresh({"source": src})["source"]
+            preds = tm(b, model_name=name)[0]
+            tm.loss("segmentation", pred=preds["seg_logit"], gt=b["seg_label"]).backward()
+        one()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        out[name] = {"scenes_per_s": round(B / (ms * 1e-3), 1), "ms": round(ms, 3), "scenes": B}
+    return out
+
+
 def cpu_baseline():
     """The CPU oracle (a port, not the reference) on 1 source + 1 target scene of the same workload, fwd+bwd."""
     from mm2d3d_amd.net2d import Net2DSeg
@@ -187,11 +213,15 @@ def main():
     for _ in range(a.warmup):
         tm.fit_step(fresh(batch))
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = tm.fit_step(fresh(batch))
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -205,13 +235,15 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: NuScenes-shaped (32x1090 sweep, 34,880 pts/scene), 5 cm voxels, 480x302 RGB + "
                                "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "
                                "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
-                   "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss.detach())},
+                   "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
+                   "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)]},
     }
     if a.workload != "c2":
         out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c2":
         print(f"[bench] timed region done: {ms:.2f} ms/step; roofline leg ...", file=sys.stderr, flush=True)
         out["roofline"] = conv_roofline(tm, batch, dev)
+        out["config"]["branch_only_fwd_bwd"] = branch_rates(tm, batch, dev)
         print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
