@@ -236,7 +236,8 @@ def main():
                                "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "
                                "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
                    "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
-                   "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)]},
+                   "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)],
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
     }
     if a.workload != "c2":
         out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
