@@ -429,7 +429,11 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
     const int row = r0 + 64 * i, hy = row / HC, hx = row - hy * HC;
     const bool used = row < HROWS;
     hyx[i] = used ? ((hy - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;  // (dy, dx) relative to the tile origin; unused rows: origin
-    hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ ((row >> 1) & 7)) << 3);
+    // bank swizzle of the halo rows by the halo COLUMN: chunk ^= (hx >> 1) & 7.  A 32-pixel MFMA fragment spans two image
+    // rows when TW = 16, and the ds_read_b128 lane groups mix pixels 0-3,12-15 of one row with 4-11 of the next: a swizzle
+    // by the linear row index collides there (PMC: 0.33-0.40 conflict cycles per LDS cycle), one by hx cannot (HC is even,
+    // so the row parity that selects the bank half is the parity of hx and the 16 lanes see 16 distinct hx mod 16).
+    hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ ((hx >> 1) & 7)) << 3);
   }
   int wl[NB];  // W DMA: source = Wp + wu (uniform, per step) + wl[i]
 #pragma unroll
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
     for (int t = 0; t < 9; t++) {
       const int kh = t / 3, kw = t % 3;
       const int row = ppy[i] * HC + ppx[i] + (p.flip ? (2 - kh) * HC + (2 - kw) : kh * HC + kw);
-      aoff[i][t] = HS0 + row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+      aoff[i][t] = HS0 + row * 128 + ((fh ^ (((row % HC) >> 1) & 7)) << 4);
     }
   }
   int boff[TN];        // LDS byte offset of cout fragment j, kk = 0, inside a W buffer
