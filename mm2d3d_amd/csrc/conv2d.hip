@@ -590,6 +590,151 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
   wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
 }
 
+// 64 -> 64 channel layers (layer1 of both backbones, 24 calls per step): the whole 3x3x64x64 weight tensor is 72 KB of
+// bf16 - it stays RESIDENT in LDS for the life of the persistent workgroup, next to a halo ring of 2.  No per-tap
+// weight DMA, no per-tap barrier: one barrier per 256-pixel item (72 MFMAs per wave between barriers).  Same item
+// schedule, fragment layouts, halo swizzle and epilogue as k_conv3x3w<64, TW>.
+template <int TW>
+__global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
+  extern __shared__ __attribute__((aligned(16))) char smemc[];
+  constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
+  constexpr int HSZB = ((HROWS + 7) / 8) * 8 * 128;  // bytes per halo buffer, whole 1-KiB DMA pieces
+  constexpr int NPIECE = (HROWS + 63) / 64;          // DMA rounds of 64 rows; the last one is partial (fewer waves issue it)
+  constexpr int BSZB = 64 * 128;                     // bytes of one tap's W tile [64 cout][64 cin]
+  constexpr int NST = 8;                             // store instructions per wave and item
+  constexpr int HS0 = 9 * BSZB;
+  char* const lds = smemc;
+  float* biasl = (float*)(lds + HS0 + 2 * HSZB);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;  // 4 (pixels) x 2 (couts)
+  const int cc = tid & 7, r0 = tid >> 3;
+  // resident weights: tap t, cout row r0, 16-B chunk cc (swizzled) -> LDS [t][row][chunk]
+#pragma unroll
+  for (int t = 0; t < 9; t++)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(p.Wp + ((int64_t)r0 * 9 + t) * 64 + ((cc ^ ((r0 >> 1) & 7)) << 3)),
+        (__attribute__((address_space(3))) void*)(lds + t * BSZB + wave * 1024), 16, 0, 0);
+  if (p.bias && tid < 64)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + tid),
+                                     (__attribute__((address_space(3))) void*)(biasl), 4, 0, 0);
+  const int nitems = p.B * p.tiles_y * p.tiles_x;
+  const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int it_begin = xcd * per + local;
+  const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
+  if (it_begin >= it_end) {
+    wait_vm<0>();
+    return;
+  }
+  auto decode = [&](int item, int& b, int& ty0, int& tx0) {
+    int t = item;
+    tx0 = (t % p.tiles_x) * TW;
+    t /= p.tiles_x;
+    ty0 = (t % p.tiles_y) * TH;
+    b = t / p.tiles_y;
+  };
+  int hl[NPIECE], hyx[NPIECE];
+#pragma unroll
+  for (int i = 0; i < NPIECE; i++) {
+    const int row = r0 + 64 * i, hy = row / HC, hx = row - hy * HC;
+    const bool used = row < HROWS;
+    hyx[i] = used ? ((hy - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
+    hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ ((hx >> 1) & 7)) << 3);
+  }
+  const bool last_piece = (NPIECE - 1) * 64 + wave * 8 < ((HROWS + 7) / 8) * 8;  // wave-uniform: this wave's rows of the partial round exist
+  const int fr_ = lane & 31, fh = lane >> 5;
+  int ppy[2], ppx[2], aoff[2][9];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int pix = 64 * wm + 32 * i + fr_;
+    ppy[i] = pix / TW, ppx[i] = pix % TW;
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      const int kh = t / 3, kw = t % 3;
+      const int row = ppy[i] * HC + ppx[i] + (p.flip ? (2 - kh) * HC + (2 - kw) : kh * HC + kw);
+      aoff[i][t] = HS0 + row * 128 + ((fh ^ (((row % HC) >> 1) & 7)) << 4);
+    }
+  }
+  const int brow = wn * 32 + fr_;
+  const int boff = brow * 128 + ((fh ^ ((brow >> 1) & 7)) << 4);
+
+  int h_item = it_begin;
+  auto issue_halo = [&](int buf) {
+    const bool live = h_item < it_end;
+    int b = 0, ty0 = 0, tx0 = 0;
+    if (live) decode(h_item, b, ty0, tx0);
+    const bool interior = live && ty0 >= 1 && ty0 + TH < p.H && tx0 >= 1 && tx0 + TW < p.W;
+    const u16* base = p.A + ((int64_t)(b * p.H + ty0) * p.W + tx0) * p.lda;
+    char* dst = lds + HS0 + buf * HSZB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NPIECE; i++) {
+      if (i == NPIECE - 1 && !last_piece) break;
+      const u16* g = base + hl[i];
+      if (!interior) {
+        const int y = ty0 + (hyx[i] >> 16), x = tx0 + (short)(hyx[i] & 0xFFFF);
+        if (!(live && y >= 0 && y < p.H && x >= 0 && x < p.W)) g = (const u16*)g_zero16;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+    }
+    h_item += G8;
+  };
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+
+  issue_halo(0);
+  bool st = false;
+  int seg = 0;
+  for (int item = it_begin; item < it_end; item += G8, seg++) {
+    // this item's halo (and, the first time, the weights) must have landed; younger in the queue: the previous item's stores
+    if (st) wait_vm<NST>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // ... for every wave, and everyone left the other halo buffer
+    issue_halo((seg + 1) & 1);
+    const int hb = (seg & 1) * HSZB;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[i] = *(const bf16x8*)(lds + ((aoff[i][tap] + hb) ^ (kk << 5)));
+        const bf16x8 bf = *(const bf16x8*)(lds + ((boff ^ (kk << 5)) + tap * BSZB));
+#pragma unroll
+        for (int i = 0; i < 2; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[i], acc[i], 0, 0, 0);  // D[cout][pixel]
+      }
+    }
+    int b, ty0, tx0;
+    decode(item, b, ty0, tx0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int y = ty0 + ppy[i], x = tx0 + ppx[i];
+      const bool inside = y < p.H && x < p.W;
+      u16* orow = p.O + ((int64_t)(b * p.H + y) * p.W + x) * p.ldo + wn * 32 + 4 * fh;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          v[e] = acc[i][4 * q + e];
+          if (p.bias) v[e] += biasl[wn * 32 + 8 * q + 4 * fh + e];
+          acc[i][4 * q + e] = 0.f;
+        }
+        uint2 o;
+        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        *(uint2*)(inside ? orow + 8 * q : (u16*)g_dump + lane * 4) = o;
+      }
+    }
+    st = true;
+  }
+  wait_vm<0>();  // the dummy halo of the tail is still in flight: drain before the LDS is released
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgP {
   const u16* X;   // [B,Hi,Wi,Ck]
@@ -1061,7 +1206,18 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       once_w = true;
     }
-    if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+    if (Ca == 64 && Cn == 64) {  // weights resident in LDS
+      const int hrows = tw == 16 ? 18 * 18 : 10 * 34;
+      const size_t ldsr = (size_t)9 * 64 * 128 + 2 * (size_t)((hrows + 7) / 8) * 8 * 128 + 256;
+      static bool once_r = false;
+      if (!once_r) {
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        once_r = true;
+      }
+      if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
+      else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
+    } else if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
     else if (bn == 64) hipLaunchKernelGGL((k_conv3x3w<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
     else if (tw == 16) hipLaunchKernelGGL((k_conv3x3w<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
     else hipLaunchKernelGGL((k_conv3x3w<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
