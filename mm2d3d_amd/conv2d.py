@@ -1,7 +1,8 @@
 """Autograd functions for the dense 2D convolutions on the bf16 MFMA implicit-GEMM kernels (csrc/conv2d.hip).
 
 Tensors keep torch's logical NCHW shape with ``channels_last`` strides (= NHWC in memory) and dtype bfloat16;
-weights stay fp32 masters in torch's layout and are packed to the kernel layouts every call (k_pack_weights).
+weights stay fp32 masters in torch's layout; their bf16 kernel-layout copies are cached per optimiser step and refreshed
+by one batched launch (``_PackRegistry``).  A map may be a channel slice of a wider NHWC buffer (``nhwc_pitch``).
 """
 from __future__ import annotations
 

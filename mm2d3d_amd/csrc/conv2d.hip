@@ -6,7 +6,7 @@
 //   G1  k_conv_gemm  out[m][n] = sum_{tap,k} A[src(m,tap)][k] * Wp[n][tap][k]
 //       one kernel for Conv2d forward, Conv2d data-gradient (stride 1 and 2), ConvTranspose2d forward (per output
 //       parity, blockIdx.z) and its data-gradient: they differ only in the pixel maps and in the packed weight
-//       layout Wp (produced by k_pack_weights from the fp32 master weights every step).
+//       layout Wp (produced by k_pack_weights / k_pack_weights_batch from the fp32 master weights once per optimiser step).
 //       128 x BN x 64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16_bf16, double-buffered LDS with register prefetch
 //       (global loads of tile s+1 are in flight while tile s is multiplied), XOR-swizzled 128-B LDS rows so the
 //       ds_read_b128 fragment reads are bank-conflict free.

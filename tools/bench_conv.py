@@ -1,4 +1,7 @@
-"""Per-shape timing of the 2D convolution kernels (forward, data gradient, weight gradient) at the bench's layer shapes."""
+"""Per-shape timing of the 2D convolution kernels (forward, data gradient, weight gradient) at the bench's layer shapes.
+
+CAUTION: host-loop event timing of back-to-back identical launches; it over-stated the non-persistent 3x3 kernel by 1.5x
+against its in-situ duration (rocprofv3 trace of bench.py).  Use the kernel trace of a real step for decisions."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
