@@ -1,0 +1,107 @@
+"""BASELINE.json's full sizes (configs[1]: 8+8 NuScenes-shaped scenes, configs[3]: 4+4 KITTI-shaped scans of 121,600 points),
+where the oracle would take minutes: size-independent properties of the voxel hash / rulebooks and of the sparse
+convolution engines, checked on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    import mm2d3d_amd  # noqa: F401
+
+    return torch.device("cuda:0")
+
+
+def _metadata(shape, scenes, split=None):
+    from mm2d3d_amd import domains
+    from mm2d3d_amd.scn.metadata import Metadata
+    from mm2d3d_amd.synthetic import make_batch
+
+    dev = _dev()
+    batch = make_batch(7, scenes, shape, img_hw=(32, 48), device=dev, augment=True)
+    coords = batch["x"][0].contiguous()
+    md = Metadata(dev, 4096, 7)
+    with domains.split(split):
+        md.build_levels(coords)
+        md.build_rulebooks()
+    return md, coords
+
+
+def _keys(c):
+    c = c.long()
+    return ((c[:, 3] * 4096 + c[:, 0]) * 4096 + c[:, 1]) * 4096 + c[:, 2]
+
+
+@pytest.mark.parametrize("shape,scenes", [("nuscenes", 16), ("kitti", 8)])
+def test_metadata_invariants_at_full_size(shape, scenes):
+    md, coords = _metadata(shape, scenes, split=scenes // 2)
+    lv0 = md.levels[0]
+    # (1) active sites = distinct voxels; every point maps to the site that holds its voxel
+    assert lv0.n == torch.unique(_keys(coords)).numel()
+    assert torch.equal(lv0.coords.long()[lv0.item2vox.long()], coords.long())
+    # first-occurrence order: the point index of a site's first item increases with the site id
+    first_item = lv0.csr_items[lv0.csr_off[:-1].long()].long()
+    assert bool((first_item[1:] > first_item[:-1]).all())
+    fine = lv0
+    for l, lv in enumerate(md.levels):
+        c = lv.coords.long()
+        assert lv.n == torch.unique(_keys(c)).numel(), l                      # ids are a bijection onto the voxels
+        assert bool((c[1:, 3] >= c[:-1, 3]).all()), l                         # rows batch-sorted (joint BN groups rely on it)
+        assert lv.seg_rows == int((c[:, 3] < scenes // 2).sum()), l           # statistics-group boundary
+        rb = lv.subm
+        off = rb.offsets_host.astype(np.int64)
+        R = int(off[27])
+        rin, rout = rb.rin[:R].long(), rb.rout[:R].long()
+        # (2) submanifold rulebook: centre bucket is the identity on all sites; buckets k and 26-k are mirror images
+        assert off[14] - off[13] == lv.n and torch.equal(rin[off[13]:off[14]], rout[off[13]:off[14]])
+        assert torch.equal(rout[off[13]:off[14]], torch.arange(lv.n, device=c.device))
+        for k in range(13):
+            assert off[k + 1] - off[k] == off[27 - k] - off[26 - k], (l, k)
+        k = 4
+        a = torch.stack([rin[off[k]:off[k + 1]], rout[off[k]:off[k + 1]]], 1)
+        b = torch.stack([rout[off[26 - k]:off[27 - k]], rin[off[26 - k]:off[27 - k]]], 1)
+        assert torch.equal(a[a[:, 1].argsort()], b[b[:, 1].argsort()]), l      # (k,i,o) <-> (26-k,o,i)
+        # every rule joins two sites whose coordinates differ by the bucket's offset, same batch item
+        kk = torch.repeat_interleave(torch.arange(27, device=c.device), torch.as_tensor(np.diff(off), device=c.device))
+        d = c[rin] - c[rout]
+        assert torch.equal(d[:, 0], kk // 9 - 1) and torch.equal(d[:, 1], (kk // 3) % 3 - 1) and torch.equal(d[:, 2], kk % 3 - 1)
+        assert bool((d[:, 3] == 0).all())
+        assert bool((rout[1:] >= rout[:-1]).logical_or(kk[1:] != kk[:-1]).all())  # buckets sorted by destination
+        if lv.coarse is not None:
+            cz = lv.coarse.coords.long()
+            rb8 = lv.down
+            off8 = rb8.offsets_host.astype(np.int64)
+            assert int(off8[8]) == lv.n                                        # each fine site has exactly one parent rule
+            r8i, r8o = rb8.rin[:lv.n].long(), rb8.rout[:lv.n].long()
+            assert torch.unique(r8i).numel() == lv.n
+            assert torch.equal(c[r8i][:, :3] >> 1, cz[r8o][:, :3]) and torch.equal(c[r8i][:, 3], cz[r8o][:, 3])
+            k8 = torch.repeat_interleave(torch.arange(8, device=c.device), torch.as_tensor(np.diff(off8), device=c.device))
+            par = c[r8i][:, :3] & 1
+            assert torch.equal(k8, (par[:, 0] * 2 + par[:, 1]) * 2 + par[:, 2])
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (64, 32), (96, 96)])
+def test_sparse_conv_linearity_and_adjoint_at_full_size(cin, cout):
+    """conv(a x + b y) = a conv(x) + b conv(y), and <conv(x), g> = <x, conv^T(g)> (forward vs data gradient) on the
+    level-0 rulebook of 16 NuScenes-shaped scenes: exact-fp32 engines below 64 input channels, split-bf16 above."""
+    from mm2d3d_amd import scn
+    from mm2d3d_amd.scn import SparseConvNetTensor
+
+    dev = _dev()
+    md, _ = _metadata("nuscenes", 16)
+    lv = md.levels[1 if cin > 32 else 0]
+    conv = scn.SubmanifoldConvolution(3, cin, cout, 3, False).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout)
+    x = torch.randn(lv.n, cin, generator=g).to(dev).requires_grad_(True)
+    y = torch.randn(lv.n, cin, generator=g).to(dev)
+    wrap = lambda f: SparseConvNetTensor(f, md, lv.spatial_size, lv)
+    fx, fy = conv(wrap(x)).features, conv(wrap(y)).features
+    fz = conv(wrap(2.0 * x.detach() - 0.5 * y)).features
+    ref = 2.0 * fx.detach() - 0.5 * fy
+    assert float((fz.detach() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    gout = torch.randn(lv.n, cout, generator=g).to(dev)
+    (gx,) = torch.autograd.grad(fx, x, gout)
+    lhs, rhs = float((fx.detach().double() * gout.double()).sum()), float((x.detach().double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + float(fx.detach().double().norm() * gout.double().norm()) * 1e-2), (lhs, rhs)
