@@ -105,3 +105,28 @@ def test_sparse_conv_linearity_and_adjoint_at_full_size(cin, cout):
     (gx,) = torch.autograd.grad(fx, x, gout)
     lhs, rhs = float((fx.detach().double() * gout.double()).sum()), float((x.detach().double() * gx.double()).sum())
     assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + float(fx.detach().double().norm() * gout.double().norm()) * 1e-2), (lhs, rhs)
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 152, 240), (128, 128, 76, 120), (256, 256, 38, 60), (512, 512, 19, 30), (192, 64, 152, 240)])
+def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W):
+    """The persistent 3x3 kernels at the joint-pass shapes of the bench (B = 16): forward and data gradient against torch's
+    fp32 convolution on the same bf16-rounded operands (tolerance = bf16 output rounding), weight gradient likewise."""
+    import torch.nn.functional as F
+
+    from mm2d3d_amd.conv2d import Conv2dFn
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + H)
+    B = 16
+    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev).requires_grad_(True)
+    y = Conv2dFn.apply(x, w, None, 1, 1)
+    gy = torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    gx, gw = torch.autograd.grad(y, [x, w], gy)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().bfloat16().float().requires_grad_(True)  # the kernels multiply the bf16-rounded weights
+    yr = F.conv2d(xr, wr, None, 1, 1)
+    gxr, gwr = torch.autograd.grad(yr, [xr, wr], gy.float())
+    rel = lambda a, b: float((a.detach().float() - b.detach()).norm() / b.detach().norm())
+    assert rel(y, yr) < 4e-3 and rel(gx, gxr) < 4e-3 and rel(gw, gwr) < 4e-3, (rel(y, yr), rel(gx, gxr), rel(gw, gwr))
+    assert float((y.detach().float() - yr.detach()).abs().max()) <= 2e-2 * float(yr.detach().abs().max())
