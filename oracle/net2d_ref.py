@@ -14,6 +14,15 @@ import torch.nn.functional as F
 
 LAYERS = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
 
+# ``emulate_bf16``: round to bfloat16 exactly where the HIP branch stores bfloat16 (input images, convolution weights,
+# every convolution output, every BatchNorm(+add+ReLU) output) while all arithmetic stays fp32.  Against this oracle the
+# HIP 2D net differs only by accumulation order (and the 1-ulp bf16 flips that order causes), not by the storage format.
+_EMULATE = [False]
+
+
+def _q(t):
+    return t.bfloat16().float() if _EMULATE[0] else t
+
 
 def _bn(sd, pre, x, training, stats_out=None):
     """nn.BatchNorm2d: eps 1e-5, momentum 0.1.  In training the updated running stats go to ``stats_out[pre]``."""
@@ -29,16 +38,16 @@ def _bn(sd, pre, x, training, stats_out=None):
 
 def _block(sd, pre, x, stride, has_down, training, so):
     idt = x
-    out = F.relu(_bn(sd, pre + ".bn1", F.conv2d(x, sd[pre + ".conv1.weight"], None, stride, 1), training, so))
-    out = _bn(sd, pre + ".bn2", F.conv2d(out, sd[pre + ".conv2.weight"], None, 1, 1), training, so)
+    out = _q(F.relu(_bn(sd, pre + ".bn1", _q(F.conv2d(x, _q(sd[pre + ".conv1.weight"]), None, stride, 1)), training, so)))
+    out = _bn(sd, pre + ".bn2", _q(F.conv2d(out, _q(sd[pre + ".conv2.weight"]), None, 1, 1)), training, so)
     if has_down:
-        idt = _bn(sd, pre + ".downsample.1", F.conv2d(x, sd[pre + ".downsample.0.weight"], None, stride, 0), training, so)
-    return F.relu(out + idt)
+        idt = _q(_bn(sd, pre + ".downsample.1", _q(F.conv2d(x, _q(sd[pre + ".downsample.0.weight"]), None, stride, 0)), training, so))
+    return _q(F.relu(out + idt))
 
 
 def backbone(sd, pre, x, training, so, dropout_masks=None):
     feats = []
-    x = F.relu(_bn(sd, pre + ".bn1", F.conv2d(x, sd[pre + ".conv1.weight"], None, 1, 3), training, so))
+    x = _q(F.relu(_bn(sd, pre + ".bn1", _q(F.conv2d(_q(x), _q(sd[pre + ".conv1.weight"]), None, 1, 3)), training, so)))
     feats.append(x)
     x = F.max_pool2d(x, 3, 2, 1)
     inpl = 64
@@ -48,17 +57,17 @@ def backbone(sd, pre, x, training, so, dropout_masks=None):
             x = _block(sd, f"{pre}.layer{li}.{b}", x, s, b == 0 and (s != 1 or inpl != planes), training, so)
         inpl = planes
         if li >= 3 and dropout_masks is not None:  # dropout p=0.4 after layer3 / layer4 (train mode): masks supplied
-            x = x * dropout_masks[(pre, li)]
+            x = _q(x * dropout_masks[(pre, li)])
         feats.append(x)
     return feats
 
 
 def _dec_conv(sd, pre, x, training, so):
-    return F.relu(_bn(sd, pre + ".1", F.conv2d(x, sd[pre + ".0.weight"], sd[pre + ".0.bias"], 1, 1), training, so))
+    return _q(F.relu(_bn(sd, pre + ".1", _q(F.conv2d(x, _q(sd[pre + ".0.weight"]), sd[pre + ".0.bias"], 1, 1)), training, so)))
 
 
 def _dec_tconv(sd, pre, x, training, so):
-    return F.relu(_bn(sd, pre + ".1", F.conv_transpose2d(x, sd[pre + ".0.weight"], sd[pre + ".0.bias"], 2), training, so))
+    return _q(F.relu(_bn(sd, pre + ".1", _q(F.conv_transpose2d(x, _q(sd[pre + ".0.weight"]), sd[pre + ".0.bias"], 2)), training, so)))
 
 
 def lift(seg, img_indices):
@@ -70,7 +79,16 @@ def lift(seg, img_indices):
     return torch.cat(out, 0)
 
 
-def net2d_forward(sd, data_batch, training=False, stats_out=None, dropout_masks=None):
+def net2d_forward(sd, data_batch, training=False, stats_out=None, dropout_masks=None, emulate_bf16=False):
+    old = _EMULATE[0]
+    _EMULATE[0] = bool(emulate_bf16)
+    try:
+        return _net2d_forward(sd, data_batch, training, stats_out, dropout_masks)
+    finally:
+        _EMULATE[0] = old
+
+
+def _net2d_forward(sd, data_batch, training, stats_out, dropout_masks):
     img, hints, idx = data_batch["img"], data_batch["depth"], data_batch["img_indices"]
     h, w = img.shape[2], img.shape[3]
     pad_h, pad_w = (-h) % 16, (-w) % 16
@@ -87,7 +105,7 @@ def net2d_forward(sd, data_batch, training=False, stats_out=None, dropout_masks=
     x = _dec_tconv(sd, "dec_t_conv_stage3", x, training, so)
     x = _dec_conv(sd, "dec_conv_stage2", torch.cat([d[1], x, r[1]], 1), training, so)
     x = _dec_tconv(sd, "dec_t_conv_stage2", x, training, so)
-    x = F.conv2d(torch.cat([d[0], x, r[0]], 1), sd["dec_conv_stage1.weight"], sd["dec_conv_stage1.bias"], 1, 1)
+    x = _q(F.conv2d(torch.cat([d[0], x, r[0]], 1), _q(sd["dec_conv_stage1.weight"]), sd["dec_conv_stage1.bias"], 1, 1))
     segm_last = x[:, :, :h, :w]
     segm = F.conv2d(F.avg_pool2d(segm_last, 5, 1, 2), sd["con1_1_avg.weight"], sd["con1_1_avg.bias"])
     avg = F.conv2d(F.avg_pool2d(segm_last, 5, 1, 2), sd["aux.con1_1_avg.weight"], sd["aux.con1_1_avg.bias"])

@@ -134,6 +134,16 @@ def test_net2d_vs_oracle(training):
     for a, b, what in ((ph["seg_logit"], pr["seg_logit"], "seg_logit"), (ah["seg_logit_avg"], ar["seg_logit_avg"], "seg_logit_avg"),
                        (ph["seg_logit_2d"], pr["seg_logit_2d"], "seg_logit_2d"), (last_h, last_r, "segm_last")):
         assert _rel(a.cpu(), b) < 6e-2, (what, _rel(a.cpu(), b))
+    # the same forward against the oracle that rounds to bf16 where the HIP branch stores bf16: what is left is accumulation
+    # order and the isolated 1-ulp bf16 flips it causes -> an order of magnitude tighter than the fp32 comparison above
+    so2 = {}
+    pq, last_q, _, aq = net2d_forward(sd, {"img": img, "depth": depth, "img_indices": idx}, training=training, stats_out=so2,
+                                      emulate_bf16=True)
+    # measured: eval 1.6e-4 (logits) / 1.9e-3 (decoder map), train (batch statistics of a 2 x 46 x 62 batch) 2.3e-3 / 7.3e-3
+    tol_logit, tol_map = (8e-3, 2.5e-2) if training else (1e-3, 6e-3)
+    for a, b, what, tol in ((ph["seg_logit"], pq["seg_logit"], "seg_logit", tol_logit),
+                            (ah["seg_logit_avg"], aq["seg_logit_avg"], "seg_logit_avg", tol_logit), (last_h, last_q, "segm_last", tol_map)):
+        assert _rel(a.cpu(), b) < tol, ("bf16-emulating oracle", what, _rel(a.cpu(), b))
     if training:
         for pre, (rm, rv) in so.items():
             assert torch.allclose(net.state_dict()[pre + ".running_mean"].cpu(), rm, atol=2e-2, rtol=5e-2), pre
