@@ -29,7 +29,7 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, optimizers, process_group=None, bucket_bytes=64 << 20, overlap=True):
+    def __init__(self, optimizers, process_group=None, bucket_bytes=64 << 20, overlap=True, tail_bytes=8 << 20):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
@@ -41,16 +41,21 @@ class GradAllReducer:
             for a in getattr(opt, "_arenas", []):
                 if a is None:
                     continue
-                hi, n_in, members = a["spans"][-1][1], 0, []
-                for i in range(len(a["params"]) - 1, -1, -1):
-                    lo = a["spans"][i][0]
-                    members.append(i)
-                    if (hi - lo) * 4 >= bucket_bytes or i == 0:
-                        b = _Bucket(a["g"], lo, hi, len(members))
-                        for j in members:
-                            self._of_param[id(a["params"][j])] = b
-                        self.buckets.append(b)
-                        hi, members = lo, []
+                # cut points in reverse parameter order (the order backward completes them).  The bucket that holds the
+                # FIRST parameters completes last and its all-reduce cannot overlap anything, so it is kept small.
+                n = len(a["params"])
+                cuts, hi_i = [], n  # buckets as index ranges [lo_i, hi_i)
+                for i in range(n - 1, -1, -1):
+                    size = (a["spans"][hi_i - 1][1] - a["spans"][i][0]) * 4
+                    tail = a["spans"][i][0] * 4  # bytes of the parameters before i
+                    if size >= bucket_bytes or i == 0 or (0 < tail <= tail_bytes and size > 0 and tail + size > tail_bytes):
+                        cuts.append((i, hi_i))
+                        hi_i = i
+                for lo_i, hi_x in cuts:
+                    b = _Bucket(a["g"], a["spans"][lo_i][0], a["spans"][hi_x - 1][1], hi_x - lo_i)
+                    for j in range(lo_i, hi_x):
+                        self._of_param[id(a["params"][j])] = b
+                    self.buckets.append(b)
                 for p in a["params"]:
                     p.register_post_accumulate_grad_hook(self._hook)
                     if hasattr(p, "_mm_hooks"):  # gradient sinks fire the same hook by hand (gradsink.py)
