@@ -885,14 +885,16 @@ struct Wg3P {
   float* partial;  // [gridDim.x][Cn][9][Ck]
 };
 
-__global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
+template <int PH>  // patch height in pixel rows: 8 (36 KB of LDS, 4 workgroups per CU) or 4 (20 KB, more resident workgroups)
+__global__ __launch_bounds__(256, PH == 8 ? 4 : 6) void k_wgrad3x3(Wg3P p) {
   // blockIdx.z = filter row kh: the workgroup accumulates the three taps (kh, 0..2) -> 48 accumulator registers and
   // 36 KB of LDS (dY patch 16 KB + the 8 halo rows this kh needs, 20 KB), i.e. 4 workgroups per CU to hide the DMA latency.
   // Everything lane-constant (DMA source offsets, the transpose-read addresses of the dY rows and of the three taps) is
   // computed once; the patch row only enters through immediate offsets (dY rows advance by 16 pixels, halo rows by 18:
   // the swizzle bit of a halo row flips with the row parity, which is one XOR of 64 bytes).
   extern __shared__ __attribute__((aligned(16))) char smw[];
-  constexpr int YB = 128 * 128;  // bytes of a dY patch [128 px][64 n]; the halo rows follow
+  constexpr int YB = PH * 16 * 128;  // bytes of a dY patch [PH*16 px][64 n]; the halo rows follow
+  constexpr int NY = PH * 16 / 32, HPX = PH * 18, NX = (HPX + 31) / 32;  // DMA rounds of the dY patch / of the halo rows
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wn = wave >> 1, wk = wave & 1;
   const int nkt = p.Ck >> 6;
@@ -910,50 +912,50 @@ __global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
   auto fsw = [](int row) { return ((row >> 1) & 1) << 2; };  // 128-B rows: conflict-free transpose reads (see k_conv_wgrad2)
 
   // DMA sources: patch origin (uniform) + lane-constant offsets; bounds are checked per lane only on edge patches
-  int yoff[4], yyx[4], xoff[5], xyx[5];
+  int yoff[NY], yyx[NY], xoff[NX], xyx[NX];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < NY; i++) {
     const int row = r0 + 32 * i;
     yyx[i] = ((row >> 4) << 16) | (row & 15);
     yoff[i] = ((row >> 4) * p.W + (row & 15)) * p.ldy + n0 + ((cc ^ fsw(row)) << 3);
   }
 #pragma unroll
-  for (int i = 0; i < 5; i++) {
+  for (int i = 0; i < NX; i++) {
     const int row = r0 + 32 * i, hy = row / 18, hx = row - hy * 18;
-    const bool used = row < 144;
+    const bool used = row < HPX;
     xyx[i] = used ? ((hy + kh - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
     xoff[i] = (used ? ((hy + kh - 1) * p.W + (hx - 1)) * p.ldx : 0) + k0 + ((cc ^ fsw(row)) << 3);
   }
-  auto issue = [&](int patch) {  // 9 DMA instructions
+  auto issue = [&](int patch) {  // NY + NX DMA instructions
     int t = patch;
     const int tx0 = (t % p.tiles_x) * 16;
     t /= p.tiles_x;
-    const int ty0 = (t % p.tiles_y) * 8;
+    const int ty0 = (t % p.tiles_y) * PH;
     const int b = t / p.tiles_y;
     const int64_t origin = (int64_t)(b * p.H + ty0) * p.W + tx0;
     const u16* yb = p.DY + origin * p.ldy;
     const u16* xb = p.X + origin * p.ldx;
     char* dst = smw + wave * 1024;
-    const bool interior = ty0 + kh >= 1 && ty0 + kh + 7 <= p.H && ty0 + 8 <= p.H && tx0 >= 1 && tx0 + 17 <= p.W;
+    const bool interior = ty0 + kh >= 1 && ty0 + kh + PH - 1 <= p.H && ty0 + PH <= p.H && tx0 >= 1 && tx0 + 17 <= p.W;
     if (interior) {
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < NY; i++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(yb + yoff[i]),
                                          (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 5; i++)
+      for (int i = 0; i < NX; i++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
                                          (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
+      for (int i = 0; i < NY; i++) {
         const int y = ty0 + (yyx[i] >> 16), x = tx0 + (yyx[i] & 0xFFFF);
         const u16* g = (y < p.H && x < p.W) ? yb + yoff[i] : (const u16*)g_zero16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < 5; i++) {
+      for (int i = 0; i < NX; i++) {
         const int y = ty0 + (xyx[i] >> 16), x = tx0 + (short)(xyx[i] & 0xFFFF);
         const u16* g = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? xb + xoff[i] : (const u16*)g_zero16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -985,7 +987,7 @@ __global__ __launch_bounds__(256, 4) void k_wgrad3x3(Wg3P p) {
     issue(patch);
     __syncthreads();  // vmcnt(0) + barrier: patch landed
 #pragma unroll
-    for (int py = 0; py < 8; py++) {  // one patch row = 16 pixels = one MFMA K step
+    for (int py = 0; py < PH; py++) {  // one patch row = 16 pixels = one MFMA K step
       const s16x4 x0 = rd(a0 + py * 16 * 128), x1 = rd(a1 + py * 16 * 128);
       const s16x8 av = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
       const bf16x8 af = __builtin_bit_cast(bf16x8, av);
@@ -1268,7 +1270,8 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
   if (is3x3 && M > 0) {
     Wg3P q;
     q.X = (const u16*)X; q.DY = (const u16*)dY; q.B = B; q.H = Hg; q.W = Wg; q.Ck = Ck; q.ldx = ldx; q.Cn = Cn; q.ldy = ldy;
-    q.tiles_y = (int)mm_cdiv(Hg, 8); q.tiles_x = (int)mm_cdiv(Wg, 16);
+    constexpr int ph = 8;  // patch height; 4 (20 KB of LDS, more resident workgroups) measured 11 % slower per step
+    q.tiles_y = (int)mm_cdiv(Hg, ph); q.tiles_x = (int)mm_cdiv(Wg, 16);
     const int64_t npatch = (int64_t)B * q.tiles_y * q.tiles_x;
     const int ntile = (Cn / 64) * (Ck / 64);
     // pixel splits: enough workgroups to fill the chip (~1024 in total), but the fp32 partial slabs (one per split) are
@@ -1285,13 +1288,8 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
       return MM_ERR_WORKSPACE;
     }
     q.partial = (float*)ws;
-    const size_t lds = (size_t)(128 * 64 + 160 * 64) * 2;
-    static bool once = false;
-    if (!once) {
-      MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      once = true;
-    }
-    hipLaunchKernelGGL(k_wgrad3x3, dim3(nsplit3, ntile, 3), dim3(256), lds, s, q);
+    const size_t lds = (size_t)(ph * 16 + ((ph * 18 + 31) / 32) * 32) * 128;
+    hipLaunchKernelGGL(k_wgrad3x3<ph>, dim3(nsplit3, ntile, 3), dim3(256), lds, s, q);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * 9 * Ck, 128)), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
                        dW, sn, st, sk, accumulate);
     MM_LAUNCH_CHECK();
