@@ -230,7 +230,7 @@ def main():
     out = {
         "metric": "LiDAR scenes/sec fwd+bwd (NuScenes ~35k pts, 5cm voxel)", "value": round(2 * B * world / (ms * 1e-3), 3),
         "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP) + f32 (3D sparse branch, fp32 as in the reference: f32 MFMA below 64 input channels, fp32-faithful 3-term split-bf16 products with fp32 accumulation from 64 up)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP) + f32 (3D sparse branch, fp32 as in the reference: f32 MFMA on narrow layers, fp32-faithful 3-term split-bf16 products with fp32 accumulation from 32 (fwd/dX) / 16 (dW) input channels up)",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: NuScenes-shaped (32x1090 sweep, 34,880 pts/scene), 5 cm voxels, 480x302 RGB + "
                                "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "

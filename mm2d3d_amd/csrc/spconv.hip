@@ -650,6 +650,15 @@ static int split_terms() {
   return nt;
 }
 
+// smallest input width that takes the split-product engines: 32 for fwd / dX (below that the fp32 engine streams as fast),
+// 16 for dW (its fp32 variant is bound by 4-byte gathers + 32-cycle MFMAs already at 16 channels).  Measured on the
+// bench step: dW 2.42 -> 2.17 ms, fwd + dX 5.04 -> 4.95 ms against a 64-channel threshold for both.
+static int split_min_cin(bool dw) {
+  static const int a = getenv("MM_SPCONV_SPLIT_MIN") ? atoi(getenv("MM_SPCONV_SPLIT_MIN")) : 32;
+  static const int d = getenv("MM_SPCONV_SPLIT_MIN_DW") ? atoi(getenv("MM_SPCONV_SPLIT_MIN_DW")) : 16;
+  return dw ? d : a;
+}
+
 template <int N, int NT>
 static int launch_s3(bool small, int nb, int nch, size_t lds, const float* in, int ld_in, const int32_t* src, const int32_t* d, float* tgt,
                      int ld_t, const __bf16* Wf3, int ncb, int K, int Cin, int tr, const KSeg& sg, hipStream_t s) {
@@ -731,7 +740,7 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
   MM_CHECK_ARG(((uintptr_t)ws % 16) == 0, "spconv_apply: workspace must be 16-B aligned");
   float* Wf = (float*)((char*)ws + tmp_bytes);
   const int nt = split_terms();
-  if (nt && !edge && Cin >= 64 && (unique_dst || Cout % 4 == 0) && R > 0) {  // matrix-rate-bound widths: split-bf16 products
+  if (nt && !edge && Cin >= split_min_cin(false) && (unique_dst || Cout % 4 == 0) && R > 0) {  // matrix-rate-bound widths: split-bf16 products
     const int nq3 = (Cin + 31) / 32;
     MM_CHECK_ARG(ws_bytes >= tmp_bytes + (size_t)K * nq3 * ncb * 64 * 16 * nt, "spconv_apply: workspace too small for the split fragments");
     __bf16* Wf3 = (__bf16*)Wf;
@@ -870,7 +879,7 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
       const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
       const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
       const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
-      const int nt = Cin >= 64 ? split_terms() : 0;  // matrix-rate-bound widths, as in mm_spconv_apply
+      const int nt = Cin >= split_min_cin(true) ? split_terms() : 0;  // matrix-rate-bound widths, as in mm_spconv_apply
 #define DWCASE(I, J)                                                                                                  \
   if (ti == I && tj == J) {                                                                                           \
     if (nt == 3)                                                                                                      \
