@@ -177,6 +177,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 as\n  python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {a.gpus} ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     local = local % max(torch.cuda.device_count(), 1)

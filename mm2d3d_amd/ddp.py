@@ -6,9 +6,15 @@ fp32 gradient buckets (25 MB) all-reduced over NCCL during backward.  MI355X-fir
     SLICE of an arena - no packing / unpacking copies;
   * buckets are cut in reverse parameter order (the order backward produces them) and launched from
     post-accumulate-grad hooks as soon as a bucket is complete, on RCCL's own stream, overlapping the rest of
-    backward; launch order is fixed (last bucket first) so every rank issues the same collective sequence even
-    when hook timing differs; parameters that receive no gradient (the reference's ``find_unused_parameters``
-    case: ``linear_global``, ``aux.linear``) simply leave zeros in their slice;
+    backward;
+  * parameters that receive no gradient (the reference's ``find_unused_parameters`` case: ``linear_global`` / ``dow`` of
+    3d_net/model.py:71-72, ``aux.linear`` of 2d_net/model.py:157) never fire a hook.  They are LEARNED in the first step
+    (which runs without overlap): a parameter whose hook has not fired by ``finish()`` is unused; the used-bitmaps of all
+    ranks are compared (MIN / MAX all-reduce), unused parameters stop counting towards their bucket's countdown, buckets
+    without any used parameter are not sent at all (their slice stays zero on every rank), and the launch order of the
+    others becomes the order in which rank 0 saw them complete (broadcast, so every rank issues the same collective
+    sequence whatever its hook timing).  The training graph of this path is static; if a learned-unused parameter does
+    receive a gradient later, ``finish()`` raises and the next step re-learns;
   * xGMI is point-to-point (7 links/GPU): fewer, larger messages are better than NVSwitch-style 25 MB buckets;
     default bucket = 64 MB (~196 MB of fp32 gradients -> 4 all-reduces per step);
   * the sum is averaged inside the fused AdamW kernel (grad_scale = 1/world), not by an extra pass.
@@ -21,11 +27,12 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("arena", "lo", "hi", "pending", "n_params", "launched", "work")
+    __slots__ = ("arena", "lo", "hi", "params", "n_used", "pending", "launched", "work", "done_at")
 
-    def __init__(self, arena, lo, hi, n_params):
-        self.arena, self.lo, self.hi, self.n_params = arena, lo, hi, n_params
-        self.pending, self.launched, self.work = n_params, False, None
+    def __init__(self, arena, lo, hi, params):
+        self.arena, self.lo, self.hi, self.params = arena, lo, hi, params
+        self.n_used = len(params)
+        self.pending, self.launched, self.work, self.done_at = self.n_used, False, None, -1
 
 
 class GradAllReducer:
@@ -33,14 +40,23 @@ class GradAllReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap
-        self.buckets = []  # launch order: as built (reverse parameter order)
+        self.buckets = []  # as built: per arena, reverse parameter order
+        self.order = []  # launch order (learned in the first step)
+        self.learned = False
+        self.consistent = True  # every rank saw the same used set
+        self.unused = set()  # ids of parameters learned as unused
         self._of_param = {}
+        self._fired = set()
+        self._late = []
+        self._tick = 0
+        self._arenas = []
         if self.world == 1:
             return
         for opt in optimizers:
             for a in getattr(opt, "_arenas", []):
                 if a is None:
                     continue
+                self._arenas.append(a)
                 # cut points in reverse parameter order (the order backward completes them).  The bucket that holds the
                 # FIRST parameters completes last and its all-reduce cannot overlap anything, so it is kept small.
                 n = len(a["params"])
@@ -52,47 +68,115 @@ class GradAllReducer:
                         cuts.append((i, hi_i))
                         hi_i = i
                 for lo_i, hi_x in cuts:
-                    b = _Bucket(a["g"], a["spans"][lo_i][0], a["spans"][hi_x - 1][1], hi_x - lo_i)
-                    for j in range(lo_i, hi_x):
-                        self._of_param[id(a["params"][j])] = b
+                    b = _Bucket(a["g"], a["spans"][lo_i][0], a["spans"][hi_x - 1][1], a["params"][lo_i:hi_x])
+                    for p in b.params:
+                        self._of_param[id(p)] = b
                     self.buckets.append(b)
                 for p in a["params"]:
                     p.register_post_accumulate_grad_hook(self._hook)
                     if hasattr(p, "_mm_hooks"):  # gradient sinks fire the same hook by hand (gradsink.py)
                         p._mm_hooks.append(self._hook)
+        self.order = list(self.buckets)
 
     @property
     def grad_scale(self):
         return 1.0 / self.world
 
+    # ------------------------------------------------------------------ parameter sync (torch DDP does it when wrapping)
+    def sync_parameters(self, src=0):
+        """Rank ``src``'s weights win: one broadcast per flat parameter arena (DDP's constructor-time broadcast)."""
+        if self.world == 1:
+            return
+        for a in self._arenas:
+            dist.broadcast(a["p"], src=src, group=self.group)
+        from . import conv2d as _c2d
+
+        _c2d.PARAM_EPOCH[0] += 1  # packed bf16 weight copies are stale
+
+    # ------------------------------------------------------------------ launch machinery
+    def _send(self, b):
+        b.work = dist.all_reduce(b.arena[b.lo : b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.launched = True
+
     def _launch_ready(self):
-        for b in self.buckets:  # strict order: a bucket goes out only after every earlier one
+        for b in self.order:  # strict order: a bucket goes out only after every earlier one of the learned order
             if b.launched:
                 continue
             if b.pending > 0:
                 break
-            b.work = dist.all_reduce(b.arena[b.lo : b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            b.launched = True
+            self._send(b)
 
     def _hook(self, param):
-        b = self._of_param.get(id(param))
-        if b is None or b.launched:
+        pid = id(param)
+        b = self._of_param.get(pid)
+        if b is None:
+            return
+        if pid in self._fired:  # a second accumulation into the same parameter within one step (not counted twice)
+            return
+        self._fired.add(pid)
+        if pid in self.unused:
+            self._late.append(param)
             return
         b.pending -= 1
-        if self.overlap and b.pending == 0:
+        self._tick += 1
+        b.done_at = self._tick  # tick of the bucket's latest gradient = when it completes once unused parameters are known
+        if b.pending == 0 and self.overlap and self.learned and self.consistent:
             self._launch_ready()
 
+    def _learn(self):
+        """End of the first step: agree on the unused set and on the launch order."""
+        params = [p for b in self.buckets for p in b.params]
+        dev = self.buckets[0].arena.device
+        used = torch.tensor([1 if id(p) in self._fired else 0 for p in params], dtype=torch.int32, device=dev)
+        lo, hi = used.clone(), used.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        self.consistent = bool(torch.equal(lo, hi))
+        # rank 0's completion order (tick of each bucket's last gradient); buckets without any gradient go last
+        key = torch.tensor([b.done_at if b.done_at >= 0 else (1 << 20) + i for i, b in enumerate(self.buckets)],
+                           dtype=torch.int64, device=dev)
+        dist.broadcast(key, src=0, group=self.group)
+        if self.consistent:
+            self.unused = {id(p) for p, u in zip(params, hi.tolist()) if not u}
+            for b in self.buckets:
+                b.n_used = sum(1 for p in b.params if id(p) not in self.unused)
+            keys = key.tolist()
+            self.order = [self.buckets[i] for i in sorted(range(len(self.buckets)), key=lambda i: keys[i])
+                          if self.buckets[i].n_used > 0]
+        else:  # ranks disagree (data-dependent graph): no early launches, everything goes out in finish() in build order
+            self.unused = set()
+            self.order = list(self.buckets)
+        self.learned = True
+
     def finish(self):
-        """Call after backward: launches what is left (unused parameters never fire hooks), waits, resets."""
+        """Call after backward: launches what is left, waits, resets the countdowns."""
         if self.world == 1:
             return
-        for b in self.buckets:
-            b.pending = 0
-        self._launch_ready()
+        late = self._late
+        if not self.learned:
+            # learning step: nothing was launched during backward; send every bucket in build order (the same on all ranks)
+            for b in self.buckets:
+                self._send(b)
+        else:
+            for b in self.order:
+                if not b.launched:
+                    self._send(b)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
-            b.pending, b.launched, b.work = b.n_params, False, None
+        if not self.learned:
+            self._learn()
+        for b in self.buckets:
+            b.pending, b.launched, b.work, b.done_at = b.n_used, False, None, -1
+        self._fired, self._late, self._tick = set(), [], 0
+        if late:
+            self.learned, self.unused = False, set()
+            for b in self.buckets:
+                b.n_used = b.pending = len(b.params)
+            self.order = list(self.buckets)
+            raise RuntimeError(
+                f"GradAllReducer: {len(late)} parameter(s) learned as unused received a gradient (the graph changed); "
+                "this step's gradients are not reduced correctly - the next step re-learns the unused set")
 
     def broadcast_buffers(self, modules, src=0):
         """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a
@@ -119,8 +203,6 @@ class GradAllReducer:
 def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):
     """DistributedSampler semantics: same seeded permutation on every rank, padded to a multiple of the
     world size by wrapping, rank r takes r, r+W, ..."""
-    import numpy as np
-
     if shuffle:
         g = torch.Generator()
         g.manual_seed(seed + epoch)
@@ -130,3 +212,21 @@ def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: 
     total = -(-n_items // world) * world
     idx += idx[: total - len(idx)]
     return idx[rank:total:world]
+
+
+def paired_shards(n_source: int, n_target: int, batch: int, rank: int, world: int, epoch: int = 0, seed: int = 0,
+                  drop_last: bool = True):
+    """The reference's two-loader epoch (run.py:280-282: ``CombinedLoader({"source", "target"}, "max_size_cycle")`` over
+    two DistributedSampler-sharded loaders): yields ``(source_indices, target_indices)`` per step for this rank.  Each
+    loader batches its own shard (``drop_last`` as the train loaders do, lib/dataset/__init__.py:161); the epoch lasts as
+    long as the LONGER loader and the shorter one restarts from its first batch each time it runs out."""
+    def batches(n):
+        idx = shard_indices(n, rank, world, epoch=epoch, shuffle=True, seed=seed)
+        nb = len(idx) // batch if drop_last else -(-len(idx) // batch)
+        return [idx[i * batch : (i + 1) * batch] for i in range(nb)]
+
+    src, trg = batches(n_source), batches(n_target)
+    if not src or not trg:
+        return
+    for i in range(max(len(src), len(trg))):
+        yield src[i % len(src)], trg[i % len(trg)]

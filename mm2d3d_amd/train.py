@@ -55,6 +55,9 @@ class TrainModel(nn.Module):
             self.optimizers.append(opt)
             self.schedulers.append(sched)
         self.reducer = GradAllReducer(self.optimizers)
+        # torch DDP broadcasts rank 0's parameters when it wraps a model (run.py:262-268): replicas start identical whatever
+        # each rank's seed was
+        self.reducer.sync_parameters(src=0)
         return self.optimizers, self.schedulers
 
     def forward(self, batch, model_name=None):
@@ -177,6 +180,14 @@ class TrainModel(nn.Module):
 
     def load_checkpoint(self, ckpt):
         self.model.load_state_dict({k[len("model."):]: v for k, v in ckpt["state_dict"].items()})
+        if not self.optimizers and self._opt_factories:
+            self.configure_optimizers()  # built lazily by fit_step otherwise: a resume before step 1 must not drop the moments
+        states = ckpt.get("optimizer_states", [])
+        if states and len(states) != len(self.optimizers):
+            raise ValueError(f"checkpoint holds {len(states)} optimizer states, the trainer has {len(self.optimizers)}")
+        from . import conv2d as _c2d
+
+        _c2d.PARAM_EPOCH[0] += 1  # weights changed under the packed bf16 copies
         for o, sd in zip(self.optimizers, ckpt.get("optimizer_states", [])):
             o.load_state_dict(sd)
         for s, sd in zip(self.schedulers, ckpt.get("lr_schedulers", [])):

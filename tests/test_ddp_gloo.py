@@ -36,18 +36,65 @@ def _worker(rank, world, port, overlap, q):
         assert spans[0][0] == 0 and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
         assert [b.lo for b in red.buckets] == sorted((b.lo for b in red.buckets), reverse=True)
         assert (red.buckets[-1].hi - red.buckets[-1].lo) * 4 <= 600
+        # local gradients come from an UNHOOKED replica (an early bucket launch would otherwise already hold the sum)
+        import copy
+
+        replica = copy.deepcopy(net)
+        for p, q_ in zip(replica.parameters(), net.parameters()):
+            p.data = q_.data.clone()
         torch.manual_seed(100 + rank)  # different data per rank
         x = torch.randn(5, 8)
-        for it in range(2):
+        n_unused = sum(p.numel() for p in unused.parameters())
+        for it in range(3):
             opt.zero_grad()
+            replica.zero_grad()
+            (replica(x) ** 2).sum().backward()
+            local = torch.cat([p.grad.reshape(-1) for p in replica.parameters()] + [torch.zeros(n_unused)])
             (net(x) ** 2).sum().backward()
-            local = opt.grad_arenas()[0].clone()
+            flags = [b.launched for b in red.order]
+            if it == 0:
+                # the learning step: unused parameters are not known yet, nothing may go out before finish()
+                assert not any(b.launched for b in red.buckets)
+            elif overlap:
+                # every bucket that holds a used parameter has been launched DURING backward - the trailing unused module
+                # (the layout of 2d_net/model.py:157 / 3d_net/model.py:71) does not hold its bucket back
+                assert flags and all(flags), f"buckets not launched before finish(): {flags}"
+            else:
+                assert not any(flags)
             red.finish()
+            if it == 0:
+                assert red.learned and red.consistent
+                assert red.unused == {id(p) for p in unused.parameters()}
+                assert all(b.n_used > 0 for b in red.order)
+                # launch order = completion order of backward = reverse parameter order here
+                assert [b.lo for b in red.order] == sorted((b.lo for b in red.order), reverse=True)
             summed = opt.grad_arenas()[0].clone()
             gathered = [torch.zeros_like(local) for _ in range(world)]
             dist.all_gather(gathered, local)
             assert torch.allclose(summed, sum(gathered), atol=1e-6), "bucketed all-reduce != sum of local gradients"
-            assert torch.equal(summed[-20:], torch.zeros(20)), "unused parameters must stay zero"
+            assert torch.equal(summed[-n_unused:], torch.zeros(n_unused)), "unused parameters must stay zero"
+        # a learned-unused parameter that does get a gradient is reported loudly and the reducer re-learns
+        opt.zero_grad()
+        (net(x) ** 2).sum().backward()
+        unused(torch.randn(2, 4)).sum().backward()
+        try:
+            red.finish()
+            raise AssertionError("late gradient of an unused parameter was not reported")
+        except RuntimeError as e:
+            assert "unused" in str(e)
+        assert not red.learned
+        opt.zero_grad()
+        (net(x) ** 2).sum().backward()
+        red.finish()
+        assert red.learned
+        # sync_parameters: rank 0's weights win (torch DDP's constructor broadcast)
+        with torch.no_grad():
+            for a in opt._arenas:
+                a["p"].add_(float(rank))
+        red.sync_parameters(src=0)
+        ref = [torch.zeros_like(opt._arenas[0]["p"]) for _ in range(world)]
+        dist.all_gather(ref, opt._arenas[0]["p"])
+        assert all(torch.equal(ref[0], r) for r in ref)
         assert abs(red.grad_scale - 1.0 / world) < 1e-12
         bufmod = nn.BatchNorm1d(3)
         bufmod.running_mean.fill_(float(rank + 1))
@@ -86,3 +133,23 @@ def test_shard_indices_matches_distributed_sampler():
                 s = DistributedSampler(data, num_replicas=world, rank=rank, shuffle=True, seed=0)
                 s.set_epoch(epoch)
                 assert shard_indices(len(data), rank, world, epoch=epoch, shuffle=True, seed=0) == list(iter(s))
+
+
+def test_paired_shards_max_size_cycle():
+    """run.py:280-282: CombinedLoader(..., "max_size_cycle") over two DistributedSampler-sharded loaders."""
+    from mm2d3d_amd.ddp import paired_shards, shard_indices
+
+    world, B = 2, 4
+    for rank in range(world):
+        steps = list(paired_shards(37, 90, B, rank, world, epoch=1, seed=0))
+        src_shard = shard_indices(37, rank, world, epoch=1)  # 19 items -> 4 full batches
+        trg_shard = shard_indices(90, rank, world, epoch=1)  # 45 items -> 11 full batches
+        assert len(steps) == 11  # as long as the longer loader
+        for i, (s_idx, t_idx) in enumerate(steps):
+            assert t_idx == trg_shard[i * B : (i + 1) * B]
+            j = i % 4  # the shorter loader restarts
+            assert s_idx == src_shard[j * B : (j + 1) * B]
+    # ranks see disjoint target scenes within an epoch
+    a = {i for _, t in paired_shards(37, 90, B, 0, world) for i in t}
+    b = {i for _, t in paired_shards(37, 90, B, 1, world) for i in t}
+    assert not (a & b)
