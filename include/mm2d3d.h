@@ -93,6 +93,33 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
                  const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
                  size_t ws_bytes, mm_stream_t stream);
 
+/* ---------------------------------------------------------------- output-stationary engine (csrc/ostable.hip, csrc/osconv.hip)
+ * The same three scn convolutions (scn_unet.py:43,45,52,68-70,75-77,114), forward and data gradient, without the
+ * tmp[rule] round trip: destination rows are ordered by neighbour bitmask, a workgroup owns a tile of them and
+ * accumulates the offsets k in ascending order in registers. */
+/* nbr[8][n_fine] for Deconvolution / d(Convolution)/d(input): nbr[octant(i)][i] = parent of fine row i, else -1 */
+int mm_up_neighbors(const int32_t* vox_coords_fine, int64_t n_fine, const int32_t* fine2coarse, int32_t* nbr,
+                    mm_stream_t stream);
+size_t mm_os_table_ws_bytes(int64_t n, int K);
+/* nbr[K][n] -> dst[npad] (rows sorted by neighbour bitmask, -1 = padding), nbrp[K][npad], tmask[nt];
+ * nt = ceil(n / tile_rows), npad = nt * tile_rows, tile_rows in {64, 128, 256} */
+int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32_t* dst, int32_t* nbrp, uint32_t* tmask,
+                      void* ws, size_t ws_bytes, mm_stream_t stream);
+/* three-term bf16 MFMA fragments of a weight tensor: element (k,ci,co) = W[kk*w_kstride + ci*s_ci + co*s_co],
+ * kk = kflip ? K-1-k : k */
+size_t mm_spconv_os_pack_bytes(int K, int Cin, int Cout);
+int64_t mm_spconv_os_pack_blocks(int K, int Cin, int Cout);
+int mm_spconv_os_pack_desc_fields(void);
+int mm_spconv_os_pack(const float* W, int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin, int Cout, void* Wf,
+                      mm_stream_t stream);
+/* descs_dev [n_desc][12] int64 (device) = {W, Wf, K, Cin, Cout, nq, ncb, w_kstride, s_ci, s_co, kflip, blk_end}: one launch
+ * packs every weight of a net after an optimiser step */
+int mm_spconv_os_pack_batch(const int64_t* descs_dev, int n_desc, int64_t total_blocks, mm_stream_t stream);
+/* out[dst[j]] = sum over present k (ascending) of in[nbrp[k][j]] . W[k];  Cin, Cout multiples of 16, rows 16-B aligned */
+int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, const void* Wf, int K,
+                       const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
+                       mm_stream_t stream);
+
 /* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
  * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */
 size_t mm_bn_ws_bytes(int C);

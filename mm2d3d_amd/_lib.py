@@ -35,6 +35,15 @@ _PROTOS = {
     "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
     "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_up_neighbors": (i32, [vp, i64, vp, vp, vp]),
+    "mm_os_table_ws_bytes": (sz, [i64, i32]),
+    "mm_os_table_build": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "mm_spconv_os_pack_bytes": (sz, [i32, i32, i32]),
+    "mm_spconv_os_pack_blocks": (i64, [i32, i32, i32]),
+    "mm_spconv_os_pack_desc_fields": (i32, []),
+    "mm_spconv_os_pack": (i32, [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "mm_spconv_os_pack_batch": (i32, [vp, i32, i64, vp]),
+    "mm_spconv_os_apply": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp]),
     "mm_bn_ws_bytes": (sz, [i32]),
     "mm_bn_fwd_train": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
@@ -127,14 +136,18 @@ def stream():
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device; kernels that use it are serialised on the current stream."""
+    """Grow-only scratch buffers, one per (device, slot, current stream): every kernel that uses a buffer is enqueued on the
+    stream the buffer belongs to, so the stream's own order serialises them (ops run on the current
+    torch HIP stream)."""
 
     def __init__(self):
         self.bufs = {}
         self.default_slot = "main"
 
     def get(self, nbytes: int, device, slot: str = None):
-        key = (device.index if device.index is not None else torch.cuda.current_device(), slot or self.default_slot)
+        # one buffer per (device, slot, stream): kernels of different streams never share scratch memory
+        key = (device.index if device.index is not None else torch.cuda.current_device(), slot or self.default_slot,
+               torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         buf = self.bufs.get(key)
         if buf is None or buf.numel() < nbytes:
             buf = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=device)

@@ -7,6 +7,8 @@ row counts (two small D2H copies per batch: one after the dedupe chain, one afte
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -19,14 +21,37 @@ I32 = torch.int32
 class Rulebook:
     """k-major rule lists + CSR over destination rows (csrc/spconv.hip header)."""
 
-    __slots__ = ("K", "rin", "rout", "offsets_dev", "offsets_host", "csr_off", "csr_pos", "n_rules", "n_out", "_keep")
+    __slots__ = ("K", "rin", "rout", "offsets_dev", "offsets_host", "csr_off", "csr_pos", "n_rules", "n_out", "_keep", "os",
+                 "os_up")
 
     def __init__(self, K):
         self.K = K
+        self.os = None     # OsTable over the rulebook's destination rows (csrc/ostable.hip): the output-stationary engine
+        self.os_up = None  # strided rulebooks only: OsTable with the roles swapped (destination = fine rows)
 
     @property
     def offsets_ptr(self):
         return self.offsets_host.ctypes.data
+
+
+class OsTable:
+    """Tile table of the output-stationary engine: destination rows sorted by neighbour bitmask, cut into tiles."""
+
+    __slots__ = ("K", "n_dst", "tile_rows", "n_tiles", "dst", "nbrp", "tmask")
+
+
+# The output-stationary engine pays off on the large levels (measured on 16 NuScenes-shaped scenes: SubM levels 0-2, strided
+# convolutions into levels 1-2); below ~200k destination rows the k-major rulebook engines keep the chip busier.
+OS_MIN_ROWS = int(os.environ.get("MM_OS_MIN_ROWS", "200000"))
+OS_BUILD_UP = os.environ.get("MM_OS_UP", "0") != "0"
+
+
+def os_tile_rows(n):
+    """Rows per workgroup tile: large tiles amortise the staged weights, small levels need the workgroups."""
+    forced = os.environ.get("MM_OS_TILE")
+    if forced:
+        return int(forced)
+    return 64
 
 
 class Level:
@@ -95,6 +120,8 @@ class Metadata:
                         t = getattr(rb, name, None)
                         if torch.is_tensor(t):
                             yield t
+                        elif isinstance(t, OsTable):
+                            yield from (t.dst, t.nbrp, t.tmask)
                         elif isinstance(t, (list, tuple)):
                             for u in t:
                                 if torch.is_tensor(u):
@@ -208,6 +235,23 @@ class Metadata:
         )
         return rb
 
+    def _os_table(self, nbr, K, n):
+        if n < OS_MIN_ROWS:
+            return None
+        L = _lib.lib()
+        dev = self.device
+        t = OsTable()
+        t.K, t.n_dst, t.tile_rows = K, n, os_tile_rows(n)
+        t.n_tiles = -(-n // t.tile_rows)
+        npad = t.n_tiles * t.tile_rows
+        t.dst = torch.empty(npad, dtype=I32, device=dev)
+        t.nbrp = torch.empty(K * npad, dtype=I32, device=dev)
+        t.tmask = torch.empty(t.n_tiles, dtype=I32, device=dev)
+        ws = _lib.workspace.get(int(L.mm_os_table_ws_bytes(n, K)), dev)
+        check(L.mm_os_table_build(ptr(nbr), K, n, t.tile_rows, ptr(t.dst), ptr(t.nbrp), ptr(t.tmask), ptr(ws), ws.numel(),
+                                  stream()), "os_table_build")
+        return t
+
     def build_rulebooks(self, levels=None):
         """Submanifold (K=27) rulebook of every level + strided (K=8) rulebook between consecutive levels."""
         L = _lib.lib()
@@ -222,6 +266,7 @@ class Metadata:
             check(L.mm_subm_neighbors(ptr(lv.coords), lv.n, lv.spatial_size, ptr(lv.tkeys), ptr(lv.tvals), lv.cap,
                                       ptr(nbr), stream()), "subm_neighbors")
             subm = self._launch_rulebook(27, lv.n, nbr, offs[j, :28])
+            subm.os = self._os_table(nbr, 27, lv.n)
             down = None
             if lv.coarse is not None and lv.down is None:
                 c = lv.coarse
@@ -229,6 +274,11 @@ class Metadata:
                 check(L.mm_down_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), c.n, ptr(nbr8), stream()),
                       "down_neighbors")
                 down = self._launch_rulebook(8, c.n, nbr8, offs[j, 28:37])
+                down.os = self._os_table(nbr8, 8, c.n)
+                if OS_BUILD_UP:  # unique-destination direction: the rulebook engine's direct scatter measured faster
+                    nbr_up = torch.empty(max(8 * lv.n, 1), dtype=I32, device=dev)
+                    check(L.mm_up_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), ptr(nbr_up), stream()), "up_neighbors")
+                    down.os_up = self._os_table(nbr_up, 8, lv.n)
             pending.append((lv, subm, down))
         host = offs.cpu().numpy()  # sync #2
         for j, (lv, subm, down) in enumerate(pending):

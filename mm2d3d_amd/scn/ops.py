@@ -1,6 +1,9 @@
 """Autograd functions over the C-ABI kernels (csrc/spconv.hip, bn.hip, point.hip)."""
 from __future__ import annotations
 
+import os
+import weakref
+
 import torch
 
 from .. import _lib, gradsink
@@ -51,6 +54,104 @@ def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_
     return out
 
 
+class _OsPacks:
+    """Three-term bf16 MFMA fragments of the sparse-conv weights (csrc/osconv.hip), cached per optimiser step.
+
+    Every (parameter, variant) pair the nets use registers once; the first stale hit after an optimiser step (PARAM_EPOCH),
+    an in-place torch update (``_version``) or a move of the parameter repacks EVERY registered pair in one launch
+    (mm_spconv_os_pack_batch) instead of one small launch per layer call."""
+
+    def __init__(self):
+        self.entries = {}  # (id(owner), transpose, kflip) -> entry dict
+        self.table = None
+        self.dirty = True
+        self.total_blocks = 0
+
+    @staticmethod
+    def _key(owner):
+        from .. import conv2d as _c2d
+
+        return (owner._version, _c2d.PARAM_EPOCH[0], owner.data_ptr())
+
+    def get(self, owner, K, cw_in, cw_out, transpose, kflip):
+        L = _lib.lib()
+        ek = (id(owner), transpose, kflip)
+        e = self.entries.get(ek)
+        key = self._key(owner)
+        if e is not None and e["owner"]() is owner and e["key"] == key:
+            return e["buf"]
+        if e is None or e["owner"]() is not owner:
+            cin, cout = (cw_out, cw_in) if transpose else (cw_in, cw_out)
+            s_ci, s_co = (1, cw_out) if transpose else (cw_out, 1)
+            e = dict(owner=weakref.ref(owner), K=K, cin=cin, cout=cout, s_ci=s_ci, s_co=s_co, kstride=cw_in * cw_out,
+                     kflip=1 if kflip else 0, key=None, ptr=0,
+                     buf=torch.empty(int(L.mm_spconv_os_pack_bytes(K, cin, cout)), dtype=torch.uint8, device=owner.device))
+            self.entries[ek] = e
+            self.dirty = True
+        self._repack_all()
+        return e["buf"]
+
+    def _repack_all(self):
+        L = _lib.lib()
+        dead = [k for k, e in self.entries.items() if e["owner"]() is None]
+        for k in dead:
+            del self.entries[k]
+            self.dirty = True
+        ents = list(self.entries.values())
+        for e in ents:
+            if e["owner"]().data_ptr() != e["ptr"]:
+                self.dirty = True
+        if self.dirty:
+            rows, blk = [], 0
+            for e in ents:
+                o = e["owner"]()
+                e["ptr"] = o.data_ptr()
+                blk += int(L.mm_spconv_os_pack_blocks(e["K"], e["cin"], e["cout"]))
+                rows.append([e["ptr"], e["buf"].data_ptr(), e["K"], e["cin"], e["cout"], (e["cin"] + 31) // 32, (e["cout"] + 15) // 16,
+                             e["kstride"], e["s_ci"], e["s_co"], e["kflip"], blk])
+            assert int(L.mm_spconv_os_pack_desc_fields()) == 12
+            self.table = torch.tensor(rows, dtype=torch.int64).to(ents[0]["buf"].device)
+            self.total_blocks = blk
+            self.dirty = False
+        check(L.mm_spconv_os_pack_batch(ptr(self.table), len(ents), self.total_blocks, stream()), "spconv_os_pack_batch")
+        for e in ents:
+            e["key"] = self._key(e["owner"]())
+
+
+_OS_PACKS = {}  # device index -> _OsPacks
+OS_ENABLED = os.environ.get("MM_SPCONV_OS", "1") != "0"
+
+
+def _os_fragments(weight, w_kcc, transpose, kflip):
+    """Packed fragments of W (or W^T, offsets flipped) for the output-stationary engine."""
+    L = _lib.lib()
+    K, cw_in, cw_out = w_kcc.shape
+    if isinstance(weight, torch.nn.Parameter) and weight.dtype == F32 and weight.is_contiguous() and weight.data_ptr() == w_kcc.data_ptr():
+        reg = _OS_PACKS.setdefault(weight.device.index, _OsPacks())
+        return reg.get(weight, K, cw_in, cw_out, bool(transpose), bool(kflip))
+    cin, cout = (cw_out, cw_in) if transpose else (cw_in, cw_out)
+    s_ci, s_co = (1, cw_out) if transpose else (cw_out, 1)
+    buf = torch.empty(int(L.mm_spconv_os_pack_bytes(K, cin, cout)), dtype=torch.uint8, device=w_kcc.device)
+    check(L.mm_spconv_os_pack(ptr(w_kcc), cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, K, cin, cout, ptr(buf), stream()),
+          "spconv_os_pack")
+    return buf
+
+
+def _os_usable(table, x, cin, cout):
+    return (OS_ENABLED and table is not None and cin % 16 == 0 and cout % 16 == 0 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and x.stride(1) == 1)
+
+
+def _apply_os(x, weight, w_kcc, table, cout, transpose, kflip):
+    """Output-stationary engine: out[dst] = sum_k x[nbr_k(dst)] . W[k], offsets ascending, no tmp rows."""
+    L = _lib.lib()
+    Wf = _os_fragments(weight, w_kcc, transpose, kflip)
+    out = torch.empty((table.n_dst, cout), dtype=F32, device=x.device)
+    check(L.mm_spconv_os_apply(ptr(x), x.stride(0), x.shape[1], ptr(out), cout, cout, ptr(Wf), table.K, ptr(table.dst),
+                               ptr(table.nbrp), ptr(table.tmask), table.n_tiles, table.tile_rows, stream()), "spconv_os_apply")
+    return out
+
+
 def _dw(x, dout, rb, src, dst, cin, cout, sink=None):
     """dW [K, cin, cout]; with ``sink`` (the parameter's slice of the gradient arena) the kernel accumulates into it."""
     L = _lib.lib()
@@ -74,14 +175,18 @@ class SparseConvFunction(torch.autograd.Function):
         w = _c(weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).to(F32))
         cout = w.shape[2]
         cin = w.shape[1]
-        if mode in ("subm", "down"):
-            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False))
-        elif mode == "up":  # roles swapped, every fine row has exactly one rule
-            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False))
-        else:
+        if mode not in ("subm", "down", "up"):
             raise ValueError(mode)
+        table = rb.os_up if mode == "up" else rb.os
+        if _os_usable(table, x, cin, cout) and table.n_dst == n_out:
+            out = _timed("fwd", rb, cin, cout, lambda: _apply_os(x, weight, w, table, cout, False, False))
+        elif mode in ("subm", "down"):
+            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False))
+        else:  # roles swapped, every fine row has exactly one rule
+            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False))
         ctx.save_for_backward(x, w)
         ctx.rb, ctx.mode, ctx.n_in, ctx.wshape = rb, mode, n_in, weight.shape
+        ctx.weight = weight
         ctx.wparam = weight if (weight.dtype == F32 and weight.is_contiguous()
                                 and gradsink.claim(ctx, weight, ctx.needs_input_grad[1])) else None
         return out
@@ -93,7 +198,13 @@ class SparseConvFunction(torch.autograd.Function):
         dout = _c(dout.to(F32))
         cin, cout = w.shape[1], w.shape[2]
         dx = dw = None
-        if ctx.needs_input_grad[0]:
+        # data gradient = the same engine over the transposed weights: subm by symmetry (k,i,o) <-> (26-k,o,i) on the same
+        # table; down (dX[child] = dOut[parent] . W[k]^T) on the fine-row table; up (dX[parent] = sum dOut[child] . W[k]^T)
+        # on the coarse-row table
+        table = rb.os if mode in ("subm", "up") else rb.os_up
+        if ctx.needs_input_grad[0] and _os_usable(table, dout, cout, cin) and table.n_dst == n_in:
+            dx = _timed("dX", rb, cin, cout, lambda: _apply_os(dout, ctx.weight, w, table, cin, True, mode == "subm"))
+        elif ctx.needs_input_grad[0]:
             if mode == "subm":  # symmetric rulebook: (k,i,o) <-> (26-k,o,i)
                 dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True))
             elif mode == "down":

@@ -107,6 +107,40 @@ def test_sparse_conv_linearity_and_adjoint_at_full_size(cin, cout):
     assert abs(lhs - rhs) <= 1e-5 * (abs(lhs) + float(fx.detach().double().norm() * gout.double().norm()) * 1e-2), (lhs, rhs)
 
 
+@pytest.mark.parametrize("level,cin,cout", [(0, 16, 16), (1, 64, 32), (2, 96, 48)])
+def test_output_stationary_engine_equals_rulebook_engine_at_full_size(level, cin, cout):
+    """At the bench's size (16 NuScenes-shaped scenes) the output-stationary engine (csrc/osconv.hip: rows sorted by
+    neighbour mask, offsets accumulated in ascending k in registers) and the k-major rulebook engine + CSR reduce
+    (csrc/spconv.hip) must give the same forward and data-gradient rows: bit-identical on the split-product widths (same
+    products, same order), <= 2e-6 relative where the rulebook engine uses the exact-fp32 MFMA (below 32 input channels)."""
+    from mm2d3d_amd.scn import ops
+
+    dev = _dev()
+    md, _ = _metadata("nuscenes", 16)
+    lv = md.levels[level]
+    assert lv.subm.os is not None, "the level is large enough for the output-stationary table"
+    g = torch.Generator(device="cpu").manual_seed(level)
+    x = torch.randn(lv.n, cin, generator=g).to(dev)
+    w = torch.nn.Parameter((torch.randn(27, 1, cin, cout, generator=g) * (2.0 / cin / 27) ** 0.5).to(dev))
+    gout = torch.randn(lv.n, cout, generator=g).to(dev)
+    res = []
+    try:
+        for on in (True, False):
+            ops.OS_ENABLED = on
+            xx = x.clone().requires_grad_(True)
+            y = ops.SparseConvFunction.apply(xx, w, lv.subm, "subm", lv.n, lv.n)
+            (gx,) = torch.autograd.grad(y, xx, gout)
+            res.append((y.detach(), gx))
+    finally:
+        ops.OS_ENABLED = True
+    (y1, g1), (y0, g0) = res
+    if cin >= 32 and cout >= 32:
+        assert torch.equal(y1, y0) and torch.equal(g1, g0)
+    else:
+        assert float((y1 - y0).abs().max()) <= 2e-6 * float(y0.abs().max())
+        assert float((g1 - g0).abs().max()) <= 2e-6 * float(g0.abs().max())
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 152, 240), (128, 128, 76, 120), (256, 256, 38, 60), (512, 512, 19, 30), (192, 64, 152, 240)])
 def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W):
     """The persistent 3x3 kernels at the joint-pass shapes of the bench (B = 16): forward and data gradient against torch's

@@ -96,8 +96,20 @@ def _pair(mod_ref, mod_hip):
     return mod_ref, mod_hip.cuda()
 
 
+@pytest.fixture(params=["rulebook", "os"])
+def engine(request):
+    """Both sparse-conv engine families: the k-major rulebook engines (csrc/spconv.hip) and the output-stationary engine
+    (csrc/osconv.hip), which the product only picks for levels of >= 200k rows: forced on here at test sizes."""
+    from mm2d3d_amd.scn import metadata
+
+    old = (metadata.OS_MIN_ROWS, metadata.OS_BUILD_UP)
+    metadata.OS_MIN_ROWS, metadata.OS_BUILD_UP = (0, True) if request.param == "os" else (1 << 60, False)
+    yield request.param
+    metadata.OS_MIN_ROWS, metadata.OS_BUILD_UP = old
+
+
 @pytest.mark.parametrize("cin,cout", [(3, 16), (16, 16), (32, 16), (16, 32), (48, 48), (5, 7), (64, 192), (192, 96), (80, 80), (112, 48)])
-def test_conv_ops_forward_backward(cin, cout):
+def test_conv_ops_forward_backward(cin, cout, engine):
     from mm2d3d_amd import scn
 
     dev = _dev()
@@ -168,7 +180,7 @@ def test_batchnorm_forward_backward_running_stats(C, leak):
 
 
 @pytest.mark.parametrize("residual", [False, True])
-def test_net3d_forward_backward_vs_oracle(residual):
+def test_net3d_forward_backward_vs_oracle(residual, engine):
     """Forward: logits within 1e-3 of the fp32 oracle (north_star).  Backward: this 50-layer BN network's fp32
     gradients are only conditioned to ~1e-2: the fp32 oracle differs from the fp64 oracle by that much, and a 1-ulp
     perturbation of the input features moves the oracle's own gradients by as much (ReLU masks and BN statistics amplify
