@@ -42,6 +42,7 @@ struct OsP {
   const uint32_t* tmask;
   int64_t npad;
   int ld_in, Cin, ld_out, nq, ncb_tot;
+  int cb_first;  // first output-channel block of this launch (k-parallel form: one launch per group of <= 4 blocks)
   int dbg;  // bring-up switches (MM_OS_DBG): 1 = no MFMA, 2 = no row gathers (row 0), 4 = no split
 };
 
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
   constexpr int NW = 4, MT = 64;
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [NW producers][4 sub-blocks][NCB][64 lanes] f32x4
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
-  const int t = gridDim.x - 1 - blockIdx.x, cb0 = blockIdx.y * NCB;
+  const int t = gridDim.x - 1 - blockIdx.x, cb0 = p.cb_first;
   const int nq = p.nq;
   const int64_t j0 = (int64_t)t * MT + rl;
   f32x4 acc[NCB];
@@ -473,19 +474,26 @@ int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_o
   while (n_tiles * nchunk < 512 && (ncb / nchunk) % 2 == 0) nchunk *= 2;
   OsP p;
   p.in = in, p.out = out, p.Wf = (const u32x4*)Wf, p.dst = dst, p.nbrp = nbrp, p.tmask = tmask;
+  p.cb_first = 0;
   p.dbg = getenv("MM_OS_DBG") ? atoi(getenv("MM_OS_DBG")) : 0;
   p.npad = n_tiles * tile_rows, p.ld_in = ld_in, p.Cin = Cin, p.ld_out = ld_out, p.nq = (Cin + 31) / 32, p.ncb_tot = ncb;
   int rc;
   static const int v3 = getenv("MM_OS_V3") ? atoi(getenv("MM_OS_V3")) : 0;
   if (tile_rows == 64 && !v3) {  // k-parallel form: at most 4 output-channel blocks per workgroup (64 KB of LDS partials)
-    nchunk = 1;
-    while (ncb % nchunk != 0 || ncb / nchunk > 4) nchunk++;
-    while (n_tiles * nchunk < 1024 && (ncb / nchunk) % 2 == 0) nchunk *= 2;
-    switch (ncb / nchunk) {
-      case 1: rc = launch_os4<1>(p, n_tiles, nchunk, s); break;
-      case 2: rc = launch_os4<2>(p, n_tiles, nchunk, s); break;
-      case 3: rc = launch_os4<3>(p, n_tiles, nchunk, s); break;
-      default: rc = launch_os4<4>(p, n_tiles, nchunk, s); break;
+    int parts = (ncb + 3) / 4;
+    // small levels: more, narrower launches (each re-gathers its rows) until the grid covers the chip
+    while (n_tiles * parts < 1024 && parts < ncb && (ncb + parts) / (parts + 1) >= 2) parts++;
+    rc = MM_OK;
+    for (int i = 0, cb = 0; i < parts && rc == MM_OK; i++) {
+      const int w = (ncb - cb + (parts - i) - 1) / (parts - i);  // near-equal parts, the wider ones first
+      p.cb_first = cb;
+      switch (w) {
+        case 1: rc = launch_os4<1>(p, n_tiles, 1, s); break;
+        case 2: rc = launch_os4<2>(p, n_tiles, 1, s); break;
+        case 3: rc = launch_os4<3>(p, n_tiles, 1, s); break;
+        default: rc = launch_os4<4>(p, n_tiles, 1, s); break;
+      }
+      cb += w;
     }
   } else if (tile_rows == 128) rc = dispatch_os<8>(ncb / nchunk, p, n_tiles, nchunk, s);
   else rc = dispatch_os<4>(ncb / nchunk, p, n_tiles, nchunk, s);
