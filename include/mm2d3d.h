@@ -76,6 +76,29 @@ size_t mm_rulebook_ws_bytes(int64_t n_out, int K);
 int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, int32_t* rout, int32_t* offsets,
                         int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes, mm_stream_t stream);
 
+/* ---------------------------------------------------------------- GPU-side sample preparation (csrc/dataprep.hip)
+ * The loader-side numpy code of the reference for a whole batch of scenes, bit-exact with it:
+ * augment_and_scale_3d + int cast + range mask (lib/utils/augmentation_3d.py:83-158, nuscenes_dataloader.py:323-332),
+ * pixel indices / last-write-wins depth and 2D label maps / fliplr / RGB point features (nuscenes_dataloader.py:262-283,
+ * 291-297,361-364), collate with the batch index as last coordinate column (lib/dataset/__init__.py:63-68,91-96).
+ * The random draws (rotation matrix, translation fractions, flips) are made on the host in the reference's order. */
+size_t mm_voxelize_ws_bytes(int64_t n_total, int B);
+/* points [n_total][3] fp32 (scene b = rows scene_off[b]..scene_off[b+1]); rot [B][9] fp32; u [B][3] fp64 (rand(3) draws)
+ * -> locs int64 [kept][4] (x,y,z,scene), keep int32 [kept] (original rows, order preserved), counts int32 [B+1] (per scene,
+ * total), min_value fp32 [B][3], offset fp64 [B][3] */
+int mm_voxelize_batch(const float* points, const int32_t* scene_off_dev, const int32_t* scene_off_host, int B, const float* rot,
+                      const double* u, int transl, float scale, int full_scale, int64_t* locs, int32_t* keep, int32_t* counts,
+                      float* min_value, double* offset, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* points_img [n_total][2] fp32 (row, col), depth_vals [n_total] -> img_indices int64 [n_total][2], depth fp32 [B][H][W],
+ * seg2d fp64 [B][H][W] (optional, needs labels); flip [B] bytes (optional); winner int32 [B*H*W] scratch; err: 1 = outside */
+int mm_project_batch(const float* points_img, const float* depth_vals, const int64_t* labels, const int32_t* scene_off_dev,
+                     const int32_t* scene_off_host, int B, int H, int W, const uint8_t* flip, int64_t* img_indices, float* depth,
+                     double* seg2d, int32_t* winner, int32_t* err, mm_stream_t stream);
+/* per-point arrays of the kept rows; feats[p][c] = image[scene(p)][c][row][col] (image fp32 [B][C][H][W]) */
+int mm_collect_points(const int32_t* keep, const int32_t* n_keep_dev, int64_t n_bound, const int64_t* locs, const int64_t* img_indices,
+                      const int64_t* labels, const float* image, int C, int H, int W, const float* points, int64_t* img_indices_out,
+                      int64_t* labels_out, float* feats_out, float* points_out, mm_stream_t stream);
+
 /* ---------------------------------------------------------------- sparse convolution engines (csrc/spconv.hip)
  * scn.SubmanifoldConvolution / Convolution / Deconvolution forward and backward. */
 size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K);

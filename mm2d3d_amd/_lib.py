@@ -35,6 +35,10 @@ _PROTOS = {
     "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
     "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_voxelize_ws_bytes": (sz, [i64, i32]),
+    "mm_voxelize_batch": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_project_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "mm_collect_points": (i32, [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mm_up_neighbors": (i32, [vp, i64, vp, vp, vp]),
     "mm_os_table_ws_bytes": (sz, [i64, i32]),
     "mm_os_table_build": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, sz, vp]),

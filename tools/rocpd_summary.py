@@ -17,6 +17,16 @@ def short(name):
 def main():
     db, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "")
     csv = "--csv" in sys.argv
+    if "--by-grid" in sys.argv:  # per (kernel, grid size): calls, average / total duration - which layer sizes cost the time
+        con = sqlite3.connect(db)
+        rows = con.execute("select name, grid_x, grid_y, grid_z, workgroup_x, count(*), avg(duration), sum(duration) from kernels "
+                           "group by name, grid_x, grid_y, grid_z order by sum(duration) desc").fetchall()
+        tot = sum(r[7] for r in rows) or 1
+        for name, gx, gy, gz, wx, n, avg, sm in rows:
+            if flt and flt not in name:
+                continue
+            print(f"{short(name)[:60]:60s} wgs {gx // max(wx, 1):7d}x{gy}x{gz} calls {n:5d} avg {avg / 1e3:9.1f} us total {sm / 1e6:8.2f} ms {100 * sm / tot:5.1f}%")
+        return
     con = sqlite3.connect(db)
     cur = con.cursor()
     rows = cur.execute("select name, count(*), avg(duration), min(duration), max(duration), sum(duration), max(vgpr_count), "
