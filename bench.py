@@ -86,10 +86,17 @@ def conv_roofline(tm, batch, dev):
         k[1] += r["e0"].elapsed_time(r["e1"])
         k[2] += 1
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    traffic = None  # PMC bytes per step, measured offline with rocprofv3 --pmc (profiles/r01/traffic_3d.json) for this workload
-    tpath = os.path.join(ROOT, "profiles", "r01", "traffic_3d.json")
-    if os.path.exists(tpath) and abs(alg_bytes / 17936522196 - 1.0) < 0.02:
-        traffic = json.load(open(tpath))["bytes_per_step"]
+    # PMC bytes per step: an OFFLINE rocprofv3 --pmc measurement of this workload (separate FETCH_SIZE / WRITE_SIZE passes,
+    # tools/pmc_traffic.py), taken from the newest profiles/rNN/traffic_3d.json whose algorithmic byte count matches this run's
+    traffic, traffic_source = None, None
+    import glob
+
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_3d.json")), reverse=True):
+        rec = json.load(open(tpath))
+        if abs(alg_bytes / float(rec.get("algorithmic_bytes_per_step", 1)) - 1.0) < 0.02:
+            traffic = rec["bytes_per_step"]
+            traffic_source = "offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, " + os.path.relpath(tpath, ROOT)
+            break
     if os.environ.get("MM_BENCH_LAYERS"):
         for r in rec[: len(rec) // 2 if os.environ["MM_BENCH_LAYERS"] == "half" else len(rec)]:
             t = r["e0"].elapsed_time(r["e1"])
@@ -97,8 +104,9 @@ def conv_roofline(tm, batch, dev):
                   f"{r['bytes']/t/1e6:8.1f} GB/s  {2*r['R']*r['cin']*r['cout']/t/1e9:6.1f} TF/s", file=sys.stderr)
     return {
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-        "traffic": traffic,
-        "kernel": "sparse-conv engines: k_gather_gemm<*> / k_gather_gemm_s3<*> + k_csr_reduce (fwd, dX), k_dw_direct<*> / k_dw_direct_s3<*> + k_dw_reduce (dW)",
+        "traffic": traffic, "traffic_source": traffic_source,
+        "kernel": "sparse-conv engines: k_osconv4<*> (fwd, dX of the levels >= 200k rows), k_gather_gemm<*> / k_gather_gemm_s3<*> + "
+                  "k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> + k_dw_reduce (dW)",
         "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
         "by_pass": {k: {"GB/s": round(v[0] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else 0.0, "ms": round(v[1], 3), "calls": v[2]}
                     for k, v in by_kind.items()},
@@ -170,8 +178,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes", type=int, default=8, help="scenes per domain per GPU")
     ap.add_argument("--no-extras", action="store_true", help="skip the roofline / cpu_baseline legs")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
-                    help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes; "
+                         "c5 = configs[4]: 10k-pt vKITTI-shaped source + KITTI-shaped target, 8/GPU, 16-bit sparse activations")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -196,15 +205,25 @@ def main():
 
     from mm2d3d_amd.synthetic import make_batch
 
+    down_src = 0
     if a.workload == "c4":
         shape, ncls, B = "kitti", 10, (a.scenes if a.scenes != 8 else 4)
         tm = build_trainer(dev, num_classes=10, class_weights=[1.0] * 10)
+    elif a.workload == "c5":
+        # source = KITTI-shaped sweeps downsampled to 10,000 points (datasets/virtual_kitti_semantic_kitti.yaml:27),
+        # target = full KITTI-shaped scans; sparse rows in bf16 between the stem and the OutputLayer (fp32 accumulation)
+        from mm2d3d_amd import scn
+
+        scn.set_activation_dtype(torch.bfloat16)
+        shape, ncls, B, down_src = "kitti", 6, a.scenes, 10000
+        tm = build_trainer(dev)
     else:
         shape, ncls, B = "nuscenes", 6, a.scenes
         tm = build_trainer(dev)
+    cid = {"c2": (2, 3), "c4": (4, 5), "c5": (6, 7)}[a.workload]
     batch = {
-        "source": make_batch(2 if a.workload == "c2" else 4, B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True),
-        "target": make_batch(3 if a.workload == "c2" else 5, B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True),
+        "source": make_batch(cid[0], B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True, downsample=down_src),
+        "target": make_batch(cid[1], B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True),
     }
     n_pts = batch["source"]["x"][0].shape[0] + batch["target"]["x"][0].shape[0]
 
@@ -242,8 +261,15 @@ def main():
                    "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)],
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
     }
-    if a.workload != "c2":
+    if a.workload == "c4":
         out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
+    if a.workload == "c5":
+        out["config"]["workload"] = ("BASELINE.json configs[4] shape: source = KITTI-shaped sweeps downsampled to 10,000 pts, target = KITTI-shaped "
+                                     "121,600-pt scans, 480x302, sparse rows bf16 between the stem and the OutputLayer, fp32 accumulation "
+                                     "(not the headline)")
+        out["dtype"] = "bf16 MFMA, fp32 accumulate (2D branch) + bf16 sparse activations / fp32 accumulate and statistics (3D branch)"
+    if rank == 0 and world == 1 and not a.no_extras and a.workload == "c5":
+        out["roofline"] = conv_roofline(tm, batch, dev)
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c2":
         print(f"[bench] timed region done: {ms:.2f} ms/step; roofline leg ...", file=sys.stderr, flush=True)
         out["roofline"] = conv_roofline(tm, batch, dev)

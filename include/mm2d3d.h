@@ -143,6 +143,21 @@ int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_o
                        const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
                        mm_stream_t stream);
 
+/* 16-bit activation mode (BASELINE.json configs[4]): the sparse rows are bf16 (in and out), the
+ * weights one bf16 term per element, accumulation fp32 in ascending k.  Same tables as above, tile_rows = 64. */
+size_t mm_spconv_os_pack_bytes_bf16(int K, int Cin, int Cout);
+int mm_spconv_os_pack_bf16(const float* W, int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin, int Cout, void* Wf,
+                           mm_stream_t stream);
+int mm_spconv_os_pack_batch_bf16(const int64_t* descs_dev, int n_desc, int64_t total_blocks, mm_stream_t stream);
+int mm_spconv_os_apply_bf16(const void* in, int ld_in, int Cin, void* out, int ld_out, int Cout, const void* Wf, int K,
+                            const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
+                            mm_stream_t stream);
+/* dW[k][ci][co] (+)= sum over the rules of bucket k of in[src][ci] * dout[dst][co]; in / dout bf16 rows, dW fp32;
+ * workspace of mm_spconv_dw_ws_bytes */
+int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+                      const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                      size_t ws_bytes, mm_stream_t stream);
+
 /* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
  * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */
 size_t mm_bn_ws_bytes(int C);
@@ -158,6 +173,17 @@ int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weig
 int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* the same three entry points over bf16 rows (16-bit activation mode): x / y / dy / dx bf16 [N, C] (ld in elements),
+ * statistics and parameters fp32 */
+int mm_bn_fwd_train_bf16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
+                         float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn_fwd_eval_bf16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                        const float* running_mean, const float* running_var, float eps, float leak, void* y, int ld_y,
+                        mm_stream_t stream);
+int mm_bn_bwd_bf16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+                   const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
+                   float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- per-point rows (csrc/point.hip) */
 size_t mm_point_ws_bytes(int Cin, int Cout);

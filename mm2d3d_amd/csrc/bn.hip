@@ -21,6 +21,26 @@ struct Vec<1> {
   typedef float type;
 };
 
+// bf16 rows (the 16-bit activation mode): 4 elements = one 8-byte access, arithmetic stays fp32
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ inline void ldv(const __bf16* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    bf16x4 t = *(const bf16x4*)p;
+    v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+  } else {
+    v[0] = (float)*p;
+  }
+}
+template <int VEC>
+__device__ inline void stv(__bf16* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *(bf16x4*)p = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  } else {
+    *p = (__bf16)v[0];
+  }
+}
+
 template <int VEC>
 __device__ inline void ldv(const float* p, float (&v)[VEC]) {
   if constexpr (VEC == 4) {
@@ -42,8 +62,8 @@ __device__ inline void stv(float* p, const float (&v)[VEC]) {
 // partial[block][0][C] = sum a, partial[block][1][C] = sum b  where (a, b) are produced by F per element
 // MODE 0: a = x, b = x*x            (forward statistics)
 // MODE 1: a = dy', b = dy' * xhat    (backward reductions), dy' = dy * act'(y)
-template <int VEC, int MODE>
-__global__ __launch_bounds__(T) void k_bn_reduce(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
+template <int VEC, int MODE, typename E>
+__global__ __launch_bounds__(T) void k_bn_reduce(const E* __restrict__ x, int ld_x, const E* __restrict__ dy,
                                                   int ld_dy, int64_t N, int C, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ weight,
                                                   const float* __restrict__ bias, float leak,
@@ -187,11 +207,11 @@ __global__ __launch_bounds__(64) void k_bn_finalize_bwd(const double* __restrict
 constexpr int APPLY_ROWS = 8;  // rows per thread in the apply kernels (parameters live in registers)
 
 // y = act((x - mean) * invstd * w + b)
-template <int VEC>
-__global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int ld_x, int64_t N, int C,
+template <int VEC, typename E>
+__global__ __launch_bounds__(T) void k_bn_apply(const E* __restrict__ x, int ld_x, int64_t N, int C,
                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
                                                  int invstd_is_var, float eps, const float* __restrict__ weight,
-                                                 const float* __restrict__ bias, float leak, float* __restrict__ y,
+                                                 const float* __restrict__ bias, float leak, E* __restrict__ y,
                                                  int ld_y, int64_t Ns, int ab0) {
   const int CV = C / VEC;
   const int rs = T / CV;
@@ -226,12 +246,12 @@ __global__ __launch_bounds__(T) void k_bn_apply(const float* __restrict__ x, int
 }
 
 // dx = w*invstd * (dy' - sum_dy/N - xhat * sum_dy_xhat/N)
-template <int VEC>
-__global__ __launch_bounds__(T) void k_bn_bwd_apply(const float* __restrict__ x, int ld_x, const float* __restrict__ dy,
+template <int VEC, typename E>
+__global__ __launch_bounds__(T) void k_bn_bwd_apply(const E* __restrict__ x, int ld_x, const E* __restrict__ dy,
                                                      int ld_dy, int64_t N, int C, const float* __restrict__ mean,
                                                      const float* __restrict__ invstd, const float* __restrict__ weight,
                                                      const float* __restrict__ bias, float leak,
-                                                     const float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dx,
+                                                     const float* __restrict__ sums /*[G][2][C]*/, E* __restrict__ dx,
                                                      int ld_dx, int64_t Ns, int ab0) {
   const int CV = C / VEC;
   const int rs = T / CV;
@@ -287,10 +307,6 @@ inline int stat_blocks(int64_t N, int C, int VEC) {
 }
 }  // namespace
 
-extern "C" {
-
-size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
-
 static void split_blocks(int64_t N, int64_t& Ns, int C, int VEC, bool stats, int& b0, int& b1) {
   if (Ns <= 0 || Ns >= N) Ns = N;
   if (stats) {
@@ -309,8 +325,9 @@ static void split_blocks(int64_t N, int64_t& Ns, int C, int VEC, bool stats, int
 // training forward: batch statistics over the N rows; running stats updated in place (scn "momentum" = keep fraction).
 // Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step) are
 // normalised with their OWN statistics; Ns = N (or 0): ordinary single batch.  save_mean / save_invstd: [G][C].
-int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
-                    float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
+template <typename E>
+static int bn_fwd_train(const E* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+                    float* running_mean, float* running_var, float eps, float momentum, float leak, E* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_y >= C, "bn_fwd: bad shape C=%d", C);
   if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
@@ -318,50 +335,52 @@ int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, cons
     return MM_ERR_WORKSPACE;
   }
   double* partial = (double*)ws;
-  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % (4 * sizeof(E)) == 0);
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
-    hipLaunchKernelGGL((k_bn_reduce<4, 0>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((k_bn_reduce<4, 0, E>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, (const E*)nullptr, 0, N, C, nullptr, nullptr, nullptr,
                        nullptr, 0.f, partial, Ns, nb0);
   else
-    hipLaunchKernelGGL((k_bn_reduce<1, 0>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, nullptr, 0, N, C, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL((k_bn_reduce<1, 0, E>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, (const E*)nullptr, 0, N, C, nullptr, nullptr, nullptr,
                        nullptr, 0.f, partial, Ns, nb0);
   hipLaunchKernelGGL(k_bn_finalize_fwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
                      save_mean, save_invstd);
   if (N > 0) {
     split_blocks(N, Ns, C, v4 ? 4 : 1, false, ab0, ab1);
     if (v4)
-      hipLaunchKernelGGL(k_bn_apply<4>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, N, C, save_mean, save_invstd, 0, eps, weight, bias,
+      hipLaunchKernelGGL((k_bn_apply<4, E>), dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, N, C, save_mean, save_invstd, 0, eps, weight, bias,
                          leak, y, ld_y, Ns, ab0);
     else
-      hipLaunchKernelGGL(k_bn_apply<1>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, N, C, save_mean, save_invstd, 0, eps, weight, bias,
+      hipLaunchKernelGGL((k_bn_apply<1, E>), dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, N, C, save_mean, save_invstd, 0, eps, weight, bias,
                          leak, y, ld_y, Ns, ab0);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
-                   const float* running_mean, const float* running_var, float eps, float leak, float* y, int ld_y,
+template <typename E>
+static int bn_fwd_eval(const E* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                   const float* running_mean, const float* running_var, float eps, float leak, E* y, int ld_y,
                    hipStream_t s) {
   MM_CHECK_ARG(C > 0 && ld_x >= C && ld_y >= C, "bn_eval: bad shape");
   if (N == 0) return MM_OK;
-  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+  const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % (4 * sizeof(E)) == 0);
   const int ab = (int)apply_blocks(N, C, v4 ? 4 : 1);
   if (v4)
-    hipLaunchKernelGGL(k_bn_apply<4>, dim3(ab), dim3(T), 0, s, x, ld_x, N, C, running_mean, running_var, 1, eps, weight, bias, leak, y,
+    hipLaunchKernelGGL((k_bn_apply<4, E>), dim3(ab), dim3(T), 0, s, x, ld_x, N, C, running_mean, running_var, 1, eps, weight, bias, leak, y,
                        ld_y, N, ab);
   else
-    hipLaunchKernelGGL(k_bn_apply<1>, dim3(ab), dim3(T), 0, s, x, ld_x, N, C, running_mean, running_var, 1, eps, weight, bias, leak, y,
+    hipLaunchKernelGGL((k_bn_apply<1, E>), dim3(ab), dim3(T), 0, s, x, ld_x, N, C, running_mean, running_var, 1, eps, weight, bias, leak, y,
                        ld_y, N, ab);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
 // training backward; dweight/dbias may be null; accumulate != 0 adds into them; Ns and [G][C] statistics as in the forward
-int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
-              const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
+template <typename E>
+static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+              const float* bias, const float* save_mean, const float* save_invstd, float leak, E* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_dy >= C && ld_dx >= C, "bn_bwd: bad shape");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
@@ -372,27 +391,69 @@ int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, i
   double* partial = (double*)ws;
   float* sums = (float*)((char*)ws + need);
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) &&
-                  (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % 16 == 0);
+                  (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % (4 * sizeof(E)) == 0);
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
-    hipLaunchKernelGGL((k_bn_reduce<4, 1>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+    hipLaunchKernelGGL((k_bn_reduce<4, 1, E>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
                        bias, leak, partial, Ns, nb0);
   else
-    hipLaunchKernelGGL((k_bn_reduce<1, 1>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+    hipLaunchKernelGGL((k_bn_reduce<1, 1, E>), dim3(nb0 + nb1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
                        bias, leak, partial, Ns, nb0);
   hipLaunchKernelGGL(k_bn_finalize_bwd, dim3(C), dim3(64), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   if (N > 0) {
     split_blocks(N, Ns, C, v4 ? 4 : 1, false, ab0, ab1);
     if (v4)
-      hipLaunchKernelGGL(k_bn_bwd_apply<4>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+      hipLaunchKernelGGL((k_bn_bwd_apply<4, E>), dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
                          bias, leak, sums, dx, ld_dx, Ns, ab0);
     else
-      hipLaunchKernelGGL(k_bn_bwd_apply<1>, dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
+      hipLaunchKernelGGL((k_bn_bwd_apply<1, E>), dim3(ab0 + ab1), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, C, save_mean, save_invstd, weight,
                          bias, leak, sums, dx, ld_dx, Ns, ab0);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;
+}
+
+extern "C" {
+
+size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
+
+
+int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+                    float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
+                    float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+  return bn_fwd_train<float>(x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak, y, ld_y, save_mean,
+                             save_invstd, ws, ws_bytes, s);
+}
+int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                   const float* running_mean, const float* running_var, float eps, float leak, float* y, int ld_y,
+                   hipStream_t s) {
+  return bn_fwd_eval<float>(x, ld_x, N, C, weight, bias, running_mean, running_var, eps, leak, y, ld_y, s);
+}
+int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+              const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
+              float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  return bn_bwd<float>(x, ld_x, dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak, dx, ld_dx, dweight, dbias,
+                       accumulate, ws, ws_bytes, s);
+}
+// the same three entry points over bf16 rows (16-bit activation mode): x / y / dy / dx are bf16 [N, C], statistics and
+// parameters stay fp32
+int mm_bn_fwd_train_bf16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+                         float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
+                         float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+  return bn_fwd_train<__bf16>((const __bf16*)x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak,
+                              (__bf16*)y, ld_y, save_mean, save_invstd, ws, ws_bytes, s);
+}
+int mm_bn_fwd_eval_bf16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                        const float* running_mean, const float* running_var, float eps, float leak, void* y, int ld_y,
+                        hipStream_t s) {
+  return bn_fwd_eval<__bf16>((const __bf16*)x, ld_x, N, C, weight, bias, running_mean, running_var, eps, leak, (__bf16*)y, ld_y, s);
+}
+int mm_bn_bwd_bf16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+                   const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
+                   float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  return bn_bwd<__bf16>((const __bf16*)x, ld_x, (const __bf16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
+                        (__bf16*)dx, ld_dx, dweight, dbias, accumulate, ws, ws_bytes, s);
 }
 
 }  // extern "C"

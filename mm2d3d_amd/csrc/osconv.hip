@@ -253,9 +253,13 @@ __global__ __launch_bounds__(NW * 64) void k_osconv(OsP p) {
 // then publishes its four partial sub-block results in LDS; after one barrier wave w adds the four partials of sub-block w
 // in wave order = ascending k (canonical order A.8 iv; bit-identical to "tmp[rule] then CSR reduce") into its final
 // accumulators.  Two barriers per FOUR offsets and no dependent-latency chain longer than one offset's q loop.
-template <int NCB>
+// BF: the 16-bit activation mode - rows are bf16 (in and out), the weights one bf16 term per
+// element ([K][nq][ncb][64 lanes] x 16 B fragments), one MFMA per block and no operand splitting; accumulation stays fp32.
+template <int NCB, bool BF>
 __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
   constexpr int NW = 4, MT = 64;
+  constexpr int NTW = BF ? 1 : 3;             // bf16 terms per weight
+  constexpr int FRB = NTW * 1024 / 16;        // 16-B pieces per (k, q, cb) fragment block
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [NW producers][4 sub-blocks][NCB][64 lanes] f32x4
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
   const int t = gridDim.x - 1 - blockIdx.x, cb0 = p.cb_first;
@@ -283,37 +287,46 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
       for (int sb = 0; sb < 4; sb++) ids[sb] = p.nbrp[(int64_t)myk * p.npad + j0 + sb * 16];
 #pragma unroll
       for (int sb = 0; sb < 4; sb++) pres[sb] = __ballot(ids[sb] >= 0) != 0ull;
-      const u32x4* wk = p.Wf + ((int64_t)myk * nq * p.ncb_tot + cb0) * (FRAG_B / 16) + lane;
+      const u32x4* wk = p.Wf + ((int64_t)myk * nq * p.ncb_tot + cb0) * FRB + lane;
       // rows without this neighbour read a zero line instead (pointer select: cheaper than zeroing eight loaded values)
-      const float* rows[4];
+      constexpr int ES = BF ? 2 : 4;  // bytes per input element
+      const char* rows[4];
 #pragma unroll
-      for (int sb = 0; sb < 4; sb++) rows[sb] = ids[sb] >= 0 ? p.in + (int64_t)ids[sb] * p.ld_in + sl * 8 : nullptr;
+      for (int sb = 0; sb < 4; sb++)
+        rows[sb] = ids[sb] >= 0 ? (const char*)p.in + ((int64_t)ids[sb] * p.ld_in + sl * 8) * ES : nullptr;
       for (int q = 0; q < nq; q++) {
-        bf16x8 wt[NCB][3];
+        bf16x8 wt[NCB][NTW];
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
-          for (int n = 0; n < 3; n++) wt[cb][n] = __builtin_bit_cast(bf16x8, wk[((int64_t)q * p.ncb_tot + cb) * (FRAG_B / 16) + n * 64]);
+          for (int n = 0; n < NTW; n++) wt[cb][n] = __builtin_bit_cast(bf16x8, wk[((int64_t)q * p.ncb_tot + cb) * FRB + n * 64]);
         const bool in_c = q * 32 + sl * 8 < p.Cin;  // Cin % 16 == 0: the 8 channels are inside or outside together
-        f32x4 x[4][2];
+        f32x4 x[4][BF ? 1 : 2];
 #pragma unroll
         for (int sb = 0; sb < 4; sb++) {  // unconditional loads
-          const float* r = (rows[sb] && in_c) ? rows[sb] + q * 32 : g_zero8;
+          const char* r = (rows[sb] && in_c) ? rows[sb] + q * 32 * ES : (const char*)g_zero8;
           x[sb][0] = *(const f32x4*)r;
-          x[sb][1] = *(const f32x4*)(r + 4);
+          if (!BF) x[sb][BF ? 0 : 1] = *(const f32x4*)(r + 16);
         }
 #pragma unroll
         for (int sb = 0; sb < 4; sb++) {
           if (pres[sb]) {
+            if constexpr (BF) {
+              const bf16x8 xb = __builtin_bit_cast(bf16x8, x[sb][0]);
+#pragma unroll
+              for (int cb = 0; cb < NCB; cb++)
+                accP[sb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][0], xb, accP[sb][cb], 0, 0, 0);
+              continue;
+            }
             bf16x8 xt[3];
-            split3(x[sb][0], x[sb][1], xt);
+            split3(x[sb][0], x[sb][BF ? 0 : 1], xt);
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
               f32x4 a = accP[sb][cb];
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][2], xt[0], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][NTW - 1], xt[0], a, 0, 0, 0);
               a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][0], xt[2], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][1], xt[1], a, 0, 0, 0);
-              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][1], xt[0], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][NTW / 2], xt[1], a, 0, 0, 0);
+              a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][NTW / 2], xt[0], a, 0, 0, 0);
               a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][0], xt[1], a, 0, 0, 0);
               a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][0], xt[0], a, 0, 0, 0);
               accP[sb][cb] = a;
@@ -336,9 +349,17 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
   }
   const int d = p.dst[j0 + wave * 16];
   if (d >= 0) {
-    float* o = p.out + (int64_t)d * p.ld_out + cb0 * 16 + sl * 4;
+    if constexpr (BF) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      __bf16* o = (__bf16*)p.out + (int64_t)d * p.ld_out + cb0 * 16 + sl * 4;
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb++) *(f32x4*)(o + cb * 16) = acc[cb];
+      for (int cb = 0; cb < NCB; cb++)
+        *(bf16x4*)(o + cb * 16) = bf16x4{(__bf16)acc[cb].x, (__bf16)acc[cb].y, (__bf16)acc[cb].z, (__bf16)acc[cb].w};
+    } else {
+      float* o = p.out + (int64_t)d * p.ld_out + cb0 * 16 + sl * 4;
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) *(f32x4*)(o + cb * 16) = acc[cb];
+    }
   }
 }
 
@@ -349,6 +370,7 @@ struct PackD {  // 12 x int64: the layout of the device descriptor table of mm_s
   int64_t W, Wf, K, Cin, Cout, nq, ncb, w_kstride, s_ci, s_co, kflip, blk_end;
 };
 
+template <int NT>
 __device__ inline void pack_one(const PackD& d, int64_t e) {
   const int64_t total = d.K * d.nq * d.ncb * 512;
   if (e >= total) return;
@@ -361,23 +383,25 @@ __device__ inline void pack_one(const PackD& d, int64_t e) {
   float r = 0.f;
   if (ci < d.Cin && co < d.Cout)
     r = ((const float*)d.W)[(d.kflip ? d.K - 1 - k : k) * d.w_kstride + (int64_t)ci * d.s_ci + (int64_t)co * d.s_co];
-  __bf16* o = (__bf16*)d.Wf + (e >> 9) * 1536 + lane * 8 + j;
+  __bf16* o = (__bf16*)d.Wf + (e >> 9) * (512 * NT) + lane * 8 + j;
 #pragma unroll
-  for (int n = 0; n < 3; n++) {
+  for (int n = 0; n < NT; n++) {
     const __bf16 h = (__bf16)r;
     o[n * 512] = h;
     r -= (float)h;
   }
 }
 
-__global__ __launch_bounds__(256) void k_os_pack(PackD d) { pack_one(d, (int64_t)blockIdx.x * 256 + threadIdx.x); }
+template <int NT>
+__global__ __launch_bounds__(256) void k_os_pack(PackD d) { pack_one<NT>(d, (int64_t)blockIdx.x * 256 + threadIdx.x); }
 
+template <int NT>
 __global__ __launch_bounds__(256) void k_os_pack_batch(const PackD* __restrict__ descs, int n) {
   int i = 0;
   while (i + 1 < n && (int64_t)blockIdx.x >= descs[i].blk_end) i++;
   const PackD d = descs[i];
   const int64_t blk0 = i ? descs[i - 1].blk_end : 0;
-  pack_one(d, ((int64_t)blockIdx.x - blk0) * 256 + threadIdx.x);
+  pack_one<NT>(d, ((int64_t)blockIdx.x - blk0) * 256 + threadIdx.x);
 }
 
 template <int NCB, int QS, int NW>
@@ -417,9 +441,10 @@ int dispatch_os(int ncbw, const OsP& p, int64_t n_tiles, int nchunk, hipStream_t
 }
 
 template <int NCB>
-int launch_os4(const OsP& p, int64_t n_tiles, int nchunk, hipStream_t s) {
+int launch_os4(const OsP& p, int64_t n_tiles, int nchunk, int bf, hipStream_t s) {
   constexpr int LDSB = 4 * 4 * NCB * 1024;
-  hipLaunchKernelGGL((k_osconv4<NCB>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
+  if (bf) hipLaunchKernelGGL((k_osconv4<NCB, true>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
+  else hipLaunchKernelGGL((k_osconv4<NCB, false>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
   return MM_OK;
 }
 
@@ -442,7 +467,26 @@ int mm_spconv_os_pack(const float* W, int64_t w_kstride, int s_ci, int s_co, int
                       hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= 32 && Cin > 0 && Cout > 0 && W && Wf, "spconv_os_pack: bad arguments");
   PackD d{(int64_t)W, (int64_t)Wf, K, Cin, Cout, (Cin + 31) / 32, (Cout + 15) / 16, w_kstride, s_ci, s_co, kflip, 0};
-  hipLaunchKernelGGL(k_os_pack, dim3((unsigned)mm_spconv_os_pack_blocks(K, Cin, Cout)), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_os_pack<3>, dim3((unsigned)mm_spconv_os_pack_blocks(K, Cin, Cout)), dim3(256), 0, s, d);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// one bf16 term per weight (the 16-bit activation mode): [K][nq][ncb][64 lanes] x 16 B
+size_t mm_spconv_os_pack_bytes_bf16(int K, int Cin, int Cout) {
+  return (size_t)K * ((Cin + 31) / 32) * ((Cout + 15) / 16) * 1024;
+}
+int mm_spconv_os_pack_bf16(const float* W, int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin, int Cout, void* Wf,
+                           hipStream_t s) {
+  MM_CHECK_ARG(K > 0 && K <= 32 && Cin > 0 && Cout > 0 && W && Wf, "spconv_os_pack_bf16: bad arguments");
+  PackD d{(int64_t)W, (int64_t)Wf, K, Cin, Cout, (Cin + 31) / 32, (Cout + 15) / 16, w_kstride, s_ci, s_co, kflip, 0};
+  hipLaunchKernelGGL(k_os_pack<1>, dim3((unsigned)mm_spconv_os_pack_blocks(K, Cin, Cout)), dim3(256), 0, s, d);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+int mm_spconv_os_pack_batch_bf16(const int64_t* descs_dev, int n_desc, int64_t total_blocks, hipStream_t s) {
+  MM_CHECK_ARG(descs_dev && n_desc > 0 && total_blocks > 0, "spconv_os_pack_batch_bf16: bad arguments");
+  hipLaunchKernelGGL(k_os_pack_batch<1>, dim3((unsigned)total_blocks), dim3(256), 0, s, (const PackD*)descs_dev, n_desc);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -451,7 +495,7 @@ int mm_spconv_os_pack(const float* W, int64_t w_kstride, int s_ci, int s_co, int
 // running sum of mm_spconv_os_pack_blocks; one launch packs every weight of the net
 int mm_spconv_os_pack_batch(const int64_t* descs_dev, int n_desc, int64_t total_blocks, hipStream_t s) {
   MM_CHECK_ARG(descs_dev && n_desc > 0 && total_blocks > 0, "spconv_os_pack_batch: bad arguments");
-  hipLaunchKernelGGL(k_os_pack_batch, dim3((unsigned)total_blocks), dim3(256), 0, s, (const PackD*)descs_dev, n_desc);
+  hipLaunchKernelGGL(k_os_pack_batch<3>, dim3((unsigned)total_blocks), dim3(256), 0, s, (const PackD*)descs_dev, n_desc);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -459,11 +503,16 @@ int mm_spconv_os_pack_batch(const int64_t* descs_dev, int n_desc, int64_t total_
 // out[dst[j]] = sum over the present offsets k (ascending) of in[nbrp[k][j]] . W[k]    for every position j of the table
 //   dst / nbrp / tmask: the tile table of mm_os_table_build (tile_rows in {64, 128, 256})
 //   Wf: fragments of mm_spconv_os_pack(_batch) for (K, Cin, Cout); Cin, Cout multiples of 16; in / out 16-B aligned, ld % 4 == 0
-int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, const void* Wf, int K,
+}  // extern "C"
+
+static int os_apply(int bf, const void* in_, int ld_in, int Cin, void* out_, int ld_out, int Cout, const void* Wf, int K,
                        const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
                        hipStream_t s) {
+  const float* in = (const float*)in_;
+  float* out = (float*)out_;
+  const int ea = bf ? 8 : 4;  // elements per 16 bytes
   MM_CHECK_ARG(K > 0 && K <= 32 && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, "spconv_os_apply: channels must be multiples of 16");
-  MM_CHECK_ARG(ld_in >= Cin && ld_out >= Cout && ld_in % 4 == 0 && ld_out % 4 == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)Wf) % 16) == 0,
+  MM_CHECK_ARG(ld_in >= Cin && ld_out >= Cout && ld_in % ea == 0 && ld_out % 4 == 0 && (((uintptr_t)in | (uintptr_t)out | (uintptr_t)Wf) % 16) == 0,
                "spconv_os_apply: rows must be 16-B aligned");
   MM_CHECK_ARG(tile_rows == 64 || tile_rows == 128, "spconv_os_apply: tile_rows must be 64 or 128");
   if (n_tiles == 0) return MM_OK;
@@ -479,7 +528,8 @@ int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_o
   p.npad = n_tiles * tile_rows, p.ld_in = ld_in, p.Cin = Cin, p.ld_out = ld_out, p.nq = (Cin + 31) / 32, p.ncb_tot = ncb;
   int rc;
   static const int v3 = getenv("MM_OS_V3") ? atoi(getenv("MM_OS_V3")) : 0;
-  if (tile_rows == 64 && !v3) {  // k-parallel form: at most 4 output-channel blocks per workgroup (64 KB of LDS partials)
+  MM_CHECK_ARG(!bf || tile_rows == 64, "spconv_os_apply_bf16: tile_rows must be 64");
+  if (tile_rows == 64 && (!v3 || bf)) {  // k-parallel form: at most 4 output-channel blocks per workgroup (64 KB of LDS partials)
     int parts = (ncb + 3) / 4;
     // small levels: more, narrower launches (each re-gathers its rows) until the grid covers the chip
     while (n_tiles * parts < 1024 && parts < ncb && (ncb + parts) / (parts + 1) >= 2) parts++;
@@ -488,10 +538,10 @@ int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_o
       const int w = (ncb - cb + (parts - i) - 1) / (parts - i);  // near-equal parts, the wider ones first
       p.cb_first = cb;
       switch (w) {
-        case 1: rc = launch_os4<1>(p, n_tiles, 1, s); break;
-        case 2: rc = launch_os4<2>(p, n_tiles, 1, s); break;
-        case 3: rc = launch_os4<3>(p, n_tiles, 1, s); break;
-        default: rc = launch_os4<4>(p, n_tiles, 1, s); break;
+        case 1: rc = launch_os4<1>(p, n_tiles, 1, bf, s); break;
+        case 2: rc = launch_os4<2>(p, n_tiles, 1, bf, s); break;
+        case 3: rc = launch_os4<3>(p, n_tiles, 1, bf, s); break;
+        default: rc = launch_os4<4>(p, n_tiles, 1, bf, s); break;
       }
       cb += w;
     }
@@ -500,6 +550,22 @@ int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_o
   if (rc) return rc;
   MM_LAUNCH_CHECK();
   return MM_OK;
+}
+
+
+extern "C" {
+
+int mm_spconv_os_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, const void* Wf, int K,
+                       const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
+                       hipStream_t s) {
+  return os_apply(0, in, ld_in, Cin, out, ld_out, Cout, Wf, K, dst, nbrp, tmask, n_tiles, tile_rows, s);
+}
+// 16-bit activation mode: in / out are bf16 rows (ld in elements, multiples of 8), Wf from mm_spconv_os_pack(_batch)_bf16,
+// fp32 accumulation in ascending k, tile_rows = 64
+int mm_spconv_os_apply_bf16(const void* in, int ld_in, int Cin, void* out, int ld_out, int Cout, const void* Wf, int K,
+                            const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
+                            hipStream_t s) {
+  return os_apply(1, in, ld_in, Cin, out, ld_out, Cout, Wf, K, dst, nbrp, tmask, n_tiles, tile_rows, s);
 }
 
 }  // extern "C"

@@ -200,13 +200,16 @@ __device__ inline void split8(const f32x4& a, const f32x4& b, bf16x8 (&t)[NT]) {
 // acc += x . w from the split terms (a: MFMA A operand, b: MFMA B operand), largest products last is not needed: fp32 adds
 template <int NT>
 __device__ inline f32x4 mfma_split(const bf16x8 (&a)[NT], const bf16x8 (&b)[NT], f32x4 acc) {
+  if constexpr (NT == 1) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+  }
   if (NT == 3) {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
   }
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[NT > 1 ? 1 : 0], b[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[NT > 1 ? 1 : 0], acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
   return acc;
 }
@@ -477,8 +480,9 @@ __global__ __launch_bounds__(256) void k_dw_direct(const float* __restrict__ in,
 // Split-bf16 variant (see engine G): 32 rules per v_mfma_f32_16x16x32_bf16; lane (rl = channel, sl) gathers the 8 rules
 // 8*sl .. 8*sl+7 of the group for its channel of every block, splits them into NT terms, and each (ci block, co block)
 // pair accumulates the partial products of mfma_split.
-template <int TI, int TJ, int NT>
-__global__ __launch_bounds__(256) void k_dw_direct_s3(const float* __restrict__ in, int ld_in, const float* __restrict__ dout,
+// E = __bf16 (16-bit activation mode, NT = 1): the gathered values are already bf16, nothing is split.
+template <int TI, int TJ, int NT, typename E = float>
+__global__ __launch_bounds__(256) void k_dw_direct_s3(const E* __restrict__ in, int ld_in, const E* __restrict__ dout,
                                                        int ld_do, const int32_t* __restrict__ src, const int32_t* __restrict__ dst,
                                                        int Cin, int Cout, int K, KSeg seg, int chunk, float* __restrict__ partial) {
   extern __shared__ float red[];  // [3 waves][TI*TJ][64 lanes] f32x4
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(256) void k_dw_direct_s3(const float* __restrict__ 
       f32x4 v0, v1;
 #pragma unroll
       for (int t = 0; t < 8; t++) {
-        const float x = (si[t] >= 0 && ci0 + i < ncib) ? in[(int64_t)si[t] * ld_in + (ci0 + i) * 16 + rl] : 0.f;
+        const float x = (si[t] >= 0 && ci0 + i < ncib) ? (float)in[(int64_t)si[t] * ld_in + (ci0 + i) * 16 + rl] : 0.f;
         if (t < 4) v0[t] = x;
         else v1[t - 4] = x;
       }
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(256) void k_dw_direct_s3(const float* __restrict__ 
       f32x4 v0, v1;
 #pragma unroll
       for (int t = 0; t < 8; t++) {
-        const float x = (si[t] >= 0 && co0 + j < ncob) ? dout[(int64_t)di[t] * ld_do + (co0 + j) * 16 + rl] : 0.f;
+        const float x = (si[t] >= 0 && co0 + j < ncob) ? (float)dout[(int64_t)di[t] * ld_do + (co0 + j) * 16 + rl] : 0.f;
         if (t < 4) v0[t] = x;
         else v1[t - 4] = x;
       }
@@ -755,7 +759,11 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     const int32_t* d = dst;
     if (!unique_dst) tgt = (float*)ws, ld_t = Cout, d = nullptr;
     int nch = 1;  // cout blocks per workgroup <= 8 and the staged W[k] slice <= 80 KiB (two workgroups per CU)
-    while (ncb % nch != 0 || ncb / nch > 8 || (size_t)nq3 * (ncb / nch) * 64 * 16 * nt > 80 * 1024) nch++;
+    while (nch < ncb && (ncb % nch != 0 || ncb / nch > 8 || (size_t)nq3 * (ncb / nch) * 64 * 16 * nt > 80 * 1024)) nch++;
+    if ((size_t)nq3 * (ncb / nch) * 64 * 16 * nt > 150 * 1024) {
+      mm_set_error("spconv_apply: %d input channels are too wide for the split-product engine", Cin);
+      return MM_ERR_UNSUPPORTED;
+    }
     const int ncbw = ncb / nch;
     const bool small = R < 200000;
     int tr = small ? 64 : TR;
@@ -772,6 +780,9 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
     break;
       SCASE(1) SCASE(2) SCASE(3) SCASE(4) SCASE(5) SCASE(6) SCASE(7) SCASE(8)
 #undef SCASE
+      default:
+        mm_set_error("spconv_apply: unsupported channel-block count %d", ncbw);
+        return MM_ERR_UNSUPPORTED;
     }
     if (rc) return rc;
     MM_LAUNCH_CHECK();
@@ -902,6 +913,37 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
         MM_HIP(hipFuncSetAttribute((const void*)k_dw_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dw_generic, dim3(nb), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, K, seg, partial);
     }
+  }
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// 16-bit activation mode: in / dout are bf16 rows (ld in elements), dW stays fp32.  Cin, Cout multiples of 16.
+int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+                      const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                      size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, "spconv_dw_bf16: channels must be multiples of 16");
+  KSeg seg;
+  const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
+  int nb = make_seg(offsets_host, K, chunk, &seg);
+  const int ne = Cin * Cout;
+  if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
+    mm_set_error("spconv_dw_bf16: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  float* partial = (float*)ws;
+  if (nb > 0) {
+    const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
+    const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
+    const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
+#define DWB(I, J)                                                                                                          \
+  if (ti == I && tj == J)                                                                                                  \
+    hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, __bf16>), dim3(nb, ny), dim3(256), lds, s, (const __bf16*)in, ld_in,        \
+                       (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);
+    DWB(1, 1) DWB(1, 2) DWB(1, 3) DWB(1, 4) DWB(2, 1) DWB(2, 2) DWB(2, 3) DWB(2, 4)
+    DWB(3, 1) DWB(3, 2) DWB(3, 3) DWB(3, 4) DWB(4, 1) DWB(4, 2) DWB(4, 3) DWB(4, 4)
+#undef DWB
   }
   hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
   MM_LAUNCH_CHECK();

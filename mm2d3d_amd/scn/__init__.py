@@ -22,8 +22,25 @@ from .metadata import Level, Metadata, Rulebook
 __all__ = [
     "SparseConvNetTensor", "Sequential", "InputLayer", "OutputLayer", "SubmanifoldConvolution", "Convolution",
     "Deconvolution", "BatchNormalization", "BatchNormReLU", "BatchNormLeakyReLU", "Identity", "ConcatTable",
-    "JoinTable", "AddTable", "NetworkInNetwork", "install_as_sparseconvnet",
+    "JoinTable", "AddTable", "NetworkInNetwork", "install_as_sparseconvnet", "set_activation_dtype",
 ]
+
+
+# 16-bit activation mode (BASELINE.json configs[4]; SURVEY.md section 8d C5 - a capability the reference's fp32-only
+# SparseConvNet does not have): between the stem and the OutputLayer every sparse row (features and their gradients) is
+# bf16; batch-norm statistics, weights, weight gradients and all accumulations stay fp32.
+ACTIVATION_DTYPE = [torch.float32]
+
+
+def set_activation_dtype(dtype):
+    """torch.float32 (the reference's behaviour) or torch.bfloat16."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("activation dtype must be float32 or bfloat16")
+    ACTIVATION_DTYPE[0] = dtype
+
+
+def act16():
+    return ACTIVATION_DTYPE[0] == torch.bfloat16
 
 
 class SparseConvNetTensor:
@@ -122,7 +139,7 @@ class InputLayer(nn.Module):
                 torch.cuda.current_stream(dev).wait_event(md.ready)
             lv0 = md.levels[0]
         else:
-            md = Metadata(dev, S, self.prebuild_levels)
+            md = Metadata(dev, S, self.prebuild_levels, act16=act16())
             lv0 = md.build_levels(coords)
         if self.mode in (3, 4):
             f = ops.InputMeanFunction.apply(feats, lv0, self.mode == 4)
@@ -157,7 +174,8 @@ class OutputLayer(nn.Module):
         self.dimension = dimension
 
     def forward(self, x):
-        return ops.OutputGatherFunction.apply(x.features, x.metadata.levels[0])
+        f = x.features
+        return ops.OutputGatherFunction.apply(f.float() if f.dtype != torch.float32 else f, x.metadata.levels[0])
 
 
 class _ConvBase(nn.Module):
@@ -189,7 +207,13 @@ class SubmanifoldConvolution(_ConvBase):
     def forward(self, x):
         lv = x.level
         rb = x.metadata.subm_rulebook(lv)
-        f = ops.SparseConvFunction.apply(x.features, self.weight, rb, "subm", lv.n, lv.n)
+        feats = x.features
+        wide = self.nIn % 16 == 0 and self.nOut % 16 == 0
+        if act16() and wide and feats.dtype != torch.bfloat16:
+            feats = feats.to(torch.bfloat16)
+        f = ops.SparseConvFunction.apply(feats, self.weight, rb, "subm", lv.n, lv.n)
+        if act16() and f.dtype != torch.bfloat16:  # the 3-channel stem runs in fp32; its output enters the 16-bit region
+            f = f.to(torch.bfloat16)
         return x._with(self._bias(f))
 
     def __repr__(self):
@@ -279,8 +303,8 @@ class NetworkInNetwork(nn.Module):
             self.bias = nn.Parameter(torch.zeros(nOut))
 
     def forward(self, x):
-        f = ops.LinearFunction.apply(x.features, self.weight.t(), getattr(self, "bias", None))
-        return x._with(f)
+        f = ops.LinearFunction.apply(x.features.float(), self.weight.t(), getattr(self, "bias", None))
+        return x._with(f.to(x.features.dtype))
 
 
 def install_as_sparseconvnet():

@@ -75,7 +75,8 @@ class Level:
 
 
 class Metadata:
-    def __init__(self, device, spatial_size, prebuild_levels=7):
+    def __init__(self, device, spatial_size, prebuild_levels=7, act16=False):
+        self.act16 = bool(act16)  # 16-bit activation mode: every level gets output-stationary tables, both directions
         self.device = device
         self.spatial_size = int(spatial_size)
         self.prebuild_levels = prebuild_levels
@@ -236,7 +237,7 @@ class Metadata:
         return rb
 
     def _os_table(self, nbr, K, n):
-        if n < OS_MIN_ROWS:
+        if n == 0 or (n < OS_MIN_ROWS and not self.act16):
             return None
         L = _lib.lib()
         dev = self.device
@@ -275,7 +276,7 @@ class Metadata:
                       "down_neighbors")
                 down = self._launch_rulebook(8, c.n, nbr8, offs[j, 28:37])
                 down.os = self._os_table(nbr8, 8, c.n)
-                if OS_BUILD_UP:  # unique-destination direction: the rulebook engine's direct scatter measured faster
+                if OS_BUILD_UP or self.act16:  # unique-destination direction: the rulebook engine's direct scatter measured faster
                     nbr_up = torch.empty(max(8 * lv.n, 1), dtype=I32, device=dev)
                     check(L.mm_up_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), ptr(nbr_up), stream()), "up_neighbors")
                     down.os_up = self._os_table(nbr_up, 8, lv.n)

@@ -16,7 +16,7 @@ F32 = torch.float32
 PROFILE = None
 
 
-def _timed(kind, rb, cin, cout, fn):
+def _timed(kind, rb, cin, cout, fn, esize=4):
     if PROFILE is None:
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -25,7 +25,7 @@ def _timed(kind, rb, cin, cout, fn):
     e1.record()
     R = rb.n_rules
     PROFILE.append(dict(kind=kind, R=R, cin=cin, cout=cout, K=rb.K, e0=e0, e1=e1,
-                        bytes=R * (cin + cout) * 4 + 8 * R + rb.K * cin * cout * 4))
+                        bytes=R * (cin + cout) * esize + 8 * R + rb.K * cin * cout * esize))
     return out
 
 
@@ -73,6 +73,8 @@ class _OsPacks:
 
         return (owner._version, _c2d.PARAM_EPOCH[0], owner.data_ptr())
 
+    bf16 = False  # the registry of the 16-bit activation mode packs one bf16 term per weight
+
     def get(self, owner, K, cw_in, cw_out, transpose, kflip):
         L = _lib.lib()
         ek = (id(owner), transpose, kflip)
@@ -85,7 +87,8 @@ class _OsPacks:
             s_ci, s_co = (1, cw_out) if transpose else (cw_out, 1)
             e = dict(owner=weakref.ref(owner), K=K, cin=cin, cout=cout, s_ci=s_ci, s_co=s_co, kstride=cw_in * cw_out,
                      kflip=1 if kflip else 0, key=None, ptr=0,
-                     buf=torch.empty(int(L.mm_spconv_os_pack_bytes(K, cin, cout)), dtype=torch.uint8, device=owner.device))
+                     buf=torch.empty(int((L.mm_spconv_os_pack_bytes_bf16 if self.bf16 else L.mm_spconv_os_pack_bytes)(K, cin, cout)),
+                                     dtype=torch.uint8, device=owner.device))
             self.entries[ek] = e
             self.dirty = True
         self._repack_all()
@@ -113,27 +116,32 @@ class _OsPacks:
             self.table = torch.tensor(rows, dtype=torch.int64).to(ents[0]["buf"].device)
             self.total_blocks = blk
             self.dirty = False
-        check(L.mm_spconv_os_pack_batch(ptr(self.table), len(ents), self.total_blocks, stream()), "spconv_os_pack_batch")
+        check((L.mm_spconv_os_pack_batch_bf16 if self.bf16 else L.mm_spconv_os_pack_batch)(ptr(self.table), len(ents), self.total_blocks,
+                                                                                        stream()), "spconv_os_pack_batch")
         for e in ents:
             e["key"] = self._key(e["owner"]())
 
 
-_OS_PACKS = {}  # device index -> _OsPacks
+class _OsPacksBf16(_OsPacks):
+    bf16 = True
+
+
+_OS_PACKS = {}  # (device index, bf16) -> _OsPacks
 OS_ENABLED = os.environ.get("MM_SPCONV_OS", "1") != "0"
 
 
-def _os_fragments(weight, w_kcc, transpose, kflip):
-    """Packed fragments of W (or W^T, offsets flipped) for the output-stationary engine."""
+def _os_fragments(weight, w_kcc, transpose, kflip, bf16=False):
+    """Packed fragments of W (or W^T, offsets flipped) for the output-stationary engine (bf16: one term per weight)."""
     L = _lib.lib()
     K, cw_in, cw_out = w_kcc.shape
     if isinstance(weight, torch.nn.Parameter) and weight.dtype == F32 and weight.is_contiguous() and weight.data_ptr() == w_kcc.data_ptr():
-        reg = _OS_PACKS.setdefault(weight.device.index, _OsPacks())
+        reg = _OS_PACKS.setdefault((weight.device.index, bf16), _OsPacksBf16() if bf16 else _OsPacks())
         return reg.get(weight, K, cw_in, cw_out, bool(transpose), bool(kflip))
     cin, cout = (cw_out, cw_in) if transpose else (cw_in, cw_out)
     s_ci, s_co = (1, cw_out) if transpose else (cw_out, 1)
-    buf = torch.empty(int(L.mm_spconv_os_pack_bytes(K, cin, cout)), dtype=torch.uint8, device=w_kcc.device)
-    check(L.mm_spconv_os_pack(ptr(w_kcc), cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, K, cin, cout, ptr(buf), stream()),
-          "spconv_os_pack")
+    nbytes, pack = (L.mm_spconv_os_pack_bytes_bf16, L.mm_spconv_os_pack_bf16) if bf16 else (L.mm_spconv_os_pack_bytes, L.mm_spconv_os_pack)
+    buf = torch.empty(int(nbytes(K, cin, cout)), dtype=torch.uint8, device=w_kcc.device)
+    check(pack(ptr(w_kcc), cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, K, cin, cout, ptr(buf), stream()), "spconv_os_pack")
     return buf
 
 
@@ -150,6 +158,32 @@ def _apply_os(x, weight, w_kcc, table, cout, transpose, kflip):
     check(L.mm_spconv_os_apply(ptr(x), x.stride(0), x.shape[1], ptr(out), cout, cout, ptr(Wf), table.K, ptr(table.dst),
                                ptr(table.nbrp), ptr(table.tmask), table.n_tiles, table.tile_rows, stream()), "spconv_os_apply")
     return out
+
+
+BF16 = torch.bfloat16
+
+
+def _apply_os_bf16(x, weight, w_kcc, table, cout, transpose, kflip):
+    """16-bit activation mode: bf16 rows in, bf16 rows out, fp32 accumulation over the offsets in ascending k."""
+    L = _lib.lib()
+    if table is None:
+        raise RuntimeError("16-bit activation mode: the level has no output-stationary table (build the metadata with act16=True)")
+    if x.shape[1] % 16 or cout % 16 or x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        raise RuntimeError("16-bit activation mode: channel counts must be multiples of 16 and rows 16-byte aligned")
+    Wf = _os_fragments(weight, w_kcc, transpose, kflip, bf16=True)
+    out = torch.empty((table.n_dst, cout), dtype=BF16, device=x.device)
+    check(L.mm_spconv_os_apply_bf16(ptr(x), x.stride(0), x.shape[1], ptr(out), cout, cout, ptr(Wf), table.K, ptr(table.dst),
+                                    ptr(table.nbrp), ptr(table.tmask), table.n_tiles, table.tile_rows, stream()), "spconv_os_apply_bf16")
+    return out
+
+
+def _dw_bf16(x, dout, rb, src, dst, cin, cout, sink=None):
+    L = _lib.lib()
+    dW = sink if sink is not None else torch.empty((rb.K, cin, cout), dtype=F32, device=x.device)
+    ws = _lib.workspace.get(int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), x.device)
+    check(L.mm_spconv_dw_bf16(ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
+                              ptr(dW), 0 if sink is None else 1, ptr(ws), ws.numel(), stream()), "spconv_dw_bf16")
+    return dW
 
 
 def _dw(x, dout, rb, src, dst, cin, cout, sink=None):
@@ -171,13 +205,23 @@ class SparseConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, rb, mode, n_in, n_out):
         _lib.require_cuda(x, "features")
-        x = _c(x.to(F32))
+        act16 = x.dtype == BF16  # 16-bit activation mode: bf16 rows, fp32 accumulation
+        x = _c(x) if act16 else _c(x.to(F32))
         w = _c(weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).to(F32))
         cout = w.shape[2]
         cin = w.shape[1]
         if mode not in ("subm", "down", "up"):
             raise ValueError(mode)
         table = rb.os_up if mode == "up" else rb.os
+        ctx.act16 = act16
+        if act16:
+            out = _timed("fwd", rb, cin, cout, lambda: _apply_os_bf16(x, weight, w, table, cout, False, False), 2)
+            ctx.save_for_backward(x, w)
+            ctx.rb, ctx.mode, ctx.n_in, ctx.wshape = rb, mode, n_in, weight.shape
+            ctx.weight = weight
+            ctx.wparam = weight if (weight.dtype == F32 and weight.is_contiguous()
+                                    and gradsink.claim(ctx, weight, ctx.needs_input_grad[1])) else None
+            return out
         if _os_usable(table, x, cin, cout) and table.n_dst == n_out:
             out = _timed("fwd", rb, cin, cout, lambda: _apply_os(x, weight, w, table, cout, False, False))
         elif mode in ("subm", "down"):
@@ -195,9 +239,24 @@ class SparseConvFunction(torch.autograd.Function):
     def backward(ctx, dout):
         x, w = ctx.saved_tensors
         rb, mode, n_in = ctx.rb, ctx.mode, ctx.n_in
-        dout = _c(dout.to(F32))
         cin, cout = w.shape[1], w.shape[2]
         dx = dw = None
+        if ctx.act16:
+            dout = _c(dout.to(BF16))
+            if ctx.needs_input_grad[0]:
+                table = rb.os if mode in ("subm", "up") else rb.os_up
+                dx = _timed("dX", rb, cin, cout, lambda: _apply_os_bf16(dout, ctx.weight, w, table, cin, True, mode == "subm"), 2)
+            if ctx.needs_input_grad[1]:
+                sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
+                a, b = (rb.rout, rb.rin) if mode == "up" else (rb.rin, rb.rout)
+                dw = _timed("dW", rb, cin, cout, lambda: _dw_bf16(x, dout, rb, a, b, cin, cout, sink), 2)
+                if sink is not None:
+                    gradsink.done(ctx.wparam)
+                    dw = None
+                else:
+                    dw = dw.reshape(ctx.wshape)
+            return dx, dw, None, None, None, None
+        dout = _c(dout.to(F32))
         # data gradient = the same engine over the transposed weights: subm by symmetry (k,i,o) <-> (26-k,o,i) on the same
         # table; down (dX[child] = dOut[parent] . W[k]^T) on the fine-row table; up (dX[parent] = sum dOut[child] . W[k]^T)
         # on the coarse-row table
@@ -230,7 +289,10 @@ class BatchNormActFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, momentum, leak, seg_rows=None):
         _lib.require_cuda(x, "features")
         L = _lib.lib()
-        x = _c(x.to(F32))
+        act16 = x.dtype == BF16
+        x = _c(x) if act16 else _c(x.to(F32))
+        ctx.act16 = act16
+        fwd_train, fwd_eval = (L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16) if act16 else (L.mm_bn_fwd_train, L.mm_bn_fwd_eval)
         N, C = x.shape
         y = torch.empty_like(x)
         if training:
@@ -239,7 +301,7 @@ class BatchNormActFunction(torch.autograd.Function):
             stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
             check(
-                L.mm_bn_fwd_train(ptr(x), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
+                fwd_train(ptr(x), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
                                   leak, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()),
                 "bn_fwd_train",
             )
@@ -251,7 +313,7 @@ class BatchNormActFunction(torch.autograd.Function):
                 ctx.sinks = (weight, bias)
         else:
             check(
-                L.mm_bn_fwd_eval(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, leak,
+                fwd_eval(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, leak,
                                  ptr(y), C, stream()),
                 "bn_fwd_eval",
             )
@@ -265,7 +327,7 @@ class BatchNormActFunction(torch.autograd.Function):
             raise RuntimeError("BatchNorm backward in eval mode is not part of the hot path")
         L = _lib.lib()
         x, weight, bias, stats = ctx.saved_tensors
-        dy = _c(dy.to(F32))
+        dy = _c(dy.to(BF16 if ctx.act16 else F32))
         N, C = x.shape
         dx = torch.empty_like(x)
         ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
@@ -278,7 +340,7 @@ class BatchNormActFunction(torch.autograd.Function):
             db = dbt = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
             acc = 0
         check(
-            L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
+            (L.mm_bn_bwd_bf16 if ctx.act16 else L.mm_bn_bwd)(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
                         ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
             "bn_bwd",
         )

@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-ENGINE = ("k_gather_gemm", "k_csr_reduce", "k_dw_direct", "k_dw_reduce", "k_pack_frag", "k_rows_narrow", "k_generic")
+ENGINE = ("k_gather_gemm", "k_csr_reduce", "k_dw_direct", "k_dw_reduce", "k_pack_frag", "k_rows_narrow", "k_generic", "k_osconv", "k_os_pack")
 
 
 def load(path, counter):

@@ -16,10 +16,15 @@ ap.add_argument("--shape", default="nuscenes")
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--act16", action="store_true", help="16-bit sparse activations (BASELINE.json configs[4])")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+if a.act16:
+    from mm2d3d_amd import scn
+
+    scn.set_activation_dtype(torch.bfloat16)
 net = Net3DSeg(6, True, dict(in_channels=3, m=16, full_scale=4096, num_planes=7)).to(dev)
 batch = make_batch(2, a.scenes, a.shape, img_hw=(32, 48), device=dev)
 coords, feats = batch["x"]
