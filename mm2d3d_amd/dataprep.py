@@ -155,6 +155,7 @@ def prepare_batch(scenes, scale=20, full_scale=4096, augmentation=None, fliplr=0
         "img_indices": [idx[bounds[i] : bounds[i + 1]] for i in range(B)],
         "points": [pkept[bounds[i] : bounds[i + 1]] for i in range(B)],
         "min_values": vox["min_value"], "offsets": vox["offset"], "rotation_matrices": np.stack(rots), "fliplr": flips,
+        "keep": vox["keep"],  # original row (in the concatenated input) of every kept point
     }
     if seg2d is not None:
         out["seg_labels_2d"] = seg2d

@@ -92,6 +92,7 @@ def make_sample(points, pts_cam_coord, points_img, seg_label, intrinsics, image_
     coords, idxs = voxelize_points(coords, full_scale)
     out.update(coords=coords, points=pts[idxs], seg_label=seg_label[idxs], img_indices=img_indices[idxs], intrinsics=intr,
                seg_labels_2d=seg2d, min_value=min_value, offset=offset, rot_matrix=rot_matrix)
+    out["_idxs"] = idxs  # the range mask (consumers that filter further per-point arrays; dropped by the dataset class)
     if output_orig:
         out.update(orig_seg_label=seg_label, orig_points_idx=idxs)
     out["feats"] = point_feats(out["img"], out["img_indices"]) if use_rgb else np.ones([len(idxs), 1], np.float32)

@@ -77,8 +77,11 @@ def make_scene(seed: int, shape: str = "nuscenes", img_hw=(302, 480), num_classe
 
 
 def collate(samples, device=None):
-    """Batch dict in the reference's collate format (lib/dataset/__init__.py:95-121)."""
+    """Batch dict in the reference's collate format (lib/dataset/__init__.py:95-121), pseudo-label keys included (:30-35,
+    53-58, 91-95: ``pseudo_label_3d`` stays an empty list when the samples carry none)."""
     locs, feats, labels, imgs, depths, idxs = [], [], [], [], [], []
+    pselab = "pseudo_label_2d" in samples[0]
+    ps2d, ps3d, psens = [], [], []
     for b, s in enumerate(samples):
         c = torch.from_numpy(s["coords"])
         locs.append(torch.cat([c, torch.full((c.shape[0], 1), b, dtype=torch.int64)], 1))
@@ -87,6 +90,11 @@ def collate(samples, device=None):
         imgs.append(torch.from_numpy(s["img"]))
         depths.append(torch.from_numpy(s["depth"]))
         idxs.append(s["img_indices"])
+        if pselab:
+            ps2d.append(torch.from_numpy(s["pseudo_label_2d"]))
+            if s["pseudo_label_3d"] is not None:
+                ps3d.append(torch.from_numpy(s["pseudo_label_3d"]))
+            psens.append(torch.from_numpy(s["pseudo_label_ensemble"]))
     out = {
         "x": [torch.cat(locs, 0), torch.cat(feats, 0)],
         "seg_label": torch.cat(labels, 0),
@@ -94,6 +102,10 @@ def collate(samples, device=None):
         "depth": torch.stack(depths),
         "img_indices": idxs,  # list of numpy int64 [n_i, 2] (row, col), as in the reference
     }
+    if pselab:
+        out["pseudo_label_2d"] = torch.cat(ps2d, 0)
+        out["pseudo_label_3d"] = torch.cat(ps3d, 0) if ps3d else ps3d
+        out["pseudo_label_ensemble"] = torch.cat(psens, 0)
     if device is not None:
         out["x"] = [out["x"][0].to(device), out["x"][1].to(device)]
         for k in ("seg_label", "img", "depth"):

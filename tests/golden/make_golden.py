@@ -248,3 +248,24 @@ if __name__ == "__main__":
     wiring_case()
     wiring_case_2d()
     print("wiring fixtures written")
+
+
+def pselab_case():
+    """lib/utils/refine_pseudo_labels.py (imported from the reference): per-class median thresholding of pseudo labels."""
+    from lib.utils.refine_pseudo_labels import refine_pseudo_labels as ref_refine
+
+    rng = np.random.default_rng(21)
+    out = {}
+    for name, n, ncls in (("even_odd", 1001, 6), ("small", 12, 3), ("single_class", 40, 1)):
+        probs = rng.random(n).astype(np.float32)
+        probs[rng.random(n) < 0.2] = 0.95  # ties above the 0.9 cap
+        labels = rng.integers(0, ncls, n).astype(np.int64)
+        out[f"{name}/probs"] = probs
+        out[f"{name}/labels"] = labels
+        out[f"{name}/refined"] = ref_refine(probs.copy(), labels.copy())
+    np.savez_compressed(os.path.join(HERE, "pselab.npz"), **out)
+
+
+if __name__ == "__main__":
+    pselab_case()
+    print("pseudo-label fixture written")
