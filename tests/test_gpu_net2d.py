@@ -130,10 +130,12 @@ def test_net2d_vs_oracle(training):
     net.to(dev)
     ph, last_h, _, ah = net({"img": img.to(dev), "depth": depth.to(dev), "img_indices": idx})
     assert last_h.shape == last_r.shape
-    # bf16 activations through ~40 layers: logits agree to a few 1e-2 relative (fp16 AMP in the reference behaves alike)
-    for a, b, what in ((ph["seg_logit"], pr["seg_logit"], "seg_logit"), (ah["seg_logit_avg"], ar["seg_logit_avg"], "seg_logit_avg"),
-                       (ph["seg_logit_2d"], pr["seg_logit_2d"], "seg_logit_2d"), (last_h, last_r, "segm_last")):
-        assert _rel(a.cpu(), b) < 6e-2, (what, _rel(a.cpu(), b))
+    # bf16 activations through ~40 layers against the fp32 oracle; bounds = 2.5x what was measured on MI355X
+    # (eval: logits 1.9e-3, decoder map 4.8e-3; batch statistics of this tiny 2 x 46 x 62 batch: logits 1.2e-2, map 1.6e-2)
+    t_logit, t_map = (3e-2, 4e-2) if training else (5e-3, 1.2e-2)
+    for a, b, what, tol in ((ph["seg_logit"], pr["seg_logit"], "seg_logit", t_logit), (ah["seg_logit_avg"], ar["seg_logit_avg"], "seg_logit_avg", t_logit),
+                            (ph["seg_logit_2d"], pr["seg_logit_2d"], "seg_logit_2d", t_map), (last_h, last_r, "segm_last", t_map)):
+        assert _rel(a.cpu(), b) < tol, (what, _rel(a.cpu(), b))
     # the same forward against the oracle that rounds to bf16 where the HIP branch stores bf16: what is left is accumulation
     # order and the isolated 1-ulp bf16 flips it causes -> an order of magnitude tighter than the fp32 comparison above
     so2 = {}
