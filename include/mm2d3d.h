@@ -300,6 +300,18 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
 int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ,
                 const float* dout, void* dx, float* dWj, void* ws, size_t ws_bytes, mm_stream_t stream);
 
+/* ---------------------------------------------------------------- exact-fp32 2D convolutions (csrc/conv2d_f32.hip)
+ * The `precision: 32` mode (config/run/test.yaml:8): plain fp32 FMAs in an LDS-tiled implicit GEMM; one kernel pair
+ * expresses Conv2d / ConvTranspose2d forward, data and weight gradients through index maps (file header). */
+int mm_conv2d_f32(const float* A, int B, int Hi, int Wi, int Ca, int ldA, float* O, int Ho, int Wo, int Cn, int ldO, int KH, int KW,
+                  int so, int sgn, int off, int up, const float* W, int64_t w_sn, int64_t w_sc, int64_t w_sy, int64_t w_sx,
+                  const float* bias, mm_stream_t stream);
+size_t mm_conv2d_f32_wgrad_ws_bytes(int64_t n_pixels, int Cg, int Ca, int KH, int KW);
+int mm_conv2d_f32_wgrad(const float* G, int B, int Hg, int Wg, int Cg, int ldG, const float* A, int Hi, int Wi, int Ca, int ldA,
+                        int KH, int KW, int so, int sgn, int off, int up, float* dW, int64_t w_sn, int64_t w_sc, int64_t w_sy,
+                        int64_t w_sx, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_colsum_f32(const float* x, int ld, int64_t N, int C, float* out, int accumulate, mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,11 @@ _PROTOS = {
     "mm_conv2d_wgrad_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_conv2d_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, i64, i32, vp, sz,
                               vp]),
+    "mm_conv2d_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp]),
+    "mm_conv2d_f32_wgrad_ws_bytes": (sz, [i64, i32, i32, i32, i32]),
+    "mm_conv2d_f32_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64,
+                                  i32, vp, sz, vp]),
+    "mm_colsum_f32": (i32, [vp, i32, i64, i32, vp, i32, vp]),
     "mm_pack_weights_bf16": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp]),
     "mm_pack_weights_bf16_batch": (i32, [vp, i32, i64, vp]),
     "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),

@@ -329,13 +329,14 @@ template <typename E>
 static int bn_fwd_train(const E* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float eps, float momentum, float leak, E* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
-  MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_y >= C, "bn_fwd: bad shape C=%d", C);
+  MM_CHECK_ARG(C > 0 && C <= 4 * T && ld_x >= C && ld_y >= C, "bn_fwd: bad shape C=%d", C);
   if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
     mm_set_error("bn_fwd: workspace too small");
     return MM_ERR_WORKSPACE;
   }
   double* partial = (double*)ws;
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % (4 * sizeof(E)) == 0);
+  MM_CHECK_ARG(C / (v4 ? 4 : 1) <= T, "bn_fwd: %d channels need 16-byte aligned rows (C multiple of 4)", C);
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
@@ -382,7 +383,7 @@ template <typename E>
 static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, E* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
-  MM_CHECK_ARG(C > 0 && C <= T && ld_x >= C && ld_dy >= C && ld_dx >= C, "bn_bwd: bad shape");
+  MM_CHECK_ARG(C > 0 && C <= 4 * T && ld_x >= C && ld_dy >= C && ld_dx >= C, "bn_bwd: bad shape");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
   if (ws_bytes < need + 4 * C * sizeof(float)) {
     mm_set_error("bn_bwd: workspace too small");
@@ -392,6 +393,7 @@ static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64
   float* sums = (float*)((char*)ws + need);
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) &&
                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % (4 * sizeof(E)) == 0);
+  MM_CHECK_ARG(C / (v4 ? 4 : 1) <= T, "bn_bwd: %d channels need 16-byte aligned rows (C multiple of 4)", C);
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)

@@ -187,6 +187,26 @@ class Net2DSeg(nn.Module):
                                nn2d.BatchNorm2d(cin, relu=True), nn2d.FusedAway())
         return conv, t_conv
 
+    def _forward_fp32(self, data_batch, img, hints, img_indices, h, w):
+        """`precision: 32` (config/run/test.yaml:8): the same modules and parameters, fp32 kernels (nn2d.set_precision(32)),
+        the decoder's concatenations as plain copies (2d_net/model.py:104-127)."""
+        r = self.rgb_backbone(img)
+        d = self.depth_backbone(hints)
+        cat = nn2d.cat_channels
+        x = self.dec_t_conv_stage5(cat([d[4], r[4]]))
+        x = self.dec_conv_stage4(cat([d[3], x, r[3]]))
+        x = self.dec_t_conv_stage4(x)
+        x = self.dec_conv_stage3(cat([d[2], x, r[2]]))
+        x = self.dec_t_conv_stage3(x)
+        x = self.dec_conv_stage2(cat([d[1], x, r[1]]))
+        x = self.dec_t_conv_stage2(x)
+        x = self.dec_conv_stage1(cat([d[0], x, r[0]]))
+        segm_last = x[:, :, 0:h, 0:w]
+        segm, avg = nn2d.fused_heads(x, h, w, self.con1_1_avg, self.aux.con1_1_avg)
+        pix = _pixel_index(data_batch, h, w, segm.device)
+        preds = {"seg_logit": lift(segm, pix), "seg_logit_2d": segm}
+        return preds, segm_last, img_indices, self.aux(segm_last, pix, avg)
+
     def forward(self, data_batch):
         img, hints, img_indices = data_batch["img"], data_batch["depth"], data_batch["img_indices"]
         h, w = img.shape[2], img.shape[3]
@@ -197,6 +217,8 @@ class Net2DSeg(nn.Module):
         # The three full-resolution decoder concats [depth | up | rgb] are never copied: their buffers exist up front and
         # the producing BatchNorm layers (stem / layer1 / layer2 of both backbones, the transposed-conv stages) write
         # straight into their channel slices; the backbones keep reading those slices as pitched NHWC maps.
+        if nn2d.fp32_mode():
+            return self._forward_fp32(data_batch, img, hints, img_indices, h, w)
         Bn, Hp, Wp = img.shape[0], img.shape[2], img.shape[3]
         cb = [nn2d.CatBuffer(Bn, (c, c, c), Hp >> l, Wp >> l, img.device) for l, c in enumerate(self.rgb_backbone.channels[:3])]
         r = self.rgb_backbone(img, outs=[b.slot(2) for b in cb])
@@ -233,3 +255,4 @@ class Net2DSeg(nn.Module):
 
 
 Model = Net2DSeg
+

@@ -19,11 +19,28 @@ import torch.nn.functional as F
 
 from . import _lib, domains, gradsink
 from . import conv2d as _c2d
+from . import conv2d_f32 as _c2f
 from ._lib import check, ptr, stream
 
 BF16 = torch.bfloat16
 CL = torch.channels_last
 F32 = torch.float32
+
+
+# 16: bf16 MFMA kernels (training hot path).  32: the whole 2D branch in fp32 (config/run/test.yaml:8 `precision: 32`) on the
+# fp32 implicit-GEMM convolutions of csrc/conv2d_f32.hip and the fp32 batch-norm rows of csrc/bn.hip; pooling, padding,
+# concatenation and the residual add are torch elementwise / pooling ops in that mode.
+PRECISION = [16]
+
+
+def set_precision(bits):
+    if bits not in (16, 32):
+        raise ValueError("precision must be 16 (bf16 MFMA) or 32 (exact fp32)")
+    PRECISION[0] = bits
+
+
+def fp32_mode():
+    return PRECISION[0] == 32
 
 
 def _need_gpu(x, what):
@@ -35,6 +52,11 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         _need_gpu(x, "Conv2d")
         k = self.kernel_size
+        if fp32_mode():
+            if not (self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and self.dilation == (1, 1)
+                    and self.groups == 1 and self.padding_mode == "zeros"):
+                raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d (fp32): {self}")
+            return _c2f.Conv2dF32Fn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
         if _c2d.hip_eligible(self.in_channels, self.out_channels, k[0], k[1], self.stride[0], self.padding[0], self.dilation[0],
                              self.groups) and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] \
                 and self.padding_mode == "zeros":
@@ -48,6 +70,11 @@ class Conv2d(nn.Conv2d):
 class ConvTranspose2d(nn.ConvTranspose2d):
     def forward(self, x, output_size=None):
         _need_gpu(x, "ConvTranspose2d")
+        if fp32_mode():
+            if not (self.kernel_size == self.stride and self.padding == (0, 0) and self.output_padding == (0, 0) and self.groups == 1
+                    and self.stride[0] == self.stride[1] and output_size is None):
+                raise NotImplementedError(f"mm2d3d_amd.nn2d.ConvTranspose2d (fp32): {self}")
+            return _c2f.ConvTranspose2dF32Fn.apply(x, self.weight, self.bias, self.stride[0])
         if not (self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and self.output_padding == (0, 0)
                 and self.groups == 1 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0 and output_size is None):
             raise NotImplementedError("hot path: ConvTranspose2d kernel 2, stride 2, channels multiple of 64")
@@ -162,6 +189,8 @@ class BatchNorm2d(nn.BatchNorm2d):
         """``residual_shared``: the residual map has another consumer (it is the block input, also read by conv1), so its
         gradient contribution from here is handed to its producer (GradHandoff) instead of being summed by autograd."""
         _need_gpu(x, "BatchNorm2d")
+        if fp32_mode():
+            return _c2f.batch_norm_f32(x, self, residual, self.relu)
         use_batch = self.training or not self.track_running_stats
         nbt = self.num_batches_tracked if (self.training and self.track_running_stats) else None  # incremented in the kernel
         track = use_batch and torch.is_grad_enabled() and x.requires_grad
@@ -214,6 +243,8 @@ class _MaxPoolFn(torch.autograd.Function):
 class MaxPool2d(nn.MaxPool2d):
     def forward(self, x):
         _need_gpu(x, "MaxPool2d")
+        if fp32_mode():
+            return torch.nn.functional.max_pool2d(x.contiguous(), self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode)
         if (self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode) != (3, 2, 1, 1, False):
             raise NotImplementedError("hot path: MaxPool2d(3, 2, 1)")
         return _MaxPoolFn.apply(x)
@@ -315,6 +346,8 @@ class CatBuffer:
 
 def cat_channels(xs):
     """torch.cat(xs, dim=1) for NHWC bf16 maps (decoder concat [depth, up, rgb])."""
+    if fp32_mode():
+        return torch.cat([_c2f.as_nhwc_f32(t) for t in xs], 1).contiguous(memory_format=CL)
     return _CatFn.apply(*xs)
 
 
@@ -358,4 +391,10 @@ class _HeadsFn(torch.autograd.Function):
 def fused_heads(x, h, w, conv_main: nn.Conv2d, conv_aux: nn.Conv2d):
     """(seg_logit_2d, seg_logit_avg_2d), each fp32 [B, num_classes, h, w], from the decoder output x (NHWC bf16, padded)."""
     _need_gpu(x, "fused_heads")
+    if fp32_mode():  # AvgPool2d(5, 1, 2) of the cropped map (torch pooling op), then the two 1x1 convolutions in fp32
+        # (plain NCHW copy of the crop: torch 2.10+rocm7.0's avg_pool2d BACKWARD returns wrong values for a sliced
+        # channels_last input - measured 1.18 relative error against the CPU - the contiguous layout is right)
+        pooled = torch.nn.functional.avg_pool2d(x[:, :, :h, :w].contiguous(), 5, 1, 2)
+        return (_c2f.Conv2dF32Fn.apply(pooled, conv_main.weight, conv_main.bias, 1, 0),
+                _c2f.Conv2dF32Fn.apply(pooled, conv_aux.weight, conv_aux.bias, 1, 0))
     return _HeadsFn.apply(x, h, w, conv_main.weight, conv_main.bias, conv_aux.weight, conv_aux.bias)

