@@ -92,9 +92,9 @@ def conv_roofline(tm, batch, dev):
     import glob
 
     for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_3d.json")), reverse=True):
-        rec = json.load(open(tpath))
-        if abs(alg_bytes / float(rec.get("algorithmic_bytes_per_step", 1)) - 1.0) < 0.02:
-            traffic = rec["bytes_per_step"]
+        trec = json.load(open(tpath))
+        if abs(alg_bytes / float(trec.get("algorithmic_bytes_per_step", 1)) - 1.0) < 0.02:
+            traffic = trec["bytes_per_step"]
             traffic_source = "offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, " + os.path.relpath(tpath, ROOT)
             break
     if os.environ.get("MM_BENCH_LAYERS"):

@@ -30,6 +30,7 @@ __all__ = [
 # SparseConvNet does not have): between the stem and the OutputLayer every sparse row (features and their gradients) is
 # bf16; batch-norm statistics, weights, weight gradients and all accumulations stay fp32.
 ACTIVATION_DTYPE = [torch.float32]
+PAD_NARROW_STEM = [True]
 
 
 def set_activation_dtype(dtype):
@@ -211,7 +212,15 @@ class SubmanifoldConvolution(_ConvBase):
         wide = self.nIn % 16 == 0 and self.nOut % 16 == 0
         if act16() and wide and feats.dtype != torch.bfloat16:
             feats = feats.to(torch.bfloat16)
-        f = ops.SparseConvFunction.apply(feats, self.weight, rb, "subm", lv.n, lv.n)
+        weight = self.weight
+        if (self.nIn < 16 and self.nOut % 16 == 0 and rb.os is not None and ops.OS_ENABLED and feats.dtype == torch.float32
+                and PAD_NARROW_STEM[0]):
+            # the 3-channel stem of a large level: zero-pad rows and weights to 16 input channels so that it runs on the
+            # output-stationary MFMA engine (forward, dX and dW) instead of the VALU kernels; the padding contributes
+            # exact zeros, autograd slices the gradients back (two small pad kernels per call)
+            feats = torch.nn.functional.pad(feats, (0, 16 - self.nIn))
+            weight = torch.nn.functional.pad(weight, (0, 0, 0, 16 - self.nIn))
+        f = ops.SparseConvFunction.apply(feats, weight, rb, "subm", lv.n, lv.n, self.nIn)
         if act16() and f.dtype != torch.bfloat16:  # the 3-channel stem runs in fp32; its output enters the 16-bit region
             f = f.to(torch.bfloat16)
         return x._with(self._bias(f))

@@ -203,13 +203,15 @@ class SparseConvFunction(torch.autograd.Function):
     """mode 'subm' | 'down' | 'up' over one rulebook."""
 
     @staticmethod
-    def forward(ctx, x, weight, rb, mode, n_in, n_out):
+    def forward(ctx, x, weight, rb, mode, n_in, n_out, account_cin=None):
+        """``account_cin``: input channels the roofline accounting charges (the zero-padded 3-channel stem is charged as 3)."""
         _lib.require_cuda(x, "features")
         act16 = x.dtype == BF16  # 16-bit activation mode (SURVEY.md section 8d C5): bf16 rows, fp32 accumulation
         x = _c(x) if act16 else _c(x.to(F32))
         w = _c(weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).to(F32))
         cout = w.shape[2]
         cin = w.shape[1]
+        acin = ctx.acin = account_cin or cin
         if mode not in ("subm", "down", "up"):
             raise ValueError(mode)
         table = rb.os_up if mode == "up" else rb.os
@@ -223,11 +225,11 @@ class SparseConvFunction(torch.autograd.Function):
                                     and gradsink.claim(ctx, weight, ctx.needs_input_grad[1])) else None
             return out
         if _os_usable(table, x, cin, cout) and table.n_dst == n_out:
-            out = _timed("fwd", rb, cin, cout, lambda: _apply_os(x, weight, w, table, cout, False, False))
+            out = _timed("fwd", rb, acin, cout, lambda: _apply_os(x, weight, w, table, cout, False, False))
         elif mode in ("subm", "down"):
-            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False))
+            out = _timed("fwd", rb, acin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False))
         else:  # roles swapped, every fine row has exactly one rule
-            out = _timed("fwd", rb, cin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False))
+            out = _timed("fwd", rb, acin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False))
         ctx.save_for_backward(x, w)
         ctx.rb, ctx.mode, ctx.n_in, ctx.wshape = rb, mode, n_in, weight.shape
         ctx.weight = weight
@@ -255,14 +257,14 @@ class SparseConvFunction(torch.autograd.Function):
                     dw = None
                 else:
                     dw = dw.reshape(ctx.wshape)
-            return dx, dw, None, None, None, None
+            return dx, dw, None, None, None, None, None
         dout = _c(dout.to(F32))
         # data gradient = the same engine over the transposed weights: subm by symmetry (k,i,o) <-> (26-k,o,i) on the same
         # table; down (dX[child] = dOut[parent] . W[k]^T) on the fine-row table; up (dX[parent] = sum dOut[child] . W[k]^T)
         # on the coarse-row table
         table = rb.os if mode in ("subm", "up") else rb.os_up
         if ctx.needs_input_grad[0] and _os_usable(table, dout, cout, cin) and table.n_dst == n_in:
-            dx = _timed("dX", rb, cin, cout, lambda: _apply_os(dout, ctx.weight, w, table, cin, True, mode == "subm"))
+            dx = _timed("dX", rb, ctx.acin, cout, lambda: _apply_os(dout, ctx.weight, w, table, cin, True, mode == "subm"))
         elif ctx.needs_input_grad[0]:
             if mode == "subm":  # symmetric rulebook: (k,i,o) <-> (26-k,o,i)
                 dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True))
@@ -273,15 +275,15 @@ class SparseConvFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
             if mode == "up":
-                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rout, rb.rin, cin, cout, sink))
+                dw = _timed("dW", rb, ctx.acin, cout, lambda: _dw(x, dout, rb, rb.rout, rb.rin, cin, cout, sink))
             else:
-                dw = _timed("dW", rb, cin, cout, lambda: _dw(x, dout, rb, rb.rin, rb.rout, cin, cout, sink))
+                dw = _timed("dW", rb, ctx.acin, cout, lambda: _dw(x, dout, rb, rb.rin, rb.rout, cin, cout, sink))
             if sink is not None:
                 gradsink.done(ctx.wparam)
                 dw = None
             else:
                 dw = dw.reshape(ctx.wshape)
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 class BatchNormActFunction(torch.autograd.Function):

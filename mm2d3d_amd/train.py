@@ -35,6 +35,17 @@ class TrainModel(nn.Module):
         # building the 3D metadata on a side stream during the 2D branch measured SLOWER (55.1-57.5 vs 53.7-54.0 ms/step:
         # its small kernels queue behind the persistent conv workgroups and the host waits longer at the read-backs): off
         self.overlap_metadata = train_kwargs.get("overlap_metadata", False)
+        # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
+        # path), 32 = the exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
+        # branch in bf16 (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so the default is fp32.
+        if "precision" in train_kwargs:
+            from . import nn2d
+
+            nn2d.set_precision(int(train_kwargs["precision"]))
+        if "sparse_activations" in train_kwargs:
+            from . import scn
+
+            scn.set_activation_dtype(torch.bfloat16 if str(train_kwargs["sparse_activations"]) in ("bf16", "16") else torch.float32)
         self._side = None
         self._opt_factories = optimizer or {}
         self.optimizers, self.schedulers = [], []
