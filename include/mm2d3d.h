@@ -72,9 +72,13 @@ int mm_down_neighbors(const int32_t* vox_coords_fine, int64_t n_fine, const int3
 
 size_t mm_rulebook_ws_bytes(int64_t n_out, int K);
 /* neighbour table -> k-major rule lists rin/rout (capacity K*n_out, pairs sorted by out id inside a bucket),
- * offsets[K+1] (device), CSR over out rows: csr_off[n_out+1], csr_pos[R] = rule positions in ascending k */
+ * offsets[K+1] (device), CSR over out rows: csr_off[n_out+1], csr_pos[R] = rule positions in ascending k.
+ * csr_off = csr_pos = NULL skips the CSR (levels served by the output-stationary engine never read it);
+ * mm_rulebook_csr builds it later from the same table (same workspace size). */
 int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, int32_t* rout, int32_t* offsets,
                         int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_rulebook_csr(const int32_t* nbr, int K, int64_t n_out, int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes,
+                    mm_stream_t stream);
 
 /* ---------------------------------------------------------------- GPU-side sample preparation (csrc/dataprep.hip)
  * The loader-side numpy code of the reference for a whole batch of scenes, bit-exact with it:
@@ -259,11 +263,17 @@ int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K,
                          int64_t sk, mm_stream_t stream);
 /* One launch for a table of weights (every conv layer of a model after an optimiser step).  desc (device memory):
  * ndesc rows of 11 int64 {in, out, Z, N, T, K, sz, sn, st, sk, first_block}; first_block = running sum of
- * ceil(Z*N*T*K / 256) over the preceding rows, total_blocks = the sum over all rows. */
+ * ceil(Z*N*T*K / 4096) over the preceding rows (Z*N*T*K < 2^31 per row), total_blocks = the sum over all rows. */
 int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- BatchNorm2d (+residual) (+ReLU), NHWC bf16 (csrc/bn2d.hip) */
 size_t mm_bn2d_ws_bytes(int C);
+/* Maps that fit on chip (every map of the headline step but the largest ones) take single-launch training kernels:
+ * one workgroup per CU keeps its rows in registers / LDS across two grid barriers, so x (and dy) are read once.
+ * mask bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd; default 3, or the environment's MM_BN2D_FUSED; 0 = always the
+ * reduce / finalize / apply kernels.  Returns the previous mask.  Use 0 when several PROCESSES share one GPU, and keep
+ * bit 1 clear while collectives of another stream overlap the backward pass (see csrc/bn2d.hip). */
+int mm_bn2d_set_fused(int mask);
 /* Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source / target halves of a jointly
  * batched step; train.py:186-292 calls each net once per domain) and the running buffers are updated group 0 first,
  * then group 1, as two consecutive calls would.  Ns = N (or 0): ordinary single batch.  save_mean/save_invstd: [G][C]. */

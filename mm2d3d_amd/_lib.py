@@ -31,6 +31,7 @@ _PROTOS = {
     "mm_down_neighbors": (i32, [vp, i64, vp, i64, vp, vp]),
     "mm_rulebook_ws_bytes": (sz, [i64, i32]),
     "mm_rulebook_compact": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_rulebook_csr": (i32, [vp, i32, i64, vp, vp, vp, sz, vp]),
     "mm_spconv_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
@@ -92,6 +93,7 @@ _PROTOS = {
     "mm_pack_weights_bf16_batch": (i32, [vp, i32, i64, vp]),
     "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_bn2d_ws_bytes": (sz, [i32]),
+    "mm_bn2d_set_fused": (i32, [i32]),
     "mm_bn2d_fwd_train": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
     "mm_bn2d_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),

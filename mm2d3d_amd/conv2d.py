@@ -127,7 +127,9 @@ def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
     e.out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
     e.in_ptr = (w.data_ptr(), owner.data_ptr())
     e.args = (Z, N, T, K, sz, sn, st, sk)
-    e.nblk = (Z * N * T * K + 255) // 256
+    if Z * N * T * K >= 1 << 31:
+        raise ValueError("conv2d: a weight of 2^31 or more elements cannot be packed")
+    e.nblk = (Z * N * T * K + 4095) // 4096  # MM_PACK_CHUNK of csrc/conv2d.hip
     check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(e.out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
     e.key = key
     cache[kind] = e

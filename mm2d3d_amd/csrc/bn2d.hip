@@ -5,6 +5,10 @@
 // Rows = B*H*W pixels, 16-B (8 x bf16) accesses, fp64 combination of the per-block partial sums (bit-stable).
 #include "common.h"
 
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+
 typedef unsigned short u16;
 
 namespace {
@@ -304,6 +308,505 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
   }
 }
 
+
+// ================================================================================================================
+// Single-launch training kernels for maps that fit in the chip's registers + LDS (everything but the full-resolution maps).
+//
+// The three-kernel path above reads x twice in the forward pass and x, dy twice in the backward pass, and pays two kernel
+// boundaries per call; on the 9..75 MB maps of the encoder/decoder it reaches 0.6-2.5 TB/s of its single-pass traffic.
+// Here ONE workgroup per CU (512 threads) loads its rows once, keeps them (FUSED_NL rows per thread in LDS, the rest
+// in VGPRs), publishes its fp64 partial sums, and meets the other workgroups at a grid barrier; the statistics of
+// channel c are then combined by one wave (channels dealt over the workgroups, fixed order: bit-stable) and, after a second
+// barrier, every workgroup normalises straight from its registers.  x is read once, dy once.
+//
+// Grid barrier: every workgroup must be resident at the same time, so the grid never exceeds the CU count and a
+// workgroup needs more than half of a CU's registers/LDS (one per CU).  Another PROCESS running the same kernel on the
+// same GPU can starve both grids: the wait is bounded (FUSED_TIMEOUT_TICKS of the 100 MHz wall clock) and ends in a
+// trap, i.e. a loud HIP error instead of a hang; MM_BN2D_FUSED=0 selects the three-kernel path for such set-ups.
+// A kernel of another stream that holds LDS on some CUs (an RCCL collective overlapping the backward pass) makes the grid wait
+// for it: the data-parallel trainer therefore keeps the backward direction on the three-kernel path (ddp.py).
+constexpr int FT = 512;       // 8 waves: 256 VGPRs per thread, and the per-thread constants are paid by half as many threads
+constexpr int FUSED_NL = 13;  // rows per thread kept in LDS: 13 x 16 B x 512 threads = 104 KB
+constexpr size_t FUSED_RED = (size_t)2 * FT * 8 * 4;  // float red[2][FT][8]
+constexpr size_t FUSED_LDS = FUSED_RED + 2 * 8192 + (size_t)FUSED_NL * FT * 16;  // red | double red2[1024] | double out[1024] | rows
+constexpr int FUSED_FLAG = 64;  // the release word sits 256 B after the arrival counter: pollers and arrivals on different lines
+constexpr unsigned long long FUSED_TIMEOUT_TICKS = 1000000000ull;  // 10 s
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ inline void unpack8(const u32x4 t, float (&v)[8]) {
+  const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+  }
+}
+__device__ inline u32x4 pack8(const float (&v)[8]) {
+  u32x4 t;
+  t.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+  t.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+  t.z = (unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16);
+  t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
+  return t;
+}
+
+// Values exchanged between workgroups INSIDE a launch go through agent-scope atomic loads / stores (sc1: they bypass the
+// per-XCD L2's non-coherent lines) and a wait for the stores' acknowledgements, NOT through __threadfence(): an agent-scope
+// release fence writes back the whole 4 MB L2 of the XCD, and with 256 workgroups doing that the barrier cost ~100 us.
+template <typename V>
+__device__ inline void xcd_store(V* p, V v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename V>
+__device__ inline V xcd_load(const V* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Pins the 16 accumulators at this point of the instruction stream.  Instruction selection is free to sink pure arithmetic
+// below every later load (only memory operations are ordered), and did: all rows' unpacked values then stay live until the end
+// of the load phase.  An (empty) volatile asm is ordered with the loads and needs its inputs computed.
+#define MM_PIN16(a, b)                                                                                                       \
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), \
+               "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]))
+
+struct FusedP {
+  const u16* x;
+  const u16* res;   // forward: residual input; backward: unused
+  u16* y;           // forward output
+  const u16* dy;
+  const u16* dy2;
+  const u16* yout;  // backward: forward output for the ReLU mask (NULL: recomputed from x)
+  u16* dx;
+  u16* dres;
+  int ld_x, ld_r, ld_y, ld_dy, ld_dy2, ld_dx, ld_dr;
+  int64_t N, Ns;
+  int C, relu, G0, G1, R;
+  const float *weight, *bias;
+  float *running_mean, *running_var;
+  int64_t* nbt;
+  float eps, momentum;
+  float *save_mean, *save_invstd;  // [groups][C]
+  float *sums, *dweight, *dbias;   // backward: sums [groups][2][C]
+  int accumulate;
+  double* partial;  // [G0+G1][2][C]
+  unsigned* sync;   // arrival counter at [0], release word at [FUSED_FLAG]
+};
+
+// Sums of a[i] / b[i] over the row slots of the workgroup -> out[p] (LDS), pair p = q*C + c (q = 0: a, 1: b), p < 2C.
+// Fixed order: FT/(2C) threads per pair stride the slots, their fp64 results are added in thread order.
+__device__ inline void fused_block_sums(const float (&a)[8], const float (&b)[8], float* red, double* red2, double* out, int C, int CV,
+                                        int rs, bool active) {
+  const int tid = threadIdx.x;
+  if (active) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      red[(size_t)tid * 8 + i] = a[i];
+      red[((size_t)FT + tid) * 8 + i] = b[i];
+    }
+  }
+  __syncthreads();
+  const int np = 2 * C;
+  if (np <= FT) {
+    const int nparts = FT / np;
+    const int pair = tid % np, part = tid / np;
+    double acc = 0.0;
+    if (part < nparts) {
+      const int q = pair / C, c = pair - q * C;
+      const float* src = red + ((size_t)q * FT + (c >> 3)) * 8 + (c & 7);
+      for (int sl = part; sl < rs; sl += nparts) acc += (double)src[(size_t)sl * CV * 8];
+    }
+    red2[tid] = acc;
+    __syncthreads();
+    if (tid < np) {
+      double tot = 0.0;
+      for (int j = 0; j < nparts; j++) tot += red2[j * np + tid];
+      out[tid] = tot;
+    }
+  } else {
+    for (int pair = tid; pair < np; pair += FT) {
+      const int q = pair / C, c = pair - q * C;
+      const float* src = red + ((size_t)q * FT + (c >> 3)) * 8 + (c & 7);
+      double acc = 0.0;
+      for (int sl = 0; sl < rs; sl++) acc += (double)src[(size_t)sl * CV * 8];
+      out[pair] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+// (sum over the workgroups [b0, b1) of partial[b][c], ... of partial[b][C + c]) by ONE wave: lanes stride the workgroups
+// (at most 4 each, independent loads), then a fixed shuffle tree.  Result valid in lane 0.
+__device__ inline void fused_wave_sums(const double* partial, int b0, int b1, int C, int c, double& s, double& q) {
+  const int lane = threadIdx.x & 63;
+  double vs[4], vq[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int bb = b0 + lane + 64 * j;
+    const int bc = bb < b1 ? bb : b0;  // unconditional loads; masked below
+    vs[j] = xcd_load(partial + (size_t)bc * 2 * C + c);
+    vq[j] = xcd_load(partial + (size_t)bc * 2 * C + C + c);
+    if (bb >= b1) vs[j] = 0.0, vq[j] = 0.0;
+  }
+  s = wave_sum((vs[0] + vs[1]) + (vs[2] + vs[3]));
+  q = wave_sum((vq[0] + vq[1]) + (vq[2] + vq[3]));
+}
+
+// Grid barrier (every workgroup of the launch is resident, see the header).  The last workgroup to arrive resets the counter
+// and advances the release word from flag_old to flag_old + 1; the others poll the release word.
+__device__ inline void fused_barrier(unsigned* sync, unsigned G, unsigned flag_old) {
+  stores_acked();   // this thread's xcd_store()s have reached the coherence point
+  __syncthreads();  // ... and so have the whole workgroup's
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(&sync[0], 1u);
+    if (t == G - 1) {
+      atomicExch(&sync[0], 0u);  // returns, i.e. has completed, before the release below; nobody arrives again before it
+      xcd_store(&sync[FUSED_FLAG], flag_old + 1u);
+    } else {
+      const unsigned long long t0 = wall_clock64();
+      while (xcd_load(&sync[FUSED_FLAG]) == flag_old) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) __builtin_trap();  // the grid is not co-resident (see the header)
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// Row geometry of the fused kernels: thread (slot, cv) of a workgroup that owns rows [r0, r1) visits rows r0 + slot + k*rs;
+// the row base r0 + k*rs is uniform.  Visits beyond r1 (or with k >= R) still load (see FusedBuf) and are masked afterwards:
+// no branch around any load.
+struct FusedGeom {
+  int CV, rs, slot, cv, grp;
+  bool active;
+  int64_t r0, r1, Ng;
+  int nrows;  // r1 - r0
+};
+
+__device__ inline FusedGeom fused_geom(const FusedP& p) {
+  FusedGeom g;
+  g.CV = p.C >> 3;
+  g.rs = FT / g.CV;
+  g.slot = threadIdx.x / g.CV;
+  g.cv = threadIdx.x - g.slot * g.CV;
+  g.active = g.slot < g.rs;
+  g.grp = (int)blockIdx.x >= p.G0;
+  const int lb = g.grp ? blockIdx.x - p.G0 : blockIdx.x, nbg = g.grp ? p.G1 : p.G0;
+  const int64_t gbase = g.grp ? p.Ns : 0;
+  g.Ng = g.grp ? p.N - p.Ns : p.Ns;
+  const int64_t rpb = (g.Ng + nbg - 1) / nbg;
+  g.r0 = gbase + (int64_t)lb * rpb;
+  g.r1 = g.r0 + rpb < gbase + g.Ng ? g.r0 + rpb : gbase + g.Ng;
+  if (g.r1 < g.r0) g.r1 = g.r0;
+  g.nrows = (int)(g.r1 - g.r0);
+  return g;
+}
+
+// Buffer addressing: a resource descriptor per tensor (scalar registers, byte size = the rows the tensor really has), the
+// uniform row base as the scalar offset and one 32-bit per-thread offset; the hardware bounds check makes an out-of-range
+// visit return zeros (loads) or vanish (stores).
+struct FusedBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff;
+  int ld2;  // row pitch in bytes
+};
+__device__ inline FusedBuf fused_buf(const void* base, int64_t N, int ld, int C, int slot, int cv) {
+  FusedBuf b;
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((N - 1) * ld + C) * 2), 0x00020000);
+  b.voff = (unsigned)(slot * ld + cv * 8) * 2u;
+  b.ld2 = ld * 2;
+  return b;
+}
+__device__ inline u32x4 fused_ld(const FusedBuf& b, int64_t row) {
+  return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)b.voff, (int)row * b.ld2, 0);
+}
+__device__ inline void fused_st(const FusedBuf& b, int64_t row, const u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, (int)b.voff, (int)row * b.ld2, 0);
+}
+
+template <int RMAX, bool RES>
+__global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* red = (float*)smem;
+  double* red2 = (double*)(smem + FUSED_RED);
+  double* outp = red2 + 1024;
+  u32x4* rows = (u32x4*)(smem + FUSED_RED + 2 * 8192);
+  constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
+  static_assert(RMAX % 4 == 0, "row groups of four");
+  const int tid = threadIdx.x;
+  const FusedGeom g = fused_geom(p);
+  const int C = p.C;
+  unsigned flag0 = 0;
+  if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
+  const int cvc = g.active ? g.cv : 0, slc = g.active ? g.slot : 0;
+  const FusedBuf bx = fused_buf(p.x, p.N, p.ld_x, C, slc, cvc), by = fused_buf(p.y, p.N, p.ld_y, C, slc, cvc),
+                 br = fused_buf(RES ? p.res : p.x, p.N, RES ? p.ld_r : p.ld_x, C, slc, cvc);
+  u32x4 xr[NREG];
+  float a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) a[i] = b[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < RMAX; k++) {
+    const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
+    u32x4 t = fused_ld(bx, g.r0 + (int64_t)k * g.rs);
+    if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+    if (k < FUSED_NL) rows[k * FT + tid] = t;
+    else xr[k < FUSED_NL ? 0 : k - FUSED_NL] = t;
+    float xv[8];
+    unpack8(t, xv);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      a[i] += xv[i];
+      b[i] = fmaf(xv[i], xv[i], b[i]);
+    }
+    if ((k & 3) == 3) {  // four rows' loads in flight at a time: bounds the live temporaries
+      MM_PIN16(a, b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  fused_block_sums(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
+  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
+  const int G = p.G0 + p.G1;
+  fused_barrier(p.sync, (unsigned)G, flag0);
+  {
+    // statistics: one wave per channel, channels dealt round-robin over the workgroups; both groups by the same wave, the
+    // running buffers updated group 0 first, then group 1 (what two consecutive forward calls do)
+    const int ngrp = p.G1 > 0 ? 2 : 1;
+    if (blockIdx.x == 0 && tid == 0 && p.nbt) *p.nbt += ngrp;
+    for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
+      for (int gi = 0; gi < ngrp; gi++) {
+        double sm, sq;
+        fused_wave_sums(p.partial, gi ? p.G0 : 0, gi ? G : p.G0, C, c, sm, sq);
+        if ((tid & 63) == 0) {
+          const int64_t Ng = gi ? p.N - p.Ns : p.Ns;
+          const double mean = Ng > 0 ? sm / (double)Ng : 0.0;
+          double var = Ng > 0 ? sq / (double)Ng - mean * mean : 0.0;
+          if (var < 0.0) var = 0.0;
+          xcd_store(p.save_mean + gi * C + c, (float)mean);
+          xcd_store(p.save_invstd + gi * C + c, (float)(1.0 / sqrt(var + (double)p.eps)));
+          if (p.running_mean) {
+            const double unbiased = Ng > 1 ? var * (double)Ng / (double)(Ng - 1) : var;
+            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)mean;
+            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+          }
+        }
+      }
+    }
+  }
+  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  if (!g.active) return;
+  const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
+  // the kept rows stay PACKED across the barrier: without this the compiler keeps the phase-1 unpacked floats alive instead
+  // (common subexpression of the two unpack8 calls), twice the registers
+#pragma unroll
+  for (int k = 0; k < NREG; k++) asm volatile("" : "+v"(xr[k]));
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int c = g.cv * 8 + i;
+    const float is = xcd_load(p.save_invstd + g.grp * C + c), m = xcd_load(p.save_mean + g.grp * C + c);
+    const float wv = wp[c], bv = bp[c];  // unconditional loads + selects: no chain of branches on the two null checks
+    sc[i] = is * (p.weight ? wv : 1.f);
+    sh[i] = (p.bias ? bv : 0.f) - m * sc[i];
+  }
+  // normalise from the kept rows, four at a time (the residual rows of a group are loaded together).  No break / continue in
+  // these loops: the compiler must unroll them completely, or the register arrays are indexed dynamically and land in scratch
+#pragma unroll
+  for (int k0 = 0; k0 < RMAX; k0 += 4) {
+    if (k0 < p.R) {
+      u32x4 rv[4];
+      if (RES) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          rv[j] = fused_ld(br, g.r0 + (int64_t)(k0 + j) * g.rs);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = k0 + j;
+        u32x4 t;
+        if (k < FUSED_NL) t = rows[k * FT + tid];
+        else t = xr[k < FUSED_NL ? 0 : k - FUSED_NL];
+        float xv[8], ad[8], yv[8];
+        unpack8(t, xv);
+        if (RES) unpack8(rv[j], ad);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          float v = fmaf(xv[i], sc[i], sh[i]);
+          if (RES) v += ad[i];
+          yv[i] = (p.relu && !(v > 0.f)) ? 0.f : v;
+        }
+        if (k < p.R && g.slot + k * g.rs < g.nrows) fused_st(by, g.r0 + (int64_t)k * g.rs, pack8(yv));
+        __builtin_amdgcn_sched_barrier(0);  // one row's arithmetic at a time (the group's loads stay in flight)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Backward: phase 1 keeps x (registers), the first FUSED_NL rows of dy (LDS) and the ReLU mask bits; sums are (sum g, sum g*x), turned
+// into sum g*xhat = invstd * (sum g*x - mean * sum g) in fp64 by the last workgroup.
+// MASK: 0 = no ReLU, 1 = mask recomputed from x, 2 = mask from the forward output
+template <int RMAX, bool DY2, int MASK>
+__global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* red = (float*)smem;
+  double* red2 = (double*)(smem + FUSED_RED);
+  double* outp = red2 + 1024;
+  u32x4* rows = (u32x4*)(smem + FUSED_RED + 2 * 8192);
+  constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
+  static_assert(RMAX % 4 == 0, "row groups of four");
+  const int tid = threadIdx.x;
+  const FusedGeom g = fused_geom(p);
+  const int C = p.C;
+  unsigned flag0 = 0;
+  if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
+  const int cvc = g.active ? g.cv : 0, slc = g.active ? g.slot : 0;
+  const FusedBuf bx = fused_buf(p.x, p.N, p.ld_x, C, slc, cvc), bd = fused_buf(p.dy, p.N, p.ld_dy, C, slc, cvc),
+                 bd2 = fused_buf(DY2 ? p.dy2 : p.dy, p.N, DY2 ? p.ld_dy2 : p.ld_dy, C, slc, cvc),
+                 byo = fused_buf(MASK == 2 ? p.yout : p.x, p.N, MASK == 2 ? p.ld_y : p.ld_x, C, slc, cvc),
+                 bdx = fused_buf(p.dx, p.N, p.ld_dx, C, slc, cvc),
+                 bdr = fused_buf(p.dres ? p.dres : p.dx, p.N, p.dres ? p.ld_dr : p.ld_dx, C, slc, cvc);
+  const float* mean = p.save_mean + g.grp * C;
+  const float* invstd = p.save_invstd + g.grp * C;
+  const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
+  u32x4 xr[RMAX];
+  unsigned mb[RMAX / 4];
+#pragma unroll
+  for (int i = 0; i < RMAX / 4; i++) mb[i] = 0u;
+  float a[8], b[8];
+  {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = cvc * 8 + i;
+      const float wv = wp[c], bv = bp[c];
+      sc[i] = invstd[c] * (p.weight ? wv : 1.f);
+      sh[i] = (p.bias ? bv : 0.f) - mean[c] * sc[i];
+      a[i] = b[i] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < RMAX; k++) {
+      const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
+      const int64_t row = g.r0 + (int64_t)k * g.rs;
+      const u32x4 tx = fused_ld(bx, row);
+      u32x4 td = fused_ld(bd, row);
+      if (!ok) td = (u32x4){0u, 0u, 0u, 0u};
+      float xv[8], dv[8], yv[8];
+      unpack8(tx, xv);
+      unpack8(td, dv);
+      if (DY2) {
+        float d2[8];
+        unpack8(fused_ld(bd2, row), d2);
+#pragma unroll
+        for (int i = 0; i < 8; i++) dv[i] = ok ? dv[i] + d2[i] : 0.f;
+      }
+      if (MASK == 2) unpack8(fused_ld(byo, row), yv);
+      unsigned m8 = 0u;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (MASK == 1) yv[i] = fmaf(xv[i], sc[i], sh[i]);
+        const bool keep = MASK == 0 || yv[i] > 0.f;
+        m8 |= keep ? (1u << i) : 0u;
+        const float gg = keep ? dv[i] : 0.f;
+        a[i] += gg;
+        b[i] = fmaf(gg, xv[i], b[i]);
+      }
+      mb[k >> 2] |= m8 << (8 * (k & 3));
+      xr[k] = tx;
+      if (k < FUSED_NL) rows[k * FT + tid] = td;  // rows beyond the LDS budget are read again in phase 2 (L2 / Infinity Cache hits)
+      if ((k & 1) == 1) {  // two rows' loads in flight at a time: bounds the live temporaries
+        MM_PIN16(a, b);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  fused_block_sums(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
+  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
+  const int G = p.G0 + p.G1;
+  fused_barrier(p.sync, (unsigned)G, flag0);
+  {
+    const int ngrp = p.G1 > 0 ? 2 : 1;
+    for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
+      float ts = 0.f, tq = 0.f;
+      for (int gi = 0; gi < ngrp; gi++) {
+        double sg, sgx;
+        fused_wave_sums(p.partial, gi ? p.G0 : 0, gi ? G : p.G0, C, c, sg, sgx);
+        const double m = (double)p.save_mean[gi * C + c], is = (double)p.save_invstd[gi * C + c];
+        const float sv = (float)sg, qv = (float)(is * (sgx - m * sg));
+        if ((tid & 63) == 0) {
+          xcd_store(p.sums + (gi * 2 + 0) * C + c, sv);
+          xcd_store(p.sums + (gi * 2 + 1) * C + c, qv);
+        }
+        ts += sv, tq += qv;  // the order two consecutive backward calls accumulate in
+      }
+      if ((tid & 63) == 0) {
+        if (p.dweight) p.dweight[c] = p.accumulate ? p.dweight[c] + tq : tq;
+        if (p.dbias) p.dbias[c] = p.accumulate ? p.dbias[c] + ts : ts;
+      }
+    }
+  }
+  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  if (!g.active) return;
+#pragma unroll
+  for (int k = 0; k < RMAX; k++) asm volatile("" : "+v"(xr[k]));  // keep the rows packed across the barrier (see the forward kernel)
+#pragma unroll
+  for (int i = 0; i < RMAX / 4; i++) asm volatile("" : "+v"(mb[i]));  // ... and the mask as bits, not as the compared floats
+  // dx = ka*g + kb*x + kc (see k_bn2d_bwd_apply)
+  float ka[8], kb[8], kc[8];
+  const float invN = 1.f / (float)g.Ng;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int c = g.cv * 8 + i;
+    const float wv = wp[c];
+    const float is = invstd[c], w = p.weight ? wv : 1.f;
+    const float sg = xcd_load(p.sums + (g.grp * 2 + 0) * C + c), sq = xcd_load(p.sums + (g.grp * 2 + 1) * C + c);
+    ka[i] = w * is;
+    kb[i] = -w * is * is * sq * invN;
+    kc[i] = -ka[i] * sg * invN - kb[i] * mean[c];
+  }
+#pragma unroll
+  for (int k0 = 0; k0 < RMAX; k0 += 4) {
+    if (k0 < p.R) {
+      u32x4 d2[4], d1[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (DY2) d2[j] = fused_ld(bd2, g.r0 + (int64_t)(k0 + j) * g.rs);
+        if (k0 + j >= FUSED_NL) d1[j] = fused_ld(bd, g.r0 + (int64_t)(k0 + j) * g.rs);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = k0 + j;
+        u32x4 td;
+        if (k < FUSED_NL) td = rows[k * FT + tid];
+        else td = d1[j];
+        float xv[8], dv[8], ov[8], gv[8];
+        unpack8(xr[k], xv);
+        unpack8(td, dv);
+        if (DY2) {
+          float e[8];
+          unpack8(d2[j], e);
+#pragma unroll
+          for (int i = 0; i < 8; i++) dv[i] += e[i];
+        }
+        const unsigned m8 = mb[k >> 2] >> (8 * (k & 3));
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const float gg = ((m8 >> i) & 1u) ? dv[i] : 0.f;
+          gv[i] = gg;
+          ov[i] = fmaf(ka[i], gg, fmaf(kb[i], xv[i], kc[i]));
+        }
+        if (k < p.R && g.slot + k * g.rs < g.nrows) {
+          fused_st(bdx, g.r0 + (int64_t)k * g.rs, pack8(ov));
+          if (p.dres) fused_st(bdr, g.r0 + (int64_t)k * g.rs, pack8(gv));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one row's arithmetic at a time (the group's loads stay in flight)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 inline unsigned apply_blocks(int64_t N, int C) {
   int rs = T / (C / 8);
   return (unsigned)mm_cdiv(N, (int64_t)rs * APPLY_ROWS);
@@ -318,7 +821,94 @@ inline int stat_blocks(int64_t N, int C) {
 }
 }  // namespace
 
+// ---- host side of the single-launch kernels
+struct FusedPlan {
+  bool ok;
+  int G0, G1, R;
+  unsigned* sync;
+};
+
+static std::mutex g_fused_mu;
+static unsigned* g_fused_sync[16];       // per device: 64 slots x 512 B (arrival counter | release word), zero-initialised
+static hipStream_t g_fused_stream[16][64];
+static int g_fused_nstream[16];
+static int g_fused_cus[16];
+static int g_fused_enabled = -1;  // bit 0: forward, bit 1: backward; -1: take MM_BN2D_FUSED (default 3) on first use
+
+// Grid and rows per thread for a map of N rows (Ns in the first statistics group) and C channels; ok = false: use the
+// three-kernel path (map too large to keep on chip, channel count outside the layout, or MM_BN2D_FUSED=0).
+static int fused_plan(int64_t N, int64_t Ns, int C, int rmax, bool backward, hipStream_t s, FusedPlan* pl) {
+  pl->ok = false;
+  if (g_fused_enabled < 0) {
+    const char* e = getenv("MM_BN2D_FUSED");
+    g_fused_enabled = e ? (atoi(e) & 3) : 3;
+  }
+  if (!(g_fused_enabled & (backward ? 2 : 1)) || N <= 0 || C % 8 != 0 || C > FT || C < 8) return MM_OK;
+  int dev = 0;
+  MM_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) return MM_OK;
+  std::lock_guard<std::mutex> lock(g_fused_mu);
+  if (!g_fused_sync[dev]) {
+    int cus = 0;
+    MM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    void* q = nullptr;
+    MM_HIP(hipMalloc(&q, 64 * 512));
+    MM_HIP(hipMemset(q, 0, 64 * 512));
+    const void* fns[] = {
+        (const void*)k_bn2d_fused_fwd<8, false>,  (const void*)k_bn2d_fused_fwd<8, true>,   (const void*)k_bn2d_fused_fwd<20, false>,
+        (const void*)k_bn2d_fused_fwd<20, true>,  (const void*)k_bn2d_fused_fwd<36, false>, (const void*)k_bn2d_fused_fwd<36, true>,
+        (const void*)k_bn2d_fused_bwd<8, false, 0>,  (const void*)k_bn2d_fused_bwd<8, false, 1>,  (const void*)k_bn2d_fused_bwd<8, false, 2>,
+        (const void*)k_bn2d_fused_bwd<8, true, 0>,   (const void*)k_bn2d_fused_bwd<8, true, 1>,   (const void*)k_bn2d_fused_bwd<8, true, 2>,
+        (const void*)k_bn2d_fused_bwd<20, false, 0>, (const void*)k_bn2d_fused_bwd<20, false, 1>, (const void*)k_bn2d_fused_bwd<20, false, 2>,
+        (const void*)k_bn2d_fused_bwd<20, true, 0>,  (const void*)k_bn2d_fused_bwd<20, true, 1>,  (const void*)k_bn2d_fused_bwd<20, true, 2>};
+    for (const void* fn : fns) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS));
+    g_fused_cus[dev] = cus;
+    g_fused_sync[dev] = (unsigned*)q;
+  }
+  int slot = -1;
+  for (int i = 0; i < g_fused_nstream[dev]; i++)
+    if (g_fused_stream[dev][i] == s) slot = i;
+  if (slot < 0) {
+    if (g_fused_nstream[dev] >= 64) return MM_OK;  // more streams than barrier slots: three-kernel path
+    slot = g_fused_nstream[dev]++;
+    g_fused_stream[dev][slot] = s;
+  }
+  const int rs = FT / (C / 8);
+  const int cus = g_fused_cus[dev];
+  if (cus < 2) return MM_OK;
+  const bool two = Ns > 0 && Ns < N;
+  int64_t G = mm_cdiv(N, (int64_t)rs * 6);  // about six rows per thread
+  if (G > cus) G = cus;
+  if (G < (two ? 2 : 1)) G = two ? 2 : 1;
+  int G0 = (int)G, G1 = 0;
+  if (two) {
+    G0 = (int)((double)G * (double)Ns / (double)N + 0.5);
+    if (G0 < 1) G0 = 1;
+    if (G0 > (int)G - 1) G0 = (int)G - 1;
+    G1 = (int)G - G0;
+  }
+  const int64_t rpb0 = mm_cdiv(two ? Ns : N, G0), rpb1 = two ? mm_cdiv(N - Ns, G1) : 0;
+  const int64_t R = mm_cdiv(rpb0 > rpb1 ? rpb0 : rpb1, rs);
+  if (R > rmax) return MM_OK;
+  pl->ok = true;
+  pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;
+  pl->sync = g_fused_sync[dev] + slot * 128;
+  return MM_OK;
+}
+
 extern "C" {
+
+// Selects the single-launch training kernels per direction: bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd (default 3, or the
+// value of the environment variable MM_BN2D_FUSED); 0 = always the reduce / finalize / apply kernels.  Returns the previous mask.
+int mm_bn2d_set_fused(int mask) {
+  if (g_fused_enabled < 0) {
+    const char* e = getenv("MM_BN2D_FUSED");
+    g_fused_enabled = e ? (atoi(e) & 3) : 3;
+  }
+  const int prev = g_fused_enabled;
+  g_fused_enabled = mask & 3;
+  return prev;
+}
 
 size_t mm_bn2d_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 
@@ -353,6 +943,32 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
   }
   double* partial = (double*)ws;
   int nb0, nb1, ab0, ab1;
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  FusedPlan pl;
+  int rc = fused_plan(N, Ns, C, 36, false, s, &pl);
+  if (rc) return rc;
+  const int64_t ldmax_f = std::max(std::max(ld_x, ld_y), res ? ld_r : 0);
+  if (pl.ok && (!res || ld_r % 8 == 0) && N * ldmax_f * 2 < (1ll << 31)) {  // 32-bit buffer offsets
+    FusedP p = {};
+    p.x = (const u16*)x, p.res = (const u16*)res, p.y = (u16*)y;
+    p.ld_x = ld_x, p.ld_r = ld_r, p.ld_y = ld_y;
+    p.N = N, p.Ns = Ns, p.C = C, p.relu = relu, p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R;
+    p.weight = weight, p.bias = bias, p.running_mean = running_mean, p.running_var = running_var, p.nbt = num_batches_tracked;
+    p.eps = eps, p.momentum = momentum, p.save_mean = save_mean, p.save_invstd = save_invstd;
+    p.partial = partial, p.sync = pl.sync;
+    const dim3 grid(pl.G0 + pl.G1), blk(FT);
+#define MM_FWD(RM)                                                                                  \
+  do {                                                                                              \
+    if (res) hipLaunchKernelGGL((k_bn2d_fused_fwd<RM, true>), grid, blk, FUSED_LDS, s, p);          \
+    else hipLaunchKernelGGL((k_bn2d_fused_fwd<RM, false>), grid, blk, FUSED_LDS, s, p);             \
+  } while (0)
+    if (pl.R <= 8) MM_FWD(8);
+    else if (pl.R <= 20) MM_FWD(20);
+    else MM_FWD(36);
+#undef MM_FWD
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
   split_blocks(N, Ns, C, true, nb0, nb1);
   hipLaunchKernelGGL(k_bn2d_reduce<0>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, nullptr, 0, nullptr, 0, 0, N, C, nullptr,
                      nullptr, partial, Ns, nb0);
@@ -395,6 +1011,39 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   double* partial = (double*)ws;
   float* sums = (float*)((char*)ws + need);
   int nb0, nb1, ab0, ab1;
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  FusedPlan pl;
+  int rc = fused_plan(N, Ns, C, 20, true, s, &pl);
+  if (rc) return rc;
+  const int64_t ldmax_b = std::max(std::max(std::max(ld_x, ld_dy), std::max(ld_dx, dy2 ? ld_dy2 : 0)), std::max(yout ? ld_y : 0, dres ? ld_dr : 0));
+  if (pl.ok && ld_x % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0 && (!dy2 || ld_dy2 % 8 == 0) && (!yout || ld_y % 8 == 0) &&
+      (!dres || ld_dr % 8 == 0) && N * ldmax_b * 2 < (1ll << 31)) {  // 32-bit buffer offsets
+    FusedP p = {};
+    p.x = (const u16*)x, p.dy = (const u16*)dy, p.dy2 = (const u16*)dy2, p.yout = (const u16*)yout, p.dx = (u16*)dx, p.dres = (u16*)dres;
+    p.ld_x = ld_x, p.ld_dy = ld_dy, p.ld_dy2 = ld_dy2, p.ld_y = ld_y, p.ld_dx = ld_dx, p.ld_dr = ld_dr;
+    p.N = N, p.Ns = Ns, p.C = C, p.relu = relu, p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R;
+    p.weight = weight, p.bias = bias, p.save_mean = (float*)save_mean, p.save_invstd = (float*)save_invstd;
+    p.sums = sums, p.dweight = dweight, p.dbias = dbias, p.accumulate = accumulate;
+    p.partial = partial, p.sync = pl.sync;
+    const dim3 grid(pl.G0 + pl.G1), blk(FT);
+    const int mask = !relu ? 0 : (yout ? 2 : 1);
+#define MM_BWD(RM, D2)                                                                                        \
+  do {                                                                                                        \
+    if (mask == 0) hipLaunchKernelGGL((k_bn2d_fused_bwd<RM, D2, 0>), grid, blk, FUSED_LDS, s, p);             \
+    else if (mask == 1) hipLaunchKernelGGL((k_bn2d_fused_bwd<RM, D2, 1>), grid, blk, FUSED_LDS, s, p);        \
+    else hipLaunchKernelGGL((k_bn2d_fused_bwd<RM, D2, 2>), grid, blk, FUSED_LDS, s, p);                       \
+  } while (0)
+    if (pl.R <= 8) {
+      if (dy2) MM_BWD(8, true);
+      else MM_BWD(8, false);
+    } else {
+      if (dy2) MM_BWD(20, true);
+      else MM_BWD(20, false);
+    }
+#undef MM_BWD
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
   split_blocks(N, Ns, C, true, nb0, nb1);
   hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y,
                      relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias, (const u16*)dy2, ld_dy2);

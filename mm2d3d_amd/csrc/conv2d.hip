@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
+#define MM_PACK_CHUNK 4096
 // packed bf16 weights: out[((z*N + n)*T + t)*K + k] = bf16(in[z*sz + n*sn + t*st + k*sk])
 __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ in, u16* __restrict__ out, int Z, int N, int T,
                                                        int K, int64_t sz, int64_t sn, int64_t st, int64_t sk) {
@@ -1058,6 +1059,8 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float* __restrict__ 
 
 // The same for a table of weights in one launch (all conv layers of a model after an optimiser step).  desc = 11 x
 // int64: in, out, Z, N, T, K, sz, sn, st, sk, first block; block -> desc by binary search over the first-block column.
+// A block converts MM_PACK_CHUNK consecutive outputs (16 independent gathers per thread): with one block per 256 outputs the
+// launch was bound by the latency of the search (8 dependent loads) and of the 64-bit index divisions, not by the 290 MB moved.
 __global__ __launch_bounds__(256) void k_pack_weights_batch(const int64_t* __restrict__ desc, int ndesc) {
   int lo = 0, hi = ndesc - 1;
   while (lo < hi) {
@@ -1068,17 +1071,27 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const int64_t* __res
   const int64_t* d = desc + (int64_t)lo * 11;
   const float* in = (const float*)d[0];
   u16* out = (u16*)d[1];
-  const int Z = (int)d[2], N = (int)d[3], T = (int)d[4], K = (int)d[5];
+  const unsigned N = (unsigned)d[3], T = (unsigned)d[4], K = (unsigned)d[5];
   const int64_t sz = d[6], sn = d[7], st = d[8], sk = d[9];
-  int64_t e = ((int64_t)blockIdx.x - d[10]) * 256 + threadIdx.x;
-  int64_t ne = (int64_t)Z * N * T * K;
-  if (e >= ne) return;
-  int k = (int)(e % K);
-  int64_t r = e / K;
-  int t = (int)(r % T);
-  r /= T;
-  int n = (int)(r % N), z = (int)(r / N);
-  out[e] = f2bf(in[z * sz + n * sn + t * st + k * sk]);
+  const unsigned ne = (unsigned)(d[2] * d[3] * d[4] * d[5]);  // < 2^31: checked where the table is built
+  const unsigned base = (unsigned)((int64_t)blockIdx.x - d[10]) * MM_PACK_CHUNK + threadIdx.x;
+  float v[MM_PACK_CHUNK / 256];
+#pragma unroll
+  for (int i = 0; i < MM_PACK_CHUNK / 256; i++) {
+    const unsigned e = base + i * 256;
+    const unsigned ec = e < ne ? e : ne - 1;
+    const unsigned k = ec % K;
+    unsigned r = ec / K;
+    const unsigned t = r % T;
+    r /= T;
+    const unsigned n = r % N, z = r / N;
+    v[i] = in[z * sz + n * sn + t * st + k * sk];
+  }
+#pragma unroll
+  for (int i = 0; i < MM_PACK_CHUNK / 256; i++) {
+    const unsigned e = base + i * 256;
+    if (e < ne) out[e] = f2bf(v[i]);
+  }
 }
 
 // NCHW fp32 -> NHWC bf16 and back (model boundary)
@@ -1337,7 +1350,7 @@ int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K,
 }
 
 // desc (device): ndesc rows of 11 int64 {in, out, Z, N, T, K, sz, sn, st, sk, first_block}, first_block = prefix sum of
-// ceil(Z*N*T*K / 256) over the preceding rows; total_blocks = the sum over all rows.
+// ceil(Z*N*T*K / 4096) over the preceding rows (Z*N*T*K < 2^31 per row); total_blocks = the sum over all rows.
 int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, hipStream_t s) {
   MM_CHECK_ARG(ndesc >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "pack_weights_batch: bad table");
   if (ndesc == 0 || total_blocks == 0) return MM_OK;

@@ -148,23 +148,27 @@ __global__ __launch_bounds__(T) void k_sort_lists(int64_t n_bound, const int32_t
   }
 }
 
-// ---- submanifold 3^3 neighbour table, k-major: nbr[k*n + o] = id of the active site at coord(o)+off(k), or -1
+// ---- submanifold 3^3 neighbour table, k-major: nbr[k*n + o] = id of the active site at coord(o)+off(k), or -1.
+// The relation is symmetric (o' = nbr[k][o]  <=>  o = nbr[26-k][o']), so only offsets 0..12 are probed in the hash table and
+// each hit also fills its mirror entry; planes 14..26 are preset to -1 by the host wrapper.  Every entry still has exactly
+// one writer.  Halves the random 8-byte probes that bound this kernel.
 __global__ __launch_bounds__(T) void k_subm_nbr(const int32_t* __restrict__ vc, int64_t n, int spatial,
                                                  const unsigned long long* __restrict__ tkeys,
                                                  const int32_t* __restrict__ tvals, long long mask,
                                                  int32_t* __restrict__ nbr) {
   int64_t o = (int64_t)blockIdx.x * T + threadIdx.x;
-  int k = blockIdx.y;
+  int k = blockIdx.y;  // 0..13
   if (o >= n) return;
+  if (k == 13) {
+    nbr[(int64_t)13 * n + o] = (int)o;
+    return;
+  }
   int x = vc[o * 4 + 0] + (k / 9 - 1), y = vc[o * 4 + 1] + ((k / 3) % 3 - 1), z = vc[o * 4 + 2] + (k % 3 - 1);
   int b = vc[o * 4 + 3];
   int r = -1;
-  if (k == 13) {
-    r = (int)o;
-  } else if (x >= 0 && y >= 0 && z >= 0 && x < spatial && y < spatial && z < spatial) {
-    r = hash_find(tkeys, tvals, mask, pack_key(x, y, z, b));
-  }
+  if (x >= 0 && y >= 0 && z >= 0 && x < spatial && y < spatial && z < spatial) r = hash_find(tkeys, tvals, mask, pack_key(x, y, z, b));
   nbr[(int64_t)k * n + o] = r;
+  if (r >= 0) nbr[(int64_t)(26 - k) * n + r] = (int)o;
 }
 
 // ---- strided 2^3 table: nbr[k*n_coarse + parent] = child
@@ -310,7 +314,8 @@ int mm_subm_neighbors(const int32_t* vox_coords, int64_t n, int32_t spatial_size
                       const int32_t* tvals, int64_t cap, int32_t* nbr, hipStream_t s) {
   MM_CHECK_ARG(n >= 0 && (cap & (cap - 1)) == 0, "subm_neighbors: bad args");
   if (n == 0) return MM_OK;
-  hipLaunchKernelGGL(k_subm_nbr, dim3(nblk(n), 27), dim3(T), 0, s, vox_coords, n, (int)spatial_size,
+  MM_HIP(hipMemsetAsync(nbr + 14 * n, 0xFF, (size_t)13 * n * 4, s));
+  hipLaunchKernelGGL(k_subm_nbr, dim3(nblk(n), 14), dim3(T), 0, s, vox_coords, n, (int)spatial_size,
                      (const unsigned long long*)tkeys, tvals, (long long)(cap - 1), nbr);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -331,12 +336,14 @@ size_t mm_rulebook_ws_bytes(int64_t n_out, int K) {
 }
 
 // nbr [K][n_out] -> k-major rule lists (rin/rout, capacity K*n_out), offsets[K+1], CSR over out rows.
+// csr_off == csr_pos == NULL: only the rule lists (levels served by the output-stationary engine never read the CSR; a
+// caller that turns out to need it builds it later with mm_rulebook_csr from the same nbr table).
 int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, int32_t* rout, int32_t* offsets,
                         int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes, hipStream_t s) {
-  MM_CHECK_ARG(K > 0 && K <= 64 && n_out >= 0, "rulebook_compact: bad args");
+  MM_CHECK_ARG(K > 0 && K <= 64 && n_out >= 0 && (csr_off == nullptr) == (csr_pos == nullptr), "rulebook_compact: bad args");
   if (n_out == 0) {
     MM_HIP(hipMemsetAsync(offsets, 0, (size_t)(K + 1) * 4, s));
-    MM_HIP(hipMemsetAsync(csr_off, 0, 4, s));
+    if (csr_off) MM_HIP(hipMemsetAsync(csr_off, 0, 4, s));
     return MM_OK;
   }
   MMArena ar(ws, ws_bytes);
@@ -352,13 +359,22 @@ int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, 
   hipLaunchKernelGGL(k_flags_from_nbr, dim3(nblk(total)), dim3(T), 0, s, nbr, total, pos);
   int rc = mm_exclusive_scan_i32(pos, pos, total, pos + total, scan_ws, sws, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_emit_rules, dim3(nblk(n_out), K), dim3(T), 0, s, nbr, pos, n_out, K, rin, rout, offsets, pos + total);
-  hipLaunchKernelGGL(k_row_counts, dim3(nblk(n_out)), dim3(T), 0, s, nbr, n_out, K, cnt);
-  rc = mm_exclusive_scan_i32(cnt, csr_off, n_out, csr_off + n_out, scan_ws, sws, s);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_row_fill, dim3(nblk(n_out)), dim3(T), 0, s, nbr, pos, n_out, K, csr_off, csr_pos);
+  if (rin) hipLaunchKernelGGL(k_emit_rules, dim3(nblk(n_out), K), dim3(T), 0, s, nbr, pos, n_out, K, rin, rout, offsets, pos + total);
+  if (csr_off) {
+    hipLaunchKernelGGL(k_row_counts, dim3(nblk(n_out)), dim3(T), 0, s, nbr, n_out, K, cnt);
+    rc = mm_exclusive_scan_i32(cnt, csr_off, n_out, csr_off + n_out, scan_ws, sws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_row_fill, dim3(nblk(n_out)), dim3(T), 0, s, nbr, pos, n_out, K, csr_off, csr_pos);
+  }
   MM_LAUNCH_CHECK();
   return MM_OK;
+}
+
+// The CSR half of mm_rulebook_compact alone (same nbr table, same workspace size): csr_off [n_out+1], csr_pos [n_rules].
+int mm_rulebook_csr(const int32_t* nbr, int K, int64_t n_out, int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes,
+                    hipStream_t s) {
+  MM_CHECK_ARG(csr_off && csr_pos, "rulebook_csr: null output");
+  return mm_rulebook_compact(nbr, K, n_out, nullptr, nullptr, nullptr, csr_off, csr_pos, ws, ws_bytes, s);
 }
 
 // out[0] = number of active rows whose batch index < split (their row ids are 0 .. out[0]-1); n_dev: device row count

@@ -59,9 +59,13 @@ __global__ __launch_bounds__(T) void k_up_nbr(const int32_t* __restrict__ vc_fin
   for (int k = 0; k < 8; k++) nbr[(int64_t)k * n_fine + i] = k == kk ? par : -1;
 }
 
+// rocPRIM's default switches to a merge sort below 2^20 keys: ~17 launch-bound passes (100 us) for the 60k..800k-row tables
+// here, where Onesweep needs one histogram + one scatter pass per 8 key bits (K = 8: a single pass).
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
+
 size_t sort_tmp_bytes(int64_t n, int K) {
   size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<int32_t>(0),
+  (void)rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<int32_t>(0),
                             (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0u, (unsigned)K, (hipStream_t)0);
   return bytes;
 }
@@ -99,7 +103,7 @@ int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32
     return MM_ERR_WORKSPACE;
   }
   hipLaunchKernelGGL(k_row_mask, dim3((unsigned)mm_cdiv(n, T)), dim3(T), 0, s, nbr, K, n, mask);
-  MM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint32_t*)mask, mask_sorted, rocprim::counting_iterator<int32_t>(0), perm,
+  MM_HIP(rocprim::radix_sort_pairs<SortCfg>(tmp, tmp_bytes, (const uint32_t*)mask, mask_sorted, rocprim::counting_iterator<int32_t>(0), perm,
                                    (size_t)n, 0u, (unsigned)K, s));
   MM_HIP(hipMemsetAsync(tmask, 0, (size_t)nt * 4, s));
   hipLaunchKernelGGL(k_os_fill, dim3((unsigned)mm_cdiv(npad, T)), dim3(T), 0, s, nbr, K, n, npad, tile_rows, mask_sorted, perm, dst,

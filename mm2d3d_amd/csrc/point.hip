@@ -164,6 +164,101 @@ __global__ __launch_bounds__(T) void k_linear_bwd_w(const float* __restrict__ x,
   }
 }
 
+// ---- the per-point heads (3d_net/model.py:50,85: 16 features -> <= 16 classes over ~560k points): one thread per ROW.
+// The generic kernels above give every (row, output) pair its own thread, which re-reads the 64-byte row Cout times through
+// 16 scalar loads each (121 us for a 36 MB input); here a thread loads its row with four 16-byte loads and keeps the whole
+// [Cout][16] weight matrix in registers via LDS broadcast reads.
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(T) void k_linear16_fwd(const float* __restrict__ x, int ld_x, int64_t N, int Cout, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ y, int ld_y) {
+  __shared__ float ws[16 * 16 + 16];
+  for (int i = threadIdx.x; i < Cout * 16; i += T) ws[i] = w[i];
+  for (int i = threadIdx.x; i < Cout; i += T) ws[256 + i] = b ? b[i] : 0.f;
+  __syncthreads();
+  const int64_t n = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (n >= N) return;
+  float xv[16];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const f32x4p t = *(const f32x4p*)(x + n * ld_x + 4 * q);
+    xv[4 * q] = t.x, xv[4 * q + 1] = t.y, xv[4 * q + 2] = t.z, xv[4 * q + 3] = t.w;
+  }
+  for (int co = 0; co < Cout; co++) {
+    float acc = ws[256 + co];
+#pragma unroll
+    for (int ci = 0; ci < 16; ci++) acc = fmaf(xv[ci], ws[co * 16 + ci], acc);
+    y[n * ld_y + co] = acc;
+  }
+}
+
+__global__ __launch_bounds__(T) void k_linear16_bwd_x(const float* __restrict__ dy, int ld_dy, int64_t N, int Cout,
+                                                       const float* __restrict__ w, float* __restrict__ dx, int ld_dx, int accumulate) {
+  __shared__ float ws[16 * 16];
+  for (int i = threadIdx.x; i < Cout * 16; i += T) ws[i] = w[i];
+  __syncthreads();
+  const int64_t n = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int ci = 0; ci < 16; ci++) acc[ci] = 0.f;
+  for (int co = 0; co < Cout; co++) {
+    const float g = dy[n * ld_dy + co];
+#pragma unroll
+    for (int ci = 0; ci < 16; ci++) acc[ci] = fmaf(g, ws[co * 16 + ci], acc[ci]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    f32x4p* d = (f32x4p*)(dx + n * ld_dx + 4 * q);
+    f32x4p v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+    if (accumulate) v += *d;
+    *d = v;
+  }
+}
+
+// partial[block][co*16+ci] = sum_n dy[n,co]*x[n,ci]; partial[block][Cout*16 + co] = sum_n dy[n,co]: every thread walks rows
+// with a block stride and keeps one output class at a time in 17 registers; the block combines through LDS in fp64 (fixed order)
+__global__ __launch_bounds__(T) void k_linear16_bwd_w(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
+                                                       int64_t N, int Cout, double* __restrict__ partial) {
+  __shared__ double red[T];
+  const int ne = Cout * 16 + Cout;
+  const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+  for (int co = 0; co < Cout; co++) {
+    float acc[17];
+#pragma unroll
+    for (int i = 0; i < 17; i++) acc[i] = 0.f;
+    for (int64_t r = r0 + threadIdx.x; r < r1; r += T) {
+      const float g = dy[r * ld_dy + co];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const f32x4p t = *(const f32x4p*)(x + r * ld_x + 4 * q);
+        acc[4 * q] = fmaf(g, t.x, acc[4 * q]);
+        acc[4 * q + 1] = fmaf(g, t.y, acc[4 * q + 1]);
+        acc[4 * q + 2] = fmaf(g, t.z, acc[4 * q + 2]);
+        acc[4 * q + 3] = fmaf(g, t.w, acc[4 * q + 3]);
+      }
+      acc[16] += g;
+    }
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+      __syncthreads();
+      red[threadIdx.x] = (double)acc[i];
+      __syncthreads();
+      for (int s2 = T / 2; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * ne + (i < 16 ? co * 16 + i : Cout * 16 + co)] = red[0];
+    }
+  }
+}
+
+static bool linear16_ok(const float* x, int ld_x, int Cin, int Cout) {
+  return Cin == 16 && Cout <= 16 && ld_x % 4 == 0 && ((uintptr_t)x % 16) == 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -219,6 +314,11 @@ int mm_row_gather(const float* vox, int ld_v, int C, const int32_t* p2v, const i
 int mm_linear_fwd(const float* x, int ld_x, int64_t N, int Cin, int Cout, const float* w, const float* b, float* y, int ld_y,
                   hipStream_t s) {
   if (N == 0) return MM_OK;
+  if (linear16_ok(x, ld_x, Cin, Cout)) {
+    hipLaunchKernelGGL(k_linear16_fwd, dim3((unsigned)mm_cdiv(N, T)), dim3(T), 0, s, x, ld_x, N, Cout, w, b, y, ld_y);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
   hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)mm_cdiv(N * Cout, T)), dim3(T), 0, s, x, ld_x, N, Cin, Cout, w, b, y, ld_y);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -231,9 +331,14 @@ int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t 
   MM_CHECK_ARG(Cin > 0 && Cout > 0 && (size_t)64 * (Cin + Cout) * 4 <= 150 * 1024, "linear_bwd: channels too wide");
   if ((size_t)64 * (Cin + Cout) * 4 > 64 * 1024)
     MM_HIP(hipFuncSetAttribute((const void*)k_linear_bwd_w, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * (Cin + Cout) * 4));
-  if (dx && N)
-    hipLaunchKernelGGL(k_linear_bwd_x, dim3((unsigned)mm_cdiv(N * Cin, T)), dim3(T), 0, s, dy, ld_dy, N, Cin, Cout, w, dx, ld_dx,
-                       accumulate_dx);
+  const bool fast = linear16_ok(x, ld_x, Cin, Cout);
+  if (dx && N) {
+    if (fast && ld_dx % 4 == 0 && ((uintptr_t)dx % 16) == 0)
+      hipLaunchKernelGGL(k_linear16_bwd_x, dim3((unsigned)mm_cdiv(N, T)), dim3(T), 0, s, dy, ld_dy, N, Cout, w, dx, ld_dx, accumulate_dx);
+    else
+      hipLaunchKernelGGL(k_linear_bwd_x, dim3((unsigned)mm_cdiv(N * Cin, T)), dim3(T), 0, s, dy, ld_dy, N, Cin, Cout, w, dx, ld_dx,
+                         accumulate_dx);
+  }
   if (dw) {
     int nb = (int)mm_cdiv(N > 0 ? N : 1, 2048);
     if (nb > MAX_PART) nb = MAX_PART;
@@ -243,8 +348,11 @@ int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t 
       return MM_ERR_WORKSPACE;
     }
     double* partial = (double*)ws;
-    hipLaunchKernelGGL(k_linear_bwd_w, dim3(nb), dim3(T), (size_t)64 * (Cin + Cout) * 4, s, x, ld_x, dy, ld_dy, N, Cin, Cout,
-                       partial);
+    if (fast)
+      hipLaunchKernelGGL(k_linear16_bwd_w, dim3(nb), dim3(T), 0, s, x, ld_x, dy, ld_dy, N, Cout, partial);
+    else
+      hipLaunchKernelGGL(k_linear_bwd_w, dim3(nb), dim3(T), (size_t)64 * (Cin + Cout) * 4, s, x, ld_x, dy, ld_dy, N, Cin, Cout,
+                         partial);
     // bias partials live behind the weight partials; when db is null they are summed into a scratch tail of ws
     float* dbp = db ? db : (float*)((char*)ws + (size_t)nb * ne * sizeof(double));
     if (!db && ws_bytes < (size_t)nb * ne * sizeof(double) + Cout * sizeof(float)) {

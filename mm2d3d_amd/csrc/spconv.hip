@@ -701,6 +701,7 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
                     int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
                     int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && ld_in >= Cin && ld_out >= Cout, "spconv_apply: bad shape");
+  MM_CHECK_ARG(unique_dst || (csr_off && csr_pos), "spconv_apply: the row CSR is required unless every destination is unique");
   const int64_t R = offsets_host[K];
   if (n_out == 0) return MM_OK;
   const bool edge = (Cin % 16 != 0) || (Cout % 16 != 0) || (ld_in % 4 != 0) || (ld_out % 4 != 0) ||

@@ -22,16 +22,32 @@ class Rulebook:
     """k-major rule lists + CSR over destination rows (csrc/spconv.hip header)."""
 
     __slots__ = ("K", "rin", "rout", "offsets_dev", "offsets_host", "csr_off", "csr_pos", "n_rules", "n_out", "_keep", "os",
-                 "os_up")
+                 "os_up", "nbr")
 
     def __init__(self, K):
         self.K = K
+        self.nbr = None    # the [K, n_out] neighbour table, kept only while the CSR has not been built (ensure_csr)
         self.os = None     # OsTable over the rulebook's destination rows (csrc/ostable.hip): the output-stationary engine
         self.os_up = None  # strided rulebooks only: OsTable with the roles swapped (destination = fine rows)
 
     @property
     def offsets_ptr(self):
         return self.offsets_host.ctypes.data
+
+    def ensure_csr(self):
+        """The destination-row CSR of the gather + reduce engine.  Rulebooks whose destination rows have an output-stationary
+        table are built without it (every convolution over them normally takes that engine); the first call that does fall back
+        to the rulebook engine builds it here from the retained neighbour table."""
+        if self.csr_pos is not None:
+            return
+        L = _lib.lib()
+        dev = self.nbr.device
+        self.csr_pos = torch.empty(max(self.n_rules, 1), dtype=I32, device=dev)
+        self.csr_off = torch.empty(self.n_out + 1, dtype=I32, device=dev)
+        ws = _lib.workspace.get(int(L.mm_rulebook_ws_bytes(self.n_out, self.K)), dev)
+        check(L.mm_rulebook_csr(ptr(self.nbr), self.K, self.n_out, ptr(self.csr_off), ptr(self.csr_pos), ptr(ws), ws.numel(), stream()),
+              "rulebook_csr")
+        self.nbr = None
 
 
 class OsTable:
@@ -217,15 +233,19 @@ class Metadata:
         return lv
 
     # ------------------------------------------------------------------ rulebooks
-    def _launch_rulebook(self, K, n_out, nbr, offsets_dev):
+    def _launch_rulebook(self, K, n_out, nbr, offsets_dev, with_csr=True):
         L = _lib.lib()
         dev = self.device
         rb = Rulebook(K)
         cap = max(K * n_out, 1)
         rb.rin = torch.empty(cap, dtype=I32, device=dev)
         rb.rout = torch.empty(cap, dtype=I32, device=dev)
-        rb.csr_pos = torch.empty(cap, dtype=I32, device=dev)
-        rb.csr_off = torch.empty(n_out + 1, dtype=I32, device=dev)
+        if with_csr:
+            rb.csr_pos = torch.empty(cap, dtype=I32, device=dev)
+            rb.csr_off = torch.empty(n_out + 1, dtype=I32, device=dev)
+        else:
+            rb.csr_pos = rb.csr_off = None
+            rb.nbr = nbr
         rb.offsets_dev = offsets_dev
         rb.n_out = n_out
         ws = _lib.workspace.get(int(L.mm_rulebook_ws_bytes(n_out, K)), dev)
@@ -266,16 +286,18 @@ class Metadata:
             nbr = torch.empty(max(27 * lv.n, 1), dtype=I32, device=dev)
             check(L.mm_subm_neighbors(ptr(lv.coords), lv.n, lv.spatial_size, ptr(lv.tkeys), ptr(lv.tvals), lv.cap,
                                       ptr(nbr), stream()), "subm_neighbors")
-            subm = self._launch_rulebook(27, lv.n, nbr, offs[j, :28])
-            subm.os = self._os_table(nbr, 27, lv.n)
+            subm_os = self._os_table(nbr, 27, lv.n)
+            subm = self._launch_rulebook(27, lv.n, nbr, offs[j, :28], with_csr=subm_os is None)
+            subm.os = subm_os
             down = None
             if lv.coarse is not None and lv.down is None:
                 c = lv.coarse
                 nbr8 = torch.empty(max(8 * c.n, 1), dtype=I32, device=dev)
                 check(L.mm_down_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), c.n, ptr(nbr8), stream()),
                       "down_neighbors")
-                down = self._launch_rulebook(8, c.n, nbr8, offs[j, 28:37])
-                down.os = self._os_table(nbr8, 8, c.n)
+                down_os = self._os_table(nbr8, 8, c.n)
+                down = self._launch_rulebook(8, c.n, nbr8, offs[j, 28:37], with_csr=down_os is None)
+                down.os = down_os
                 if OS_BUILD_UP or self.act16:  # unique-destination direction: the rulebook engine's direct scatter measured faster
                     nbr_up = torch.empty(max(8 * lv.n, 1), dtype=I32, device=dev)
                     check(L.mm_up_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), ptr(nbr_up), stream()), "up_neighbors")
@@ -290,7 +312,8 @@ class Metadata:
                 rb.n_rules = int(rb.offsets_host[rb.K])
                 rb.rin = rb.rin[: max(rb.n_rules, 1)]
                 rb.rout = rb.rout[: max(rb.n_rules, 1)]
-                rb.csr_pos = rb.csr_pos[: max(rb.n_rules, 1)]
+                if rb.csr_pos is not None:
+                    rb.csr_pos = rb.csr_pos[: max(rb.n_rules, 1)]
             lv.subm = subm
             if down is not None:
                 lv.down = down

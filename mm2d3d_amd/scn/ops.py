@@ -44,6 +44,8 @@ def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_
     else:
         s_ci, s_co = cw_out, 1
     out = torch.empty((n_out, cout), dtype=F32, device=x.device)
+    if not unique:
+        rb.ensure_csr()
     ws = _lib.workspace.get(int(L.mm_spconv_ws_bytes(rb.n_rules, cin, cout, K)), x.device)
     check(
         L.mm_spconv_apply(ptr(x), x.stride(0), cin, ptr(out), cout, cout, n_out, ptr(src), ptr(dst), ptr(rb.offsets_dev),

@@ -93,3 +93,31 @@ def test_stem_conv7x7_fwd_and_weight_grad(cin):
     yr.backward(g.float())
     yh.backward(g)
     assert _rel(wh.grad, wr.grad) < 5e-3
+
+
+def test_batched_weight_repack_equals_single_packs():
+    """After an optimiser step every cached bf16 weight copy is refreshed by ONE launch (mm_pack_weights_bf16_batch); the
+    result must equal the per-weight kernel for every layout in use (conv fwd/dgrad, transposed-conv fwd/dgrad), including
+    sizes that are not a multiple of the 4096-element block chunk."""
+    from mm2d3d_amd import conv2d as c2
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(3)
+    owners, specs = [], []
+    for (cout, cin, t) in [(64, 64, 9), (128, 64, 9), (64, 192, 1), (192, 64, 1), (64, 128, 4)]:
+        w = torch.nn.Parameter(torch.randn(cout, cin, t, generator=g).to(dev))
+        owners.append(w)
+        if t == 4:  # ConvTranspose2d weight [Cin, Cout, 2, 2] seen as (cin=cout here)
+            specs.append([(4, cin, 1, cout, 1, 4, 0, cin * 4, "tfwd"), (1, cout, 4, cin, 0, cin * 4, 1, 4, "tdgrad")])
+        else:
+            specs.append([(1, cout, t, cin, 0, cin * t, 1, t, "fwd"), (1, cin, t, cout, 0, t, 1, cin * t, "dgrad")])
+    first = [[c2._pack(w.data, *sp[:8], owner=w, kind=sp[8]).clone() for sp in sps] for w, sps in zip(owners, specs)]
+    with torch.no_grad():
+        for w in owners:
+            w.mul_(1.5)  # bumps _version: every cached pack is stale now
+    again = [[c2._pack(w.data, *sp[:8], owner=w, kind=sp[8]) for sp in sps] for w, sps in zip(owners, specs)]
+    for w, sps, a, f in zip(owners, specs, again, first):
+        for sp, got, old in zip(sps, a, f):
+            exp = c2._pack(w.data, *sp[:8])
+            assert torch.equal(got.view(torch.int16), exp.view(torch.int16)), sp
+            assert not torch.equal(got.view(torch.int16), old.view(torch.int16))

@@ -266,3 +266,80 @@ def test_conv2d_f32_kernels_vs_torch(cin, cout, k, s, p):
         yh2.backward(g2.to(dev))
         for a, c, what in ((yh2, yr2, "yT"), (xh2.grad, xr2.grad, "dxT"), (wh2.grad, wr2.grad, "dwT")):
             assert float((a.detach().cpu() - c.detach()).abs().max()) <= 2e-5 * max(1.0, float(c.abs().max())), what
+
+
+def _bn2d_call(L, fused, x, ldx, res, dy, dy2, N, Ns, C, relu, w, b, use_yout):
+    """mm_bn2d_fwd_train + mm_bn2d_bwd through the C-ABI with the single-launch kernels on or off."""
+    from mm2d3d_amd import _lib
+    from mm2d3d_amd._lib import check, ptr, stream
+
+    dev = x.device
+    prev = L.mm_bn2d_set_fused(3 if fused else 0)
+    try:
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        nbt = torch.zeros(1, dtype=torch.int64, device=dev)
+        y = torch.zeros(N, C, dtype=torch.bfloat16, device=dev)
+        dx = torch.zeros(N, C, dtype=torch.bfloat16, device=dev)
+        dres = torch.zeros(N, C, dtype=torch.bfloat16, device=dev) if res is not None else None
+        dw, db = torch.full((C,), 0.25, device=dev), torch.full((C,), -0.5, device=dev)  # accumulate = 1 adds to these
+        stats = torch.zeros((2, 2 if 0 < Ns < N else 1, C), device=dev)
+        ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), dev)
+        check(L.mm_bn2d_fwd_train(ptr(x), ldx, ptr(res), C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), ptr(nbt), 1e-5, 0.1, int(relu), ptr(y), C,
+                                  ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "fwd")
+        yout = y if use_yout else None
+        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), C, ptr(dy2), C if dy2 is not None else 0, ptr(yout), C, int(relu), N, Ns, C, ptr(w), ptr(b),
+                            ptr(stats[0]), ptr(stats[1]), ptr(dx), C, ptr(dres), C, ptr(dw), ptr(db), 1, ptr(ws), ws.numel(), stream()), "bwd")
+        torch.cuda.synchronize()
+    finally:
+        L.mm_bn2d_set_fused(prev)
+    return dict(y=y, dx=dx, dres=dres, dw=dw, db=db, stats=stats, rm=rm, rv=rv, nbt=nbt)
+
+
+@pytest.mark.parametrize("N,Ns,C,res,relu,two,sliced", [
+    (663, 663, 64, False, True, False, False),       # one row per thread, one statistics group
+    (9120, 4560, 512, True, True, True, False),      # the 15x10 maps of the headline step: two groups, residual, second gradient
+    (36480, 18240, 256, False, True, False, False),  # 30x19 maps, mask recomputed from x
+    (36481, 20001, 96, True, False, False, True),    # ragged rows, 12 column groups (42 row slots), x a channel slice, no ReLU
+    (145920, 72960, 128, True, True, True, False),   # 60x38 maps: 18 rows per thread, dy rows beyond the LDS budget re-read
+    (145920, 145920, 128, False, False, False, False),
+    (583680, 291840, 64, True, True, False, False),  # 240x151 maps: forward on chip (36 rows per thread), backward three-kernel
+    (300, 7, 8, False, True, False, False),          # tiny first group, 8 channels
+])
+def test_bn2d_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, res, relu, two, sliced):
+    """csrc/bn2d.hip: the grid-barrier kernels (rows kept in registers / LDS, statistics combined by the last workgroup) against
+    the reduce / finalize / apply kernels on the same inputs.  The statistics are combined in a different (fixed) order, so
+    means and variances agree to fp32 rounding and the bf16 outputs may differ by one rounding step on a few elements."""
+    from mm2d3d_amd import _lib
+
+    dev = _dev()
+    L = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(N + C)
+    ld = C + 32 if sliced else C
+    xbuf = (torch.randn(N, ld, generator=g) * 1.7 + 0.4).to(dev).bfloat16()
+    x = xbuf[:, 16:16 + C] if sliced else xbuf
+    r = torch.randn(N, C, generator=g).to(dev).bfloat16() if res else None
+    dy = torch.randn(N, C, generator=g).to(dev).bfloat16()
+    dy2 = torch.randn(N, C, generator=g).to(dev).bfloat16() if two else None
+    w = (torch.rand(C, generator=g) + 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+    use_yout = res or not relu
+    a = _bn2d_call(L, True, x, ld, r, dy, dy2, N, Ns, C, relu, w, b, use_yout)
+    c = _bn2d_call(L, False, x, ld, r, dy, dy2, N, Ns, C, relu, w, b, use_yout)
+    assert int(a["nbt"]) == int(c["nbt"]) == (2 if 0 < Ns < N else 1)
+    assert torch.allclose(a["stats"][0], c["stats"][0], rtol=1e-5, atol=1e-6), "saved means"
+    assert torch.allclose(a["stats"][1], c["stats"][1], rtol=1e-5, atol=0), "saved inverse standard deviations"
+    assert torch.allclose(a["rm"], c["rm"], rtol=1e-5, atol=1e-7) and torch.allclose(a["rv"], c["rv"], rtol=1e-5, atol=0)
+    for k in ("y", "dx", "dres"):
+        if a[k] is None:
+            continue
+        u, v = a[k].float(), c[k].float()
+        bad = (u != v)
+        assert bad.float().mean().item() < 2e-3, k  # almost every element identical
+        # ... and never more than one bf16 step apart; the absolute term covers values that are themselves the small
+        # difference of two O(1) fp32 terms (normalised x + residual), where one fp32 rounding of the scale / shift shows
+        assert ((u - v).abs() <= 2.0 ** -7 * v.abs() + 4e-6 * (1.0 + float(v.abs().max()))).all(), k
+    # gamma / beta gradients: sums over up to 5.8e5 rows, combined in fp64 in both paths (the single-launch kernels form
+    # sum g*xhat from sum g*x and sum g)
+    scale = float(c["dw"].abs().max())
+    assert (a["dw"] - c["dw"]).abs().max().item() <= 2e-5 * scale + 1e-4, "dweight"
+    assert (a["db"] - c["db"]).abs().max().item() <= 2e-5 * float(c["db"].abs().max()) + 1e-4, "dbias"

@@ -3,6 +3,8 @@ per-kernel averages of the PMC counters when the run collected any.
 
     python tools/rocpd_summary.py <results.db> [name-filter] [--csv]
 """
+import glob
+import os
 import re
 import sqlite3
 import sys
@@ -16,6 +18,11 @@ def short(name):
 
 def main():
     db, flt = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "")
+    if os.path.isdir(db):  # the -d directory of a rocprofv3 run: take its newest database
+        found = sorted(glob.glob(os.path.join(db, "**", "*.db"), recursive=True), key=os.path.getmtime)
+        if not found:
+            raise SystemExit(f"no rocpd database under {db}")
+        db = found[-1]
     csv = "--csv" in sys.argv
     if "--by-grid" in sys.argv:  # per (kernel, grid size): calls, average / total duration - which layer sizes cost the time
         con = sqlite3.connect(db)
