@@ -860,7 +860,9 @@ static int fused_plan(int64_t N, int64_t Ns, int C, int rmax, bool backward, hip
         (const void*)k_bn2d_fused_bwd<8, false, 0>,  (const void*)k_bn2d_fused_bwd<8, false, 1>,  (const void*)k_bn2d_fused_bwd<8, false, 2>,
         (const void*)k_bn2d_fused_bwd<8, true, 0>,   (const void*)k_bn2d_fused_bwd<8, true, 1>,   (const void*)k_bn2d_fused_bwd<8, true, 2>,
         (const void*)k_bn2d_fused_bwd<20, false, 0>, (const void*)k_bn2d_fused_bwd<20, false, 1>, (const void*)k_bn2d_fused_bwd<20, false, 2>,
-        (const void*)k_bn2d_fused_bwd<20, true, 0>,  (const void*)k_bn2d_fused_bwd<20, true, 1>,  (const void*)k_bn2d_fused_bwd<20, true, 2>};
+        (const void*)k_bn2d_fused_bwd<20, true, 0>,  (const void*)k_bn2d_fused_bwd<20, true, 1>,  (const void*)k_bn2d_fused_bwd<20, true, 2>,
+        (const void*)k_bn2d_fused_bwd<36, false, 0>, (const void*)k_bn2d_fused_bwd<36, false, 1>, (const void*)k_bn2d_fused_bwd<36, false, 2>,
+        (const void*)k_bn2d_fused_bwd<36, true, 0>,  (const void*)k_bn2d_fused_bwd<36, true, 1>,  (const void*)k_bn2d_fused_bwd<36, true, 2>};
     for (const void* fn : fns) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS));
     g_fused_cus[dev] = cus;
     g_fused_sync[dev] = (unsigned*)q;
@@ -1013,7 +1015,7 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   int nb0, nb1, ab0, ab1;
   if (Ns <= 0 || Ns >= N) Ns = N;
   FusedPlan pl;
-  int rc = fused_plan(N, Ns, C, 20, true, s, &pl);
+  int rc = fused_plan(N, Ns, C, 36, true, s, &pl);
   if (rc) return rc;
   const int64_t ldmax_b = std::max(std::max(std::max(ld_x, ld_dy), std::max(ld_dx, dy2 ? ld_dy2 : 0)), std::max(yout ? ld_y : 0, dres ? ld_dr : 0));
   if (pl.ok && ld_x % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0 && (!dy2 || ld_dy2 % 8 == 0) && (!yout || ld_y % 8 == 0) &&
@@ -1036,9 +1038,12 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
     if (pl.R <= 8) {
       if (dy2) MM_BWD(8, true);
       else MM_BWD(8, false);
-    } else {
+    } else if (pl.R <= 20) {
       if (dy2) MM_BWD(20, true);
       else MM_BWD(20, false);
+    } else {
+      if (dy2) MM_BWD(36, true);
+      else MM_BWD(36, false);
     }
 #undef MM_BWD
     MM_LAUNCH_CHECK();

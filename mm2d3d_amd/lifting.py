@@ -17,6 +17,16 @@ from ._lib import check, ptr, stream
 F32 = torch.float32
 
 
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    s = _COPY_STREAMS.get(dev.index)
+    if s is None:
+        s = _COPY_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
 class PixelIndex:
     """Batch-level index built from ``img_indices`` (list of numpy int64 [n_i, 2] = (row, col))."""
 
@@ -29,9 +39,21 @@ class PixelIndex:
         self.n = int(sum(counts))
         self.H, self.W, self.device = H, W, device
         rc = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int64)
-        rc_d = torch.from_numpy(np.ascontiguousarray(rc)).to(device, non_blocking=True)
-        b = torch.repeat_interleave(torch.arange(len(rows), device=device),
-                                    torch.tensor(counts, device=device), output_size=self.n)
+        # Host -> device through pinned staging on a copy stream: a copy from pageable memory queued on the compute stream
+        # makes the host wait until everything queued before it has run (measured: 12 ms per step inside this constructor
+        # when it was called at the end of the 2D forward).
+        dev = torch.device(device)
+        cur = torch.cuda.current_stream(dev)
+        cs = _copy_stream(dev)
+        rc_h = torch.from_numpy(np.ascontiguousarray(rc)).pin_memory()
+        cnt_h = torch.tensor(counts if counts else [0], dtype=torch.int64).pin_memory()
+        with torch.cuda.stream(cs):
+            rc_d = rc_h.to(dev, non_blocking=True)
+            cnt_d = cnt_h.to(dev, non_blocking=True)[: len(counts)]
+        cur.wait_stream(cs)
+        rc_d.record_stream(cur)
+        cnt_d.record_stream(cur)
+        b = torch.repeat_interleave(torch.arange(len(rows), device=device), cnt_d, output_size=self.n)
         self.b, self.r, self.c = b, rc_d[:, 0], rc_d[:, 1]
         key = (b * H + self.r) * W + self.c                   # flat pixel id b*H*W + r*W + c
         self.skey, self.order = torch.sort(key, stable=True)  # stable: ascending point order inside a pixel

@@ -16,9 +16,16 @@ F32 = torch.float32
 PROFILE = None
 
 
+PROFILE_LEAD_CYCLES = 0  # bench.py: GPU spin (clock cycles) queued before the first timed call of a step
+
+
 def _timed(kind, rb, cin, cout, fn, esize=4):
     if PROFILE is None:
         return fn()
+    if PROFILE_LEAD_CYCLES and not PROFILE:
+        # first engine call of the step: the sparse metadata build has just read back its counts, so the queue is empty and
+        # the next few event pairs would time the host's launch cadence, not the kernels.  Park the GPU to give the host a lead.
+        torch.cuda._sleep(int(PROFILE_LEAD_CYCLES))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     out = fn()

@@ -7,6 +7,8 @@ logged keys ``train/loss_segmentation`` ...), and ``fit_step`` does what Lightni
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -46,7 +48,9 @@ class TrainModel(nn.Module):
             from . import scn
 
             scn.set_activation_dtype(torch.bfloat16 if str(train_kwargs["sparse_activations"]) in ("bf16", "16") else torch.float32)
+        self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self._side = None
+        self._s3d = None
         self._opt_factories = optimizer or {}
         self.optimizers, self.schedulers = [], []
         self.reducer = None
@@ -110,7 +114,22 @@ class TrainModel(nn.Module):
                     if self._side is None:
                         self._side = torch.cuda.Stream(dev)
                     prep(both, self._side, step_start)
-                p3d, _, aux3d = self(both, model_name=n3d)
+                if self.overlap_branches:
+                    # the 3D branch (gathers, HBM-bound) on its own stream beside the 2D branch (MFMA / LDS-bound persistent
+                    # workgroups): autograd runs each branch's backward on the stream of its forward
+                    if self._s3d is None:
+                        self._s3d = torch.cuda.Stream(dev)
+                    main = torch.cuda.current_stream(dev)
+                    self._s3d.wait_event(step_start)
+                    with torch.cuda.stream(self._s3d):
+                        for t in both["x"]:
+                            t.record_stream(self._s3d)
+                        p3d, _, aux3d = self(both, model_name=n3d)
+                    main.wait_stream(self._s3d)
+                    for t in (p3d["seg_logit"], aux3d["seg_logit_point"]):
+                        t.record_stream(main)
+                else:
+                    p3d, _, aux3d = self(both, model_name=n3d)
             l2d, a2d, l3d, a3d = p2d["seg_logit"], aux2d["seg_logit_avg"], p3d["seg_logit"], aux3d["seg_logit_point"]
             seg2d = self.loss("segmentation", pred=l2d[:P], gt=src["seg_label"])
             seg3d = self.loss("segmentation", pred=l3d[:P], gt=src["seg_label"])
