@@ -119,6 +119,11 @@ class TrainModel(nn.Module):
                     # workgroups): autograd runs each branch's backward on the stream of its forward
                     if self._s3d is None:
                         self._s3d = torch.cuda.Stream(dev)
+                        # the single-launch BatchNorm2d kernels need every CU at once and would starve behind the other
+                        # stream's workgroups (csrc/bn2d.hip): three-kernel path while the branches share the GPU
+                        from . import _lib
+
+                        _lib.lib().mm_bn2d_set_fused(0)
                     main = torch.cuda.current_stream(dev)
                     self._s3d.wait_event(step_start)
                     with torch.cuda.stream(self._s3d):
