@@ -164,6 +164,9 @@ int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int 
 
 /* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
  * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */
+/* Row sets that fit on chip take single-launch training kernels (fp32 rows; see mm_bn2d_set_fused for the rules):
+ * mask bit 0 = mm_bn_fwd_train, bit 1 = mm_bn_bwd; default 3 or the environment's MM_BN_FUSED.  Returns the previous mask. */
+int mm_bn_set_fused(int mask);
 size_t mm_bn_ws_bytes(int C);
 /* Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step;
  * train.py:186-292 calls the net once per domain) are normalised with their OWN batch statistics and the running

@@ -3,6 +3,7 @@
 // HBM-bound: two passes over x in training (stats, then normalise+activate), fp64 accumulation of the
 // per-channel sums so the variance does not lose digits at N ~ 2.5e5 rows.
 #include "common.h"
+#include "fused_bn.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -293,6 +294,266 @@ __global__ __launch_bounds__(T) void k_bn_bwd_apply(const E* __restrict__ x, int
   }
 }
 
+
+// ---- single-launch training kernels over fp32 rows (skeleton and grid-barrier rules: fused_bn.h / bn2d.hip): a thread owns
+// 4-channel (16-byte) pieces of its rows; x is read once in the forward pass, x and dy once in the backward pass.
+struct Fused3P {
+  const float *x, *dy;
+  float *y, *dx;
+  int ld_x, ld_y, ld_dy, ld_dx;
+  int64_t N, Ns;
+  int C, G0, G1, R;
+  const float *weight, *bias;
+  float *running_mean, *running_var;
+  float eps, momentum, leak;
+  float *save_mean, *save_invstd;
+  float *sums, *dweight, *dbias;
+  int accumulate;
+  double* partial;
+  unsigned* sync;
+};
+
+__device__ inline FusedBuf fused_buf32(const void* base, int64_t N, int ld, int C, int slot, int cv) {
+  FusedBuf b;
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((N - 1) * ld + C) * 4), 0x00020000);
+  b.voff = (unsigned)(slot * ld + cv * 4) * 4u;
+  b.ld2 = ld * 4;
+  return b;
+}
+__device__ inline void unpack4(const u32x4 t, float (&v)[4]) {
+  v[0] = __uint_as_float(t.x), v[1] = __uint_as_float(t.y), v[2] = __uint_as_float(t.z), v[3] = __uint_as_float(t.w);
+}
+__device__ inline u32x4 pack4(const float (&v)[4]) {
+  return (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+}
+
+template <int RMAX>
+__global__ __launch_bounds__(FT) void k_bn_fused_fwd(const Fused3P p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* red = (float*)smem;
+  double* red2 = (double*)(smem + FUSED_RED);
+  double* outp = red2 + 1024;
+  u32x4* rows = (u32x4*)(smem + FUSED_RED + 2 * 8192);
+  constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
+  static_assert(RMAX % 4 == 0, "row groups of four");
+  const int tid = threadIdx.x;
+  const int C = p.C;
+  const FusedGeom g = fused_geom(p.N, p.Ns, C >> 2, p.G0, p.G1);
+  unsigned flag0 = 0;
+  if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
+  const int cvc = g.active ? g.cv : 0, slc = g.active ? g.slot : 0;
+  const FusedBuf bx = fused_buf32(p.x, p.N, p.ld_x, C, slc, cvc), by = fused_buf32(p.y, p.N, p.ld_y, C, slc, cvc);
+  u32x4 xr[NREG];
+  float a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) a[i] = b[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < RMAX; k++) {
+    const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
+    u32x4 t = fused_ld(bx, g.r0 + (int64_t)k * g.rs);
+    if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+    if (k < FUSED_NL) rows[k * FT + tid] = t;
+    else xr[k < FUSED_NL ? 0 : k - FUSED_NL] = t;
+    float xv[4];
+    unpack4(t, xv);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      a[i] += xv[i];
+      b[i] = fmaf(xv[i], xv[i], b[i]);
+    }
+    if ((k & 3) == 3) {
+      MM_PIN8(a, b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  fused_block_sums<4>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
+  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
+  const int G = p.G0 + p.G1;
+  fused_barrier(p.sync, (unsigned)G, flag0);
+  {
+    const int ngrp = p.G1 > 0 ? 2 : 1;
+    for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
+      for (int gi = 0; gi < ngrp; gi++) {
+        double sm, sq;
+        fused_wave_sums(p.partial, gi ? p.G0 : 0, gi ? G : p.G0, C, c, sm, sq);
+        if ((tid & 63) == 0) {
+          const int64_t Ng = gi ? p.N - p.Ns : p.Ns;
+          const double mean = Ng > 0 ? sm / (double)Ng : 0.0;
+          double var = Ng > 0 ? sq / (double)Ng - mean * mean : 0.0;
+          if (var < 0.0) var = 0.0;
+          xcd_store(p.save_mean + gi * C + c, (float)mean);
+          xcd_store(p.save_invstd + gi * C + c, (float)(1.0 / sqrt(var + (double)p.eps)));
+          if (p.running_mean) {  // scn semantics: momentum = the fraction of the old value kept (see k_bn_finalize_fwd)
+            const double unbiased = Ng > 1 ? var * (double)Ng / (double)(Ng - 1) : var;
+            p.running_mean[c] = p.momentum * p.running_mean[c] + (1.f - p.momentum) * (float)mean;
+            p.running_var[c] = p.momentum * p.running_var[c] + (1.f - p.momentum) * (float)unbiased;
+          }
+        }
+      }
+    }
+  }
+  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  if (!g.active) return;
+  const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
+#pragma unroll
+  for (int k = 0; k < NREG; k++) asm volatile("" : "+v"(xr[k]));
+  float m[4], sc[4], sh[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = g.cv * 4 + i;
+    const float is = xcd_load(p.save_invstd + g.grp * C + c);
+    const float wv = wp[c], bv = bp[c];
+    m[i] = xcd_load(p.save_mean + g.grp * C + c);
+    sc[i] = is * (p.weight ? wv : 1.f);
+    sh[i] = p.bias ? bv : 0.f;
+  }
+#pragma unroll
+  for (int k0 = 0; k0 < RMAX; k0 += 4) {
+    if (k0 < p.R) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = k0 + j;
+        u32x4 t;
+        if (k < FUSED_NL) t = rows[k * FT + tid];
+        else t = xr[k < FUSED_NL ? 0 : k - FUSED_NL];
+        float xv[4], yv[4];
+        unpack4(t, xv);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float v = (xv[i] - m[i]) * sc[i] + sh[i];  // the arithmetic of k_bn_apply
+          yv[i] = v > 0.f ? v : v * p.leak;
+        }
+        if (k < p.R && g.slot + k * g.rs < g.nrows) fused_st(by, g.r0 + (int64_t)k * g.rs, pack4(yv));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
+template <int RMAX>
+__global__ __launch_bounds__(FT) void k_bn_fused_bwd(const Fused3P p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* red = (float*)smem;
+  double* red2 = (double*)(smem + FUSED_RED);
+  double* outp = red2 + 1024;
+  u32x4* rows = (u32x4*)(smem + FUSED_RED + 2 * 8192);  // the masked gradient g of the first FUSED_NL rows
+  static_assert(RMAX % 4 == 0, "row groups of four");
+  const int tid = threadIdx.x;
+  const int C = p.C;
+  const FusedGeom g = fused_geom(p.N, p.Ns, C >> 2, p.G0, p.G1);
+  unsigned flag0 = 0;
+  if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
+  const int cvc = g.active ? g.cv : 0, slc = g.active ? g.slot : 0;
+  const FusedBuf bx = fused_buf32(p.x, p.N, p.ld_x, C, slc, cvc), bd = fused_buf32(p.dy, p.N, p.ld_dy, C, slc, cvc),
+                 bdx = fused_buf32(p.dx, p.N, p.ld_dx, C, slc, cvc);
+  const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
+  u32x4 xr[RMAX];
+  float m[4], is[4], w[4], bb[4], a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = cvc * 4 + i;
+    const float wv = wp[c], bv = bp[c];
+    m[i] = p.save_mean[g.grp * C + c];
+    is[i] = p.save_invstd[g.grp * C + c];
+    w[i] = p.weight ? wv : 1.f;
+    bb[i] = p.bias ? bv : 0.f;
+    a[i] = b[i] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < RMAX; k++) {
+    const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
+    const int64_t row = g.r0 + (int64_t)k * g.rs;
+    const u32x4 tx = fused_ld(bx, row);
+    const u32x4 td = fused_ld(bd, row);
+    float xv[4], dv[4], gv[4];
+    unpack4(tx, xv);
+    unpack4(td, dv);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const float xh = (xv[i] - m[i]) * is[i];  // the arithmetic of k_bn_reduce<*, 1> / k_bn_bwd_apply
+      const float yy = xh * w[i] + bb[i];
+      const float gg = ok ? (yy > 0.f ? dv[i] : dv[i] * p.leak) : 0.f;
+      gv[i] = gg;
+      a[i] += gg;
+      b[i] = fmaf(gg, xh, b[i]);
+    }
+    xr[k] = tx;
+    if (k < FUSED_NL) rows[k * FT + tid] = pack4(gv);
+    if ((k & 1) == 1) {
+      MM_PIN8(a, b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  fused_block_sums<4>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
+  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
+  const int G = p.G0 + p.G1;
+  fused_barrier(p.sync, (unsigned)G, flag0);
+  {
+    const int ngrp = p.G1 > 0 ? 2 : 1;
+    for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
+      float ts = 0.f, tq = 0.f;
+      for (int gi = 0; gi < ngrp; gi++) {
+        double sg, sq;
+        fused_wave_sums(p.partial, gi ? p.G0 : 0, gi ? G : p.G0, C, c, sg, sq);
+        if ((tid & 63) == 0) {
+          xcd_store(p.sums + (gi * 2 + 0) * C + c, (float)sg);
+          xcd_store(p.sums + (gi * 2 + 1) * C + c, (float)sq);
+        }
+        ts += (float)sg, tq += (float)sq;
+      }
+      if ((tid & 63) == 0) {
+        if (p.dweight) p.dweight[c] = p.accumulate ? p.dweight[c] + tq : tq;
+        if (p.dbias) p.dbias[c] = p.accumulate ? p.dbias[c] + ts : ts;
+      }
+    }
+  }
+  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  if (!g.active) return;
+#pragma unroll
+  for (int k = 0; k < RMAX; k++) asm volatile("" : "+v"(xr[k]));
+  float s1[4], s2[4];
+  const float invN = 1.f / (float)g.Ng;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = g.cv * 4 + i;
+    s1[i] = xcd_load(p.sums + (g.grp * 2 + 0) * C + c) * invN;
+    s2[i] = xcd_load(p.sums + (g.grp * 2 + 1) * C + c) * invN;
+  }
+#pragma unroll
+  for (int k0 = 0; k0 < RMAX; k0 += 4) {
+    if (k0 < p.R) {
+      u32x4 d1[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (k0 + j >= FUSED_NL) d1[j] = fused_ld(bd, g.r0 + (int64_t)(k0 + j) * g.rs);  // rows beyond the LDS budget: dy again
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int k = k0 + j;
+        float xv[4], gv[4], ov[4];
+        unpack4(xr[k], xv);
+        if (k < FUSED_NL) {
+          unpack4(rows[k * FT + tid], gv);
+        } else {
+          float dv[4];
+          unpack4(d1[j], dv);
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const float xh = (xv[i] - m[i]) * is[i];
+            gv[i] = (xh * w[i] + bb[i]) > 0.f ? dv[i] : dv[i] * p.leak;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float xh = (xv[i] - m[i]) * is[i];
+          ov[i] = w[i] * is[i] * (gv[i] - s1[i] - xh * s2[i]);
+        }
+        if (k < p.R && g.slot + k * g.rs < g.nrows) fused_st(bdx, g.r0 + (int64_t)k * g.rs, pack4(ov));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 inline unsigned apply_blocks(int64_t N, int C, int VEC) {
   int rs = T / (C / VEC);
   return (unsigned)mm_cdiv(N, (int64_t)rs * APPLY_ROWS);
@@ -306,6 +567,33 @@ inline int stat_blocks(int64_t N, int C, int VEC) {
   return (int)nb;
 }
 }  // namespace
+
+
+static const void* const k_fused3_fns[] = {(const void*)k_bn_fused_fwd<8>,  (const void*)k_bn_fused_fwd<20>, (const void*)k_bn_fused_fwd<36>,
+                                           (const void*)k_bn_fused_bwd<8>,  (const void*)k_bn_fused_bwd<20>, (const void*)k_bn_fused_bwd<36>};
+
+// true: launched.  fp32 rows with 16-byte pieces only; maps too large for the chip fall through to the three-kernel path
+static int bn_fused_try(bool backward, Fused3P& p, int64_t ldmax, hipStream_t s, bool* done) {
+  *done = false;
+  if (p.C % 4 != 0 || (p.ld_x % 4) || p.N * ldmax * 4 >= (1ll << 31)) return MM_OK;
+  FusedPlan pl;
+  int rc = fused_plan(p.N, p.Ns, p.C, 4, 36, backward, "MM_BN_FUSED", k_fused3_fns, 6, s, &pl);
+  if (rc || !pl.ok) return rc;
+  p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R, p.sync = pl.sync;
+  const dim3 grid(pl.G0 + pl.G1), blk(FT);
+  if (!backward) {
+    if (pl.R <= 8) hipLaunchKernelGGL(k_bn_fused_fwd<8>, grid, blk, FUSED_LDS, s, p);
+    else if (pl.R <= 20) hipLaunchKernelGGL(k_bn_fused_fwd<20>, grid, blk, FUSED_LDS, s, p);
+    else hipLaunchKernelGGL(k_bn_fused_fwd<36>, grid, blk, FUSED_LDS, s, p);
+  } else {
+    if (pl.R <= 8) hipLaunchKernelGGL(k_bn_fused_bwd<8>, grid, blk, FUSED_LDS, s, p);
+    else if (pl.R <= 20) hipLaunchKernelGGL(k_bn_fused_bwd<20>, grid, blk, FUSED_LDS, s, p);
+    else hipLaunchKernelGGL(k_bn_fused_bwd<36>, grid, blk, FUSED_LDS, s, p);
+  }
+  MM_LAUNCH_CHECK();
+  *done = true;
+  return MM_OK;
+}
 
 static void split_blocks(int64_t N, int64_t& Ns, int C, int VEC, bool stats, int& b0, int& b1) {
   if (Ns <= 0 || Ns >= N) Ns = N;
@@ -337,6 +625,17 @@ static int bn_fwd_train(const E* x, int ld_x, int64_t N, int64_t Ns, int C, cons
   double* partial = (double*)ws;
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_y % 4 == 0) && (((uintptr_t)x | (uintptr_t)y) % (4 * sizeof(E)) == 0);
   MM_CHECK_ARG(C / (v4 ? 4 : 1) <= T, "bn_fwd: %d channels need 16-byte aligned rows (C multiple of 4)", C);
+  if constexpr (sizeof(E) == 4) {
+    if (v4 && N > 0) {
+      Fused3P p = {};
+      p.x = (const float*)x, p.y = (float*)y, p.ld_x = ld_x, p.ld_y = ld_y, p.N = N, p.Ns = (Ns <= 0 || Ns >= N) ? N : Ns, p.C = C;
+      p.weight = weight, p.bias = bias, p.running_mean = running_mean, p.running_var = running_var;
+      p.eps = eps, p.momentum = momentum, p.leak = leak, p.save_mean = save_mean, p.save_invstd = save_invstd, p.partial = partial;
+      bool done;
+      int rc = bn_fused_try(false, p, std::max(ld_x, ld_y), s, &done);
+      if (rc || done) return rc;
+    }
+  }
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
@@ -394,6 +693,18 @@ static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64
   const bool v4 = (C % 4 == 0) && (ld_x % 4 == 0) && (ld_dy % 4 == 0) && (ld_dx % 4 == 0) &&
                   (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) % (4 * sizeof(E)) == 0);
   MM_CHECK_ARG(C / (v4 ? 4 : 1) <= T, "bn_bwd: %d channels need 16-byte aligned rows (C multiple of 4)", C);
+  if constexpr (sizeof(E) == 4) {
+    if (v4 && N > 0) {
+      Fused3P p = {};
+      p.x = (const float*)x, p.dy = (const float*)dy, p.dx = (float*)dx, p.ld_x = ld_x, p.ld_dy = ld_dy, p.ld_dx = ld_dx;
+      p.N = N, p.Ns = (Ns <= 0 || Ns >= N) ? N : Ns, p.C = C, p.weight = weight, p.bias = bias, p.leak = leak;
+      p.save_mean = (float*)save_mean, p.save_invstd = (float*)save_invstd, p.sums = sums, p.dweight = dweight, p.dbias = dbias;
+      p.accumulate = accumulate, p.partial = partial;
+      bool done;
+      int rc = bn_fused_try(true, p, std::max(std::max(ld_x, ld_dy), ld_dx), s, &done);
+      if (rc || done) return rc;
+    }
+  }
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, v4 ? 4 : 1, true, nb0, nb1);
   if (v4)
@@ -417,6 +728,14 @@ static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64
 }
 
 extern "C" {
+
+// Single-launch training kernels of the fp32 row path: bit 0 = mm_bn_fwd_train, bit 1 = mm_bn_bwd (default 3, or the
+// environment variable MM_BN_FUSED); returns the previous mask.  Same residency rules as mm_bn2d_set_fused.
+int mm_bn_set_fused(int mask) {
+  const int prev = fused_mask("MM_BN_FUSED");
+  g_fused_enabled = mask & 3;
+  return prev;
+}
 
 size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 

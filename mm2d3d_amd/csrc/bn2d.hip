@@ -4,10 +4,8 @@
 // normalise/add/activate pass; backward = one reduction pass + one pass that writes dx and the residual gradient.
 // Rows = B*H*W pixels, 16-B (8 x bf16) accesses, fp64 combination of the per-block partial sums (bit-stable).
 #include "common.h"
+#include "fused_bn.h"
 
-#include <algorithm>
-#include <cstdlib>
-#include <mutex>
 
 typedef unsigned short u16;
 
@@ -309,31 +307,7 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
 }
 
 
-// ================================================================================================================
-// Single-launch training kernels for maps that fit in the chip's registers + LDS (everything but the full-resolution maps).
-//
-// The three-kernel path above reads x twice in the forward pass and x, dy twice in the backward pass, and pays two kernel
-// boundaries per call; on the 9..75 MB maps of the encoder/decoder it reaches 0.6-2.5 TB/s of its single-pass traffic.
-// Here ONE workgroup per CU (512 threads) loads its rows once, keeps them (FUSED_NL rows per thread in LDS, the rest
-// in VGPRs), publishes its fp64 partial sums, and meets the other workgroups at a grid barrier; the statistics of
-// channel c are then combined by one wave (channels dealt over the workgroups, fixed order: bit-stable) and, after a second
-// barrier, every workgroup normalises straight from its registers.  x is read once, dy once.
-//
-// Grid barrier: every workgroup must be resident at the same time, so the grid never exceeds the CU count and a
-// workgroup needs more than half of a CU's registers/LDS (one per CU).  Another PROCESS running the same kernel on the
-// same GPU can starve both grids: the wait is bounded (FUSED_TIMEOUT_TICKS of the 100 MHz wall clock) and ends in a
-// trap, i.e. a loud HIP error instead of a hang; MM_BN2D_FUSED=0 selects the three-kernel path for such set-ups.
-// A kernel of another stream that holds LDS on some CUs (an RCCL collective overlapping the backward pass) makes the grid wait
-// for it: the data-parallel trainer therefore keeps the backward direction on the three-kernel path (ddp.py).
-constexpr int FT = 512;       // 8 waves: 256 VGPRs per thread, and the per-thread constants are paid by half as many threads
-constexpr int FUSED_NL = 13;  // rows per thread kept in LDS: 13 x 16 B x 512 threads = 104 KB
-constexpr size_t FUSED_RED = (size_t)2 * FT * 8 * 4;  // float red[2][FT][8]
-constexpr size_t FUSED_LDS = FUSED_RED + 2 * 8192 + (size_t)FUSED_NL * FT * 16;  // red | double red2[1024] | double out[1024] | rows
-constexpr int FUSED_FLAG = 64;  // the release word sits 256 B after the arrival counter: pollers and arrivals on different lines
-constexpr unsigned long long FUSED_TIMEOUT_TICKS = 1000000000ull;  // 10 s
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
+// ---- single-launch training kernels (shared skeleton: fused_bn.h)
 __device__ inline void unpack8(const u32x4 t, float (&v)[8]) {
   const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
@@ -350,26 +324,6 @@ __device__ inline u32x4 pack8(const float (&v)[8]) {
   t.w = (unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16);
   return t;
 }
-
-// Values exchanged between workgroups INSIDE a launch go through agent-scope atomic loads / stores (sc1: they bypass the
-// per-XCD L2's non-coherent lines) and a wait for the stores' acknowledgements, NOT through __threadfence(): an agent-scope
-// release fence writes back the whole 4 MB L2 of the XCD, and with 256 workgroups doing that the barrier cost ~100 us.
-template <typename V>
-__device__ inline void xcd_store(V* p, V v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <typename V>
-__device__ inline V xcd_load(const V* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void stores_acked() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// Pins the 16 accumulators at this point of the instruction stream.  Instruction selection is free to sink pure arithmetic
-// below every later load (only memory operations are ordered), and did: all rows' unpacked values then stay live until the end
-// of the load phase.  An (empty) volatile asm is ordered with the loads and needs its inputs computed.
-#define MM_PIN16(a, b)                                                                                                       \
-  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]), \
-               "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]))
 
 struct FusedP {
   const u16* x;
@@ -394,137 +348,6 @@ struct FusedP {
   unsigned* sync;   // arrival counter at [0], release word at [FUSED_FLAG]
 };
 
-// Sums of a[i] / b[i] over the row slots of the workgroup -> out[p] (LDS), pair p = q*C + c (q = 0: a, 1: b), p < 2C.
-// Fixed order: FT/(2C) threads per pair stride the slots, their fp64 results are added in thread order.
-__device__ inline void fused_block_sums(const float (&a)[8], const float (&b)[8], float* red, double* red2, double* out, int C, int CV,
-                                        int rs, bool active) {
-  const int tid = threadIdx.x;
-  if (active) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      red[(size_t)tid * 8 + i] = a[i];
-      red[((size_t)FT + tid) * 8 + i] = b[i];
-    }
-  }
-  __syncthreads();
-  const int np = 2 * C;
-  if (np <= FT) {
-    const int nparts = FT / np;
-    const int pair = tid % np, part = tid / np;
-    double acc = 0.0;
-    if (part < nparts) {
-      const int q = pair / C, c = pair - q * C;
-      const float* src = red + ((size_t)q * FT + (c >> 3)) * 8 + (c & 7);
-      for (int sl = part; sl < rs; sl += nparts) acc += (double)src[(size_t)sl * CV * 8];
-    }
-    red2[tid] = acc;
-    __syncthreads();
-    if (tid < np) {
-      double tot = 0.0;
-      for (int j = 0; j < nparts; j++) tot += red2[j * np + tid];
-      out[tid] = tot;
-    }
-  } else {
-    for (int pair = tid; pair < np; pair += FT) {
-      const int q = pair / C, c = pair - q * C;
-      const float* src = red + ((size_t)q * FT + (c >> 3)) * 8 + (c & 7);
-      double acc = 0.0;
-      for (int sl = 0; sl < rs; sl++) acc += (double)src[(size_t)sl * CV * 8];
-      out[pair] = acc;
-    }
-  }
-  __syncthreads();
-}
-
-// (sum over the workgroups [b0, b1) of partial[b][c], ... of partial[b][C + c]) by ONE wave: lanes stride the workgroups
-// (at most 4 each, independent loads), then a fixed shuffle tree.  Result valid in lane 0.
-__device__ inline void fused_wave_sums(const double* partial, int b0, int b1, int C, int c, double& s, double& q) {
-  const int lane = threadIdx.x & 63;
-  double vs[4], vq[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int bb = b0 + lane + 64 * j;
-    const int bc = bb < b1 ? bb : b0;  // unconditional loads; masked below
-    vs[j] = xcd_load(partial + (size_t)bc * 2 * C + c);
-    vq[j] = xcd_load(partial + (size_t)bc * 2 * C + C + c);
-    if (bb >= b1) vs[j] = 0.0, vq[j] = 0.0;
-  }
-  s = wave_sum((vs[0] + vs[1]) + (vs[2] + vs[3]));
-  q = wave_sum((vq[0] + vq[1]) + (vq[2] + vq[3]));
-}
-
-// Grid barrier (every workgroup of the launch is resident, see the header).  The last workgroup to arrive resets the counter
-// and advances the release word from flag_old to flag_old + 1; the others poll the release word.
-__device__ inline void fused_barrier(unsigned* sync, unsigned G, unsigned flag_old) {
-  stores_acked();   // this thread's xcd_store()s have reached the coherence point
-  __syncthreads();  // ... and so have the whole workgroup's
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&sync[0], 1u);
-    if (t == G - 1) {
-      atomicExch(&sync[0], 0u);  // returns, i.e. has completed, before the release below; nobody arrives again before it
-      xcd_store(&sync[FUSED_FLAG], flag_old + 1u);
-    } else {
-      const unsigned long long t0 = wall_clock64();
-      while (xcd_load(&sync[FUSED_FLAG]) == flag_old) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) __builtin_trap();  // the grid is not co-resident (see the header)
-      }
-    }
-  }
-  __syncthreads();
-}
-
-// Row geometry of the fused kernels: thread (slot, cv) of a workgroup that owns rows [r0, r1) visits rows r0 + slot + k*rs;
-// the row base r0 + k*rs is uniform.  Visits beyond r1 (or with k >= R) still load (see FusedBuf) and are masked afterwards:
-// no branch around any load.
-struct FusedGeom {
-  int CV, rs, slot, cv, grp;
-  bool active;
-  int64_t r0, r1, Ng;
-  int nrows;  // r1 - r0
-};
-
-__device__ inline FusedGeom fused_geom(const FusedP& p) {
-  FusedGeom g;
-  g.CV = p.C >> 3;
-  g.rs = FT / g.CV;
-  g.slot = threadIdx.x / g.CV;
-  g.cv = threadIdx.x - g.slot * g.CV;
-  g.active = g.slot < g.rs;
-  g.grp = (int)blockIdx.x >= p.G0;
-  const int lb = g.grp ? blockIdx.x - p.G0 : blockIdx.x, nbg = g.grp ? p.G1 : p.G0;
-  const int64_t gbase = g.grp ? p.Ns : 0;
-  g.Ng = g.grp ? p.N - p.Ns : p.Ns;
-  const int64_t rpb = (g.Ng + nbg - 1) / nbg;
-  g.r0 = gbase + (int64_t)lb * rpb;
-  g.r1 = g.r0 + rpb < gbase + g.Ng ? g.r0 + rpb : gbase + g.Ng;
-  if (g.r1 < g.r0) g.r1 = g.r0;
-  g.nrows = (int)(g.r1 - g.r0);
-  return g;
-}
-
-// Buffer addressing: a resource descriptor per tensor (scalar registers, byte size = the rows the tensor really has), the
-// uniform row base as the scalar offset and one 32-bit per-thread offset; the hardware bounds check makes an out-of-range
-// visit return zeros (loads) or vanish (stores).
-struct FusedBuf {
-  __amdgpu_buffer_rsrc_t rsrc;
-  unsigned voff;
-  int ld2;  // row pitch in bytes
-};
-__device__ inline FusedBuf fused_buf(const void* base, int64_t N, int ld, int C, int slot, int cv) {
-  FusedBuf b;
-  b.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((N - 1) * ld + C) * 2), 0x00020000);
-  b.voff = (unsigned)(slot * ld + cv * 8) * 2u;
-  b.ld2 = ld * 2;
-  return b;
-}
-__device__ inline u32x4 fused_ld(const FusedBuf& b, int64_t row) {
-  return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)b.voff, (int)row * b.ld2, 0);
-}
-__device__ inline void fused_st(const FusedBuf& b, int64_t row, const u32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, (int)b.voff, (int)row * b.ld2, 0);
-}
-
 template <int RMAX, bool RES>
 __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -535,7 +358,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
   constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
   static_assert(RMAX % 4 == 0, "row groups of four");
   const int tid = threadIdx.x;
-  const FusedGeom g = fused_geom(p);
+  const FusedGeom g = fused_geom(p.N, p.Ns, p.C >> 3, p.G0, p.G1);
   const int C = p.C;
   unsigned flag0 = 0;
   if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
@@ -565,7 +388,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  fused_block_sums(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
+  fused_block_sums<8>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
   for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
   fused_barrier(p.sync, (unsigned)G, flag0);
@@ -657,7 +480,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
   constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
   static_assert(RMAX % 4 == 0, "row groups of four");
   const int tid = threadIdx.x;
-  const FusedGeom g = fused_geom(p);
+  const FusedGeom g = fused_geom(p.N, p.Ns, p.C >> 3, p.G0, p.G1);
   const int C = p.C;
   unsigned flag0 = 0;
   if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
@@ -721,7 +544,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
       }
     }
   }
-  fused_block_sums(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
+  fused_block_sums<8>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
   for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
   fused_barrier(p.sync, (unsigned)G, flag0);
@@ -821,93 +644,23 @@ inline int stat_blocks(int64_t N, int C) {
 }
 }  // namespace
 
-// ---- host side of the single-launch kernels
-struct FusedPlan {
-  bool ok;
-  int G0, G1, R;
-  unsigned* sync;
-};
-
-static std::mutex g_fused_mu;
-static unsigned* g_fused_sync[16];       // per device: 64 slots x 512 B (arrival counter | release word), zero-initialised
-static hipStream_t g_fused_stream[16][64];
-static int g_fused_nstream[16];
-static int g_fused_cus[16];
-static int g_fused_enabled = -1;  // bit 0: forward, bit 1: backward; -1: take MM_BN2D_FUSED (default 3) on first use
-
-// Grid and rows per thread for a map of N rows (Ns in the first statistics group) and C channels; ok = false: use the
-// three-kernel path (map too large to keep on chip, channel count outside the layout, or MM_BN2D_FUSED=0).
-static int fused_plan(int64_t N, int64_t Ns, int C, int rmax, bool backward, hipStream_t s, FusedPlan* pl) {
-  pl->ok = false;
-  if (g_fused_enabled < 0) {
-    const char* e = getenv("MM_BN2D_FUSED");
-    g_fused_enabled = e ? (atoi(e) & 3) : 3;
-  }
-  if (!(g_fused_enabled & (backward ? 2 : 1)) || N <= 0 || C % 8 != 0 || C > FT || C < 8) return MM_OK;
-  int dev = 0;
-  MM_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return MM_OK;
-  std::lock_guard<std::mutex> lock(g_fused_mu);
-  if (!g_fused_sync[dev]) {
-    int cus = 0;
-    MM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    void* q = nullptr;
-    MM_HIP(hipMalloc(&q, 64 * 512));
-    MM_HIP(hipMemset(q, 0, 64 * 512));
-    const void* fns[] = {
-        (const void*)k_bn2d_fused_fwd<8, false>,  (const void*)k_bn2d_fused_fwd<8, true>,   (const void*)k_bn2d_fused_fwd<20, false>,
-        (const void*)k_bn2d_fused_fwd<20, true>,  (const void*)k_bn2d_fused_fwd<36, false>, (const void*)k_bn2d_fused_fwd<36, true>,
-        (const void*)k_bn2d_fused_bwd<8, false, 0>,  (const void*)k_bn2d_fused_bwd<8, false, 1>,  (const void*)k_bn2d_fused_bwd<8, false, 2>,
-        (const void*)k_bn2d_fused_bwd<8, true, 0>,   (const void*)k_bn2d_fused_bwd<8, true, 1>,   (const void*)k_bn2d_fused_bwd<8, true, 2>,
-        (const void*)k_bn2d_fused_bwd<20, false, 0>, (const void*)k_bn2d_fused_bwd<20, false, 1>, (const void*)k_bn2d_fused_bwd<20, false, 2>,
-        (const void*)k_bn2d_fused_bwd<20, true, 0>,  (const void*)k_bn2d_fused_bwd<20, true, 1>,  (const void*)k_bn2d_fused_bwd<20, true, 2>,
-        (const void*)k_bn2d_fused_bwd<36, false, 0>, (const void*)k_bn2d_fused_bwd<36, false, 1>, (const void*)k_bn2d_fused_bwd<36, false, 2>,
-        (const void*)k_bn2d_fused_bwd<36, true, 0>,  (const void*)k_bn2d_fused_bwd<36, true, 1>,  (const void*)k_bn2d_fused_bwd<36, true, 2>};
-    for (const void* fn : fns) MM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS));
-    g_fused_cus[dev] = cus;
-    g_fused_sync[dev] = (unsigned*)q;
-  }
-  int slot = -1;
-  for (int i = 0; i < g_fused_nstream[dev]; i++)
-    if (g_fused_stream[dev][i] == s) slot = i;
-  if (slot < 0) {
-    if (g_fused_nstream[dev] >= 64) return MM_OK;  // more streams than barrier slots: three-kernel path
-    slot = g_fused_nstream[dev]++;
-    g_fused_stream[dev][slot] = s;
-  }
-  const int rs = FT / (C / 8);
-  const int cus = g_fused_cus[dev];
-  if (cus < 2) return MM_OK;
-  const bool two = Ns > 0 && Ns < N;
-  int64_t G = mm_cdiv(N, (int64_t)rs * 6);  // about six rows per thread
-  if (G > cus) G = cus;
-  if (G < (two ? 2 : 1)) G = two ? 2 : 1;
-  int G0 = (int)G, G1 = 0;
-  if (two) {
-    G0 = (int)((double)G * (double)Ns / (double)N + 0.5);
-    if (G0 < 1) G0 = 1;
-    if (G0 > (int)G - 1) G0 = (int)G - 1;
-    G1 = (int)G - G0;
-  }
-  const int64_t rpb0 = mm_cdiv(two ? Ns : N, G0), rpb1 = two ? mm_cdiv(N - Ns, G1) : 0;
-  const int64_t R = mm_cdiv(rpb0 > rpb1 ? rpb0 : rpb1, rs);
-  if (R > rmax) return MM_OK;
-  pl->ok = true;
-  pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;
-  pl->sync = g_fused_sync[dev] + slot * 128;
-  return MM_OK;
-}
+static const void* const k_fused_fns[] = {
+    (const void*)k_bn2d_fused_fwd<8, false>,     (const void*)k_bn2d_fused_fwd<8, true>,      (const void*)k_bn2d_fused_fwd<20, false>,
+    (const void*)k_bn2d_fused_fwd<20, true>,     (const void*)k_bn2d_fused_fwd<36, false>,    (const void*)k_bn2d_fused_fwd<36, true>,
+    (const void*)k_bn2d_fused_bwd<8, false, 0>,  (const void*)k_bn2d_fused_bwd<8, false, 1>,  (const void*)k_bn2d_fused_bwd<8, false, 2>,
+    (const void*)k_bn2d_fused_bwd<8, true, 0>,   (const void*)k_bn2d_fused_bwd<8, true, 1>,   (const void*)k_bn2d_fused_bwd<8, true, 2>,
+    (const void*)k_bn2d_fused_bwd<20, false, 0>, (const void*)k_bn2d_fused_bwd<20, false, 1>, (const void*)k_bn2d_fused_bwd<20, false, 2>,
+    (const void*)k_bn2d_fused_bwd<20, true, 0>,  (const void*)k_bn2d_fused_bwd<20, true, 1>,  (const void*)k_bn2d_fused_bwd<20, true, 2>,
+    (const void*)k_bn2d_fused_bwd<36, false, 0>, (const void*)k_bn2d_fused_bwd<36, false, 1>, (const void*)k_bn2d_fused_bwd<36, false, 2>,
+    (const void*)k_bn2d_fused_bwd<36, true, 0>,  (const void*)k_bn2d_fused_bwd<36, true, 1>,  (const void*)k_bn2d_fused_bwd<36, true, 2>};
+constexpr int k_fused_nfns = (int)(sizeof(k_fused_fns) / sizeof(k_fused_fns[0]));
 
 extern "C" {
 
 // Selects the single-launch training kernels per direction: bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd (default 3, or the
 // value of the environment variable MM_BN2D_FUSED); 0 = always the reduce / finalize / apply kernels.  Returns the previous mask.
 int mm_bn2d_set_fused(int mask) {
-  if (g_fused_enabled < 0) {
-    const char* e = getenv("MM_BN2D_FUSED");
-    g_fused_enabled = e ? (atoi(e) & 3) : 3;
-  }
-  const int prev = g_fused_enabled;
+  const int prev = fused_mask("MM_BN2D_FUSED");
   g_fused_enabled = mask & 3;
   return prev;
 }
@@ -947,7 +700,7 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
   int nb0, nb1, ab0, ab1;
   if (Ns <= 0 || Ns >= N) Ns = N;
   FusedPlan pl;
-  int rc = fused_plan(N, Ns, C, 36, false, s, &pl);
+  int rc = fused_plan(N, Ns, C, 8, 36, false, "MM_BN2D_FUSED", k_fused_fns, k_fused_nfns, s, &pl);
   if (rc) return rc;
   const int64_t ldmax_f = std::max(std::max(ld_x, ld_y), res ? ld_r : 0);
   if (pl.ok && (!res || ld_r % 8 == 0) && N * ldmax_f * 2 < (1ll << 31)) {  // 32-bit buffer offsets
@@ -1015,7 +768,7 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
   int nb0, nb1, ab0, ab1;
   if (Ns <= 0 || Ns >= N) Ns = N;
   FusedPlan pl;
-  int rc = fused_plan(N, Ns, C, 36, true, s, &pl);
+  int rc = fused_plan(N, Ns, C, 8, 36, true, "MM_BN2D_FUSED", k_fused_fns, k_fused_nfns, s, &pl);
   if (rc) return rc;
   const int64_t ldmax_b = std::max(std::max(std::max(ld_x, ld_dy), std::max(ld_dx, dy2 ? ld_dy2 : 0)), std::max(yout ? ld_y : 0, dres ? ld_dr : 0));
   if (pl.ok && ld_x % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0 && (!dy2 || ld_dy2 % 8 == 0) && (!yout || ld_y % 8 == 0) &&

@@ -53,11 +53,12 @@ class GradAllReducer:
         if self.world == 1:
             return
         if overlap and torch.cuda.is_available():
-            # The single-launch BatchNorm2d kernels (csrc/bn2d.hip) need every CU at once; a collective that runs beside the
+            # The single-launch batch-norm kernels (csrc/bn2d.hip, csrc/bn.hip) need every CU at once; a collective that runs beside the
             # backward pass holds some, and the whole grid would wait for it.  Forward passes have no collective next to them.
             from . import _lib
 
             _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & 1)
+            _lib.lib().mm_bn_set_fused(_lib.lib().mm_bn_set_fused(0) & 1)
         for opt in optimizers:
             for a in getattr(opt, "_arenas", []):
                 if a is None:

@@ -124,6 +124,7 @@ class TrainModel(nn.Module):
                         from . import _lib
 
                         _lib.lib().mm_bn2d_set_fused(0)
+                        _lib.lib().mm_bn_set_fused(0)
                     main = torch.cuda.current_stream(dev)
                     self._s3d.wait_event(step_start)
                     with torch.cuda.stream(self._s3d):

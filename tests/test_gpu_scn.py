@@ -178,6 +178,55 @@ def test_batchnorm_forward_backward_running_stats(C, leak):
     r.eval(), h.eval()
     _close(h(th).features, r(tr).features, what="bn eval")
 
+@pytest.mark.parametrize("N,Ns,C,leak,pitch", [
+    (3001, 3001, 16, 0.0, 16),          # one statistics group, a few rows per thread
+    (558080, 279040, 16, 0.0, 16),      # level 0 of the headline step: 17 rows per thread
+    (558080, 300001, 32, 0.333, 32),    # the widest level-0 map (34 rows per thread), leaky, uneven groups
+    (120007, 60000, 112, 0.0, 112),     # 28 column groups (18 row slots of the 512 threads)
+    (250000, 125000, 48, 0.0, 96),      # rows that are a channel slice of a wider buffer
+])
+def test_batchnorm_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, leak, pitch):
+    """csrc/bn.hip: the grid-barrier kernels (fp32 rows kept in registers / LDS) against reduce / finalize / apply on the same
+    inputs, through the C-ABI.  Same arithmetic per element; only the order in which the per-workgroup partial sums are combined
+    differs, so statistics agree to fp32 rounding and outputs to a few ulp of their scale."""
+    from mm2d3d_amd import _lib
+    from mm2d3d_amd._lib import check, ptr, stream
+
+    dev = _dev()
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N % 1000 + C)
+    xb = (torch.randn(N, pitch, generator=g) * 1.5 + 0.3).to(dev)
+    x = xb[:, pitch - C:]
+    dy = torch.randn(N, C, generator=g).to(dev)
+    w = (torch.rand(C, generator=g) + 0.5).to(dev)
+    b = torch.randn(C, generator=g).to(dev)
+
+    def run(mask):
+        prev = L.mm_bn_set_fused(mask)
+        try:
+            rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+            y, dx = torch.zeros(N, C, device=dev), torch.zeros(N, C, device=dev)
+            dw, db = torch.full((C,), 0.5, device=dev), torch.full((C,), -1.0, device=dev)
+            stats = torch.zeros((2, 2 if 0 < Ns < N else 1, C), device=dev)
+            ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, dev)
+            check(L.mm_bn_fwd_train(ptr(x), pitch, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), 1e-4, 0.9, leak, ptr(y), C, ptr(stats[0]),
+                                    ptr(stats[1]), ptr(ws), ws.numel(), stream()), "fwd")
+            check(L.mm_bn_bwd(ptr(x), pitch, ptr(dy), C, N, Ns, C, ptr(w), ptr(b), ptr(stats[0]), ptr(stats[1]), leak, ptr(dx), C, ptr(dw),
+                              ptr(db), 1, ptr(ws), ws.numel(), stream()), "bwd")
+            torch.cuda.synchronize()
+        finally:
+            L.mm_bn_set_fused(prev)
+        return dict(y=y, dx=dx, dw=dw, db=db, stats=stats, rm=rm, rv=rv)
+
+    a, c = run(3), run(0)
+    assert torch.allclose(a["stats"], c["stats"], rtol=2e-6, atol=1e-7)
+    assert torch.allclose(a["rm"], c["rm"], rtol=2e-6, atol=1e-8) and torch.allclose(a["rv"], c["rv"], rtol=2e-6, atol=0)
+    for k in ("y", "dx"):
+        scale = float(c[k].abs().max())
+        assert float((a[k] - c[k]).abs().max()) <= 4e-6 * scale, k
+    assert float((a["dw"] - c["dw"]).abs().max()) <= 1e-5 * float(c["dw"].abs().max()) + 1e-5
+    assert float((a["db"] - c["db"]).abs().max()) <= 1e-5 * float(c["db"].abs().max()) + 1e-5
+
 
 @pytest.mark.parametrize("residual", [False, True])
 def test_net3d_forward_backward_vs_oracle(residual, engine):
