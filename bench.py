@@ -193,6 +193,11 @@ def main():
                          f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {a.gpus} ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if world > max(torch.cuda.device_count(), 1):
+        # rehearsal with several ranks per GPU: the single-launch batch-norm kernels need a whole GPU to themselves
+        # (csrc/fused_bn.h); two processes' grids would wait for each other's CUs
+        os.environ["MM_BN2D_FUSED"] = "0"
+        os.environ["MM_BN_FUSED"] = "0"
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

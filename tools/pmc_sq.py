@@ -1,0 +1,52 @@
+"""Reduces a rocprofv3 --pmc run (rocpd database) of the SQ counters into per-kernel fractions of the wave cycles.
+
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
+              SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d <dir> -- python3 bench.py --steps 3 --warmup 2 --no-extras
+    python tools/pmc_sq.py <dir> > profiles/rNN/pmc_sq_step.json
+
+SQ_* counters tick in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles (divided by 4 here), so every figure is a fraction of the
+wave cycles of the kernel's waves.  MFMA pipe utilisation = mfma_busy_cycles_per_wave_cycle x resident waves per SIMD.
+"""
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*", "", name)
+
+
+def main():
+    d = sys.argv[1]
+    db = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True), key=os.path.getmtime)[-1] if os.path.isdir(d) else d
+    con = sqlite3.connect(db)
+    rows = con.execute("select k.name, p.counter_name, sum(p.value) from counters_collection p join kernels k on "
+                       "p.dispatch_id = k.dispatch_id group by k.name, p.counter_name").fetchall()
+    times = {short(n): (c, t) for n, c, t in con.execute("select name, count(*), sum(duration) from kernels group by name")}
+    by = {}
+    for name, c, v in rows:
+        by.setdefault(short(name), {})[c] = float(v)
+    out = {}
+    for name, c in sorted(by.items(), key=lambda kv: -times.get(kv[0], (0, 0))[1]):
+        wc = c.get("SQ_WAVE_CYCLES", 0.0)
+        if wc <= 0 or times[name][1] < 2e6:
+            continue
+        lds = c.get("SQ_LDS_IDX_ACTIVE", 0.0)
+        out[name] = {
+            "calls": times[name][0], "time_ms": round(times[name][1] / 1e6, 2),
+            "wait_any": round(c.get("SQ_WAIT_ANY", 0) / wc, 3), "wait_inst_any": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+            "active_inst_any": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
+            "mfma_busy_cycles_per_wave_cycle": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 4 / wc, 3),
+            "wait_inst_lds": round(c.get("SQ_WAIT_INST_LDS", 0) / wc, 3),
+            "lds_bank_conflict_per_lds_active": round(c.get("SQ_LDS_BANK_CONFLICT", 0) / lds, 3) if lds > 0 else 0.0,
+        }
+    print(json.dumps({"what": __doc__.strip().split("\n\n")[1].replace("\n", " "), "kernels": out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
