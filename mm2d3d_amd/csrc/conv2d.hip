@@ -1011,34 +1011,66 @@ __global__ __launch_bounds__(256, PH == 8 ? 4 : 6) void k_wgrad3x3(Wg3P p) {
     }
 }
 
+// phase 1 of k_wgrad_reduce for a compile-time tap count: two slabs x NT taps = up to 18 independent loads per thread and pass
+template <int NT>
+__device__ inline void wgrad_reduce_slices(const float* __restrict__ src, int64_t ne, int Ck, int nsplit, int sl, int kl,
+                                           float (*red)[16][33]) {
+  float s[NT];
+#pragma unroll
+  for (int tp = 0; tp < NT; tp++) s[tp] = 0.f;
+  for (int i = sl; i < nsplit; i += 16) {
+    const bool two = i + 8 < nsplit;
+    float v0[NT], v1[NT];
+#pragma unroll
+    for (int tp = 0; tp < NT; tp++) {
+      v0[tp] = src[(int64_t)i * ne + (int64_t)tp * Ck];
+      v1[tp] = src[(int64_t)(two ? i + 8 : i) * ne + (int64_t)tp * Ck];
+    }
+#pragma unroll
+    for (int tp = 0; tp < NT; tp++) {
+      s[tp] += v0[tp];
+      if (two) s[tp] += v1[tp];
+    }
+  }
+#pragma unroll
+  for (int tp = 0; tp < NT; tp++) red[sl][tp][kl] = s[tp];
+}
+
 // dW_torch[idx(n,tap,k)] (+)= sum_splits partial[s][n][tap][k];  out strides (sn, st, sk) express the torch layout
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
                                                        float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
                                                        int accumulate) {
-  // block = 32 float4 columns (128 consecutive elements) x 8 split slices; slices combined in a fixed order (bit-stable).
-  // ne is a multiple of 4 (Ck % 64 == 0), so the 16-byte loads never straddle the end.
-  __shared__ float4 red[8][32];
-  const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  // A workgroup owns (n, 32 consecutive k) for ALL taps.  Phase 1: thread (k, slice) adds the slabs i = slice, slice + 8, ...
+  // of every tap (4-byte loads, 128-byte segments per 32 lanes, all independent).  Phase 2: the 8 slices are combined in a
+  // fixed order (bit-stable) and the 32 x ntaps results are written in the ORDER OF THE DESTINATION: for a Conv2d weight
+  // [Cn][Ck][3][3] (st = 1, sk = 9) that is one contiguous 1,152-byte run.  (Writing four k of one tap per thread, as the
+  // first version did, touched every 36-byte weight row nine times from nine workgroups: the read-modify-write of the gradient
+  // arena cost more than reading the slabs.)
+  __shared__ float red[8][16][33];
+  const int kl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int nkb = Ck >> 5;
+  const int n = blockIdx.x / nkb, k0 = (blockIdx.x - n * nkb) << 5;
   const int64_t ne = (int64_t)Cn * ntaps * Ck;
-  const int64_t e = ((int64_t)blockIdx.x * 32 + col) * 4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e < ne)
-    for (int i = sl; i < nsplit; i += 8) {
-      const float4 v = *(const float4*)(partial + (int64_t)i * ne + e);
-      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  const float* src = partial + ((int64_t)n * ntaps) * Ck + k0 + kl;
+  if (ntaps == 9) wgrad_reduce_slices<9>(src, ne, Ck, nsplit, sl, kl, red);
+  else if (ntaps == 4) wgrad_reduce_slices<4>(src, ne, Ck, nsplit, sl, kl, red);
+  else if (ntaps == 1) wgrad_reduce_slices<1>(src, ne, Ck, nsplit, sl, kl, red);
+  else
+    for (int tp = 0; tp < ntaps; tp++) {
+      float s = 0.f;
+      for (int i = sl; i < nsplit; i += 8) s += src[(int64_t)i * ne + (int64_t)tp * Ck];
+      red[sl][tp][kl] = s;
     }
-  red[sl][col] = s;
   __syncthreads();
-  if (sl == 0 && e < ne) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
+  // destination order: the faster-varying of (tap, k) in the output layout runs along the threads
+  const bool tap_fast = st < sk;
+  for (int o = threadIdx.x; o < 32 * ntaps; o += 256) {
+    const int tp = tap_fast ? o % ntaps : o >> 5, k = tap_fast ? o / ntaps : o & 31;
+    float t = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) t[0] += red[i][col].x, t[1] += red[i][col].y, t[2] += red[i][col].z, t[3] += red[i][col].w;
-    const int k = (int)(e % Ck);  // the 4 elements share n and tap (Ck % 4 == 0)
-    const int64_t r = e / Ck;
-    const int tp = (int)(r % ntaps), n = (int)(r / ntaps);
-    float* d = dW + n * sn + tp * st + k * sk;
-#pragma unroll
-    for (int j = 0; j < 4; j++) d[j * sk] = accumulate ? d[j * sk] + t[j] : t[j];
+    for (int i = 0; i < 8; i++) t += red[i][tp][k];
+    float* d = dW + n * sn + tp * st + (int64_t)(k0 + k) * sk;
+    *d = accumulate ? *d + t : t;
   }
 }
 
@@ -1303,7 +1335,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
     q.partial = (float*)ws;
     const size_t lds = (size_t)(ph * 16 + ((ph * 18 + 31) / 32) * 32) * 128;
     hipLaunchKernelGGL(k_wgrad3x3<ph>, dim3(nsplit3, ntile, 3), dim3(256), lds, s, q);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * 9 * Ck, 128)), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
                        dW, sn, st, sk, accumulate);
     MM_LAUNCH_CHECK();
     return MM_OK;
@@ -1325,7 +1357,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
       hipLaunchKernelGGL(k_conv_wgrad2<64>, dim3(nsplit, (Cn / 64) * nkt, ntaps), dim3(256), lds, s, p);
     }
   }
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)mm_cdiv((int64_t)Cn * ntaps * Ck, 128)), dim3(256), 0, s, p.partial,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, p.partial,
                      M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;

@@ -345,7 +345,20 @@ __global__ __launch_bounds__(256) void k_csr_reduce(const float* __restrict__ tm
   if (row >= n_out) return;
   int a = csr_off[row], b = csr_off[row + 1];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int e = a; e < b; e++) acc += *(const f32x4*)(tmp + (int64_t)csr_pos[e] * ld_tmp + c4 * 4);
+  // four rules at a time: the four positions, then the four tmp rows, are independent loads (a rule-by-rule loop is a chain
+  // of two dependent memory round trips per rule); rules beyond the row's last one re-read it and are not added.  The sum
+  // stays in ascending rule order = ascending k.
+  for (int e = a; e < b; e += 4) {
+    int pos[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) pos[j] = csr_pos[e + j < b ? e + j : b - 1];
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = *(const f32x4*)(tmp + (int64_t)pos[j] * ld_tmp + c4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (e + j < b) acc += v[j];
+  }
   *(f32x4*)(out + row * ld_out + c4 * 4) = acc;
 }
 
