@@ -60,7 +60,14 @@ __global__ void k_sum_partials(const double* __restrict__ partial, int nblk, int
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= ne) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; b++) s += partial[(int64_t)b * ne + e];
+  for (int b = 0; b < nblk; b += 8) {  // eight independent loads per pass (a rolled loop is one memory round trip per block)
+    double v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = partial[(int64_t)(b + j < nblk ? b + j : nblk - 1) * ne + e];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (b + j < nblk) s += v[j];
+  }
   float* d = e < n0 ? out0 + e : out1 + (e - n0);
   *d = accumulate ? *d + (float)s : (float)s;
 }
@@ -216,42 +223,60 @@ __global__ __launch_bounds__(T) void k_linear16_bwd_x(const float* __restrict__ 
   }
 }
 
-// partial[block][co*16+ci] = sum_n dy[n,co]*x[n,ci]; partial[block][Cout*16 + co] = sum_n dy[n,co]: every thread walks rows
-// with a block stride and keeps one output class at a time in 17 registers; the block combines through LDS in fp64 (fixed order)
+// partial[block][co*16+ci] = sum_n dy[n,co]*x[n,ci]; partial[block][Cout*16 + co] = sum_n dy[n,co].  Every thread walks rows
+// with a block stride and accumulates SIX classes at a time (6 x 17 registers; x is read once per group of six classes, not
+// once per class); the 64 lanes of a wave are added by a fixed butterfly in fp32, the four waves in fp64.
 __global__ __launch_bounds__(T) void k_linear16_bwd_w(const float* __restrict__ x, int ld_x, const float* __restrict__ dy, int ld_dy,
                                                        int64_t N, int Cout, double* __restrict__ partial) {
-  __shared__ double red[T];
+  constexpr int CG = 6;
+  __shared__ float red[T / 64][CG * 17];
   const int ne = Cout * 16 + Cout;
   const int64_t rows_per_block = (N + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
-  for (int co = 0; co < Cout; co++) {
-    float acc[17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < Cout; c0 += CG) {
+    float acc[CG][17];
 #pragma unroll
-    for (int i = 0; i < 17; i++) acc[i] = 0.f;
+    for (int c = 0; c < CG; c++)
+#pragma unroll
+      for (int i = 0; i < 17; i++) acc[c][i] = 0.f;
     for (int64_t r = r0 + threadIdx.x; r < r1; r += T) {
-      const float g = dy[r * ld_dy + co];
+      float xv[16], g[CG];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const f32x4p t = *(const f32x4p*)(x + r * ld_x + 4 * q);
-        acc[4 * q] = fmaf(g, t.x, acc[4 * q]);
-        acc[4 * q + 1] = fmaf(g, t.y, acc[4 * q + 1]);
-        acc[4 * q + 2] = fmaf(g, t.z, acc[4 * q + 2]);
-        acc[4 * q + 3] = fmaf(g, t.w, acc[4 * q + 3]);
+        xv[4 * q] = t.x, xv[4 * q + 1] = t.y, xv[4 * q + 2] = t.z, xv[4 * q + 3] = t.w;
       }
-      acc[16] += g;
+#pragma unroll
+      for (int c = 0; c < CG; c++) g[c] = c0 + c < Cout ? dy[r * ld_dy + c0 + c] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CG; c++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[c][i] = fmaf(g[c], xv[i], acc[c][i]);
+        acc[c][16] += g[c];
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 17; i++) {
-      __syncthreads();
-      red[threadIdx.x] = (double)acc[i];
-      __syncthreads();
-      for (int s2 = T / 2; s2 > 0; s2 >>= 1) {
-        if ((int)threadIdx.x < s2) red[threadIdx.x] += red[threadIdx.x + s2];
-        __syncthreads();
+    for (int c = 0; c < CG; c++)
+#pragma unroll
+      for (int i = 0; i < 17; i++) {
+        float v = acc[c][i];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0) red[wave][c * 17 + i] = v;
       }
-      if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * ne + (i < 16 ? co * 16 + i : Cout * 16 + co)] = red[0];
+    __syncthreads();
+    if ((int)threadIdx.x < CG * 17) {
+      const int c = threadIdx.x / 17, i = threadIdx.x - c * 17;
+      if (c0 + c < Cout) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < T / 64; w++) sum += (double)red[w][threadIdx.x];
+        partial[(int64_t)blockIdx.x * ne + (i < 16 ? (c0 + c) * 16 + i : Cout * 16 + c0 + c)] = sum;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -340,8 +365,9 @@ int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t 
                          accumulate_dx);
   }
   if (dw) {
-    int nb = (int)mm_cdiv(N > 0 ? N : 1, 2048);
+    int nb = (int)mm_cdiv(N > 0 ? N : 1, fast ? 4096 : 2048);  // the row-per-thread kernel streams 34 rows per thread at 558k rows
     if (nb > MAX_PART) nb = MAX_PART;
+    if (fast && nb > 128) nb = 128;
     const int ne = Cout * Cin + Cout;
     if (ws_bytes < (size_t)nb * ne * sizeof(double)) {
       mm_set_error("linear_bwd: workspace too small");
