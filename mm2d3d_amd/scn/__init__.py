@@ -48,10 +48,21 @@ class SparseConvNetTensor:
     """features [n_active, C] + the metadata that owns the active sets / rulebooks (scn_unet.py:29-31)."""
 
     def __init__(self, features=None, metadata=None, spatial_size=None, level=None):
-        self.features = features
+        self._features = features
+        self._parts = None  # JoinTable: the rows that WOULD be concatenated (built only if somebody reads .features)
         self.metadata = metadata
         self.spatial_size = spatial_size
         self.level = level
+
+    @property
+    def features(self):
+        if self._features is None and self._parts is not None:
+            self._features = torch.cat(self._parts, 1)  # the plain JoinTable (scn_unet.py:81)
+        return self._features
+
+    @features.setter
+    def features(self, value):
+        self._features, self._parts = value, None
 
     def _with(self, features, level=None, spatial_size=None):
         return SparseConvNetTensor(features, self.metadata, spatial_size if spatial_size is not None else self.spatial_size,
@@ -100,8 +111,13 @@ class ConcatTable(nn.Sequential):
 
 
 class JoinTable(nn.Module):
+    """Channel concatenation.  The joined rows are built lazily: a BatchNormalization that follows (the U-Net's case,
+    scn_unet.py:81-82) normalises the parts straight into one buffer (ops.BatchNormActJoinFunction) and nothing is copied."""
+
     def forward(self, xs):
-        return xs[0]._with(torch.cat([t.features for t in xs], 1))
+        out = xs[0]._with(None)
+        out._parts = [t.features for t in xs]
+        return out
 
 
 class AddTable(nn.Module):
@@ -283,6 +299,13 @@ class BatchNormalization(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x):
+        parts = x._parts if x._features is None else None
+        if (parts is not None and self.weight is not None and all(t.is_cuda and t.shape[1] % 4 == 0 and t.dtype == parts[0].dtype
+                                                                   and t.dtype in (torch.float32, torch.bfloat16) for t in parts)):
+            f = ops.BatchNormActJoinFunction.apply(self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                                   float(self.eps), float(self.momentum), float(self.leakiness),
+                                                   getattr(x.level, "seg_rows", None), *parts)
+            return x._with(f)
         f = ops.BatchNormActFunction.apply(x.features, self.weight, self.bias, self.running_mean, self.running_var,
                                            self.training, float(self.eps), float(self.momentum), float(self.leakiness),
                                            getattr(x.level, "seg_rows", None))

@@ -360,6 +360,83 @@ class BatchNormActFunction(torch.autograd.Function):
             gradsink.done(bp)
         return dx, dw, db, None, None, None, None, None, None, None
 
+class BatchNormActJoinFunction(torch.autograd.Function):
+    """BatchNorm(+leaky ReLU) of ``JoinTable([x_0, x_1, ...])`` without building the joined rows (scn_unet.py:81 followed by
+    the block's first BatchNormReLU): batch norm is per channel, so part i is normalised with channels
+    [off_i, off_i + C_i) of the parameters and written into columns [off_i, off_i + C_i) of the output (every kernel takes a row
+    pitch).  Backward reads dy through the same pitch and produces one contiguous gradient per part: no concat copy forward,
+    no slice copies backward."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, running_mean, running_var, training, eps, momentum, leak, seg_rows, *xs):
+        L = _lib.lib()
+        act16 = xs[0].dtype == BF16
+        xs = [_c(x) if act16 else _c(x.to(F32)) for x in xs]
+        for x in xs:
+            _lib.require_cuda(x, "features")
+        es = 2 if act16 else 4
+        fwd_train, fwd_eval = (L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16) if act16 else (L.mm_bn_fwd_train, L.mm_bn_fwd_eval)
+        N = xs[0].shape[0]
+        widths = [x.shape[1] for x in xs]
+        C = sum(widths)
+        y = torch.empty((N, C), dtype=xs[0].dtype, device=xs[0].device)
+        Ns = seg_rows if (training and seg_rows is not None and 0 < seg_rows < N) else N
+        stats, off = [], 0
+        for x, c in zip(xs, widths):
+            w, b = ptr(weight) + 4 * off, ptr(bias) + 4 * off
+            rm, rv = ptr(running_mean) + 4 * off, ptr(running_var) + 4 * off
+            if training:
+                st = torch.empty((2, 2 if Ns < N else 1, c), dtype=F32, device=x.device)
+                ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
+                check(fwd_train(ptr(x), c, N, Ns, c, w, b, rm, rv, eps, momentum, leak, ptr(y) + es * off, C, ptr(st[0]), ptr(st[1]),
+                                ptr(ws), ws.numel(), stream()), "bn_fwd_train")
+                stats.append(st)
+            else:
+                check(fwd_eval(ptr(x), c, N, c, w, b, rm, rv, eps, leak, ptr(y) + es * off, C, stream()), "bn_fwd_eval")
+            off += c
+        ctx.training, ctx.act16, ctx.widths, ctx.leak, ctx.Ns = training, act16, widths, leak, Ns
+        ctx.sinks = None
+        if training:
+            ctx.save_for_backward(weight, bias, *stats, *xs)
+            if gradsink.claim(ctx, weight, ctx.needs_input_grad[0]):
+                gradsink.claim(ctx, bias, True)
+                ctx.sinks = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise RuntimeError("BatchNorm backward in eval mode is not part of the hot path")
+        L = _lib.lib()
+        n = len(ctx.widths)
+        weight, bias = ctx.saved_tensors[:2]
+        stats, xs = ctx.saved_tensors[2 : 2 + n], ctx.saved_tensors[2 + n :]
+        es = 2 if ctx.act16 else 4
+        dy = _c(dy.to(BF16 if ctx.act16 else F32))
+        N, C = dy.shape
+        if ctx.sinks is not None:
+            wp, bp = ctx.sinks
+            dw = db = None
+            dwt, dbt, acc = wp._mm_sink, bp._mm_sink, 1
+        else:
+            dw = dwt = torch.empty(C, dtype=F32, device=dy.device)
+            db = dbt = torch.empty(C, dtype=F32, device=dy.device)
+            acc = 0
+        bwd = L.mm_bn_bwd_bf16 if ctx.act16 else L.mm_bn_bwd
+        dxs, off = [], 0
+        for x, st, c in zip(xs, stats, ctx.widths):
+            dx = torch.empty_like(x)
+            ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
+            check(bwd(ptr(x), c, ptr(dy) + es * off, C, N, ctx.Ns, c, ptr(weight) + 4 * off, ptr(bias) + 4 * off, ptr(st[0]), ptr(st[1]),
+                      ctx.leak, ptr(dx), c, ptr(dwt) + 4 * off, ptr(dbt) + 4 * off, acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
+            dxs.append(dx)
+            off += c
+        if ctx.sinks is not None:
+            gradsink.done(wp)
+            gradsink.done(bp)
+        return (dw, db, None, None, None, None, None, None, None, *dxs)
+
+
 
 class InputMeanFunction(torch.autograd.Function):
     """InputLayer modes 3 (sum) / 4 (mean) over the voxel->points CSR of level 0."""

@@ -227,6 +227,49 @@ def test_batchnorm_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, l
     assert float((a["dw"] - c["dw"]).abs().max()) <= 1e-5 * float(c["dw"].abs().max()) + 1e-5
     assert float((a["db"] - c["db"]).abs().max()) <= 1e-5 * float(c["db"].abs().max()) + 1e-5
 
+@pytest.mark.parametrize("leak,split", [(0.0, None), (0.333, 1200)])
+def test_join_table_followed_by_batchnorm_builds_no_concat(leak, split):
+    """scn_unet.py:81-82: JoinTable -> BatchNormReLU.  Here the join is lazy and the batch norm normalises the parts straight into
+    one buffer (ops.BatchNormActJoinFunction); it must equal batch norm over the concatenated rows, forward and backward, in
+    training (also with two statistics groups) and in eval mode."""
+    import copy
+    import types
+
+    from mm2d3d_amd import scn
+
+    dev = _dev()
+    torch.manual_seed(7)
+    N, ca, cb = 3001, 16, 32
+    a0, b0 = (torch.randn(N, ca) * 2 + 0.5).to(dev), (torch.randn(N, cb) - 0.3).to(dev)
+    bn1 = (scn.BatchNormLeakyReLU(ca + cb, leakiness=leak) if leak else scn.BatchNormReLU(ca + cb)).to(dev)
+    with torch.no_grad():
+        bn1.weight.uniform_(0.5, 1.5)
+        bn1.bias.uniform_(-0.5, 0.5)
+    bn2 = copy.deepcopy(bn1)
+    level = types.SimpleNamespace(seg_rows=split)
+    a1, b1 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    a2, b2 = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    joined = scn.JoinTable()([scn.SparseConvNetTensor(a1, None, 8, level), scn.SparseConvNetTensor(b1, None, 8, level)])
+    assert joined._features is None and len(joined._parts) == 2
+    y1 = bn1(joined).features
+    assert joined._features is None  # nobody built the concatenation
+    y2 = bn2(scn.SparseConvNetTensor(torch.cat([a2, b2], 1), None, 8, level)).features
+    assert torch.allclose(y1, y2, rtol=1e-5, atol=1e-5)
+    g = torch.randn_like(y1)
+    (y1 * g).sum().backward()
+    (y2 * g).sum().backward()
+    for u, v, what in ((a1.grad, a2.grad, "dx part 0"), (b1.grad, b2.grad, "dx part 1"), (bn1.weight.grad, bn2.weight.grad, "dgamma"),
+                       (bn1.bias.grad, bn2.bias.grad, "dbeta")):
+        assert torch.allclose(u, v, rtol=1e-4, atol=1e-4 * float(v.abs().max())), what
+    assert torch.allclose(bn1.running_mean, bn2.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(bn1.running_var, bn2.running_var, rtol=1e-5)
+    bn1.eval(), bn2.eval()
+    e1 = bn1(scn.JoinTable()([scn.SparseConvNetTensor(a0, None, 8, level), scn.SparseConvNetTensor(b0, None, 8, level)])).features
+    e2 = bn2(scn.SparseConvNetTensor(torch.cat([a0, b0], 1), None, 8, level)).features
+    assert torch.allclose(e1, e2, rtol=1e-5, atol=1e-5)
+    # anything else that reads .features still gets the plain concatenation
+    t = scn.JoinTable()([scn.SparseConvNetTensor(a0, None, 8, level), scn.SparseConvNetTensor(b0, None, 8, level)])
+    assert torch.equal(t.features, torch.cat([a0, b0], 1))
+
 
 @pytest.mark.parametrize("residual", [False, True])
 def test_net3d_forward_backward_vs_oracle(residual, engine):
