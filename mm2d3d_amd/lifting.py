@@ -27,6 +27,23 @@ def _copy_stream(dev):
     return s
 
 
+_STAGING = {}
+
+
+def _staging(dev, n_int64):
+    """One of two persistent pinned int64 buffers of the device, free for reuse (its previous upload has finished)."""
+    ring = _STAGING.setdefault(dev.index, {"next": 0, "slots": [None, None]})
+    i = ring["next"]
+    ring["next"] = 1 - i
+    slot = ring["slots"][i]
+    if slot is not None:
+        slot["event"].synchronize()
+    if slot is None or slot["buf"].numel() < n_int64:
+        slot = ring["slots"][i] = {"buf": torch.empty(max(int(n_int64 * 1.25), 1024), dtype=torch.int64).pin_memory(),
+                                   "event": torch.cuda.Event()}
+    return slot
+
+
 class PixelIndex:
     """Batch-level index built from ``img_indices`` (list of numpy int64 [n_i, 2] = (row, col))."""
 
@@ -41,18 +58,23 @@ class PixelIndex:
         rc = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int64)
         # Host -> device through pinned staging on a copy stream: a copy from pageable memory queued on the compute stream
         # makes the host wait until everything queued before it has run (measured: 12 ms per step inside this constructor
-        # when it was called at the end of the 2D forward).
+        # when it was called at the end of the 2D forward).  The staging buffers are persistent (two per device, reused
+        # alternately once their last copy has completed): `Tensor.pin_memory()` registers fresh host pages on every call,
+        # 4.6 ms for the 9 MB of a 16-scene batch.
         dev = torch.device(device)
         cur = torch.cuda.current_stream(dev)
         cs = _copy_stream(dev)
-        rc_h = torch.from_numpy(np.ascontiguousarray(rc)).pin_memory()
-        cnt_h = torch.tensor(counts if counts else [0], dtype=torch.int64).pin_memory()
+        nb = len(counts)
+        stage = _staging(dev, nb + 2 * self.n)
+        host = stage["buf"].numpy()
+        host[:nb] = counts
+        host[nb : nb + 2 * self.n] = rc.reshape(-1)
         with torch.cuda.stream(cs):
-            rc_d = rc_h.to(dev, non_blocking=True)
-            cnt_d = cnt_h.to(dev, non_blocking=True)[: len(counts)]
+            both = stage["buf"][: nb + 2 * self.n].to(dev, non_blocking=True)
+            stage["event"].record(cs)
         cur.wait_stream(cs)
-        rc_d.record_stream(cur)
-        cnt_d.record_stream(cur)
+        both.record_stream(cur)
+        cnt_d, rc_d = both[:nb], both[nb:].view(-1, 2)
         b = torch.repeat_interleave(torch.arange(len(rows), device=device), cnt_d, output_size=self.n)
         self.b, self.r, self.c = b, rc_d[:, 0], rc_d[:, 1]
         key = (b * H + self.r) * W + self.c                   # flat pixel id b*H*W + r*W + c
