@@ -530,7 +530,10 @@ static int os_apply(int bf, const void* in_, int ld_in, int Cin, void* out_, int
   static const int v3 = getenv("MM_OS_V3") ? atoi(getenv("MM_OS_V3")) : 0;
   MM_CHECK_ARG(!bf || tile_rows == 64, "spconv_os_apply_bf16: tile_rows must be 64");
   if (tile_rows == 64 && (!v3 || bf)) {  // k-parallel form: at most 4 output-channel blocks per workgroup (64 KB of LDS partials)
-    int parts = (ncb + 3) / 4;
+    // at most THREE blocks per launch: the four-block instance needs 64 accumulator + 48 fragment registers and loses the
+    // occupancy that hides the gathers (64 output channels from 32: 184 us as one launch of four, 124 us as two of two)
+    static const int maxw = getenv("MM_OS_MAXW") ? atoi(getenv("MM_OS_MAXW")) : 3;
+    int parts = (ncb + maxw - 1) / maxw;
     // small levels: more, narrower launches (each re-gathers its rows) until the grid covers the chip
     while (n_tiles * parts < 1024 && parts < ncb && (ncb + parts) / (parts + 1) >= 2) parts++;
     rc = MM_OK;
