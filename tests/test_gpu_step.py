@@ -204,6 +204,56 @@ def test_joint_domain_pass_equals_the_two_call_sequence():
         cos = torch.nn.functional.cosine_similarity(p.grad.flatten().double(), q.grad.flatten().double(), dim=0).item()
         assert cos > 0.98 or q.grad.norm() < 1e-3, (name, cos)
 
+def test_branches_on_two_streams_equal_the_single_stream_step():
+    """train_kwargs["overlap_branches"]: the 3D branch runs on its own stream (forward and, through autograd's stream rules,
+    backward).  Same kernels, same order within each branch: every loss term and every gradient must be BIT-identical to the
+    single-stream step with the same (three-kernel) batch norm - a missing stream dependency shows up as a difference."""
+    import copy
+
+    from mm2d3d_amd import _lib
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = _dev()
+    L = _lib.lib()
+    prev2, prev3 = L.mm_bn2d_set_fused(0), L.mm_bn_set_fused(0)
+    try:
+        torch.manual_seed(1)
+        kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+        W = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]
+        n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+        for m in n2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+        mk = lambda: {"source": make_batch(5, 2, "nuscenes", (96, 128), device=dev), "target": make_batch(6, 2, "nuscenes", (96, 128), device=dev)}
+        loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
+        kwargs = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False)
+        one = TrainModel({"2d_net": n2, "3d_net": n3}, None, loss, dict(kwargs))
+        two = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(kwargs, overlap_branches=1))
+        for _ in range(3):  # several steps: the stream handoffs repeat with recycled allocator blocks
+            for tm in (one, two):
+                for p in tm.model.parameters():
+                    p.grad = None
+            t1 = one.training_step(mk())
+            t1.backward()
+            t2 = two.training_step(mk())
+            t2.backward()
+            torch.cuda.synchronize()
+            for k, v in one.last_logs.items():
+                assert two.last_logs[k].detach().item() == v.detach().item(), k
+            for (name, p), (_, q) in zip(list(n2.named_parameters()) + list(n3.named_parameters()),
+                                         list(n2b.named_parameters()) + list(n3b.named_parameters())):
+                assert (p.grad is None) == (q.grad is None), name
+                if p.grad is not None:
+                    assert torch.equal(p.grad, q.grad), name
+    finally:
+        L.mm_bn2d_set_fused(prev2)
+        L.mm_bn_set_fused(prev3)
+
 
 def test_gradient_sinks_equal_autograd_accumulation():
     """With FlatAdamW installed, weight-gradient kernels accumulate straight into the flat arena (gradsink.py); the arena
