@@ -252,7 +252,8 @@ static int fused_plan(int64_t N, int64_t Ns, int C, int vec, int rmax, bool back
   const int cus = g_fused_cus[dev];
   if (cus < 2) return MM_OK;
   const bool two = Ns > 0 && Ns < N;
-  int64_t G = mm_cdiv(N, (int64_t)rs * 6);  // about six rows per thread
+  static const int rows_target = getenv("MM_BN_ROWS") ? atoi(getenv("MM_BN_ROWS")) : 6;
+  int64_t G = mm_cdiv(N, (int64_t)rs * rows_target);  // about six rows per thread
   if (G > cus) G = cus;
   if (G < (two ? 2 : 1)) G = two ? 2 : 1;
   int G0 = (int)G, G1 = 0;
