@@ -294,6 +294,40 @@ class SparseConvFunction(torch.autograd.Function):
                 dw = dw.reshape(ctx.wshape)
         return dx, dw, None, None, None, None, None
 
+def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, y, ldy, st):
+    """bf16 rows.  With a plain ReLU (leak 0) the rows ARE an NHWC bf16 map of N pixels: the BatchNorm2d entry points apply
+    (same statistics groups, pitches, fp32 parameters) and bring the single-launch kernels of csrc/bn2d.hip; torch's momentum
+    convention is 1 - scn's keep fraction.  Other leak values take the row kernels of csrc/bn.hip."""
+    if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0:
+        if training:
+            ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
+            check(L.mm_bn2d_fwd_train(x_ptr(x), ldx, None, c, N, Ns, c, w, b, rm, rv, None, eps, 1.0 - momentum, 1, y, ldy, ptr(st[0]),
+                                      ptr(st[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
+        else:
+            check(L.mm_bn2d_fwd_eval(x_ptr(x), ldx, None, c, N, c, w, b, rm, rv, eps, 1, y, ldy, stream()), "bn2d_fwd_eval")
+        return
+    if training:
+        ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
+        check(L.mm_bn_fwd_train_bf16(x_ptr(x), ldx, N, Ns, c, w, b, rm, rv, eps, momentum, leak, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws),
+                                     ws.numel(), stream()), "bn_fwd_train")
+    else:
+        check(L.mm_bn_fwd_eval_bf16(x_ptr(x), ldx, N, c, w, b, rm, rv, eps, leak, y, ldy, stream()), "bn_fwd_eval")
+
+
+def _bn16_bwd(L, x, ldx, dy, lddy, N, Ns, c, w, b, st, leak, dx, dwt, dbt, acc):
+    if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and lddy % 8 == 0:
+        ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
+        check(L.mm_bn2d_bwd(x_ptr(x), ldx, dy, lddy, None, 0, None, c, 1, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), ptr(dx), c, None, c, dwt, dbt,
+                            acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
+        return
+    ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
+    check(L.mm_bn_bwd_bf16(x_ptr(x), ldx, dy, lddy, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), leak, ptr(dx), c, dwt, dbt, acc, ptr(ws), ws.numel(),
+                           stream()), "bn_bwd")
+
+
+def x_ptr(x):
+    return x if isinstance(x, int) else ptr(x)
+
 
 class BatchNormActFunction(torch.autograd.Function):
     @staticmethod
@@ -310,18 +344,26 @@ class BatchNormActFunction(torch.autograd.Function):
             Ns = seg_rows if (seg_rows is not None and 0 < seg_rows < N) else N  # per-domain statistics of a joint batch
             ctx.Ns = Ns
             stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
-            ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
-            check(
-                fwd_train(ptr(x), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
-                                  leak, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()),
-                "bn_fwd_train",
-            )
+            if act16 and weight is not None:
+                _bn16_fwd(L, x, C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), True, eps, momentum, leak,
+                          ptr(y), C, stats)
+            else:
+                ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
+                check(
+                    fwd_train(ptr(x), C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, momentum,
+                                      leak, ptr(y), C, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()),
+                    "bn_fwd_train",
+                )
             ctx.save_for_backward(x, weight, bias, stats)
             ctx.leak = leak
             ctx.sinks = None
             if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[1]):
                 gradsink.claim(ctx, bias, True)
                 ctx.sinks = (weight, bias)
+        elif act16 and weight is not None:
+            _bn16_fwd(L, x, C, N, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), False, eps, momentum, leak, ptr(y), C,
+                      None)
+            ctx.save_for_backward()
         else:
             check(
                 fwd_eval(ptr(x), C, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), eps, leak,
@@ -350,11 +392,16 @@ class BatchNormActFunction(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device) if weight is not None else None
             db = dbt = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
             acc = 0
-        check(
-            (L.mm_bn_bwd_bf16 if ctx.act16 else L.mm_bn_bwd)(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
-                        ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
-            "bn_bwd",
-        )
+        if ctx.act16 and weight is not None:
+            _bn16_bwd(L, x, C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), stats, ctx.leak, dx, ptr(dwt), ptr(dbt), acc)
+        else:
+            check(
+                L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
+                            ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()) if not ctx.act16 else
+                L.mm_bn_bwd_bf16(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
+                                 ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
+                "bn_bwd",
+            )
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
@@ -385,14 +432,17 @@ class BatchNormActJoinFunction(torch.autograd.Function):
         for x, c in zip(xs, widths):
             w, b = ptr(weight) + 4 * off, ptr(bias) + 4 * off
             rm, rv = ptr(running_mean) + 4 * off, ptr(running_var) + 4 * off
-            if training:
-                st = torch.empty((2, 2 if Ns < N else 1, c), dtype=F32, device=x.device)
+            st = torch.empty((2, 2 if Ns < N else 1, c), dtype=F32, device=x.device) if training else None
+            if act16:
+                _bn16_fwd(L, x, c, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, ptr(y) + es * off, C, st)
+            elif training:
                 ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
                 check(fwd_train(ptr(x), c, N, Ns, c, w, b, rm, rv, eps, momentum, leak, ptr(y) + es * off, C, ptr(st[0]), ptr(st[1]),
                                 ptr(ws), ws.numel(), stream()), "bn_fwd_train")
-                stats.append(st)
             else:
                 check(fwd_eval(ptr(x), c, N, c, w, b, rm, rv, eps, leak, ptr(y) + es * off, C, stream()), "bn_fwd_eval")
+            if training:
+                stats.append(st)
             off += c
         ctx.training, ctx.act16, ctx.widths, ctx.leak, ctx.Ns = training, act16, widths, leak, Ns
         ctx.sinks = None
@@ -426,9 +476,13 @@ class BatchNormActJoinFunction(torch.autograd.Function):
         dxs, off = [], 0
         for x, st, c in zip(xs, stats, ctx.widths):
             dx = torch.empty_like(x)
-            ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
-            check(bwd(ptr(x), c, ptr(dy) + es * off, C, N, ctx.Ns, c, ptr(weight) + 4 * off, ptr(bias) + 4 * off, ptr(st[0]), ptr(st[1]),
-                      ctx.leak, ptr(dx), c, ptr(dwt) + 4 * off, ptr(dbt) + 4 * off, acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
+            if ctx.act16:
+                _bn16_bwd(L, x, c, ptr(dy) + es * off, C, N, ctx.Ns, c, ptr(weight) + 4 * off, ptr(bias) + 4 * off, st, ctx.leak, dx,
+                          ptr(dwt) + 4 * off, ptr(dbt) + 4 * off, acc)
+            else:
+                ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
+                check(bwd(ptr(x), c, ptr(dy) + es * off, C, N, ctx.Ns, c, ptr(weight) + 4 * off, ptr(bias) + 4 * off, ptr(st[0]), ptr(st[1]),
+                          ctx.leak, ptr(dx), c, ptr(dwt) + 4 * off, ptr(dbt) + 4 * off, acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
             dxs.append(dx)
             off += c
         if ctx.sinks is not None:
