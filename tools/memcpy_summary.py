@@ -1,3 +1,7 @@
+"""Memory copies of a rocprofv3 --memory-copy-trace run (rocpd database) grouped by direction and size.
+
+    python tools/memcpy_summary.py <dir>
+"""
 import glob, os, sqlite3, sys
 d=sys.argv[1]
 db=sorted(glob.glob(os.path.join(d,"**","*.db"),recursive=True),key=os.path.getmtime)[-1]

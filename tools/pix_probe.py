@@ -1,3 +1,5 @@
+"""Host cost of lifting.PixelIndex (pinned staging vs pin_memory), the branch-only rates, a host profile of the 2D branch and
+the full step with the cyclic collector on / off."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())

@@ -1,3 +1,5 @@
+"""Per-step GPU (HIP events) and host times of 40 training steps plus the cyclic collector's pauses (gc.callbacks):
+finds stalls that an average hides.  FREEZE=1 freezes the long-lived objects first (what TrainModel does)."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.getcwd())
