@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import os
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -87,7 +89,19 @@ class Level:
         self.subm = None
         self.down = None       # Rulebook (K=8) to self.coarse
         self.coarse = None
-        self.fine = None
+        self._fine = None      # weak: coarse <-> fine strong references would be a cycle, and a step's hash tables / rulebooks
+                               # (hundreds of MB) would wait for a full pass of Python's cyclic collector instead of dying with the step
+
+
+def _get_fine(self):
+    return self._fine() if self._fine is not None else None
+
+
+def _set_fine(self, lv):
+    self._fine = weakref.ref(lv) if lv is not None else None
+
+
+Level.fine = property(_get_fine, _set_fine)
 
 
 class Metadata:

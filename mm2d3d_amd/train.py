@@ -36,7 +36,7 @@ class TrainModel(nn.Module):
         self.joint_domains = train_kwargs.get("joint_domains", True)
         # building the 3D metadata on a side stream during the 2D branch measured SLOWER (55.1-57.5 vs 53.7-54.0 ms/step:
         # its small kernels queue behind the persistent conv workgroups and the host waits longer at the read-backs): off
-        self.overlap_metadata = train_kwargs.get("overlap_metadata", False)
+        self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "0") != "0"))
         # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
         # path), 32 = the exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
         # branch in bf16 (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so the default is fp32.
@@ -76,8 +76,8 @@ class TrainModel(nn.Module):
         self.reducer.sync_parameters(src=0)
         if self.gc_freeze:
             # Everything built so far (modules, parameters, optimiser state, torch itself) is long-lived.  Left in the collector's
-            # oldest generation it is re-traversed by every full collection: 50-90 ms, every 12-40 steps, during which the GPU
-            # queue drains (measured: steps of 85-95 ms among 45 ms ones).  Frozen objects are skipped by the collector.
+            # oldest generation it is re-traversed by every full collection (87 ms measured for one pass here, during which the
+            # GPU queue drains).  Frozen objects are skipped by the collector.
             import gc
 
             gc.unfreeze()  # a previous trainer of this process may have frozen objects that are garbage by now

@@ -18,17 +18,21 @@ gc.callbacks.append(cb)
 if os.environ.get('FREEZE'):
     gc.collect(); gc.freeze()
 torch.cuda.synchronize()
-N = 40
+N = int(os.environ.get('STEPS', '40'))
 marks = [torch.cuda.Event(enable_timing=True) for _ in range(N + 1)]
-host = []
+host, allocs = [], []
 marks[0].record()
 for i in range(N):
     t0 = time.perf_counter()
     tm.fit_step(bench.fresh(batch))
     host.append((time.perf_counter() - t0) * 1e3)
+    st = torch.cuda.memory_stats(dev)
+    allocs.append((st.get('num_device_alloc', 0), st.get('num_device_free', 0), st.get('num_alloc_retries', 0), st['reserved_bytes.all.current'] >> 20))
     marks[i + 1].record()
 torch.cuda.synchronize()
 gpu = [marks[i].elapsed_time(marks[i + 1]) for i in range(N)]
 print("gpu :", " ".join(f"{t:.0f}" for t in gpu))
 print("gc gen>=1:", [(g, round(ms, 1), c) for g, ms, c in log if g >= 1 or ms > 2])
+print("device allocs (count, frees, retries, reserved MiB) at the slow steps:", [(i, allocs[i], allocs[i-1]) for i in range(1, N) if gpu[i] > 1.3 * sorted(gpu)[N // 2]])
+print("reserved MiB first/last:", allocs[0][3], allocs[-1][3], " device allocs first/last:", allocs[0][0], allocs[-1][0])
 print("host:", " ".join(f"{t:.0f}" for t in host))
