@@ -179,7 +179,7 @@ def prebuild_metadata(coords, spatial_size, side_stream=None, after=None, prebui
     c = coords if coords.dtype == torch.int64 and coords.is_contiguous() else coords.to(torch.int64).contiguous()
     if c.shape[1] == 3:
         c = torch.cat([c, c.new_zeros((c.shape[0], 1))], 1).contiguous()
-    md = Metadata.prebuild(c, int(spatial_size), prebuild_levels, side_stream, after)
+    md = Metadata.prebuild(c, int(spatial_size), prebuild_levels, side_stream, after, act16=act16())
     md._coords_keepalive = c
     coords._mm_metadata = md
     return md

@@ -118,12 +118,12 @@ class Metadata:
 
     # ------------------------------------------------------------------ active sets
     @classmethod
-    def prebuild(cls, coords_i64, spatial_size, prebuild_levels=7, side_stream=None, after=None):
+    def prebuild(cls, coords_i64, spatial_size, prebuild_levels=7, side_stream=None, after=None, act16=False):
         """Active sets and every rulebook of the level chain for ``coords``, optionally on ``side_stream`` (its kernels
         and its two small host read-backs then overlap whatever the caller already queued on the current stream, e.g. the
         2D branch).  ``after``: event the side stream waits for first (so that it cannot run ahead into memory the previous
         step still uses).  The result carries ``ready``: consumers on another stream wait for it (InputLayer does)."""
-        md = cls(coords_i64.device, spatial_size, prebuild_levels)
+        md = cls(coords_i64.device, spatial_size, prebuild_levels, act16=act16)
         if side_stream is None:
             md.build_levels(coords_i64)
             md.build_rulebooks()

@@ -34,9 +34,12 @@ class TrainModel(nn.Module):
         # the rows per launch.  The batch-norm layers keep per-domain statistics (mm2d3d_amd/domains.py), so the
         # arithmetic is that of the reference's two calls.  False: the literal two-call sequence.
         self.joint_domains = train_kwargs.get("joint_domains", True)
-        # building the 3D metadata on a side stream during the 2D branch measured SLOWER (55.1-57.5 vs 53.7-54.0 ms/step:
-        # its small kernels queue behind the persistent conv workgroups and the host waits longer at the read-backs): off
-        self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "0") != "0"))
+        # Build the 3D metadata (voxel hash, rulebooks, tile tables: ~100 small kernels and two host read-backs) on a side stream
+        # while the GPU works through the 2D forward.  Round 1 measured this slower (the host then still waited inside the 2D
+        # forward); with that wait gone the host reaches the read-backs early, queues the whole 3D forward behind the 2D branch and
+        # stays ahead of the GPU: 45.3 -> 43.2 ms per step (A/B x3 on one box).  The single-launch batch-norm kernels of the 2D
+        # forward share the GPU with these kernels; they are short and finite, so a grid waits a few microseconds at worst.
+        self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "1") != "0"))
         # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
         # path), 32 = the exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
         # branch in bf16 (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so the default is fp32.

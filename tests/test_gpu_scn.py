@@ -462,3 +462,41 @@ def test_act16_net3d_vs_fp32(act16_mode):
         c = float((ga @ gb) / (ga.norm() * gb.norm() + 1e-30))
         cos.append((c, n))
     assert min(cos)[0] > 0.8 and float(np.median([c for c, _ in cos])) > 0.9, sorted(cos)[:5]
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_metadata_prebuilt_on_a_side_stream_gives_the_same_network_output(mode):
+    """scn.prebuild_metadata builds hash, rulebooks and tile tables on a side stream ahead of the forward (TrainModel overlaps
+    it with the 2D branch).  Logits and gradients must be bit-identical to the in-line build, in fp32 and in the 16-bit
+    activation mode (which needs tables for every level and both directions)."""
+    import copy
+
+    from mm2d3d_amd import scn
+    from mm2d3d_amd.net3d import Net3DSeg
+
+    dev = _dev()
+    torch.manual_seed(0)
+    scn.set_activation_dtype(torch.bfloat16 if mode == "bf16" else torch.float32)
+    try:
+        batch = _lidar_batch(2)
+        kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+        net_a = Net3DSeg(6, True, kw).to(dev)
+        net_b = copy.deepcopy(net_a)
+        coords, feats = batch["x"]
+        w = torch.randn(coords.shape[0], 6, device=dev)
+        pa, _, _ = net_a({"x": [coords.to(dev), feats.clone().to(dev)]})
+        (pa["seg_logit"] * w).sum().backward()
+        cb = coords.to(dev)
+        side = torch.cuda.Stream(dev)
+        net_b.prepare({"x": [cb, None]}, side, torch.cuda.current_stream(dev).record_event())
+        assert getattr(cb, "_mm_metadata", None) is not None
+        pb, _, _ = net_b({"x": [cb, feats.clone().to(dev)]})
+        (pb["seg_logit"] * w).sum().backward()
+        torch.cuda.synchronize()
+        assert torch.equal(pa["seg_logit"], pb["seg_logit"])
+        for (n, a), (_, b) in zip(net_a.named_parameters(), net_b.named_parameters()):
+            assert (a.grad is None) == (b.grad is None), n
+            if a.grad is not None:
+                assert torch.equal(a.grad, b.grad), n
+    finally:
+        scn.set_activation_dtype(torch.float32)
