@@ -180,7 +180,10 @@ def prebuild_metadata(coords, spatial_size, side_stream=None, after=None, prebui
     if c.shape[1] == 3:
         c = torch.cat([c, c.new_zeros((c.shape[0], 1))], 1).contiguous()
     md = Metadata.prebuild(c, int(spatial_size), prebuild_levels, side_stream, after, act16=act16())
-    md._coords_keepalive = c
+    if c is not coords:
+        md._coords_keepalive = c  # a converted copy must outlive the side stream's kernels; the caller's own tensor does anyway
+    # NOT md -> coords when c is coords: coords -> md -> coords would be a reference cycle, and a step's metadata (hundreds
+    # of MB) would wait for a full pass of the cyclic collector instead of dying with the batch
     coords._mm_metadata = md
     return md
 

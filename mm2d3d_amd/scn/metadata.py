@@ -131,6 +131,7 @@ class Metadata:
         cur = torch.cuda.current_stream(coords_i64.device)
         if after is not None:
             side_stream.wait_event(after)
+        coords_i64.record_stream(side_stream)  # allocated on the caller's stream, read by the side stream's kernels
         with torch.cuda.stream(side_stream), _lib.workspace_slot("meta"):
             md.build_levels(coords_i64)
             md.build_rulebooks()

@@ -34,12 +34,13 @@ class TrainModel(nn.Module):
         # the rows per launch.  The batch-norm layers keep per-domain statistics (mm2d3d_amd/domains.py), so the
         # arithmetic is that of the reference's two calls.  False: the literal two-call sequence.
         self.joint_domains = train_kwargs.get("joint_domains", True)
-        # Build the 3D metadata (voxel hash, rulebooks, tile tables: ~100 small kernels and two host read-backs) on a side stream
-        # while the GPU works through the 2D forward.  Round 1 measured this slower (the host then still waited inside the 2D
-        # forward); with that wait gone the host reaches the read-backs early, queues the whole 3D forward behind the 2D branch and
-        # stays ahead of the GPU: 45.3 -> 43.2 ms per step (A/B x3 on one box).  The single-launch batch-norm kernels of the 2D
-        # forward share the GPU with these kernels; they are short and finite, so a grid waits a few microseconds at worst.
-        self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "1") != "0"))
+        # Optional: build the 3D metadata (voxel hash, rulebooks, tile tables: ~100 small kernels and two host read-backs) on a side
+        # stream while the GPU works through the 2D forward.  The host then reaches the read-backs early, queues the 3D forward
+        # behind the 2D branch and stays ahead of the GPU.  The single-launch batch-norm kernels must not share the GPU with that
+        # stream (with both on, one run in three aborted on the barrier's time limit after ~300 steps; 43.2 ms per step while it
+        # lasted), so the 2D FORWARD batch norms take the three-kernel path when this is on: 43.7 ms against 44.1 ms without
+        # the side stream, for 7 GB more reserved memory.  Off by default.
+        self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "0") != "0"))
         # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
         # path), 32 = the exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
         # branch in bf16 (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so the default is fp32.
@@ -120,12 +121,15 @@ class TrainModel(nn.Module):
                 dev = both["img"].device
                 step_start = torch.cuda.current_stream(dev).record_event()
                 prep = getattr(self.model[n3d], "prepare", None)
+                if prep is not None and self.overlap_metadata and self._side is None:
+                    self._side = torch.cuda.Stream(dev)
+                    from . import _lib
+
+                    _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & 2)  # backward only, see __init__
                 p2d, _, _, aux2d = self(both, model_name=n2d)
                 # the 2D branch is queued: build the voxel hash / rulebooks of the 3D branch on a side stream while the GPU
                 # works through it (the build's two host read-backs would otherwise drain the queue)
                 if prep is not None and self.overlap_metadata:
-                    if self._side is None:
-                        self._side = torch.cuda.Stream(dev)
                     prep(both, self._side, step_start)
                 if self.overlap_branches:
                     # the 3D branch (gathers, HBM-bound) on its own stream beside the 2D branch (MFMA / LDS-bound persistent
