@@ -53,12 +53,18 @@ class GradAllReducer:
         if self.world == 1:
             return
         if overlap and torch.cuda.is_available():
-            # The single-launch batch-norm kernels (csrc/bn2d.hip, csrc/bn.hip) need every CU at once; a collective that runs beside the
-            # backward pass holds some, and the whole grid would wait for it.  Forward passes have no collective next to them.
+            # The single-launch batch-norm kernels (csrc/bn2d.hip, csrc/bn.hip) need every CU at once; a collective that runs
+            # beside the backward pass holds some, and the whole grid would wait for it.  The forward passes have no collective
+            # next to them, but RCCL was never available to test that claim (and another second stream - the sparse metadata
+            # build - did stall such a grid once in ~2,200 steps for reasons not understood): data-parallel runs take the
+            # three-kernel path in both directions.  MM_DDP_BN_FUSED=1 keeps the forward direction on the single-launch kernels.
+            import os
+
             from . import _lib
 
-            _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & 1)
-            _lib.lib().mm_bn_set_fused(_lib.lib().mm_bn_set_fused(0) & 1)
+            keep = 1 if os.environ.get("MM_DDP_BN_FUSED", "0") != "0" else 0
+            _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & keep)
+            _lib.lib().mm_bn_set_fused(_lib.lib().mm_bn_set_fused(0) & keep)
         for opt in optimizers:
             for a in getattr(opt, "_arenas", []):
                 if a is None:
