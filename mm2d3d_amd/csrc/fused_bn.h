@@ -23,8 +23,9 @@ namespace {
 // workgroup needs more than half of a CU's registers/LDS (one per CU).  Another PROCESS running the same kernel on the
 // same GPU can starve both grids: the wait is bounded (FUSED_TIMEOUT_TICKS of the 100 MHz wall clock) and ends in a
 // trap, i.e. a loud HIP error instead of a hang; MM_BN2D_FUSED=0 selects the three-kernel path for such set-ups.
-// A kernel of another stream that holds LDS on some CUs (an RCCL collective overlapping the backward pass) makes the grid wait
-// for it: the data-parallel trainer therefore takes the three-kernel path (ddp.py), and so do the directions that share the GPU
+// A kernel of another stream that holds LDS on some CUs makes the grid wait for it, and one that spin-waits across its own
+// workgroups (decoupled look-back scan / Onesweep sort, an RCCL collective) can DEADLOCK with it - each holds CUs the other's
+// missing workgroups need (tools/barrier_stress.py reproduces this with torch.cumsum on a second stream): the data-parallel trainer therefore takes the three-kernel path (ddp.py), and so do the directions that share the GPU
 // with an optional second stream of the trainer (train.py: overlap_branches, overlap_metadata).
 constexpr int FT = 512;       // 8 waves: 256 VGPRs per thread, and the per-thread constants are paid by half as many threads
 constexpr int FUSED_NL = 13;  // rows per thread kept in LDS: 13 x 16 B x 512 threads = 104 KB
