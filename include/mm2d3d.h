@@ -128,6 +128,10 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
 int mm_up_neighbors(const int32_t* vox_coords_fine, int64_t n_fine, const int32_t* fine2coarse, int32_t* nbr,
                     mm_stream_t stream);
 size_t mm_os_table_ws_bytes(int64_t n, int K);
+/* The sort behind mm_os_table_build: 0 = Onesweep radix sort (default), 1 = merge sort (identical result; its workgroups do not
+ * wait for each other, which makes the build safe on a stream that runs beside grid-barrier kernels, see mm_bn2d_set_fused).
+ * Returns the previous setting. */
+int mm_os_table_set_sort(int merge);
 /* nbr[K][n] -> dst[npad] (rows sorted by neighbour bitmask, -1 = padding), nbrp[K][npad], tmask[nt];
  * nt = ceil(n / tile_rows), npad = nt * tile_rows, tile_rows in {64, 128, 256} */
 int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32_t* dst, int32_t* nbrp, uint32_t* tmask,

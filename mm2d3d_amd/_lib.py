@@ -42,6 +42,7 @@ _PROTOS = {
     "mm_collect_points": (i32, [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mm_up_neighbors": (i32, [vp, i64, vp, vp, vp]),
     "mm_os_table_ws_bytes": (sz, [i64, i32]),
+    "mm_os_table_set_sort": (i32, [i32]),
     "mm_os_table_build": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, sz, vp]),
     "mm_spconv_os_pack_bytes": (sz, [i32, i32, i32]),
     "mm_spconv_os_pack_blocks": (i64, [i32, i32, i32]),

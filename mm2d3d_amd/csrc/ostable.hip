@@ -62,17 +62,36 @@ __global__ __launch_bounds__(T) void k_up_nbr(const int32_t* __restrict__ vc_fin
 // rocPRIM's default switches to a merge sort below 2^20 keys: ~17 launch-bound passes (100 us) for the 60k..800k-row tables
 // here, where Onesweep needs one histogram + one scatter pass per 8 key bits (K = 8: a single pass).
 using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
+// The same sort as a merge sort at every size: block sorts + merge passes, workgroups independent of each other.  Onesweep's
+// workgroups spin on their predecessors' partial sums (decoupled look-back); beside a kernel with a grid barrier (the single-launch
+// batch norms) on another stream that can deadlock, so a build that runs on a side stream selects this one (mm_os_table_set_sort).
+using SortCfgMerge = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, ((size_t)1 << 40)>;
+int g_os_sort_merge = 0;
+
+template <typename Cfg>
+hipError_t sort_masks(void* tmp, size_t& bytes, const uint32_t* mask, uint32_t* mask_sorted, int32_t* perm, int64_t n, int K, hipStream_t s) {
+  return rocprim::radix_sort_pairs<Cfg>(tmp, bytes, mask, mask_sorted, rocprim::counting_iterator<int32_t>(0), perm, (size_t)(n > 0 ? n : 1),
+                                        0u, (unsigned)K, s);
+}
 
 size_t sort_tmp_bytes(int64_t n, int K) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs<SortCfg>(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, rocprim::counting_iterator<int32_t>(0),
-                            (int32_t*)nullptr, (size_t)(n > 0 ? n : 1), 0u, (unsigned)K, (hipStream_t)0);
-  return bytes;
+  size_t a = 0, b = 0;
+  (void)sort_masks<SortCfg>(nullptr, a, nullptr, nullptr, nullptr, n, K, (hipStream_t)0);
+  (void)sort_masks<SortCfgMerge>(nullptr, b, nullptr, nullptr, nullptr, n, K, (hipStream_t)0);
+  return a > b ? a : b;
 }
 
 }  // namespace
 
 extern "C" {
+
+// 0 (default): Onesweep radix sort; 1: merge sort (no workgroup of the sort waits for another: safe beside grid-barrier kernels
+// of other streams).  Same result (both stable).  Returns the previous setting; applies to the calls of this process.
+int mm_os_table_set_sort(int merge) {
+  const int prev = g_os_sort_merge;
+  g_os_sort_merge = merge ? 1 : 0;
+  return prev;
+}
 
 size_t mm_os_table_ws_bytes(int64_t n, int K) {
   return 3 * mm_align((size_t)(n + 1) * 4) + mm_align(sort_tmp_bytes(n, K)) + 1024;
@@ -103,8 +122,8 @@ int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32
     return MM_ERR_WORKSPACE;
   }
   hipLaunchKernelGGL(k_row_mask, dim3((unsigned)mm_cdiv(n, T)), dim3(T), 0, s, nbr, K, n, mask);
-  MM_HIP(rocprim::radix_sort_pairs<SortCfg>(tmp, tmp_bytes, (const uint32_t*)mask, mask_sorted, rocprim::counting_iterator<int32_t>(0), perm,
-                                   (size_t)n, 0u, (unsigned)K, s));
+  if (g_os_sort_merge) MM_HIP(sort_masks<SortCfgMerge>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
+  else MM_HIP(sort_masks<SortCfg>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
   MM_HIP(hipMemsetAsync(tmask, 0, (size_t)nt * 4, s));
   hipLaunchKernelGGL(k_os_fill, dim3((unsigned)mm_cdiv(npad, T)), dim3(T), 0, s, nbr, K, n, npad, tile_rows, mask_sorted, perm, dst,
                      nbrp, tmask);

@@ -132,10 +132,17 @@ class Metadata:
         if after is not None:
             side_stream.wait_event(after)
         coords_i64.record_stream(side_stream)  # allocated on the caller's stream, read by the side stream's kernels
-        with torch.cuda.stream(side_stream), _lib.workspace_slot("meta"):
-            md.build_levels(coords_i64)
-            md.build_rulebooks()
-            md.ready = side_stream.record_event()
+        # Nothing on the side stream may spin-wait across workgroups (the caller's stream may run single-launch batch norms,
+        # csrc/fused_bn.h): the tile-table sort switches from Onesweep to the merge sort, everything else here is already free of
+        # inter-workgroup waits (three-kernel scans, bounded CAS loops).
+        prev = _lib.lib().mm_os_table_set_sort(1)
+        try:
+            with torch.cuda.stream(side_stream), _lib.workspace_slot("meta"):
+                md.build_levels(coords_i64)
+                md.build_rulebooks()
+                md.ready = side_stream.record_event()
+        finally:
+            _lib.lib().mm_os_table_set_sort(prev)
         # the tensors were allocated on the side stream and are consumed on ``cur``: tell the caching allocator
         for t in md.tensors():
             t.record_stream(cur)
