@@ -36,10 +36,10 @@ class TrainModel(nn.Module):
         self.joint_domains = train_kwargs.get("joint_domains", True)
         # Optional: build the 3D metadata (voxel hash, rulebooks, tile tables: ~100 small kernels and two host read-backs) on a side
         # stream while the GPU works through the 2D forward.  The host then reaches the read-backs early, queues the 3D forward
-        # behind the 2D branch and stays ahead of the GPU: 45.3 -> 43.2 ms per step.  Off by default for two reasons (DESIGN.md
-        # section 8): with the Onesweep tile-table sort on the side stream a single-launch batch norm of the 2D forward hit the
-        # grid barrier's time limit once in ~2,200 steps (the side build uses the merge sort now: 7,500 steps without), and one
-        # run in five was not bit-reproducible (1e-6 in the loss after a few steps; cause not found).
+        # behind the 2D branch and stays ahead of the GPU.  The single-launch batch norms of the 2D forward must not share the GPU
+        # with that stream (with both on, runs abort on the grid barrier's time limit once in a few thousand steps, also with
+        # the merge-sort tile tables), so with this option the 2D FORWARD batch norms take the three-kernel
+        # path: 43.7 ms per step against 44.1 ms without the side stream, for 7 GB more reserved memory.  Off by default.
         self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "0") != "0"))
         # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
         # path), 32 = the exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
@@ -123,6 +123,9 @@ class TrainModel(nn.Module):
                 prep = getattr(self.model[n3d], "prepare", None)
                 if prep is not None and self.overlap_metadata and self._side is None:
                     self._side = torch.cuda.Stream(dev)
+                    from . import _lib
+
+                    _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & 2)  # no grid barrier beside the side stream
                 p2d, _, _, aux2d = self(both, model_name=n2d)
                 # the 2D branch is queued: build the voxel hash / rulebooks of the 3D branch on a side stream while the GPU
                 # works through it (the build's two host read-backs would otherwise drain the queue)
