@@ -17,16 +17,6 @@ from ._lib import check, ptr, stream
 F32 = torch.float32
 
 
-_COPY_STREAMS = {}
-
-
-def _copy_stream(dev):
-    s = _COPY_STREAMS.get(dev.index)
-    if s is None:
-        s = _COPY_STREAMS[dev.index] = torch.cuda.Stream(dev)
-    return s
-
-
 _STAGING = {}
 
 
@@ -56,24 +46,20 @@ class PixelIndex:
         self.n = int(sum(counts))
         self.H, self.W, self.device = H, W, device
         rc = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int64)
-        # Host -> device through pinned staging on a copy stream: a copy from pageable memory queued on the compute stream
-        # makes the host wait until everything queued before it has run (measured: 12 ms per step inside this constructor
-        # when it was called at the end of the 2D forward).  The staging buffers are persistent (two per device, reused
-        # alternately once their last copy has completed): `Tensor.pin_memory()` registers fresh host pages on every call,
-        # 4.6 ms for the 9 MB of a 16-scene batch.
+        # Host -> device from PINNED staging, asynchronously on the current stream: a copy from pageable memory makes the host
+        # wait until everything queued before it has run (measured: 12 ms per step inside this constructor when it was called
+        # at the end of the 2D forward).  The staging buffers are persistent (two per device, reused alternately once their last
+        # copy has completed): `Tensor.pin_memory()` registers fresh host pages on every call, 4.6-30 ms for the 9 MB of a
+        # 16-scene batch.  No copy stream: the step stays on ONE stream (the single-launch batch norms need that, fused_bn.h).
         dev = torch.device(device)
         cur = torch.cuda.current_stream(dev)
-        cs = _copy_stream(dev)
         nb = len(counts)
         stage = _staging(dev, nb + 2 * self.n)
         host = stage["buf"].numpy()
         host[:nb] = counts
         host[nb : nb + 2 * self.n] = rc.reshape(-1)
-        with torch.cuda.stream(cs):
-            both = stage["buf"][: nb + 2 * self.n].to(dev, non_blocking=True)
-            stage["event"].record(cs)
-        cur.wait_stream(cs)
-        both.record_stream(cur)
+        both = stage["buf"][: nb + 2 * self.n].to(dev, non_blocking=True)
+        stage["event"].record(cur)
         cnt_d, rc_d = both[:nb], both[nb:].view(-1, 2)
         b = torch.repeat_interleave(torch.arange(len(rows), device=device), cnt_d, output_size=self.n)
         self.b, self.r, self.c = b, rc_d[:, 0], rc_d[:, 1]

@@ -210,8 +210,8 @@ class Net2DSeg(nn.Module):
     def forward(self, data_batch):
         img, hints, img_indices = data_batch["img"], data_batch["depth"], data_batch["img_indices"]
         h, w = img.shape[2], img.shape[3]
-        # the point -> pixel index first: its host arrays are uploaded beside the stream (lifting.PixelIndex) before any of
-        # this forward is queued, so the host never waits for the convolutions to drain
+        # the point -> pixel index first: its host arrays are uploaded asynchronously from pinned staging (lifting.PixelIndex)
+        # before any of this forward is queued, so the host never waits for the convolutions to drain
         _pixel_index(data_batch, h, w, img.device)
         pad_h, pad_w = (-h) % 16, (-w) % 16
         if pad_h or pad_w:
