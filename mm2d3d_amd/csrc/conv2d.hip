@@ -41,6 +41,7 @@ struct ConvP {
   int zpar;
   const float* bias;
   int out_f32;
+  int nbuf;  // LDS stage buffers: 2 (tile s+1 in flight while tile s is multiplied) or 1 when the whole K is one step
 };
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
@@ -55,8 +56,8 @@ __device__ inline u16 f2bf(float f) {  // round to nearest even (inputs are fini
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   extern __shared__ __attribute__((aligned(16))) u16 smem[];
-  u16* As = smem;                 // [2][128*64]
-  u16* Bs = smem + 2 * 128 * 64;  // [2][BN*64]
+  u16* As = smem;                      // [nbuf][128*64]
+  u16* Bs = smem + p.nbuf * 128 * 64;  // [nbuf][BN*64]
   constexpr int NBI = BN / 32;    // B staging chunks per thread
   constexpr int TN = BN / 64;     // 32-wide MFMA tiles per wave along n
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -166,9 +167,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   issue(0, 0);
   const int fr_ = lane & 31, fh = lane >> 5;
   for (int s = 0; s < nsteps; s++) {
-    const int buf = s & 1;
+    const int buf = s & (p.nbuf - 1);
+    if (p.nbuf == 1 && s > 0) {  // one stage: tile s is requested only when everybody has finished with tile s-1
+      __syncthreads();
+      issue(s, 0);
+    }
     __syncthreads();  // (vmcnt(0) + barrier) tile s has landed; every wave is done reading buffer buf^1
-    if (s + 1 < nsteps) issue(s + 1, buf ^ 1);
+    if (p.nbuf == 2 && s + 1 < nsteps) issue(s + 1, buf ^ 1);
     const u16* Ab = As + buf * 128 * 64;
     const u16* Bb = Bs + buf * BN * 64;
 #pragma unroll
@@ -1197,14 +1202,21 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
   }
   const int64_t M = (int64_t)B * Hg * Wg;
   if (M == 0) return MM_OK;
+  // Short K (1x1 layers, the stems, the transposed convolutions: <= 4 steps of 64 channels) with 64 output channels: these
+  // launches are bound by load latency, not by MFMA time; one stage buffer (24 KB) lets five workgroups share a CU instead of
+  // three, which hides more of it than the one-step prefetch did (18240-tile stems 269 -> 231 us, 4560x4 transposed conv 441 -> 385).
+  {
+    static const int single_max = getenv("MM_GEMM_SINGLE") ? atoi(getenv("MM_GEMM_SINGLE")) : 4;
+    p.nbuf = (ntaps * (Ca / 64) <= single_max && (Cn <= 64 || ntaps * (Ca / 64) == 1)) ? 1 : 2;
+  }
   if (Cn <= 64) {
-    size_t lds = (size_t)(2 * 128 * 64 + 2 * 64 * 64) * 2;
+    size_t lds = (size_t)p.nbuf * (128 * 64 + 64 * 64) * 2;
     hipLaunchKernelGGL(k_conv_gemm<64>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 64), nz), dim3(256), lds, s, p);
   } else {
-    size_t lds = (size_t)(2 * 128 * 64 + 2 * 128 * 64) * 2;
+    size_t lds = (size_t)p.nbuf * (128 * 64 + 128 * 64) * 2;
     static bool once = false;
     if (!once) {
-      MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (128 * 64 + 128 * 64) * 2)));
       once = true;
     }
     hipLaunchKernelGGL(k_conv_gemm<128>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 128), nz), dim3(256), lds, s, p);
