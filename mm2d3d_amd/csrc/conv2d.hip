@@ -193,33 +193,57 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 
-  // epilogue: acc[i][j][reg]: pixel row = wm*64 + i*32 + (reg&3) + 8*(reg>>2) + 4*fh ; channel = n0 + wn*BN/2 + j*32 + fr_
+  // epilogue.  The MFMA ran as W x A^T, so acc[i][j][reg] is channel n0 + wn*BN/2 + j*32 + (reg&3) + 8*(reg>>2) + 4*fh of
+  // pixel row wm*64 + i*32 + fr_: a lane holds runs of 4 consecutive channels of ONE pixel -> one pixel map per tile half
+  // and 8-byte (bf16) / 16-byte (fp32) stores instead of 2-byte ones.
+  const bool vec = !(p.Cn & 3) && !(p.ldo & 3) && !((uintptr_t)p.O & (p.out_f32 ? 15 : 7)) && !((uintptr_t)p.bias & 15);
 #pragma unroll
   for (int i = 0; i < 2; i++) {
+    const int64_t m = m0 + wm * 64 + i * 32 + fr_;
+    if (m >= M) continue;
+    int64_t orow = m;
+    if (p.so != 1 || ooy || oox || p.Ho != p.Hg || p.Wo != p.Wg) {
+      int gx = (int)(m % p.Wg);
+      int64_t t = m / p.Wg;
+      int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
+      orow = ((int64_t)b * p.Ho + gy * p.so + ooy) * p.Wo + gx * p.so + oox;
+    }
 #pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      int64_t m = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * fh;
-      if (m >= M) continue;
-      int64_t orow = m;
-      if (p.so != 1 || ooy || oox || p.Ho != p.Hg || p.Wo != p.Wg) {
-        int gx = (int)(m % p.Wg);
-        int64_t t = m / p.Wg;
-        int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
-        orow = ((int64_t)b * p.Ho + gy * p.so + ooy) * p.Wo + gx * p.so + oox;
-      }
+    for (int j = 0; j < TN; j++) {
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        int n = n0 + wn * (BN / 2) + j * 32 + fr_;
-        if (n < p.Cn) {
-          float v = acc[i][j][reg] + (p.bias ? p.bias[n] : 0.f);
-          if (p.out_f32)
-            ((float*)p.O)[orow * p.ldo + n] = v;
-          else
-            ((u16*)p.O)[orow * p.ldo + n] = f2bf(v);
+      for (int q = 0; q < 4; q++) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + 8 * q + 4 * fh;
+        if (n >= p.Cn) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e];
+        if (vec) {
+          if (p.bias) {
+            const float4 bb = *(const float4*)&p.bias[n];
+            v[0] += bb.x, v[1] += bb.y, v[2] += bb.z, v[3] += bb.w;
+          }
+          if (p.out_f32) {
+            *(float4*)&((float*)p.O)[orow * p.ldo + n] = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 o;
+            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *(uint2*)&((u16*)p.O)[orow * p.ldo + n] = o;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (n + e < p.Cn) {
+              const float w = v[e] + (p.bias ? p.bias[n + e] : 0.f);
+              if (p.out_f32)
+                ((float*)p.O)[orow * p.ldo + n + e] = w;
+              else
+                ((u16*)p.O)[orow * p.ldo + n + e] = f2bf(w);
+            }
         }
       }
     }
