@@ -10,7 +10,7 @@
 //       128 x BN x 64 tiles, 4 waves (2x2), v_mfma_f32_32x32x16_bf16, double-buffered LDS with register prefetch
 //       (global loads of tile s+1 are in flight while tile s is multiplied), XOR-swizzled 128-B LDS rows so the
 //       ds_read_b128 fragment reads are bank-conflict free.
-//   G2  k_conv_wgrad2 / k_wgrad3x3  dW[n][tap][k] = sum_m dY[m][n] * X[src(m,tap)][k]
+//   G2  k_conv_wgrad2 / k_wgrad3x3n  dW[n][tap][k] = sum_m dY[m][n] * X[src(m,tap)][k]
 //       reduction over pixels: both MFMA operands are read from pixel-major LDS tiles with the hardware transpose
 //       read ds_read_b64_tr_b16; split over pixel chunks into fp32 partial slabs, reduced in a fixed order.
 #include <hip/hip_bf16.h>
@@ -901,142 +901,239 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
       }
 }
 
-// Weight gradient of a 3x3 stride-1 pad-1 convolution from halo tiles: a workgroup walks 8x16 pixel patches, stages the
-// dY patch [128 px][64 n] and the X halo [10x18 px][64 k] ONCE per patch and accumulates all 9 taps
-// (9 accumulator tiles of 32x32 per wave; the X operand of tap (kh,kw) is the halo read at rows shifted by kh*18+kw).
-// 9x less staging traffic than one workgroup per tap.  Output tile 64 (n) x 64 (k); grid.y enumerates the tiles.
-struct Wg3P {
+// Weight gradient of a 3x3 stride-1 pad-1 convolution from halo tiles, ALL NINE taps in one workgroup, software-pipelined.
+// (The round-1 kernel ran one workgroup per filter row kh: a patch was 36 KB of LDS-DMA for 24 MFMAs per wave, nothing
+// overlapped inside a workgroup - request, wait, multiply - and the LDS capped the bytes in flight per CU, so a patch cost
+// its DMA latency: 2.4-5 us per patch and workgroup in the step trace, 60-78 us per layer against 43-46 us now.)
+// One workgroup per CU owns a 64 (n) x 64 (k) tile of all 9 taps: per patch it stages
+// dY [128 px][64 n] + the full halo [10 x 18 px][64 k] (39 KB) for 72 MFMAs per multiplying wave and keeps the next three
+// patches in flight in a ring of four LDS stages (raw s_barrier + counted vmcnt, as k_conv3x3w).
+// Two roles, one wave of each per SIMD: waves 0-3 MULTIPLY (9 accumulator tiles = 144 registers per lane, never touch
+// vmcnt), waves 4-7 LOAD (all DMA pieces, 10 per wave and patch).  An LDS-DMA instruction blocks the wave that issues it
+// for ~190 cycles whatever stands around it: with the loads in the multiplying waves - issued as a burst, spread one per
+// MFMA row, or with the patch rows split over two multiplying waves per SIMD - a patch cost the SUM of its DMA issue
+// (0.6-0.8 us) and its multiply (1.4-1.8 us) in every arrangement measured.
+// The multiply walks the 10 halo rows: the three X fragments of a row (kw = 0..2) are read once and serve the taps
+// (kh, kw) of the dY rows py = row - kh, whose fragments sit in a 4-deep register window: 76 transpose reads per 72 MFMAs.
+// Split-K over patches as before (fp32 partial slabs, fixed-order reduce); the workgroups of one split are consecutive on
+// one XCD and share its L2.
+struct Wg9P {
   const u16* X;   // [B,H,W,Ck]
   const u16* DY;  // [B,H,W,Cn]
   int B, H, W, Ck, ldx, Cn, ldy;
   int tiles_y, tiles_x;
-  int patches_per_wg;
-  float* partial;  // [gridDim.x][Cn][9][Ck]
+  int patches_per_wg, ntile;
+  float* partial;  // [nsplit][Cn][9][Ck]
 };
 
-template <int PH>  // patch height in pixel rows: 8 (36 KB of LDS, 4 workgroups per CU) or 4 (20 KB, more resident workgroups)
-__global__ __launch_bounds__(256, PH == 8 ? 4 : 6) void k_wgrad3x3(Wg3P p) {
-  // blockIdx.z = filter row kh: the workgroup accumulates the three taps (kh, 0..2) -> 48 accumulator registers and
-  // 36 KB of LDS (dY patch 16 KB + the 8 halo rows this kh needs, 20 KB), i.e. 4 workgroups per CU to hide the DMA latency.
-  // Everything lane-constant (DMA source offsets, the transpose-read addresses of the dY rows and of the three taps) is
-  // computed once; the patch row only enters through immediate offsets (dY rows advance by 16 pixels, halo rows by 18:
-  // the swizzle bit of a halo row flips with the row parity, which is one XOR of 64 bytes).
+__global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
   extern __shared__ __attribute__((aligned(16))) char smw[];
-  constexpr int YB = PH * 16 * 128;  // bytes of a dY patch [PH*16 px][64 n]; the halo rows follow
-  constexpr int NY = PH * 16 / 32, HPX = PH * 18, NX = (HPX + 31) / 32;  // DMA rounds of the dY patch / of the halo rows
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr int YB = 128 * 128;   // dY patch [8*16 px][64 n]
+  constexpr int HB = 184 * 128;   // halo [10*18 = 180 px (+4 of the last DMA piece)][64 k]
+  constexpr int STG = YB + HB;    // one stage (39,936 B)
+  constexpr int NSTG = 4;         // ring: 159,744 B, one workgroup per CU
+  const bool loader = threadIdx.x >= 256;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;  // wave = index within the role
   const int wn = wave >> 1, wk = wave & 1;
+  int v = blockIdx.x;
+  if (!(gridDim.x & 7)) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // an XCD owns a contiguous range
+  const int split = v / p.ntile, tile = v - split * p.ntile;
   const int nkt = p.Ck >> 6;
-  const int n0 = (blockIdx.y / nkt) * 64, k0 = (blockIdx.y % nkt) * 64;
-  const int kh = blockIdx.z;
+  const int n0 = (tile / nkt) * 64, k0 = (tile % nkt) * 64;
   const int npatch = p.B * p.tiles_y * p.tiles_x;
-  const int pb = blockIdx.x * p.patches_per_wg;
+  const int pb = split * p.patches_per_wg;
   const int pe = min(npatch, pb + p.patches_per_wg);
-  f32x16 acc[3];
+  f32x16 acc[9];
 #pragma unroll
-  for (int t = 0; t < 3; t++)
+  for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
   const int cc = tid & 7, r0 = tid >> 3;
-  auto fsw = [](int row) { return ((row >> 1) & 1) << 2; };  // 128-B rows: conflict-free transpose reads (see k_conv_wgrad2)
+  auto fsw = [](int row) { return ((row >> 1) & 1) << 2; };
 
-  // DMA sources: patch origin (uniform) + lane-constant offsets; bounds are checked per lane only on edge patches
-  int yoff[NY], yyx[NY], xoff[NX], xyx[NX];
+  int yoff[4], xoff[6];
 #pragma unroll
-  for (int i = 0; i < NY; i++) {
+  for (int i = 0; i < 4; i++) {
     const int row = r0 + 32 * i;
-    yyx[i] = ((row >> 4) << 16) | (row & 15);
     yoff[i] = ((row >> 4) * p.W + (row & 15)) * p.ldy + n0 + ((cc ^ fsw(row)) << 3);
   }
 #pragma unroll
-  for (int i = 0; i < NX; i++) {
+  for (int i = 0; i < 6; i++) {
     const int row = r0 + 32 * i, hy = row / 18, hx = row - hy * 18;
-    const bool used = row < HPX;
-    xyx[i] = used ? ((hy + kh - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
-    xoff[i] = (used ? ((hy + kh - 1) * p.W + (hx - 1)) * p.ldx : 0) + k0 + ((cc ^ fsw(row)) << 3);
+    xoff[i] = (row < 180 ? ((hy - 1) * p.W + (hx - 1)) * p.ldx : 0) + k0 + ((cc ^ fsw(row)) << 3);
   }
-  auto issue = [&](int patch) {  // NY + NX DMA instructions
+  // 10 DMA instructions per patch for waves 0..2, 9 for wave 3 (its last halo piece, rows 184..191, does not exist)
+  auto issue = [&](int patch, int stage) {
     int t = patch;
     const int tx0 = (t % p.tiles_x) * 16;
     t /= p.tiles_x;
-    const int ty0 = (t % p.tiles_y) * PH;
+    const int ty0 = (t % p.tiles_y) * 8;
     const int b = t / p.tiles_y;
     const int64_t origin = (int64_t)(b * p.H + ty0) * p.W + tx0;
     const u16* yb = p.DY + origin * p.ldy;
     const u16* xb = p.X + origin * p.ldx;
-    char* dst = smw + wave * 1024;
-    const bool interior = ty0 + kh >= 1 && ty0 + kh + PH - 1 <= p.H && ty0 + PH <= p.H && tx0 >= 1 && tx0 + 17 <= p.W;
+    char* dst = smw + stage * STG + wave * 1024;
+    const bool interior = ty0 >= 1 && ty0 + 9 <= p.H && tx0 >= 1 && tx0 + 17 <= p.W;
     if (interior) {
 #pragma unroll
-      for (int i = 0; i < NY; i++)
+      for (int i = 0; i < 4; i++)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(yb + yoff[i]),
                                          (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
 #pragma unroll
-      for (int i = 0; i < NX; i++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
-                                         (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
+      for (int i = 0; i < 6; i++)
+        if (i < 5 || wave < 3)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xb + xoff[i]),
+                                           (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
     } else {
 #pragma unroll
-      for (int i = 0; i < NY; i++) {
-        const int y = ty0 + (yyx[i] >> 16), x = tx0 + (yyx[i] & 0xFFFF);
+      for (int i = 0; i < 4; i++) {
+        const int row = r0 + 32 * i;
+        const int y = ty0 + (row >> 4), x = tx0 + (row & 15);
         const u16* g = (y < p.H && x < p.W) ? yb + yoff[i] : (const u16*)g_zero16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
       }
 #pragma unroll
-      for (int i = 0; i < NX; i++) {
-        const int y = ty0 + (xyx[i] >> 16), x = tx0 + (short)(xyx[i] & 0xFFFF);
-        const u16* g = (y >= 0 && y < p.H && x >= 0 && x < p.W) ? xb + xoff[i] : (const u16*)g_zero16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
-      }
+      for (int i = 0; i < 6; i++)
+        if (i < 5 || wave < 3) {
+          const int row = r0 + 32 * i, hy = row / 18, hx = row - hy * 18;
+          const int y = ty0 + hy - 1, x = tx0 + hx - 1;
+          const u16* g = (row < 180 && y >= 0 && y < p.H && x >= 0 && x < p.W) ? xb + xoff[i] : (const u16*)g_zero16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                           (__attribute__((address_space(3))) void*)(dst + YB + i * 4096), 16, 0, 0);
+        }
     }
   };
 
-  // transpose-read addresses (bytes, patch row 0): lane (g, q, pp)
+  // transpose-read addresses (bytes, stage 0, patch / halo row 0): lane (g, q, pp), see k_wgrad3x3
   const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int c0 = 8 * (g >> 1) + q;
   const int cA = (wn * 32 + 16 * (g & 1)) >> 3, cB = (wk * 32 + 16 * (g & 1)) >> 3;
-  const int a0 = (c0 * 64 + (((cA + (pp >> 1)) ^ fsw(c0)) << 3) + 4 * (pp & 1)) * 2;
-  const int a1 = ((c0 + 4) * 64 + (((cA + (pp >> 1)) ^ fsw(c0 + 4)) << 3) + 4 * (pp & 1)) * 2;
-  int b0[3], b1[3];
+  const int a0 = (c0 * 64 + (((cA + (pp >> 1)) ^ fsw(c0)) << 3) + 4 * (pp & 1)) * 2;  // second half of the fragment: + 4 rows = + 512 B
+  int b0[3];
 #pragma unroll
   for (int kw = 0; kw < 3; kw++) {
     const int hr = kw + c0;
     b0[kw] = YB + (hr * 64 + (((cB + (pp >> 1)) ^ fsw(hr)) << 3) + 4 * (pp & 1)) * 2;
-    b1[kw] = YB + ((hr + 4) * 64 + (((cB + (pp >> 1)) ^ fsw(hr + 4)) << 3) + 4 * (pp & 1)) * 2;
   }
+  // The transpose reads are inline asm: hipcc treats the ds_read_tr builtin as a possible LDS store and drains every LDS-DMA
+  // in flight before it (s_waitcnt vmcnt(0)), which would serialise the two stages.  So the LDS counter is waited for by
+  // hand: LGKM0 names the fragment registers it guards ("+v"), which orders the MFMAs that consume them behind the wait.
   typedef short s16x8 __attribute__((ext_vector_type(8)));
-  auto rd = [&](int byte_off) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(smw + byte_off));
+#define MM_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+  auto frag = [](s16x4 u, s16x4 w) {
+    const s16x8 o = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+    return __builtin_bit_cast(bf16x8, o);
   };
 
-  for (int patch = pb; patch < pe; patch++) {
-    __syncthreads();  // everyone finished reading the previous patch
-    issue(patch);
-    __syncthreads();  // vmcnt(0) + barrier: patch landed
-#pragma unroll
-    for (int py = 0; py < PH; py++) {  // one patch row = 16 pixels = one MFMA K step
-      const s16x4 x0 = rd(a0 + py * 16 * 128), x1 = rd(a1 + py * 16 * 128);
-      const s16x8 av = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-      const bf16x8 af = __builtin_bit_cast(bf16x8, av);
-      const int flip = (py & 1) << 6;  // halo rows advance by 18 pixels: their swizzle bit alternates with the row parity
-#pragma unroll
-      for (int kw = 0; kw < 3; kw++) {
-        const s16x4 y0 = rd((b0[kw] ^ flip) + py * 18 * 128), y1 = rd((b1[kw] ^ flip) + py * 18 * 128);
-        const s16x8 bv = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
-        acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, bv), acc[kw], 0, 0, 0);
+  // Ring of NSTG stages: while patch i is multiplied, the DMAs of patches i+1 .. i+NSTG-2 are in flight and patch i+NSTG-1
+  // is requested right after the barrier that ends patch i-1.  ONE barrier per patch (all 8 waves): it says both "every
+  // multiplying wave has finished reading the stage of patch i-1" and "every loader's pieces of patch i have landed".
+  if (loader) {
+    auto wait_patch = [&](int newer) {  // wait until at most `newer` younger patches of this wave are still in flight
+      if (wave == 3) {
+        if (newer >= 2) wait_vm<18>();
+        else if (newer == 1) wait_vm<9>();
+        else wait_vm<0>();
+      } else {
+        if (newer >= 2) wait_vm<20>();
+        else if (newer == 1) wait_vm<10>();
+        else wait_vm<0>();
       }
-    }
-  }
-  float* P = p.partial + (int64_t)blockIdx.x * p.Cn * 9 * p.Ck;
+    };
+    // the barrier that ends patch i (the one before the loop: i = pb - 1) publishes the patches <= i + 2: the multiplying
+    // waves request the first fragments of patch i + 1 before they reach the barrier that ends patch i
 #pragma unroll
-  for (int kw = 0; kw < 3; kw++)
+    for (int d = 0; d < NSTG - 1; d++)
+      if (pb + d < pe) issue(pb + d, d);
+    wait_patch(min(pb + 2, pe - 1) - min(pb + 1, pe - 1));
+    __builtin_amdgcn_s_barrier();
+    int stage = 0;
+    for (int patch = pb; patch < pe; patch++) {
+      if (patch + NSTG - 1 < pe) issue(patch + NSTG - 1, (stage + NSTG - 1) & (NSTG - 1));
+      wait_patch(min(patch + 3, pe - 1) - min(patch + 2, pe - 1));
+      __builtin_amdgcn_s_barrier();
+      stage = (stage + 1) & (NSTG - 1);
+    }
+    return;
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  int stage = 0;
+  s16x4 Au[4], Aw[4];        // dY rows py, window of 4 (row py is used by the halo rows py .. py + 2)
+  s16x4 Bu[2][3], Bw[2][3];  // X fragments of halo row r (set r & 1), requested one row ahead - row 0 of the NEXT patch too
+  MM_TR(Au[0], a0, 0);
+  MM_TR(Aw[0], a0, 512);
+#pragma unroll
+  for (int kw = 0; kw < 3; kw++) {
+    MM_TR(Bu[0][kw], b0[kw], 0);
+    MM_TR(Bw[0][kw], b0[kw], 512);
+  }
+  for (int patch = pb; patch < pe; patch++) {
+    const int sb = stage * STG, sn = ((stage + 1) & (NSTG - 1)) * STG;
+    const int A = a0 + sb;
+    int Bq[3], Bx[3];  // halo rows advance by 18 pixels: the swizzle bit alternates with the row parity (XOR 64 B)
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) {
+      Bq[kw] = b0[kw] + sb;
+      Bx[kw] = (b0[kw] ^ 64) + sb;
+    }
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+      const int cur = r & 1;
+      if (r < 8)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(Au[r & 3]), "+v"(Aw[r & 3]), "+v"(Bu[cur][0]), "+v"(Bw[cur][0]), "+v"(Bu[cur][1]), "+v"(Bw[cur][1]),
+                       "+v"(Bu[cur][2]), "+v"(Bw[cur][2]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(Bu[cur][0]), "+v"(Bw[cur][0]), "+v"(Bu[cur][1]), "+v"(Bw[cur][1]), "+v"(Bu[cur][2]), "+v"(Bw[cur][2]));
+      if (r + 1 < 10) {
+        if (r + 1 < 8) {
+          MM_TR(Au[(r + 1) & 3], A, (r + 1) * 16 * 128);
+          MM_TR(Aw[(r + 1) & 3], A, (r + 1) * 16 * 128 + 512);
+        }
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          MM_TR(Bu[cur ^ 1][kw], ((r + 1) & 1) ? Bx[kw] : Bq[kw], (r + 1) * 18 * 128);
+          MM_TR(Bw[cur ^ 1][kw], ((r + 1) & 1) ? Bx[kw] : Bq[kw], (r + 1) * 18 * 128 + 512);
+        }
+      } else if (patch + 1 < pe) {  // row 0 of the next patch (landed: see the loader), into dY slot 0 and X set 0
+        MM_TR(Au[0], a0 + sn, 0);
+        MM_TR(Aw[0], a0 + sn, 512);
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          MM_TR(Bu[0][kw], b0[kw] + sn, 0);
+          MM_TR(Bw[0][kw], b0[kw] + sn, 512);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);  // the requests of row r + 1 stay ahead of the MFMAs of row r
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++) {
+        const int py = r - kh;
+        if (py >= 0 && py < 8) {
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Au[py & 3], Aw[py & 3]), frag(Bu[cur][kw], Bw[cur][kw]),
+                                                                       acc[kh * 3 + kw], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    stage = (stage + 1) & (NSTG - 1);
+  }
+#undef MM_TR
+  float* P = p.partial + (int64_t)split * p.Cn * 9 * p.Ck;
+#pragma unroll
+  for (int t = 0; t < 9; t++)
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
-      int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-      int k = k0 + wk * 32 + (lane & 31);
-      if (n < p.Cn && k < p.Ck) P[((int64_t)n * 9 + kh * 3 + kw) * p.Ck + k] = acc[kw][reg];
+      const int n = n0 + wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int k = k0 + wk * 32 + (lane & 31);
+      P[((int64_t)n * 9 + t) * p.Ck + k] = acc[t][reg];
     }
 }
 
@@ -1349,29 +1446,38 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
   bool is3x3 = (ntaps == 9 && sa == 1 && Hi == Hg && Wi == Wg);
   for (int i = 0; i < 9 && is3x3; i++) is3x3 = (ty[i] == i / 3 - 1) && (tx[i] == i % 3 - 1);
   if (is3x3 && M > 0) {
-    Wg3P q;
+    Wg9P q;
     q.X = (const u16*)X; q.DY = (const u16*)dY; q.B = B; q.H = Hg; q.W = Wg; q.Ck = Ck; q.ldx = ldx; q.Cn = Cn; q.ldy = ldy;
-    constexpr int ph = 8;  // patch height; 4 (20 KB of LDS, more resident workgroups) measured 11 % slower per step
-    q.tiles_y = (int)mm_cdiv(Hg, ph); q.tiles_x = (int)mm_cdiv(Wg, 16);
+    q.tiles_y = (int)mm_cdiv(Hg, 8); q.tiles_x = (int)mm_cdiv(Wg, 16);
     const int64_t npatch = (int64_t)B * q.tiles_y * q.tiles_x;
-    const int ntile = (Cn / 64) * (Ck / 64);
-    // pixel splits: enough workgroups to fill the chip (~1024 in total), but the fp32 partial slabs (one per split) are
-    // written and re-read, so layers with big weights / few pixels get few splits (<= 32 MB of partials)
-    int64_t nwg = mm_cdiv(1024, ntile);
-    const int64_t cap = (int64_t)(32u << 20) / ((int64_t)Cn * 9 * Ck * 4);
-    if (nwg > cap) nwg = cap;
-    if (nwg > npatch) nwg = npatch;
-    if (nwg < 1) nwg = 1;
-    q.patches_per_wg = (int)mm_cdiv(npatch, nwg);
-    const int nsplit3 = (int)mm_cdiv(npatch, q.patches_per_wg);
-    if ((size_t)nsplit3 * Cn * 9 * Ck * sizeof(float) > ws_bytes) {
+    q.ntile = (Cn / 64) * (Ck / 64);
+    // pixel splits: one workgroup per CU (the kernel is MFMA-bound per patch, so the makespan is the longest patch list),
+    // bounded by 40 MB of fp32 partial slabs, which are written and re-read
+    static const int ncu = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+      return n > 1024 ? 1024 : n;
+    }();
+    int64_t nsp = ncu / q.ntile;
+    const int64_t cap = (int64_t)(40u << 20) / ((int64_t)Cn * 9 * Ck * 4);
+    if (nsp > cap) nsp = cap;
+    if (nsp > npatch) nsp = npatch;
+    if (nsp < 1) nsp = 1;
+    q.patches_per_wg = (int)mm_cdiv(npatch, nsp);
+    const int nsplit9 = (int)mm_cdiv(npatch, q.patches_per_wg);
+    if ((size_t)nsplit9 * Cn * 9 * Ck * sizeof(float) > ws_bytes) {
       mm_set_error("conv2d_wgrad(3x3): workspace too small");
       return MM_ERR_WORKSPACE;
     }
     q.partial = (float*)ws;
-    const size_t lds = (size_t)(ph * 16 + ((ph * 18 + 31) / 32) * 32) * 128;
-    hipLaunchKernelGGL(k_wgrad3x3<ph>, dim3(nsplit3, ntile, 3), dim3(256), lds, s, q);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit3, Cn, 9, Ck,
+    constexpr int lds9 = 4 * (128 + 184) * 128;
+    static bool attr9 = false;
+    if (!attr9) {
+      MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3n, hipFuncAttributeMaxDynamicSharedMemorySize, lds9));
+      attr9 = true;
+    }
+    hipLaunchKernelGGL(k_wgrad3x3n, dim3((unsigned)(nsplit9 * q.ntile)), dim3(512), lds9, s, q);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,
                        dW, sn, st, sk, accumulate);
     MM_LAUNCH_CHECK();
     return MM_OK;

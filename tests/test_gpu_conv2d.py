@@ -121,3 +121,32 @@ def test_batched_weight_repack_equals_single_packs():
             exp = c2._pack(w.data, *sp[:8])
             assert torch.equal(got.view(torch.int16), exp.view(torch.int16)), sp
             assert not torch.equal(got.view(torch.int16), old.view(torch.int16))
+
+
+@pytest.mark.parametrize("cin,cout,B,hw", [
+    (256, 256, 8, (40, 48)),   # 16 tiles x 16 splits, 8 patches per workgroup: the four-stage ring wraps twice
+    (512, 512, 5, (24, 40)),   # 64 tiles x 4 splits of 12, 12, 12 and 9 patches
+    (512, 256, 3, (16, 33)),   # 3 patches per workgroup (prologue only), ragged right edge
+    (512, 512, 2, (19, 30)),   # the bench's deepest map: 3 patches per workgroup, every patch touches the border
+    (256, 256, 2, (24, 32)),   # 1 patch per workgroup
+    (128, 64, 5, (33, 50)),    # Cn != Ck, 100 splits of one patch
+    (64, 64, 6, (72, 112)),    # one tile, the splits fill the chip: 378 patches over 189 workgroups
+])
+def test_conv3x3_weight_grad_patch_ring(cin, cout, B, hw):
+    """k_wgrad3x3n at patch counts per workgroup around and beyond its ring depth (1, 2, 3, 8, 12): the products are exact
+    in fp32 (bf16 operands), so only the summation order differs from torch's fp32 weight gradient."""
+    from mm2d3d_amd.conv2d import Conv2dFn
+
+    dev = _dev()
+    torch.manual_seed(cin * 7 + cout + B)
+    H, W = hw
+    x = torch.randn(B, cin, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
+    g = torch.randn(B, cout, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    wh = w.clone().requires_grad_(True)
+    Conv2dFn.apply(x, wh, None, 1, 1).backward(g)
+    ref = torch.nn.grad.conv2d_weight(x.float(), w.shape, g.float(), stride=1, padding=1)
+    assert _rel(wh.grad, ref) < 1e-4
+    again = w.clone().requires_grad_(True)
+    Conv2dFn.apply(x, again, None, 1, 1).backward(g)
+    assert torch.equal(again.grad, wh.grad)  # fixed summation order
