@@ -114,6 +114,14 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
                     const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
                     int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
                     int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* The same with the weights' three-term bf16 fragments supplied by the caller (Wpk: written by mm_spconv_os_pack /
+ * mm_spconv_os_pack_batch for the same K, Cin, Cout, strides and kflip; NULL = pack inside the call): a net packs every
+ * layer once per optimiser step in one launch instead of once per layer call. */
+int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
+                           const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
+                           int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
+                           int64_t w_kstride, int s_ci, int s_co, int kflip, const void* Wpk, void* ws, size_t ws_bytes,
+                           mm_stream_t stream);
 size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout);
 /* dW[k][ci][co] (+)= sum over rules r of bucket k: in[src[r]][ci] * dout[dst[r]][co] */
 int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_do, int Cout, const int32_t* src,

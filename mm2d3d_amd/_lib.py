@@ -34,6 +34,7 @@ _PROTOS = {
     "mm_rulebook_csr": (i32, [vp, i32, i64, vp, vp, vp, sz, vp]),
     "mm_spconv_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
+    "mm_spconv_apply_packed": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, sz, vp]),
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
     "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
     "mm_voxelize_ws_bytes": (sz, [i64, i32]),

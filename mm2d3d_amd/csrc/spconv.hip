@@ -214,7 +214,9 @@ __device__ inline f32x4 mfma_split(const bf16x8 (&a)[NT], const bf16x8 (&b)[NT],
   return acc;
 }
 
-// Wf3[k][q][cb][lane][term][0..7] = bf16 terms of W[kk][ci = 32q + 8(lane>>4) + j][co = 16cb + (lane&15)]  (0 beyond Cin)
+// Wf3[k][q][cb][term][lane][0..7] = bf16 terms of W[kk][ci = 32q + 8(lane>>4) + j][co = 16cb + (lane&15)]  (0 beyond Cin):
+// the layout of the output-stationary engine's fragments (csrc/osconv.hip pack_one), so that a caller that keeps those per
+// optimiser step (mm_spconv_os_pack_batch) can hand them to mm_spconv_apply_packed and skip this launch
 template <int NT>
 __global__ __launch_bounds__(256) void k_pack_frag_s3(const float* __restrict__ W, int64_t w_kstride, int s_ci, int s_co, int kflip,
                                                        int K, int Cin, int Cout, int nq, int ncb, __bf16* __restrict__ Wf) {
@@ -229,11 +231,11 @@ __global__ __launch_bounds__(256) void k_pack_frag_s3(const float* __restrict__ 
   int ci = 32 * q + 8 * (lane >> 4) + j, co = 16 * cb + (lane & 15);
   float r = 0.f;
   if (ci < Cin && co < Cout) r = W[(int64_t)(kflip ? K - 1 - k : k) * w_kstride + (int64_t)ci * s_ci + (int64_t)co * s_co];
-  const int64_t base = (e >> 3) * (8 * NT);
+  const int64_t base = (e >> 9) * (512 * NT) + lane * 8 + j;
 #pragma unroll
   for (int n = 0; n < NT; n++) {
     const __bf16 h = (__bf16)r;
-    Wf[base + 8 * n + j] = h;
+    Wf[base + 512 * n] = h;
     r -= (float)h;
   }
 }
@@ -246,7 +248,7 @@ __global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict_
                                                          const int32_t* __restrict__ dst, float* __restrict__ out, int ld_out,
                                                          const __bf16* __restrict__ Wf, int ncb_tot, int K, int Cin, int tr,
                                                          KSeg seg) {
-  extern __shared__ __attribute__((aligned(16))) char wlds[];  // [nq][NCB][64 lanes][NT][16 B]
+  extern __shared__ __attribute__((aligned(16))) char wlds[];  // [nq][NCB][NT][64 lanes][16 B]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
   const int k = find_k(seg, blockIdx.x, K);
   const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * tr;
@@ -280,11 +282,11 @@ __global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict_
       split8<NT>(x0, x1, xt);
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) {
-        const bf16x8* w8 = LDSW ? (const bf16x8*)wlds + ((q * NCB + cb) * 64 + lane) * NT
-                                : Wk + (((int64_t)q * ncb_tot + cb) * 64 + lane) * NT;
+        const bf16x8* w8 = LDSW ? (const bf16x8*)wlds + (q * NCB + cb) * 64 * NT + lane
+                                : Wk + ((int64_t)q * ncb_tot + cb) * 64 * NT + lane;
         bf16x8 wt[NT];
 #pragma unroll
-        for (int n = 0; n < NT; n++) wt[n] = w8[n];
+        for (int n = 0; n < NT; n++) wt[n] = w8[n * 64];
         acc[cb] = mfma_split<NT>(wt, xt, acc[cb]);
       }
     }
@@ -709,10 +711,13 @@ size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K) {
 //   unique_dst == 0 : destinations reduced through the CSR (csr_off/csr_pos over n_out rows), k ascending
 //   weight element (k, ci, co) is W[kk*w_kstride + ci*s_ci + co*s_co], kk = kflip ? K-1-k : k
 //   rows of out without a rule are written as zeros (CSR path) or left untouched (unique path: caller pre-zeros if needed)
-int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
-                    const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
-                    int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
-                    int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, hipStream_t s) {
+//   Wpk (nullable): the three-term fragments of the same weights (same strides, kflip) as written by mm_spconv_os_pack /
+//   mm_spconv_os_pack_batch; used by the split-product kernels in place of their own per-call pack
+int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
+                           const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
+                           int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
+                           int64_t w_kstride, int s_ci, int s_co, int kflip, const void* Wpk, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && ld_in >= Cin && ld_out >= Cout, "spconv_apply: bad shape");
   MM_CHECK_ARG(unique_dst || (csr_off && csr_pos), "spconv_apply: the row CSR is required unless every destination is unique");
   const int64_t R = offsets_host[K];
@@ -761,13 +766,15 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
   if (nt && !edge && Cin >= split_min_cin(false) && (unique_dst || Cout % 4 == 0) && R > 0) {  // matrix-rate-bound widths: split-bf16 products
     const int nq3 = (Cin + 31) / 32;
     MM_CHECK_ARG(ws_bytes >= tmp_bytes + (size_t)K * nq3 * ncb * 64 * 16 * nt, "spconv_apply: workspace too small for the split fragments");
-    __bf16* Wf3 = (__bf16*)Wf;
-    if (nt == 3)
+    const __bf16* Wf3 = (const __bf16*)Wf;
+    if (Wpk && nt == 3 && ((uintptr_t)Wpk % 16) == 0)
+      Wf3 = (const __bf16*)Wpk;
+    else if (nt == 3)
       hipLaunchKernelGGL(k_pack_frag_s3<3>, dim3((unsigned)mm_cdiv((int64_t)K * nq3 * ncb * 512, 256)), dim3(256), 0, s, W, w_kstride,
-                         s_ci, s_co, kflip, K, Cin, Cout, nq3, ncb, Wf3);
+                         s_ci, s_co, kflip, K, Cin, Cout, nq3, ncb, (__bf16*)Wf);
     else
       hipLaunchKernelGGL(k_pack_frag_s3<2>, dim3((unsigned)mm_cdiv((int64_t)K * nq3 * ncb * 512, 256)), dim3(256), 0, s, W, w_kstride,
-                         s_ci, s_co, kflip, K, Cin, Cout, nq3, ncb, Wf3);
+                         s_ci, s_co, kflip, K, Cin, Cout, nq3, ncb, (__bf16*)Wf);
     float* tgt = out;
     int ld_t = ld_out;
     const int32_t* d = dst;
@@ -876,6 +883,14 @@ static int dw_chunk(int64_t R, int Cin, int Cout) {
   if (c < 64) c = 64;
   if (c > 8192) c = 8192;
   return (int)c;
+}
+
+int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
+                    const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
+                    int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
+                    int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, hipStream_t s) {
+  return mm_spconv_apply_packed(in, ld_in, Cin, out, ld_out, Cout, n_out, src, dst, offsets_dev, offsets_host, K, csr_off, csr_pos,
+                                unique_dst, W, w_kstride, s_ci, s_co, kflip, nullptr, ws, ws_bytes, s);
 }
 
 size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout) {

@@ -40,8 +40,10 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_csr_of=None):
-    """out[dst] (+)= x[src] . W[k].  w_kcc: [K, Cin_w, Cout_w] contiguous; transpose_w uses W[k]^T."""
+def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_csr_of=None, weight=None):
+    """out[dst] (+)= x[src] . W[k].  w_kcc: [K, Cin_w, Cout_w] contiguous; transpose_w uses W[k]^T.
+    ``weight``: the parameter behind ``w_kcc``: its split fragments come from the per-optimiser-step registry (one batched
+    pack for every layer of the net, shared with the output-stationary engine) instead of a pack launch per call."""
     L = _lib.lib()
     cin = x.shape[1]
     K = rb.K
@@ -54,10 +56,13 @@ def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_
     if not unique:
         rb.ensure_csr()
     ws = _lib.workspace.get(int(L.mm_spconv_ws_bytes(rb.n_rules, cin, cout, K)), x.device)
+    wpk = None
+    if weight is not None and OS_ENABLED and cin % 16 == 0 and cout % 16 == 0 and cin >= 32:
+        wpk = _os_fragments(weight, w_kcc, transpose_w, kflip)
     check(
-        L.mm_spconv_apply(ptr(x), x.stride(0), cin, ptr(out), cout, cout, n_out, ptr(src), ptr(dst), ptr(rb.offsets_dev),
-                          rb.offsets_ptr, K, ptr(rb.csr_off), ptr(rb.csr_pos), 1 if unique else 0, ptr(w_kcc),
-                          cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, ptr(ws), ws.numel(), stream()),
+        L.mm_spconv_apply_packed(ptr(x), x.stride(0), cin, ptr(out), cout, cout, n_out, ptr(src), ptr(dst), ptr(rb.offsets_dev),
+                                 rb.offsets_ptr, K, ptr(rb.csr_off), ptr(rb.csr_pos), 1 if unique else 0, ptr(w_kcc),
+                                 cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, ptr(wpk), ptr(ws), ws.numel(), stream()),
         "spconv_apply",
     )
     return out
@@ -236,9 +241,9 @@ class SparseConvFunction(torch.autograd.Function):
         if _os_usable(table, x, cin, cout) and table.n_dst == n_out:
             out = _timed("fwd", rb, acin, cout, lambda: _apply_os(x, weight, w, table, cout, False, False))
         elif mode in ("subm", "down"):
-            out = _timed("fwd", rb, acin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False))
+            out = _timed("fwd", rb, acin, cout, lambda: _apply(x, w, rb, rb.rin, rb.rout, n_out, cout, False, False, False, weight=weight))
         else:  # roles swapped, every fine row has exactly one rule
-            out = _timed("fwd", rb, acin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False))
+            out = _timed("fwd", rb, acin, cout, lambda: _apply(x, w, rb, rb.rout, rb.rin, n_out, cout, True, False, False, weight=weight))
         ctx.save_for_backward(x, w)
         ctx.rb, ctx.mode, ctx.n_in, ctx.wshape = rb, mode, n_in, weight.shape
         ctx.weight = weight
@@ -276,11 +281,11 @@ class SparseConvFunction(torch.autograd.Function):
             dx = _timed("dX", rb, ctx.acin, cout, lambda: _apply_os(dout, ctx.weight, w, table, cin, True, mode == "subm"))
         elif ctx.needs_input_grad[0]:
             if mode == "subm":  # symmetric rulebook: (k,i,o) <-> (26-k,o,i)
-                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True))
+                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True, weight=ctx.weight))
             elif mode == "down":
-                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False))
+                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False, weight=ctx.weight))
             else:
-                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False))
+                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False, weight=ctx.weight))
         if ctx.needs_input_grad[1]:
             sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
             if mode == "up":

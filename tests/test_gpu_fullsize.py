@@ -141,6 +141,36 @@ def test_output_stationary_engine_equals_rulebook_engine_at_full_size(level, cin
         assert float((g1 - g0).abs().max()) <= 2e-6 * float(g0.abs().max())
 
 
+@pytest.mark.parametrize("level,cin,cout", [(3, 64, 64), (4, 160, 80), (5, 96, 96)])
+def test_rulebook_engine_with_per_step_fragments_equals_per_call_pack(level, cin, cout):
+    """The k-major engine takes its weights' three-term fragments either from the per-optimiser-step registry
+    (mm_spconv_apply_packed, the layout of mm_spconv_os_pack_batch) or from its own pack launch (mm_spconv_apply): the same
+    terms in the same places, so forward and data gradient are bit-identical."""
+    from mm2d3d_amd.scn import ops
+
+    dev = _dev()
+    md, _ = _metadata("nuscenes", 16)
+    lv = md.levels[level]
+    assert lv.subm.os is None, "a level the k-major engines serve"
+    g = torch.Generator(device="cpu").manual_seed(level)
+    x = torch.randn(lv.n, cin, generator=g).to(dev)
+    w = torch.nn.Parameter((torch.randn(27, 1, cin, cout, generator=g) * (2.0 / cin / 27) ** 0.5).to(dev))
+    gout = torch.randn(lv.n, cout, generator=g).to(dev)
+    res = []
+    try:
+        for on in (True, False):
+            ops.OS_ENABLED = on  # off: no registry, the call packs its own fragments
+            xx = x.clone().requires_grad_(True)
+            y = ops.SparseConvFunction.apply(xx, w, lv.subm, "subm", lv.n, lv.n)
+            (gx,) = torch.autograd.grad(y, xx, gout)
+            res.append((y.detach(), gx))
+    finally:
+        ops.OS_ENABLED = True
+    (y1, g1), (y0, g0) = res
+    assert torch.equal(y1, y0) and torch.equal(g1, g0)
+    assert float(y1.abs().max()) > 0
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 152, 240), (128, 128, 76, 120), (256, 256, 38, 60), (512, 512, 19, 30), (192, 64, 152, 240)])
 def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W):
     """The persistent 3x3 kernels at the joint-pass shapes of the bench (B = 16): forward and data gradient against torch's
