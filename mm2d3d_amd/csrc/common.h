@@ -49,7 +49,8 @@ struct MMArena {
   }
 };
 
-// exclusive scan of int32 -> int32 (n up to 2^31), total written to *total_out (device); scan.hip
+// exclusive scan of int32 -> int32 (n up to 2^31), total written to *total_out (device); scan.hip.
+// `in` and `out` must hold n + 1 elements when total_out is given (the single-pass path scans n + 1 and leaves the total in out[n]).
 int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_out, void* ws, size_t ws_bytes,
                           hipStream_t s);
 size_t mm_scan_ws_bytes(int64_t n);

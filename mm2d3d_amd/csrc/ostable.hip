@@ -20,6 +20,8 @@
 
 #include "common.h"
 
+int g_os_sort_merge = 0;  // also read by csrc/scan.hip
+
 namespace {
 
 constexpr int T = 256;
@@ -66,7 +68,6 @@ using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::def
 // workgroups spin on their predecessors' partial sums (decoupled look-back); beside a kernel with a grid barrier (the single-launch
 // batch norms) on another stream that can deadlock, so a build that runs on a side stream selects this one (mm_os_table_set_sort).
 using SortCfgMerge = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, ((size_t)1 << 40)>;
-int g_os_sort_merge = 0;
 
 template <typename Cfg>
 hipError_t sort_masks(void* tmp, size_t& bytes, const uint32_t* mask, uint32_t* mask_sorted, int32_t* perm, int64_t n, int K, hipStream_t s) {

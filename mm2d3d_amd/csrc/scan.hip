@@ -1,6 +1,12 @@
 // Exclusive prefix sum (int32) used by the voxel-dedupe and rulebook compaction kernels.
-// Reduce-then-scan in three launches: per-block sums, one-block scan of the sums, per-block rescan.
+// Default: rocPRIM's single-pass scan (decoupled look-back: one state-init launch + one scan launch, each element read and
+// written once).  Its workgroups wait for their predecessors' partial sums, so - like the Onesweep sort of csrc/ostable.hip -
+// it must not run beside a grid-barrier kernel of another stream; a build on a side stream selects the three-launch
+// reduce-then-scan below (per-block sums, one-block scan of the sums, per-block rescan: no workgroup waits for another)
+// with mm_os_table_set_sort(1).  Same result either way (integer sums).
 #include <stdarg.h>
+
+#include <rocprim/device/device_scan.hpp>
 
 #include "common.h"
 
@@ -93,7 +99,18 @@ __global__ __launch_bounds__(SCAN_T) void k_rescan(const int32_t* __restrict__ i
 }
 }  // namespace
 
-size_t mm_scan_ws_bytes(int64_t n) { return mm_align((size_t)(mm_cdiv(n, SCAN_BLK) + 1) * sizeof(int32_t)); }
+extern int g_os_sort_merge;  // csrc/ostable.hip: 1 = no kernel whose workgroups wait for each other
+
+static size_t lookback_bytes(int64_t n) {
+  size_t b = 0;
+  (void)rocprim::exclusive_scan(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t)0, (size_t)(n > 0 ? n : 1),
+                                rocprim::plus<int32_t>(), (hipStream_t)0);
+  return b;
+}
+
+size_t mm_scan_ws_bytes(int64_t n) {
+  return mm_align((size_t)(mm_cdiv(n, SCAN_BLK) + 1) * sizeof(int32_t)) + mm_align(lookback_bytes(n + 1)) + 256;
+}
 
 int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_out, void* ws, size_t ws_bytes,
                           hipStream_t s) {
@@ -107,6 +124,17 @@ int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* t
   }
   int32_t* sums = (int32_t*)ws;
   int64_t nb = mm_cdiv(n, SCAN_BLK);
+  if (!g_os_sort_merge && total_out) {
+    // in and out hold n + 1 elements (common.h): scan n + 1 of them, out[n] = the total (in[n] is read, its value does not
+    // enter out[0..n])
+    size_t tb = lookback_bytes(n + 1);
+    char* tmp = (char*)ws + mm_align((size_t)(nb + 1) * sizeof(int32_t));
+    if ((size_t)(tmp - (char*)ws) + tb <= ws_bytes) {
+      MM_HIP(rocprim::exclusive_scan((void*)tmp, tb, in, out, (int32_t)0, (size_t)(n + 1), rocprim::plus<int32_t>(), s));
+      if (total_out != out + n) MM_HIP(hipMemcpyAsync(total_out, out + n, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+      return MM_OK;
+    }
+  }
   hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, sums, n);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, sums, nb, total_out);
   hipLaunchKernelGGL(k_rescan, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, sums, n);
