@@ -108,13 +108,26 @@ __global__ __launch_bounds__(T) void k_assign(const CT* __restrict__ coords, int
   }
 }
 
+// also clears flag[p]: the array is free from here on and serves as the per-voxel cursor of k_fill_lists
 __global__ __launch_bounds__(T) void k_store_ids(int64_t n_bound, const int32_t* __restrict__ n_dev,
-                                                  const int32_t* __restrict__ slot_of, const int32_t* __restrict__ flag,
+                                                  const int32_t* __restrict__ slot_of, int32_t* __restrict__ flag,
                                                   const int32_t* __restrict__ rank, int32_t* __restrict__ tvals) {
   int64_t p = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (p > n_bound) return;
   int64_t n = n_dev ? (int64_t)*n_dev : n_bound;
-  if (p >= n) return;
-  if (flag[p]) tvals[slot_of[p]] = rank[p];
+  if (p < n && flag[p]) tvals[slot_of[p]] = rank[p];
+  flag[p] = 0;
+}
+
+// one launch instead of three fills: empty hash table (keys all ones, values 0x7F7F7F7F) and zero counters
+__global__ __launch_bounds__(T) void k_dedupe_init(unsigned long long* __restrict__ tkeys, int32_t* __restrict__ tvals, int64_t cap,
+                                                    int32_t* __restrict__ cnt, int64_t ncnt) {
+  int64_t i = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (i < cap) {
+    tkeys[i] = ~0ull;
+    tvals[i] = 0x7F7F7F7F;
+  }
+  if (i < ncnt) cnt[i] = 0;
 }
 
 __global__ __launch_bounds__(T) void k_fill_lists(int64_t n_bound, const int32_t* __restrict__ n_dev,
@@ -274,9 +287,10 @@ int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, cons
     mm_set_error("dedupe: workspace too small (%zu < %zu)", ws_bytes, mm_dedupe_ws_bytes(n_bound));
     return MM_ERR_WORKSPACE;
   }
-  MM_HIP(hipMemsetAsync(tkeys, 0xFF, (size_t)cap * 8, s));
-  MM_HIP(hipMemsetAsync(tvals, 0x7F, (size_t)cap * 4, s));
-  MM_HIP(hipMemsetAsync(cnt, 0, (size_t)(n_bound + 1) * 4, s));
+  {
+    const int64_t ni = cap > n_bound + 1 ? cap : n_bound + 1;
+    hipLaunchKernelGGL(k_dedupe_init, dim3(nblk(ni)), dim3(T), 0, s, (unsigned long long*)tkeys, tvals, cap, cnt, n_bound + 1);
+  }
   if (n_bound == 0) {
     MM_HIP(hipMemsetAsync(n_active_dev, 0, 4, s));
     MM_HIP(hipMemsetAsync(csr_off, 0, 4, s));
@@ -299,12 +313,11 @@ int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, cons
   else
     hipLaunchKernelGGL(k_assign<int32_t>, dim3(g), dim3(T), 0, s, (const int32_t*)coords, n_bound, n_dev, shift, slot_of,
                        tvals, rank, item2vox, vox_coords, cnt);
-  hipLaunchKernelGGL(k_store_ids, dim3(g), dim3(T), 0, s, n_bound, n_dev, slot_of, flag, rank, tvals);
+  hipLaunchKernelGGL(k_store_ids, dim3(nblk(n_bound + 1)), dim3(T), 0, s, n_bound, n_dev, slot_of, flag, rank, tvals);
   // csr over voxels (bound n_bound); csr_off[n_bound] = number of items
   rc = mm_exclusive_scan_i32(cnt, csr_off, n_bound, csr_off + n_bound, scan_ws, sws, s);
   if (rc) return rc;
-  MM_HIP(hipMemsetAsync(cnt, 0, (size_t)(n_bound + 1) * 4, s));
-  hipLaunchKernelGGL(k_fill_lists, dim3(g), dim3(T), 0, s, n_bound, n_dev, item2vox, csr_off, cnt, csr_items);
+  hipLaunchKernelGGL(k_fill_lists, dim3(g), dim3(T), 0, s, n_bound, n_dev, item2vox, csr_off, flag, csr_items);
   hipLaunchKernelGGL(k_sort_lists, dim3(g), dim3(T), 0, s, n_bound, n_active_dev, csr_off, csr_items);
   MM_LAUNCH_CHECK();
   return MM_OK;
