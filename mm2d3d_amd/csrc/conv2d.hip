@@ -385,16 +385,19 @@ __global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void k_conv3x3(C3P p) {
 // its fixed costs (first halo from HBM, output stores, dispatch) are several, and every workgroup re-streams the whole
 // weight tensor of its cout block from L2: measured with MFMAs and all streaming switched off, the kernel above still
 // takes 2/3 of its time, and the L2->LDS weight traffic (pixels/128 x |W|) is 3-20x the activation bytes.
-// Here ONE 8-wave workgroup per CU stays resident and walks a list of (256-pixel tile, BN-cout block) items - half the
+// Here ONE workgroup per CU stays resident and walks a list of (256-pixel tile, BN-cout block) items - half the
 // weight traffic per FLOP, half the LDS-DMA issues per MFMA - with everything software-pipelined ACROSS items and LDS-DMA
 // kept in flight over raw barriers (counted s_waitcnt vmcnt, cdna_hip_programming.md "Pipelining across barriers"):
 //   halo ring of 2: the halo of the next (item, 64-channel chunk) is requested while the current chunk is multiplied
-//   W ring of 3   : weight tiles are requested two taps ahead
-//   the bf16 output stores of item t drain while item t+1 is already computing.
+//   W ring of 4 (BN = 128) / 6 (BN = 64): weight tiles are requested three / five taps ahead
+// Two roles of 8 waves each (round 2): waves 0-7 multiply and store, waves 8-15 issue every LDS-DMA and own the vmcnt
+// counting (an LDS-DMA instruction holds the wave that issues it for ~190 cycles; in the multiplying waves that was ~0.27 us
+// of a 0.94 us tap step).  The split alone changed nothing while the ring was 3 deep - a step then could not be shorter
+// than half a tile's issue -> landed latency - and the deeper ring alone does not fit the multiplying waves' schedule; the
+// two together: 3-8 % per layer (tools/conv3x3_scan.py), -0.55 ms per step.
 // MFMA operands are swapped (D = W x X^T) so that a lane owns 4 consecutive output channels of one pixel: 8-byte stores.
-// Every DMA / store instruction is issued unconditionally (padding reads come from g_zero16, out-of-image stores go to
-// g_dump) so the per-wave VMEM instruction counts the waits rely on are exact (checked in the disassembly: the
-// global_load_lds sit outside the exec-masked address selection, NST global_store_dwordx2 per item).
+// Every DMA instruction is issued unconditionally (padding reads come from g_zero16; out-of-image stores go to g_dump) so
+// the per-wave DMA counts the waits rely on are exact.
 // TW = 16: 16 x 16 pixel tiles (large maps); TW = 32: 8 x 32 (low-resolution maps waste fewer out-of-image pixels).
 __device__ __attribute__((aligned(16))) unsigned int g_dump[256];  // sink for the stores of out-of-image pixels
 
@@ -404,31 +407,36 @@ __device__ inline void wait_vm() {
 }
 
 template <int BN, int TW>
-__global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
+__global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
   extern __shared__ __attribute__((aligned(16))) char smemc[];
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
-  constexpr int HSZB = 384 * 128;  // bytes per halo buffer: 6 DMA rounds of 64 rows of 128 B
+  constexpr int HSZB = 344 * 128;  // bytes per halo buffer: 43 one-KiB DMA pieces (5 rounds of 8 waves + waves 0..2 of a sixth)
+  constexpr int RW = BN == 128 ? 4 : 6;  // W ring depth: tiles are requested RW - 1 tap steps ahead
   constexpr int BSZB = BN * 128;   // bytes per W buffer
   constexpr int NB = BN / 64;      // W DMA instructions per thread and tile
   constexpr int TN = BN / 64;      // 32-cout fragments per wave
-  constexpr int NST = 2 * TN * 4;  // store instructions per wave and item
-  static_assert(HROWS <= 384, "halo does not fit its 6 DMA rounds");
-  // LDS map (bytes): W ring [3][BSZB] at 0 (so the ring slot fits the 16-bit ds_read offset), halo ring [2][HSZB], bias
-  constexpr int HS0 = 3 * BSZB;
+  static_assert(HROWS <= 344, "halo does not fit its 43 DMA pieces");
+  // LDS map (bytes): W ring [RW][BSZB] at 0, halo ring [2][HSZB], bias: 157,696 B for BN = 128
+  constexpr int HS0 = RW * BSZB;
   char* const lds = smemc;
   float* biasl = (float*)(lds + HS0 + 2 * HSZB);  // [Cn <= 1024] when p.bias
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // two roles of 8 waves each (16 waves, 4 per SIMD): threads 0..511 multiply, threads 512..1023 issue every LDS-DMA
+  const bool loader = threadIdx.x >= 512;
+  const int tid = threadIdx.x & 511, wave = tid >> 6, lane = tid & 63;  // wave = index within the role
   const int wm = wave >> 1, wn = wave & 1;  // 4 (pixels) x 2 (couts)
   const int cc = tid & 7, r0 = tid >> 3;
   const int nchunk = p.Ca >> 6, ncb = p.Cn / BN;
-  if (p.bias) {  // staged once by DMA: an ordinary global load inside the pipeline would make hipcc drain it (vmcnt(0))
-    for (int k0 = 0; k0 < p.Cn; k0 += 512) {
-      const int k = k0 + tid < p.Cn ? k0 + tid : p.Cn - 1;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + k),
-                                       (__attribute__((address_space(3))) void*)(biasl + k0 + wave * 64), 4, 0, 0);
+  if (p.bias) {  // staged once by DMA (loaders)
+    if (loader) {
+      for (int k0 = 0; k0 < p.Cn; k0 += 512) {
+        const int k = k0 + tid < p.Cn ? k0 + tid : p.Cn - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + k),
+                                         (__attribute__((address_space(3))) void*)(biasl + k0 + wave * 64), 4, 0, 0);
+      }
+      wait_vm<0>();
     }
-    wait_vm<0>();
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
   }
   const int nitems = p.B * p.tiles_y * p.tiles_x * ncb;
   // item schedule: the 8 XCDs own contiguous item ranges (blockIdx round-robins over XCDs), so the workgroups that share
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
   // producer cursors advance incrementally: no divisions between a barrier and the MFMAs
   int h_item = it_begin, h_c = 0, h_b, h_ty0, h_tx0, h_n0;
   decode(h_item, h_b, h_ty0, h_tx0, h_n0);
-  auto issue_halo = [&](int buf) {  // 6 DMA instructions, always; then advance the cursor
+  auto issue_halo = [&](int buf) {  // 6 DMA instructions (5 for waves 3..7), always; then advance the cursor
     const bool live = h_item < it_end;
     const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
     const u16* base = p.A + ((int64_t)(h_b * p.H + h_ty0) * p.W + h_tx0) * p.lda + h_c * 64;
@@ -502,11 +510,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
     if (interior) {
 #pragma unroll
       for (int i = 0; i < 6; i++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+        if (i < 5 || wave < 3)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
+                                           (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
     } else {
 #pragma unroll
       for (int i = 0; i < 6; i++) {
+        if (i == 5 && wave >= 3) break;
         const int y = h_ty0 + (hyx[i] >> 16), x = h_tx0 + (short)(hyx[i] & 0xFFFF);
         const bool ok = live && y >= 0 && y < p.H && x >= 0 && x < p.W;
         const u16* g = ok ? base + hl[i] : (const u16*)g_zero16;
@@ -539,6 +549,37 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
     }
   };
 
+  // One barrier (all 16 waves) per step g = (segment, tap).  A loader passes it once ITS pieces of W(g) - and, at tap 0, of
+  // this segment's halo, which is older - have landed; a multiplying wave once it has finished step g-1, which frees the W
+  // ring slot (g-1) % RW and, at tap 0, the halo buffer (seg+1) & 1: the loaders refill those right behind the barrier with
+  // W(g+RW-1) and the next segment's halo.  Younger than W(g) in a loader's queue: W(g+1 .. g+RW-2) and, at taps 1 .. RW-2,
+  // the halo requested at tap 0 (it went into the queue behind W(g0+RW-2)).  With RW = 3 a step could not be shorter than
+  // half the issue -> landed latency of a tile: the kernel ran at DMA latency, not at its multiply (measured 0.94 us per
+  // step against 0.6 us of multiply; with the loads in the multiplying waves their issue time came on top).
+  if (loader) {
+    issue_halo(0);
+#pragma unroll
+    for (int d = 0; d < RW - 1; d++) issue_w(d);
+    int wslot = RW - 1;  // slot of the next W request
+    for (int seg = 0; seg < nseg; seg++) {
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        if (tap >= 1 && tap <= RW - 2) {
+          if (wave < 3) wait_vm<(RW - 2) * NB + 6>();
+          else wait_vm<(RW - 2) * NB + 5>();
+        } else {
+          wait_vm<(RW - 2) * NB>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (tap == 0) issue_halo((seg + 1) & 1);
+        issue_w(wslot);
+        wslot = wslot + 1 == RW ? 0 : wslot + 1;
+      }
+    }
+    wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
+    return;
+  }
+
   f32x16 acc[2][TN];
 #pragma unroll
   for (int i = 0; i < 2; i++)
@@ -547,30 +588,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  issue_halo(0);
-  issue_w(0);
-  issue_w(1);
-  bool st = false;                 // the previous segment ended an item: its NST stores sit in the VMEM queue behind W(g+1)
   int c_item = it_begin, c_c = 0;  // consumer cursor
+  int slot = 0;                    // byte offset of the W ring slot of the current step
   for (int seg = 0; seg < nseg; seg++) {
     const int hb = (seg & 1) * HSZB;
 #pragma unroll
     for (int tap = 0; tap < 9; tap++) {  // unrolled: the W ring slot is tap % 3 (9 taps per segment) and aoff[][tap] is static
-      // W(g) [and, at tap 0, this segment's halo, which is older] must have landed.  Younger than W(g) in the queue:
-      // W(g+1) (NB); the next halo (6) when the previous step was a tap 0; the previous item's stores (NST) for two steps.
-      if (tap == 0) {
-        if (st) wait_vm<NB + NST>();
-        else wait_vm<NB>();
-      } else if (tap == 1) {
-        if (st) wait_vm<NB + 6 + NST>();
-        else wait_vm<NB + 6>();
-      } else {
-        wait_vm<NB>();
-      }
-      __builtin_amdgcn_s_barrier();  // everyone finished step g-1: ring slots (g+2)%3 and (seg+1)&1 are free
-      if (tap == 0) issue_halo((seg + 1) & 1);
-      issue_w((tap + 2) % 3);
-      const int slot = (tap % 3) * BSZB;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         bf16x8 af[2], bf[TN];
@@ -584,8 +610,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
           for (int j = 0; j < TN; j++)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);  // D[cout][pixel]
       }
+      slot = slot + BSZB == RW * BSZB ? 0 : slot + BSZB;
     }
-    st = false;
     if (++c_c == nchunk) {  // item finished: D row (reg&3) + 8*(reg>>2) + 4*fh = output channel, column fr_ = pixel
       int b, ty0, tx0, n0;
       decode(c_item, b, ty0, tx0, n0);
@@ -613,10 +639,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3w(C3P p) {
             *(uint2*)(inside ? orow + 32 * j + 8 * q : (u16*)g_dump + lane * 4) = o;
           }
       }
-      st = true;
     }
   }
-  wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
 }
 
 // 64 -> 64 channel layers (layer1 of both backbones, 24 calls per step): the whole 3x3x64x64 weight tensor is 72 KB of
@@ -1374,12 +1398,12 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
     p.tiles_y = (int)mm_cdiv(H, 256 / tw); p.tiles_x = (int)mm_cdiv(W, tw);
     const int64_t nitems = (int64_t)B * p.tiles_y * p.tiles_x * (Cn / bn);
     MM_CHECK_ARG(nitems < (1ll << 30), "conv2d_3x3s1: too many tiles");
-    const size_t ldsw = (size_t)(2 * 384 * 64 + 3 * bn * 64) * 2 + (bias ? (size_t)mm_cdiv(Cn, 512) * 512 * 4 : 0);
+    const size_t ldsw = (size_t)(2 * 344 * 64 + (bn == 128 ? 4 : 6) * bn * 64) * 2 + (bias ? (size_t)mm_cdiv(Cn, 512) * 512 * 4 : 0);
     int64_t grid = mm_cdiv(nitems, 8) * 8;  // a multiple of the 8 XCDs
     if (grid > 256) grid = 256;             // one resident 8-wave workgroup per CU
     static bool once_w = false;
     if (!once_w) {
-      const int mx = (2 * 384 * 64 + 3 * 128 * 64) * 2 + 4096;
+      const int mx = (2 * 344 * 64 + 4 * 128 * 64) * 2 + 4096;
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
@@ -1397,10 +1421,10 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
-    } else if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
-    else if (bn == 64) hipLaunchKernelGGL((k_conv3x3w<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
-    else if (tw == 16) hipLaunchKernelGGL((k_conv3x3w<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
-    else hipLaunchKernelGGL((k_conv3x3w<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+    } else if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv3x3w<64, 32>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
+    else if (tw == 16) hipLaunchKernelGGL((k_conv3x3w<128, 16>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
+    else hipLaunchKernelGGL((k_conv3x3w<128, 32>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
   }
   MM_LAUNCH_CHECK();
   return MM_OK;
