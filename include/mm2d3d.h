@@ -141,7 +141,7 @@ size_t mm_os_table_ws_bytes(int64_t n, int K);
  * Returns the previous setting. */
 int mm_os_table_set_sort(int merge);
 /* nbr[K][n] -> dst[npad] (rows sorted by neighbour bitmask, -1 = padding), nbrp[K][npad], tmask[nt];
- * nt = ceil(n / tile_rows), npad = nt * tile_rows, tile_rows in {64, 128, 256} */
+ * nt = ceil(n / tile_rows), npad = nt * tile_rows, tile_rows a multiple of 64 (the engine takes 64) */
 int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32_t* dst, int32_t* nbrp, uint32_t* tmask,
                       void* ws, size_t ws_bytes, mm_stream_t stream);
 /* three-term bf16 MFMA fragments of a weight tensor: element (k,ci,co) = W[kk*w_kstride + ci*s_ci + co*s_co],

@@ -65,10 +65,7 @@ OS_BUILD_UP = os.environ.get("MM_OS_UP", "0") != "0"
 
 
 def os_tile_rows(n):
-    """Rows per workgroup tile: large tiles amortise the staged weights, small levels need the workgroups."""
-    forced = os.environ.get("MM_OS_TILE")
-    if forced:
-        return int(forced)
+    """Rows per workgroup tile of the output-stationary engine (csrc/osconv.hip: four 16-row MFMA sub-blocks, one per wave)."""
     return 64
 
 
