@@ -106,13 +106,16 @@ def project_batch(points_img, depth_vals, labels, lengths, H, W, flips=None, wan
     return idx, depth, seg2d, err
 
 
-def prepare_batch(scenes, scale=20, full_scale=4096, augmentation=None, fliplr=0.0, want_seg2d=False, device="cuda"):
+def prepare_batch(scenes, scale=20, full_scale=4096, augmentation=None, fliplr=0.0, want_seg2d=False, device="cuda", use_rgb=True):
     """The reference's ``__getitem__`` (per scene) + ``collate_scn_base`` for a list of decoded scenes, on the GPU.
 
     Each scene: dict(points [n,3] f32 = the coordinates that are voxelised (camera or LiDAR frame, as the dataset is
     configured), points_img [n,2] (row, col) scaled to the network image, depth [n] = camera z, seg_label [n] int64,
     img [3,H,W] f32 already normalised and, when this scene's fliplr draw says so, NOT yet flipped).  RNG draws per
-    scene in the reference's order: fliplr ``rand()`` first (nuscenes_dataloader.py:291), then ``augment_and_scale_3d``'s.
+    scene in the reference's order: fliplr ``rand()`` first (nuscenes_dataloader.py:291), then ``augment_and_scale_3d``'s;
+    a scene that carries ``draws = (flip, rot, u)`` was drawn by the caller (datasets.gpu_batch draws scene by scene, between
+    each scene's crop draws, as the reference's ``__getitem__`` sequence does).  ``use_rgb=False``: the constant feature of
+    nuscenes_dataloader.py:365-368, ones [n, 1] with n = the scene's point count BEFORE the range mask (as in the reference).
     Returns the batch dict of lib/dataset/__init__.py:95-121 with every tensor on ``device`` (img_indices: list of
     device int64 [n_i,2]; use ``[t.cpu().numpy() for t in ...]`` where numpy arrays are required)."""
     L = _lib.lib()
@@ -121,9 +124,13 @@ def prepare_batch(scenes, scale=20, full_scale=4096, augmentation=None, fliplr=0
     B = len(scenes)
     lengths = [int(s["points"].shape[0]) for s in scenes]
     flips, rots, us = [], [], []
-    for _ in scenes:
-        flips.append(bool(np.random.rand() < fliplr))
-        r, u = augmentation_draws(**aug)
+    for sc in scenes:
+        if "draws" in sc:
+            f, r, u = sc["draws"]
+        else:
+            f = bool(np.random.rand() < fliplr)
+            r, u = augmentation_draws(**aug)
+        flips.append(bool(f))
         rots.append(r)
         us.append(u)
     cat = lambda key, dt: torch.from_numpy(np.ascontiguousarray(np.concatenate([np.asarray(s[key]) for s in scenes], 0).astype(dt))).to(dev)
@@ -140,13 +147,15 @@ def prepare_batch(scenes, scale=20, full_scale=4096, augmentation=None, fliplr=0
     kept = vox["locs"].shape[0]
     idx = torch.empty((kept, 2), dtype=torch.int64, device=dev)
     lab = torch.empty(kept, dtype=torch.int64, device=dev)
-    feats = torch.empty((kept, img.shape[1]), dtype=torch.float32, device=dev)
+    feats = torch.empty((kept, img.shape[1]), dtype=torch.float32, device=dev) if use_rgb else None
     pkept = torch.empty((kept, 3), dtype=torch.float32, device=dev)
     check(L.mm_collect_points(ptr(vox["keep"]), ptr(vox["counts_dev"][B:]), kept, ptr(vox["locs"]), ptr(idx_all), ptr(labels), ptr(img.contiguous()),
                               img.shape[1], H, W, ptr(pts), ptr(idx), ptr(lab), ptr(feats), ptr(pkept), stream()), "collect_points")
     if int(err.item()) != 0:
         raise AssertionError("projected point outside the image (nuscenes_dataloader.py:279-283)")
     bounds = np.concatenate([[0], np.cumsum(vox["counts"])])
+    if not use_rgb:
+        feats = torch.ones((int(sum(lengths)), 1), dtype=torch.float32, device=dev)
     out = {
         "x": [vox["locs"], feats],
         "seg_label": lab,

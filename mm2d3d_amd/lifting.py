@@ -35,32 +35,48 @@ def _staging(dev, n_int64):
 
 
 class PixelIndex:
-    """Batch-level index built from ``img_indices`` (list of numpy int64 [n_i, 2] = (row, col))."""
+    """Batch-level index built from ``img_indices``: a list of int64 [n_i, 2] = (row, col) per scene, either numpy arrays
+    (the reference's collate, lib/dataset/__init__.py:74,111) or tensors already on the device (the GPU data path,
+    mm2d3d_amd/dataprep.prepare_batch / datasets.gpu_batch).  Device tensors are concatenated on the device: no host copy,
+    no synchronisation; their bounds were checked by the kernel that produced them (``k_proj_index`` sets the batch's
+    error flag) and are checked again here on the device, reported through :meth:`check`."""
 
     def __init__(self, img_indices, H, W, device):
-        rows = [np.asarray(ix, dtype=np.int64).reshape(-1, 2) for ix in img_indices]
-        for ix in rows:  # the reference asserts these bounds in the loader (nuscenes_dataloader.py:280-283)
-            if len(ix) and (ix.min() < 0 or ix[:, 0].max() >= H or ix[:, 1].max() >= W):
-                raise IndexError("img_indices out of the image bounds")
-        counts = [len(ix) for ix in rows]
-        self.n = int(sum(counts))
-        self.H, self.W, self.device = H, W, device
-        rc = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int64)
-        # Host -> device from PINNED staging, asynchronously on the current stream: a copy from pageable memory makes the host
-        # wait until everything queued before it has run (measured: 12 ms per step inside this constructor when it was called
-        # at the end of the 2D forward).  The staging buffers are persistent (two per device, reused alternately once their last
-        # copy has completed): `Tensor.pin_memory()` registers fresh host pages on every call, 4.6-30 ms for the 9 MB of a
-        # 16-scene batch.  No copy stream: the step stays on ONE stream (the single-launch batch norms need that, fused_bn.h).
         dev = torch.device(device)
-        cur = torch.cuda.current_stream(dev)
-        nb = len(counts)
-        stage = _staging(dev, nb + 2 * self.n)
-        host = stage["buf"].numpy()
-        host[:nb] = counts
-        host[nb : nb + 2 * self.n] = rc.reshape(-1)
-        both = stage["buf"][: nb + 2 * self.n].to(dev, non_blocking=True)
-        stage["event"].record(cur)
-        cnt_d, rc_d = both[:nb], both[nb:].view(-1, 2)
+        self.H, self.W, self.device = H, W, device
+        self._bad = None
+        if len(img_indices) and all(isinstance(ix, torch.Tensor) and ix.is_cuda for ix in img_indices):
+            counts = [int(ix.shape[0]) for ix in img_indices]
+            self.n = int(sum(counts))
+            rc_d = torch.cat([ix.reshape(-1, 2) for ix in img_indices], 0).to(dev, torch.int64)
+            cnt_d = torch.tensor(counts, dtype=torch.int64).to(dev, non_blocking=True)
+            if self.n:
+                self._bad = ((rc_d < 0).any() | (rc_d[:, 0] >= H).any() | (rc_d[:, 1] >= W).any())
+                # whatever the caller passed, the gather / scatter kernels only ever see addresses inside the map
+                rc_d = torch.stack([rc_d[:, 0].clamp(0, H - 1), rc_d[:, 1].clamp(0, W - 1)], 1)
+            rows = img_indices
+        else:
+            rows = [np.asarray(ix.cpu() if isinstance(ix, torch.Tensor) else ix, dtype=np.int64).reshape(-1, 2) for ix in img_indices]
+            for ix in rows:  # the reference asserts these bounds in the loader (nuscenes_dataloader.py:280-283)
+                if len(ix) and (ix.min() < 0 or ix[:, 0].max() >= H or ix[:, 1].max() >= W):
+                    raise IndexError("img_indices out of the image bounds")
+            counts = [len(ix) for ix in rows]
+            self.n = int(sum(counts))
+            rc = np.concatenate(rows, 0) if rows else np.zeros((0, 2), np.int64)
+            # Host -> device from PINNED staging, asynchronously on the current stream: a copy from pageable memory makes the host
+            # wait until everything queued before it has run (measured: 12 ms per step inside this constructor when it was called
+            # at the end of the 2D forward).  The staging buffers are persistent (two per device, reused alternately once their last
+            # copy has completed): `Tensor.pin_memory()` registers fresh host pages on every call, 4.6-30 ms for the 9 MB of a
+            # 16-scene batch.  No copy stream: the step stays on ONE stream (the single-launch batch norms need that, fused_bn.h).
+            cur = torch.cuda.current_stream(dev)
+            nb = len(counts)
+            stage = _staging(dev, nb + 2 * self.n)
+            host = stage["buf"].numpy()
+            host[:nb] = counts
+            host[nb : nb + 2 * self.n] = rc.reshape(-1)
+            both = stage["buf"][: nb + 2 * self.n].to(dev, non_blocking=True)
+            stage["event"].record(cur)
+            cnt_d, rc_d = both[:nb], both[nb:].view(-1, 2)
         b = torch.repeat_interleave(torch.arange(len(rows), device=device), cnt_d, output_size=self.n)
         self.b, self.r, self.c = b, rc_d[:, 0], rc_d[:, 1]
         key = (b * H + self.r) * W + self.c                   # flat pixel id b*H*W + r*W + c
@@ -70,6 +86,11 @@ class PixelIndex:
             first[1:] = self.skey[1:] != self.skey[:-1]
         self.first = first.to(torch.uint8)
         self._cache = {}
+
+    def check(self):
+        """Raises IndexError if a device-side index was out of the image (one small read-back; call it off the hot path)."""
+        if self._bad is not None and bool(self._bad.item()):
+            raise IndexError("img_indices out of the image bounds")
 
     def offsets(self, sb, sy, sx, sorted_order=False):
         """Element offset of channel 0 of every point's pixel in a [B,C,H,W] map with strides (sb, *, sy, sx); with

@@ -9,8 +9,9 @@ per sample in the loader.  Image decoding / resizing (PIL) and colour jitter (to
 function takes the already decoded float image.  RNG draws happen in the reference's order (fliplr ``rand()`` first,
 then the draws of ``augment_and_scale_3d``), so a seeded run selects the same augmentations.
 
-The reference's dataset package cannot be imported in this image (pytorch_lightning absent), so this module is pinned
-by hand-computed cases (tests/test_projection.py), not by imported goldens.
+Pinned by fixtures generated from the reference's own dataset classes (tests/golden/make_golden_loaders.py imports
+lib.dataset over stand-ins for the absent pytorch_lightning / omegaconf / torchvision.transforms; tests/test_loader_golden.py)
+and by hand-computed cases (tests/test_projection.py).  The dataset classes of mm2d3d_amd/datasets.py call the pieces below.
 """
 from __future__ import annotations
 
@@ -40,7 +41,8 @@ def rasterise(points_img, depth_values, seg_label, H, W):
     depth = np.zeros((H, W))
     depth[img_indices[:, 0], img_indices[:, 1]] = depth_values
     seg2d = np.ones((H, W)) * (-100)
-    seg2d[img_indices[:, 0], img_indices[:, 1]] = seg_label
+    if seg_label is not None:
+        seg2d[img_indices[:, 0], img_indices[:, 1]] = seg_label
     return img_indices, depth, seg2d
 
 
