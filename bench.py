@@ -17,6 +17,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -173,7 +175,31 @@ def cpu_baseline():
             "seconds": round(sum(dts), 2)}
 
 
-def main():
+def launch_ranks(a, argv):
+    """``python bench.py --gpus N`` without a launcher around it (no WORLD_SIZE in the environment): start the N ranks as CHILD
+    processes through torch.distributed.run - one process per GPU, as the reference's Lightning DDP strategy spawns them
+    (run.py:262-268) - pass rank 0's JSON line through and exit with the children's status.  Nothing in this parent touches
+    the GPU before or after the spawn (``torch.cuda.device_count()`` does not initialise it on this image; is_available() /
+    set_device() would, and a process that has initialised the GPU must not start or become another GPU program here)."""
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < a.gpus and "MM_BENCH_BACKEND" not in env:
+        # fewer cards than ranks: a rehearsal with several ranks per card, which RCCL refuses - gradients go through gloo
+        print(f"[bench] {a.gpus} ranks on {n_dev} GPU(s): rehearsal over the gloo backend (MM_BENCH_BACKEND=gloo)", file=sys.stderr, flush=True)
+        env["MM_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as sock:  # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    res = subprocess.run(cmd, env=env)
+    raise SystemExit(res.returncode)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -183,14 +209,15 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes; "
                          "c5 = configs[4]: 10k-pt vKITTI-shaped source + KITTI-shaped target, 8/GPU, 16-bit sparse activations")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a, argv)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 as\n  python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {a.gpus} --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus {a.gpus} ...")
+        raise SystemExit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if world > max(torch.cuda.device_count(), 1):
@@ -201,6 +228,7 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  MM_BENCH_BACKEND=gloo is a rehearsal mode (several ranks sharing one GPU box).
@@ -251,10 +279,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    rank_ms = [dt / a.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(e.item()) / a.steps * 1e3 for e in every]
+        dt = max(float(e.item()) for e in every)  # the slowest rank sets the job's step time
     ms = dt / a.steps * 1e3
     out = {
         "metric": "LiDAR scenes/sec fwd+bwd (NuScenes ~35k pts, 5cm voxel)", "value": round(2 * B * world / (ms * 1e-3), 3),
@@ -268,6 +299,14 @@ def main():
                    "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)],
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
     }
+    if world > 1:
+        st = tm.reducer.stats
+        out["config"].update({
+            "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "rccl_ranks": world if backend == "nccl" else 0,
+            "ms_per_step_by_rank": [round(v, 3) for v in rank_ms],
+            "allreduce_bytes_per_step": st["bytes"], "allreduce_buckets_per_step": st["buckets"],
+            "buckets_launched_before_finish": st["early"],  # sent from backward hooks, i.e. overlapped with the rest of backward
+        })
     if a.workload == "c4":
         out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
     if a.workload == "c5":

@@ -179,6 +179,10 @@ int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int 
 /* Row sets that fit on chip take single-launch training kernels (fp32 rows; see mm_bn2d_set_fused for the rules):
  * mask bit 0 = mm_bn_fwd_train, bit 1 = mm_bn_bwd; default 3 or the environment's MM_BN_FUSED.  Returns the previous mask. */
 int mm_bn_set_fused(int mask);
+/* 1 if a single-launch kernel gave up at its grid barrier since the last call (its grid was not co-resident: another process or
+ * a spin-waiting kernel of another stream held CUs).  That launch's outputs are invalid; the kernels are switched off for the
+ * rest of the process (three-kernel path) and the barrier words re-armed.  A host-memory read when nothing happened. */
+int mm_bn_fused_fault(void);
 size_t mm_bn_ws_bytes(int C);
 /* Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step;
  * train.py:186-292 calls the net once per domain) are normalised with their OWN batch statistics and the running
@@ -289,6 +293,7 @@ size_t mm_bn2d_ws_bytes(int C);
  * reduce / finalize / apply kernels.  Returns the previous mask.  Use 0 when several PROCESSES share one GPU, and keep
  * bit 1 clear while collectives of another stream overlap the backward pass (see csrc/bn2d.hip). */
 int mm_bn2d_set_fused(int mask);
+int mm_bn2d_fused_fault(void); /* as mm_bn_fused_fault, for the BatchNorm2d kernels */
 /* Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source / target halves of a jointly
  * batched step; train.py:186-292 calls each net once per domain) and the running buffers are updated group 0 first,
  * then group 1, as two consecutive calls would.  Ns = N (or 0): ordinary single batch.  save_mean/save_invstd: [G][C]. */

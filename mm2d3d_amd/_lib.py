@@ -97,6 +97,8 @@ _PROTOS = {
     "mm_bn2d_ws_bytes": (sz, [i32]),
     "mm_bn2d_set_fused": (i32, [i32]),
     "mm_bn_set_fused": (i32, [i32]),
+    "mm_bn_fused_fault": (i32, []),
+    "mm_bn2d_fused_fault": (i32, []),
     "mm_bn2d_fwd_train": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
     "mm_bn2d_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),

@@ -314,11 +314,7 @@ struct Fused3P {
 };
 
 __device__ inline FusedBuf fused_buf32(const void* base, int64_t N, int ld, int C, int slot, int cv) {
-  FusedBuf b;
-  b.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((N - 1) * ld + C) * 4), 0x00020000);
-  b.voff = (unsigned)(slot * ld + cv * 4) * 4u;
-  b.ld2 = ld * 4;
-  return b;
+  return fused_buf_bytes(base, N, ld, C, slot, cv, 4, 4);
 }
 __device__ inline void unpack4(const u32x4 t, float (&v)[4]) {
   v[0] = __uint_as_float(t.x), v[1] = __uint_as_float(t.y), v[2] = __uint_as_float(t.z), v[3] = __uint_as_float(t.w);
@@ -731,6 +727,8 @@ extern "C" {
 
 // Single-launch training kernels of the fp32 row path: bit 0 = mm_bn_fwd_train, bit 1 = mm_bn_bwd (default 3, or the
 // environment variable MM_BN_FUSED); returns the previous mask.  Same residency rules as mm_bn2d_set_fused.
+int mm_bn_fused_fault(void) { return fused_fault_poll(); }
+
 int mm_bn_set_fused(int mask) {
   const int prev = fused_mask("MM_BN_FUSED");
   g_fused_enabled = mask & 3;

@@ -659,6 +659,8 @@ extern "C" {
 
 // Selects the single-launch training kernels per direction: bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd (default 3, or the
 // value of the environment variable MM_BN2D_FUSED); 0 = always the reduce / finalize / apply kernels.  Returns the previous mask.
+int mm_bn2d_fused_fault(void) { return fused_fault_poll(); }
+
 int mm_bn2d_set_fused(int mask) {
   const int prev = fused_mask("MM_BN2D_FUSED");
   g_fused_enabled = mask & 3;

@@ -21,8 +21,10 @@ namespace {
 //
 // Grid barrier: every workgroup must be resident at the same time, so the grid never exceeds the CU count and a
 // workgroup needs more than half of a CU's registers/LDS (one per CU).  Another PROCESS running the same kernel on the
-// same GPU can starve both grids: the wait is bounded (FUSED_TIMEOUT_TICKS of the 100 MHz wall clock) and ends in a
-// trap, i.e. a loud HIP error instead of a hang; MM_BN2D_FUSED=0 selects the three-kernel path for such set-ups.
+// same GPU can starve both grids: the wait is bounded (FUSED_TIMEOUT_TICKS of the 100 MHz wall clock); a barrier that runs
+// out of time raises a fault word in pinned host memory, releases the grid and lets the launch finish with invalid outputs
+// (no trap: the HIP context survives); the host polls the word (mm_bn_fused_fault / mm_bn2d_fused_fault; the trainer does it
+// every step and raises), which also switches the process to the three-kernel path.  MM_BN2D_FUSED=0 selects that path up front.
 // A kernel of another stream that holds LDS on some CUs makes the grid wait for it, and one that spin-waits across its own
 // workgroups (decoupled look-back scan / Onesweep sort, an RCCL collective) can DEADLOCK with it - each holds CUs the other's
 // missing workgroups need (tools/barrier_stress.py reproduces this with torch.cumsum on a second stream): the data-parallel trainer therefore takes the three-kernel path (ddp.py), and so do the directions that share the GPU
@@ -35,6 +37,11 @@ constexpr int FUSED_FLAG = 64;  // the release word sits 256 B after the arrival
 constexpr unsigned long long FUSED_TIMEOUT_TICKS = 1000000000ull;  // 10 s
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Where a grid barrier that ran out of time reports it: a word of pinned host memory (set once per device by fused_plan).
+// The launch then runs out with invalid outputs instead of killing the HIP context with a trap; the host polls the word
+// (mm_bn_fused_fault / mm_bn2d_fused_fault), switches the single-launch kernels off and re-arms the barrier words.
+__device__ unsigned* g_fused_fault_dev;
 
 
 __device__ inline double fused_wave_sum(double v) {
@@ -138,7 +145,12 @@ __device__ inline void fused_barrier(unsigned* sync, unsigned G, unsigned flag_o
       const unsigned long long t0 = wall_clock64();
       while (xcd_load(&sync[FUSED_FLAG]) == flag_old) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) __builtin_trap();  // the grid is not co-resident (see the header)
+        if (wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) {
+          // the grid is not co-resident (see the header): report it, release everybody, let the launch run out
+          if (g_fused_fault_dev) __hip_atomic_store(g_fused_fault_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          xcd_store(&sync[FUSED_FLAG], flag_old + 1u);
+          break;
+        }
       }
     }
   }
@@ -174,26 +186,41 @@ __device__ inline FusedGeom fused_geom(int64_t N, int64_t Ns, int CV, int G0, in
   return g;
 }
 
-// Buffer addressing: a resource descriptor per tensor (scalar registers, byte size = the rows the tensor really has), the
-// uniform row base as the scalar offset and one 32-bit per-thread offset; the hardware bounds check makes an out-of-range
-// visit return zeros (loads) or vanish (stores).
+// Buffer addressing: resource descriptors in scalar registers and one 32-bit per-thread offset per tensor; the hardware
+// bounds check makes an out-of-range visit return zeros (loads) or vanish (stores).
+// The hardware's range check covers the per-thread offset only, NOT a scalar offset (raw buffers), so the uniform row base
+// does not travel as the scalar offset: every access builds its descriptor AT the row base (scalar arithmetic: base + row *
+// pitch, bytes left from there), and the per-thread offset is then checked against exactly what is left of the tensor - a
+// visit past the last row returns zeros / is dropped whatever slab it belongs to, nothing is read beyond the allocation, and
+// no 32-bit product of a row beyond N is formed.
 struct FusedBuf {
-  __amdgpu_buffer_rsrc_t rsrc;
+  const char* base;
+  long long total;  // bytes from base to the end of the tensor's last row
   unsigned voff;
   int ld2;  // row pitch in bytes
 };
-__device__ inline FusedBuf fused_buf(const void* base, int64_t N, int ld, int C, int slot, int cv) {
+__device__ inline FusedBuf fused_buf_bytes(const void* base, int64_t N, int ld, int C, int slot, int cv, int esize, int vec) {
   FusedBuf b;
-  b.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((N - 1) * ld + C) * 2), 0x00020000);
-  b.voff = (unsigned)(slot * ld + cv * 8) * 2u;
-  b.ld2 = ld * 2;
+  b.base = (const char*)base;
+  b.total = ((N - 1) * (long long)ld + C) * esize;
+  b.voff = (unsigned)(slot * ld + cv * vec) * (unsigned)esize;
+  b.ld2 = ld * esize;
   return b;
 }
+__device__ inline FusedBuf fused_buf(const void* base, int64_t N, int ld, int C, int slot, int cv) {
+  return fused_buf_bytes(base, N, ld, C, slot, cv, 2, 8);
+}
+__device__ inline __amdgpu_buffer_rsrc_t fused_rsrc(const FusedBuf& b, int64_t row) {
+  const long long off = row * (long long)b.ld2;  // uniform
+  const long long left = b.total - off;
+  const bool in = left > 0;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(b.base + (in ? off : 0)), 0, in ? (int)left : 0, 0x00020000);
+}
 __device__ inline u32x4 fused_ld(const FusedBuf& b, int64_t row) {
-  return __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)b.voff, (int)row * b.ld2, 0);
+  return __builtin_amdgcn_raw_buffer_load_b128(fused_rsrc(b, row), (int)b.voff, 0, 0);
 }
 __device__ inline void fused_st(const FusedBuf& b, int64_t row, const u32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(v, b.rsrc, (int)b.voff, (int)row * b.ld2, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v, fused_rsrc(b, row), (int)b.voff, 0, 0);
 }
 
 }  // namespace
@@ -210,6 +237,8 @@ static unsigned* g_fused_sync[16];       // per device: 64 slots x 512 B (arriva
 static hipStream_t g_fused_stream[16][64];
 static int g_fused_nstream[16];
 static int g_fused_cus[16];
+static int g_fused_state[16];             // 0: not probed, 1: usable, -1: this device cannot run the single-launch kernels
+static unsigned* g_fused_fault_host;      // pinned, mapped: written by a kernel whose grid barrier timed out
 static int g_fused_enabled = -1;  // bit 0: forward, bit 1: backward; -1: take the environment variable (default 3) on first use
 
 static int fused_mask(const char* env) {
@@ -232,16 +261,37 @@ static int fused_plan(int64_t N, int64_t Ns, int C, int vec, int rmax, bool back
   MM_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) return MM_OK;
   std::lock_guard<std::mutex> lock(g_fused_mu);
-  if (!g_fused_sync[dev]) {
-    int cus = 0;
-    MM_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (g_fused_state[dev] == 0) {
+    // one probe per device; any failure marks the device "three-kernel path only" instead of failing every BN call
+    g_fused_state[dev] = -1;
+    int cus = 0, lds_max = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || (size_t)lds_max < FUSED_LDS) {
+      (void)hipGetLastError();
+      return MM_OK;
+    }
     void* q = nullptr;
-    MM_HIP(hipMalloc(&q, 64 * 512));
-    MM_HIP(hipMemset(q, 0, 64 * 512));
-    for (int i = 0; i < nfns; i++) MM_HIP(hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS));
-    g_fused_cus[dev] = cus;
+    bool good = hipMalloc(&q, 64 * 512) == hipSuccess && hipMemset(q, 0, 64 * 512) == hipSuccess;
+    for (int i = 0; good && i < nfns; i++)
+      good = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS) == hipSuccess;
+    if (good && !g_fused_fault_host) {
+      good = hipHostMalloc((void**)&g_fused_fault_host, 64, hipHostMallocMapped) == hipSuccess;
+      if (good) *g_fused_fault_host = 0;
+    }
+    unsigned* fault_dev = nullptr;
+    good = good && hipHostGetDevicePointer((void**)&fault_dev, g_fused_fault_host, 0) == hipSuccess &&
+           hipMemcpyToSymbol(HIP_SYMBOL(g_fused_fault_dev), &fault_dev, sizeof(fault_dev)) == hipSuccess;
+    if (!good) {
+      (void)hipGetLastError();
+      if (q) (void)hipFree(q);
+      return MM_OK;
+    }
+    // fused_wave_sums combines at most 4 x 64 workgroups per statistics group: never plan a wider grid than that
+    g_fused_cus[dev] = cus < 256 ? cus : 256;
     g_fused_sync[dev] = (unsigned*)q;
+    g_fused_state[dev] = 1;
   }
+  if (g_fused_state[dev] < 0) return MM_OK;
   int slot = -1;
   for (int i = 0; i < g_fused_nstream[dev]; i++)
     if (g_fused_stream[dev][i] == s) slot = i;
@@ -272,5 +322,25 @@ static int fused_plan(int64_t N, int64_t Ns, int C, int vec, int rmax, bool back
   pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;
   pl->sync = g_fused_sync[dev] + slot * 128;
   return MM_OK;
+}
+
+// 1 if a single-launch kernel of this translation unit gave up at its grid barrier since the last call (that launch's
+// outputs, and everything computed from them, are invalid).  The single-launch kernels are then switched off for the rest
+// of the process (three-kernel path) and the barrier words re-armed.  Costs one read of host memory when nothing happened.
+static int fused_fault_poll() {
+  if (!g_fused_fault_host || !__atomic_load_n(g_fused_fault_host, __ATOMIC_RELAXED)) return 0;
+  std::lock_guard<std::mutex> lock(g_fused_mu);
+  g_fused_enabled = 0;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int d = 0; d < 16; d++) {
+    if (!g_fused_sync[d]) continue;
+    (void)hipSetDevice(d);
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(g_fused_sync[d], 0, 64 * 512);
+  }
+  (void)hipSetDevice(cur);
+  __atomic_store_n(g_fused_fault_host, 0u, __ATOMIC_RELAXED);
+  return 1;
 }
 

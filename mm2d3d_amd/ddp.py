@@ -36,9 +36,17 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, optimizers, process_group=None, bucket_bytes=64 << 20, overlap=True, tail_bytes=8 << 20):
+    def __init__(self, optimizers, process_group=None, bucket_bytes=64 << 20, overlap=True, tail_bytes=8 << 20, force=None):
+        """``force`` (default: MM_DDP_FORCE=1 in the environment): run the whole bucket / hook / collective machinery also in a
+        world of ONE rank - the only way to execute the RCCL path on a one-GPU box (a one-rank all-reduce is still an RCCL
+        launch on RCCL's stream beside the backward pass)."""
+        import os
+
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if force is None:
+            force = os.environ.get("MM_DDP_FORCE", "0") != "0"
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.overlap = overlap
         self.buckets = []  # as built: per arena, reverse parameter order
         self.order = []  # launch order (learned in the first step)
@@ -50,7 +58,11 @@ class GradAllReducer:
         self._late = []
         self._tick = 0
         self._arenas = []
-        if self.world == 1:
+        self._in_finish = False
+        self._flag = None
+        self.stats = {"bytes": 0, "buckets": 0, "early": 0}  # of the last finished step
+        self._step_stats = {"bytes": 0, "buckets": 0, "early": 0}
+        if not self.active:
             return
         if overlap and torch.cuda.is_available():
             # The single-launch batch-norm kernels (csrc/bn2d.hip, csrc/bn.hip) need every CU at once; a collective that runs
@@ -98,7 +110,7 @@ class GradAllReducer:
     # ------------------------------------------------------------------ parameter sync (torch DDP does it when wrapping)
     def sync_parameters(self, src=0):
         """Rank ``src``'s weights win: one broadcast per flat parameter arena (DDP's constructor-time broadcast)."""
-        if self.world == 1:
+        if not self.active:
             return
         for a in self._arenas:
             dist.broadcast(a["p"], src=src, group=self.group)
@@ -110,6 +122,10 @@ class GradAllReducer:
     def _send(self, b):
         b.work = dist.all_reduce(b.arena[b.lo : b.hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         b.launched = True
+        st = self._step_stats
+        st["bytes"] += (b.hi - b.lo) * 4
+        st["buckets"] += 1
+        st["early"] += 0 if self._in_finish else 1
 
     def _launch_ready(self):
         for b in self.order:  # strict order: a bucket goes out only after every earlier one of the learned order
@@ -163,9 +179,16 @@ class GradAllReducer:
 
     def finish(self):
         """Call after backward: launches what is left, waits, resets the countdowns."""
-        if self.world == 1:
+        if not self.active:
             return
-        late = self._late
+        self._in_finish = True
+        # "a parameter learned as unused received a gradient" is a LOCAL observation (a data-dependent branch may take it on
+        # some ranks only).  The decision to re-learn must be collective, or the ranks' collective sequences diverge in the
+        # next step (ADVICE r2): one int goes out with the buckets, MAX over the ranks.
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=self.buckets[0].arena.device)
+        self._flag.fill_(1 if self._late else 0)
+        flag_work = dist.all_reduce(self._flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         if not self.learned:
             # learning step: nothing was launched during backward; send every bucket in build order (the same on all ranks)
             for b in self.buckets:
@@ -177,24 +200,30 @@ class GradAllReducer:
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
+        flag_work.wait()
+        late_anywhere = bool(int(self._flag.item()))
+        n_late = len(self._late)
         if not self.learned:
             self._learn()
         for b in self.buckets:
             b.pending, b.launched, b.work, b.done_at = b.n_used, False, None, -1
         self._fired, self._late, self._tick = set(), [], 0
-        if late:
+        self.stats, self._step_stats = self._step_stats, {"bytes": 0, "buckets": 0, "early": 0}
+        self._in_finish = False
+        if late_anywhere:  # every rank takes this branch together: all re-learn in the next step, all raise now
             self.learned, self.unused = False, set()
             for b in self.buckets:
                 b.n_used = b.pending = len(b.params)
             self.order = list(self.buckets)
             raise RuntimeError(
-                f"GradAllReducer: {len(late)} parameter(s) learned as unused received a gradient (the graph changed); "
-                "this step's gradients are not reduced correctly - the next step re-learns the unused set")
+                f"GradAllReducer: a parameter learned as unused received a gradient on some rank ({n_late} on this one; the graph "
+                "changed); this step's gradients are not reduced correctly on any rank - skip the optimiser step everywhere; the next "
+                "step re-learns the unused set")
 
     def broadcast_buffers(self, modules, src=0):
         """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a
         dtype travel in ONE coalesced broadcast (≈0.15 MB), as DDP does."""
-        if self.world == 1:
+        if not self.active:
             return
         by_dtype = {}
         for m in modules:

@@ -12,7 +12,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import domains
+from . import _lib, domains
 from .ddp import GradAllReducer
 from .losses import Loss, cross_modal_loss
 from .metrics import SegIoU
@@ -254,9 +254,14 @@ class TrainModel(nn.Module):
     def fit_step(self, batch):
         if not self.optimizers:
             self.configure_optimizers()
+        L = _lib.lib()
+        if L.mm_bn2d_fused_fault() | L.mm_bn_fused_fault():  # a read of pinned host memory; set by a kernel of an EARLIER step
+            raise RuntimeError("a single-launch batch-norm kernel of an earlier step gave up at its grid barrier (its grid shared the GPU "
+                               "with another process or a spin-waiting kernel): that step's results are invalid - restore the last "
+                               "checkpoint; the process now uses the three-kernel batch norms")
         for o in self.optimizers:
             o.zero_grad()
-        if self.broadcast_buffers and self.reducer.world > 1:
+        if self.broadcast_buffers and self.reducer.active:
             self.reducer.broadcast_buffers(self.model.values())  # DDP syncs module buffers from rank 0 before each forward
         loss = self.training_step(batch, self.global_step)
         loss.backward()

@@ -38,6 +38,37 @@ import torch.nn.functional as F
 
 KEY_BITS = 16  # per coordinate; batch index takes the top 16 bits
 
+# 16-bit activation emulation (BASELINE.json configs[4]; the reference's SparseConvNet is fp32-only, so this mode has no
+# reference behaviour - it emulates WHERE the HIP path of mm2d3d_amd/scn stores 16-bit values, so that a test against it
+# measures accumulation order, not the storage format): None = plain fp32; torch.bfloat16 / torch.float16 = every sparse
+# row between the stem's output and the OutputLayer is rounded to that type when it is stored (conv outputs, batch-norm
+# outputs; gradients on the way back through the same points), the 16-channel-multiple convolutions multiply weights
+# rounded to that type (fp32 master weights keep the gradient), all sums and the batch-norm statistics stay fp32.
+EMULATE16 = [None]
+
+
+class _Round16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def _q(x):
+    dt = EMULATE16[0]
+    return x if dt is None else _Round16.apply(x, dt)
+
+
+def _qw(w, wide):
+    dt = EMULATE16[0]
+    if dt is None or not wide:
+        return w
+    return w + (w.detach().to(dt).to(w.dtype) - w.detach())  # rounded value forward, identity gradient to the fp32 master
+
 
 def pack_keys(coords: np.ndarray) -> np.ndarray:
     """(x, y, z, b) int64 rows -> one uint64 key per row; requires 0 <= c < 2**16."""
@@ -281,10 +312,11 @@ class SubmanifoldConvolution(nn.Module):
 
     def forward(self, x):
         rb = subm_rulebook(x.level)
-        f = rule_conv(x.features, self.weight[:, 0], rb, x.level.n)
+        wide = self.nIn % 16 == 0 and self.nOut % 16 == 0  # the 3-channel stem multiplies in fp32, its OUTPUT enters the 16-bit region
+        f = rule_conv(_q(x.features) if wide else x.features, _qw(self.weight[:, 0], wide), rb, x.level.n)
         if hasattr(self, "bias"):
             f = f + self.bias
-        return _carry(x, f)
+        return _carry(x, _q(f))
 
 
 class Convolution(nn.Module):
@@ -299,10 +331,10 @@ class Convolution(nn.Module):
 
     def forward(self, x):
         rb, coarse = down_rulebook(x.level)
-        f = rule_conv(x.features, self.weight[:, 0], rb, coarse.n)
+        f = rule_conv(x.features, _qw(self.weight[:, 0], True), rb, coarse.n)
         if hasattr(self, "bias"):
             f = f + self.bias
-        t = _carry(x, f, coarse)
+        t = _carry(x, _q(f), coarse)
         coarse.parent_fine = x.level
         return t
 
@@ -321,10 +353,10 @@ class Deconvolution(nn.Module):
         fine = x.level.parent_fine  # reuse the Convolution rulebook, roles swapped
         rb, coarse = down_rulebook(fine)
         assert coarse is x.level
-        f = rule_conv(x.features, self.weight[:, 0], rb, fine.n, transpose_roles=True)
+        f = rule_conv(x.features, _qw(self.weight[:, 0], True), rb, fine.n, transpose_roles=True)
         if hasattr(self, "bias"):
             f = f + self.bias
-        return _carry(x, f, fine)
+        return _carry(x, _q(f), fine)
 
 
 class BatchNormalization(nn.Module):
@@ -346,7 +378,7 @@ class BatchNormalization(nn.Module):
         )
         if self.leakiness != 1:
             y = F.leaky_relu(y, self.leakiness) if self.leakiness != 0 else F.relu(y)
-        return _carry(x, y)
+        return _carry(x, _q(y))
 
 
 class BatchNormReLU(BatchNormalization):

@@ -87,6 +87,29 @@ def _worker(rank, world, port, overlap, q):
         (net(x) ** 2).sum().backward()
         red.finish()
         assert red.learned
+        assert red.stats["buckets"] == len(red.buckets) and red.stats["early"] == 0  # a learning step launches in finish()
+        # ... and on ONE rank only (a data-dependent branch): the decision is collective - every rank raises and every rank
+        # re-learns in the next step, so the ranks' collective sequences cannot diverge
+        opt.zero_grad()
+        (net(x) ** 2).sum().backward()
+        if rank == 1:
+            unused(torch.randn(2, 4)).sum().backward()
+        try:
+            red.finish()
+            raise AssertionError(f"rank {rank}: a late gradient on rank 1 was not reported on this rank")
+        except RuntimeError as e:
+            assert "unused" in str(e)
+        assert not red.learned
+        opt.zero_grad()
+        (net(x) ** 2).sum().backward()
+        red.finish()
+        assert red.learned and red.consistent
+        opt.zero_grad()
+        (net(x) ** 2).sum().backward()
+        red.finish()
+        used_bytes = sum((b.hi - b.lo) * 4 for b in red.order)
+        assert red.stats["bytes"] == used_bytes and red.stats["buckets"] == len(red.order)
+        assert red.stats["early"] == (len(red.order) if overlap else 0)
         # sync_parameters: rank 0's weights win (torch DDP's constructor broadcast)
         with torch.no_grad():
             for a in opt._arenas:

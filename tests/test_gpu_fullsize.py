@@ -252,6 +252,64 @@ def test_full_joint_step_at_bench_size(workload):
         assert torch.equal(n3.linear.weight.grad, g1)
 
 
+def test_full_joint_step_at_bench_size_c5_16bit_rows():
+    """BASELINE.json configs[4] at its bench size: 8 source scans downsampled to 10,000 points + 8 KITTI-shaped target scans
+    (121,600 points), 480x302, sparse rows stored in 16 bits (`bench.py --workload c5`).  The joint [source | target] pass
+    must give the losses of the literal two-call sequence; the step is repeatable bit for bit; three optimiser steps on the
+    fixed batch lower the loss and stay finite."""
+    import copy
+
+    from mm2d3d_amd import scn
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = _dev()
+    torch.manual_seed(0)
+    scn.set_activation_dtype(torch.bfloat16)
+    try:
+        kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+        n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+        for m in n2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+        src = make_batch(6, 8, "kitti", (302, 480), 6, device=dev, augment=True, downsample=10000)
+        trg = make_batch(7, 8, "kitti", (302, 480), 6, device=dev, augment=True)
+        assert src["x"][0].shape[0] <= 80000 and trg["x"][0].shape[0] > 900000
+
+        def mk():
+            f = lambda b: dict(b, x=[b["x"][0], b["x"][1].clone()])
+            return {"source": f(src), "target": f(trg)}
+
+        loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
+        tk = dict(lambda_xm_src=0.1, lambda_xm_trg=0.01)  # the vKITTI experiment's weights (config.yaml:107-108)
+        opts = {}
+        for k in ("2d_net", "3d_net"):
+            o = Optimizer("adamw", lr=0.001)
+            o.set_scheduler("one_cycle", max_lr=0.005, total_steps=1000)
+            opts[k] = o
+        one = TrainModel({"2d_net": n2, "3d_net": n3}, opts, loss, dict(tk, gc_freeze=False))
+        two = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(tk, joint_domains=False))
+        t1 = one.training_step(mk())
+        logs1 = {k: float(v) for k, v in one.last_logs.items()}
+        t2 = two.training_step(mk())
+        logs2 = {k: float(v) for k, v in two.last_logs.items()}
+        assert len(logs1) == 6 and all(np.isfinite(v) for v in logs1.values())
+        for k, v in logs2.items():
+            assert abs(logs1[k] - v) <= 3e-3 * max(1.0, abs(v)), (k, logs1[k], v)  # 16-bit rows / bf16 2D logits on both sides
+        t3 = one.training_step(mk())
+        assert float(t3) == float(t1), "the 16-bit step is not repeatable"
+        del t1, t2, t3, two
+        losses = [float(one.fit_step(mk())) for _ in range(4)]
+        assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+    finally:
+        scn.set_activation_dtype(torch.float32)
+
+
 def test_mid_level_sparse_conv_at_kitti_size_vs_oracle():
     """SubmanifoldConvolution 48 -> 48 on level 2 of one KITTI-shaped scan (121,600 points): the HIP engines against the
     CPU oracle's rule-book convolution (forward, data gradient, weight gradient) on the scan's own level-2 active set."""

@@ -1,0 +1,78 @@
+"""The RCCL path of the data-parallel trainer, executed on the one GPU a test box has: a process group of ONE rank over the
+"nccl" (= RCCL) backend with the reducer forced on (mm2d3d_amd/ddp.py ``force``).  Every bucket is all-reduced by RCCL on
+RCCL's stream, launched from the backward hooks beside the rest of backward - the launch / wait / stream-ordering machinery is
+the real one; what a single card cannot show is the xGMI transfer itself (covered by logic on gloo, tests/test_ddp_gloo.py)."""
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_forced_one_rank_rccl_step_equals_the_plain_step_bit_for_bit(monkeypatch):
+    import copy
+
+    from mm2d3d_amd import _lib
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    prev2, prev3 = L.mm_bn2d_set_fused(0), L.mm_bn_set_fused(0)  # both runs on the three-kernel batch norms (what DDP selects)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(0)
+        kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+        n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+        for m in n2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+
+        def opts():
+            out = {}
+            for k in ("2d_net", "3d_net"):
+                o = Optimizer("adamw", lr=0.001)
+                o.set_scheduler("one_cycle", max_lr=0.005, total_steps=100)
+                out[k] = o
+            return out
+
+        mk = lambda: {"source": make_batch(5, 2, "nuscenes", (96, 128), device=dev), "target": make_batch(6, 2, "nuscenes", (96, 128), device=dev)}
+        loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
+        tk = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False)
+        monkeypatch.setenv("MM_DDP_FORCE", "1")
+        ddp = TrainModel({"2d_net": n2, "3d_net": n3}, opts(), loss, dict(tk))
+        ddp.configure_optimizers()
+        monkeypatch.setenv("MM_DDP_FORCE", "0")
+        plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, opts(), loss, dict(tk))
+        plain.configure_optimizers()
+        assert ddp.reducer.active and len(ddp.reducer.buckets) >= 2 and not plain.reducer.active
+        for step in range(4):
+            la, lb = ddp.fit_step(mk()), plain.fit_step(mk())
+            torch.cuda.synchronize()
+            assert float(la) == float(lb), (step, float(la), float(lb))
+            st = ddp.reducer.stats
+            assert st["buckets"] == len(ddp.reducer.order) or step == 0
+            if step >= 1:  # from the second step on every bucket goes out DURING backward
+                assert st["early"] == st["buckets"] > 0, st
+        assert ddp.reducer.learned and ddp.reducer.consistent and len(ddp.reducer.unused) > 0
+        for a, b in zip(ddp.optimizers, plain.optimizers):
+            for x, y in zip(a._arenas, b._arenas):
+                if x is not None:
+                    assert torch.equal(x["p"], y["p"]), "parameters after 4 optimiser steps differ"
+    finally:
+        dist.destroy_process_group()
+        L.mm_bn2d_set_fused(prev2)
+        L.mm_bn_set_fused(prev3)
