@@ -346,8 +346,7 @@ __global__ __launch_bounds__(FT) void k_bn_fused_fwd(const Fused3P p) {
 #pragma unroll
   for (int k = 0; k < RMAX; k++) {
     const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
-    u32x4 t = fused_ld(bx, g.r0 + (int64_t)k * g.rs);
-    if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+    const u32x4 t = fused_ld(bx, g.r0 + (int64_t)k * g.rs, ok);  // zeros where !ok
     if (k < FUSED_NL) rows[k * FT + tid] = t;
     else xr[k < FUSED_NL ? 0 : k - FUSED_NL] = t;
     float xv[4];
@@ -459,8 +458,8 @@ __global__ __launch_bounds__(FT) void k_bn_fused_bwd(const Fused3P p) {
   for (int k = 0; k < RMAX; k++) {
     const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
     const int64_t row = g.r0 + (int64_t)k * g.rs;
-    const u32x4 tx = fused_ld(bx, row);
-    const u32x4 td = fused_ld(bd, row);
+    const u32x4 tx = fused_ld(bx, row, ok);
+    const u32x4 td = fused_ld(bd, row, ok);
     float xv[4], dv[4], gv[4];
     unpack4(tx, xv);
     unpack4(td, dv);
@@ -521,7 +520,8 @@ __global__ __launch_bounds__(FT) void k_bn_fused_bwd(const Fused3P p) {
       u32x4 d1[4];
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        if (k0 + j >= FUSED_NL) d1[j] = fused_ld(bd, g.r0 + (int64_t)(k0 + j) * g.rs);  // rows beyond the LDS budget: dy again
+        if (k0 + j >= FUSED_NL)  // rows beyond the LDS budget: dy again
+          d1[j] = fused_ld(bd, g.r0 + (int64_t)(k0 + j) * g.rs, g.active && k0 + j < p.R && g.slot + (k0 + j) * g.rs < g.nrows);
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int k = k0 + j;

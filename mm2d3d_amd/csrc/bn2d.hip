@@ -372,8 +372,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
 #pragma unroll
   for (int k = 0; k < RMAX; k++) {
     const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
-    u32x4 t = fused_ld(bx, g.r0 + (int64_t)k * g.rs);
-    if (!ok) t = (u32x4){0u, 0u, 0u, 0u};
+    const u32x4 t = fused_ld(bx, g.r0 + (int64_t)k * g.rs, ok);  // zeros where !ok
     if (k < FUSED_NL) rows[k * FT + tid] = t;
     else xr[k < FUSED_NL ? 0 : k - FUSED_NL] = t;
     float xv[8];
@@ -442,7 +441,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
       if (RES) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-          rv[j] = fused_ld(br, g.r0 + (int64_t)(k0 + j) * g.rs);
+          rv[j] = fused_ld(br, g.r0 + (int64_t)(k0 + j) * g.rs, g.active && k0 + j < p.R && g.slot + (k0 + j) * g.rs < g.nrows);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
@@ -512,19 +511,18 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
     for (int k = 0; k < RMAX; k++) {
       const bool ok = g.active && k < p.R && g.slot + k * g.rs < g.nrows;
       const int64_t row = g.r0 + (int64_t)k * g.rs;
-      const u32x4 tx = fused_ld(bx, row);
-      u32x4 td = fused_ld(bd, row);
-      if (!ok) td = (u32x4){0u, 0u, 0u, 0u};
+      const u32x4 tx = fused_ld(bx, row, ok);
+      const u32x4 td = fused_ld(bd, row, ok);  // zeros where !ok
       float xv[8], dv[8], yv[8];
       unpack8(tx, xv);
       unpack8(td, dv);
       if (DY2) {
         float d2[8];
-        unpack8(fused_ld(bd2, row), d2);
+        unpack8(fused_ld(bd2, row, ok), d2);
 #pragma unroll
         for (int i = 0; i < 8; i++) dv[i] = ok ? dv[i] + d2[i] : 0.f;
       }
-      if (MASK == 2) unpack8(fused_ld(byo, row), yv);
+      if (MASK == 2) unpack8(fused_ld(byo, row, ok), yv);
       unsigned m8 = 0u;
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -594,8 +592,9 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
       u32x4 d2[4], d1[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        if (DY2) d2[j] = fused_ld(bd2, g.r0 + (int64_t)(k0 + j) * g.rs);
-        if (k0 + j >= FUSED_NL) d1[j] = fused_ld(bd, g.r0 + (int64_t)(k0 + j) * g.rs);
+        const bool okj = g.active && k0 + j < p.R && g.slot + (k0 + j) * g.rs < g.nrows;
+        if (DY2) d2[j] = fused_ld(bd2, g.r0 + (int64_t)(k0 + j) * g.rs, okj);
+        if (k0 + j >= FUSED_NL) d1[j] = fused_ld(bd, g.r0 + (int64_t)(k0 + j) * g.rs, okj);
       }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
