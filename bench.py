@@ -92,14 +92,26 @@ def conv_roofline(tm, batch, dev):
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     # PMC bytes per step: an OFFLINE rocprofv3 --pmc measurement of this workload (separate FETCH_SIZE / WRITE_SIZE passes,
     # tools/pmc_traffic.py), taken from the newest profiles/rNN/traffic_3d.json whose algorithmic byte count matches this run's
+    # and whose fingerprint of the engine sources (csrc/{spconv,osconv,ostable}.hip) is THIS tree's: a record taken on other
+    # kernels is refused (traffic = null) rather than reported
     traffic, traffic_source = None, None
     import glob
+    import hashlib
 
+    h = hashlib.sha256()
+    for f in ("spconv.hip", "osconv.hip", "ostable.hip"):
+        h.update(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f), "rb").read())
+    fingerprint = h.hexdigest()
     for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic_3d.json")), reverse=True):
         trec = json.load(open(tpath))
+        if trec.get("engine_sources_sha256") != fingerprint:
+            traffic_source = (f"none: {os.path.relpath(tpath, ROOT)} was taken on other engine sources (git {trec.get('git')}); "
+                              "re-run tools/pmc_traffic.py")
+            continue
         if abs(alg_bytes / float(trec.get("algorithmic_bytes_per_step", 1)) - 1.0) < 0.02:
             traffic = trec["bytes_per_step"]
-            traffic_source = "offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, " + os.path.relpath(tpath, ROOT)
+            traffic_source = (f"offline rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE (separate passes), {os.path.relpath(tpath, ROOT)}, "
+                              f"taken at git {trec.get('git')} on these engine sources (sha256 {fingerprint[:12]})")
             break
     if os.environ.get("MM_BENCH_LAYERS"):
         for r in rec[: len(rec) // 2 if os.environ["MM_BENCH_LAYERS"] == "half" else len(rec)]:
@@ -169,10 +181,25 @@ def cpu_baseline():
         if i:
             dts.append(time.perf_counter() - t0)
     dt = sorted(dts)[len(dts) // 2]
+    # one scene, forward only, both networks (plumbing configuration, configs[0])
+    from oracle.net2d_ref import net2d_forward
+
+    one = make_batch(1, 1, "nuscenes", (302, 480))
+    c1 = []
+    with torch.no_grad():
+        for i in range(3):
+            t0 = time.perf_counter()
+            net2d_forward(sd, one, training=False)
+            net3d({"x": [one["x"][0], one["x"][1].clone()]})
+            if i:
+                c1.append(time.perf_counter() - t0)
     return {"value": round(2 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
-            "sample": "CPU oracle (torch-CPU 2D + oracle sparse ops), 1 source + 1 target NuScenes-shaped scene at 480x302, "
-                      "fwd+bwd of the full two-domain step (no optimiser step), median of 4 passes after 1 warm-up",
-            "seconds": round(sum(dts), 2)}
+            "sample": "CPU oracle (torch-CPU 2D + oracle sparse ops): 1 source + 1 target NuScenes-shaped scene at 480x302 = 1/8 of the "
+                      "C2 batch (8 + 8; the full batch needs ~18 GB of autograd state and ~20 s per pass on the host), fwd+bwd of the "
+                      "full two-domain step (no optimiser step), median of 4 passes after 1 warm-up; c1_fwd_only = BASELINE.md C1 "
+                      "(one scene, forward only, both networks, eval mode), best of 2 after 1 warm-up",
+            "c1_fwd_only_scenes_per_s": round(1.0 / min(c1), 4),
+            "seconds": round(sum(dts) + sum(c1), 2)}
 
 
 def launch_ranks(a, argv):

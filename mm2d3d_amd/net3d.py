@@ -58,17 +58,25 @@ def UNet(dimension, reps, nPlanes, residual_blocks=False, downsample=(2, 2), lea
 
 
 class UNetSCN(nn.Module):
-    def __init__(self, in_channels=1, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7):
+    def __init__(self, in_channels=1, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7, bn_momentum=None):
+        """``bn_momentum`` (not in the reference): keep-fraction of the batch-norm running statistics for every layer of this
+        net, see scn.DEFAULT_BN_MOMENTUM (0.9 per SURVEY.md A.5; 0.99 is the other reading of the un-vendored dependency)."""
         super().__init__()
         self.in_channels = in_channels
         self.out_channels = m
         n_planes = [(n + 1) * m for n in range(num_planes)]
-        self.layer1 = scn.InputLayer(DIMENSION, full_scale, mode=4)
-        self.layer1.prebuild_levels = num_planes
-        self.layer2 = scn.SubmanifoldConvolution(DIMENSION, in_channels, m, 3, False)
-        self.layer3 = UNet(DIMENSION, block_reps, n_planes, residual_blocks)
-        self.layer4 = scn.BatchNormReLU(m)
-        self.layer5 = scn.OutputLayer(DIMENSION)
+        prev = scn.DEFAULT_BN_MOMENTUM[0]
+        if bn_momentum is not None:
+            scn.set_default_bn_momentum(bn_momentum)
+        try:
+            self.layer1 = scn.InputLayer(DIMENSION, full_scale, mode=4)
+            self.layer1.prebuild_levels = num_planes
+            self.layer2 = scn.SubmanifoldConvolution(DIMENSION, in_channels, m, 3, False)
+            self.layer3 = UNet(DIMENSION, block_reps, n_planes, residual_blocks)
+            self.layer4 = scn.BatchNormReLU(m)
+            self.layer5 = scn.OutputLayer(DIMENSION)
+        finally:
+            scn.set_default_bn_momentum(prev)
 
     def forward(self, x):
         x = self.layer1(x)

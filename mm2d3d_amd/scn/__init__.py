@@ -286,11 +286,26 @@ class Deconvolution(_ConvBase):
         return f"Deconvolution {self.nIn}->{self.nOut} C2/2"
 
 
-class BatchNormalization(nn.Module):
-    """eps 1e-4, momentum 0.9 = keep fraction of the running stats; leakiness 1 = no activation."""
+# Keep-fraction of the running statistics used when a batch-norm layer is built without an explicit ``momentum``.
+# OPEN QUESTION of the SparseConvNet boundary (the dependency is not in the image): SURVEY.md A.5 states 0.9 (what the
+# dependency's docstring says); three independent recollections of the pinned commit's constructor say ``momentum=0.99``.
+# It affects only the running statistics, i.e. eval-mode outputs after training - not the training step.  The default stays
+# at the survey's 0.9; ``set_default_bn_momentum(0.99)`` (or ``backbone_3d_kwargs["bn_momentum"]``) selects the other reading
+# for every layer built afterwards, also for the reference's own scn_unet.py running over this module.
+DEFAULT_BN_MOMENTUM = [0.9]
 
-    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1):
+
+def set_default_bn_momentum(value):
+    DEFAULT_BN_MOMENTUM[0] = float(value)
+
+
+class BatchNormalization(nn.Module):
+    """eps 1e-4, momentum = keep fraction of the running stats (None: DEFAULT_BN_MOMENTUM); leakiness 1 = no
+    activation."""
+
+    def __init__(self, nPlanes, eps=1e-4, momentum=None, affine=True, leakiness=1):
         super().__init__()
+        momentum = DEFAULT_BN_MOMENTUM[0] if momentum is None else momentum
         self.nPlanes, self.eps, self.momentum, self.leakiness = nPlanes, eps, momentum, leakiness
         self.register_buffer("running_mean", torch.zeros(nPlanes))
         self.register_buffer("running_var", torch.ones(nPlanes))
@@ -319,12 +334,12 @@ class BatchNormalization(nn.Module):
 
 
 class BatchNormReLU(BatchNormalization):
-    def __init__(self, nPlanes, eps=1e-4, momentum=0.9):
+    def __init__(self, nPlanes, eps=1e-4, momentum=None):
         super().__init__(nPlanes, eps, momentum, True, 0)
 
 
 class BatchNormLeakyReLU(BatchNormalization):
-    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333):
+    def __init__(self, nPlanes, eps=1e-4, momentum=None, leakiness=0.333):
         super().__init__(nPlanes, eps, momentum, True, leakiness)
 
 

@@ -359,9 +359,13 @@ class Deconvolution(nn.Module):
         return _carry(x, _q(f), fine)
 
 
+DEFAULT_BN_MOMENTUM = [0.9]  # SURVEY A.5; the other reading of the un-vendored dependency is 0.99 (see mm2d3d_amd/scn)
+
+
 class BatchNormalization(nn.Module):
-    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, affine=True, leakiness=1):
+    def __init__(self, nPlanes, eps=1e-4, momentum=None, affine=True, leakiness=1):
         super().__init__()
+        momentum = DEFAULT_BN_MOMENTUM[0] if momentum is None else momentum
         self.nPlanes, self.eps, self.momentum, self.leakiness = nPlanes, eps, momentum, leakiness
         self.register_buffer("running_mean", torch.zeros(nPlanes))
         self.register_buffer("running_var", torch.ones(nPlanes))
@@ -382,12 +386,12 @@ class BatchNormalization(nn.Module):
 
 
 class BatchNormReLU(BatchNormalization):
-    def __init__(self, nPlanes, eps=1e-4, momentum=0.9):
+    def __init__(self, nPlanes, eps=1e-4, momentum=None):
         super().__init__(nPlanes, eps, momentum, True, 0)
 
 
 class BatchNormLeakyReLU(BatchNormalization):
-    def __init__(self, nPlanes, eps=1e-4, momentum=0.9, leakiness=0.333):
+    def __init__(self, nPlanes, eps=1e-4, momentum=None, leakiness=0.333):
         super().__init__(nPlanes, eps, momentum, True, leakiness)
 
 

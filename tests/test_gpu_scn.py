@@ -147,14 +147,16 @@ def test_conv_ops_forward_backward(cin, cout, engine):
         _close(b.weight.grad, a.weight.grad, what=f"dW {name}")
 
 
+@pytest.mark.parametrize("momentum", [0.9, 0.99])
 @pytest.mark.parametrize("C,leak", [(16, 0.0), (48, 0.333), (7, 0.0), (224, 0.0)])
-def test_batchnorm_forward_backward_running_stats(C, leak):
+def test_batchnorm_forward_backward_running_stats(C, leak, momentum):
     from mm2d3d_amd import scn
 
     dev = _dev()
     torch.manual_seed(C)
     x = torch.randn(3001, C) * 2 + 0.5
-    r, h = scn_ref.BatchNormLeakyReLU(C, leakiness=leak), scn.BatchNormLeakyReLU(C, leakiness=leak)
+    # both readings of the un-vendored dependency's running-statistics constant (scn.DEFAULT_BN_MOMENTUM): keep 0.9 / keep 0.99
+    r, h = scn_ref.BatchNormLeakyReLU(C, leakiness=leak, momentum=momentum), scn.BatchNormLeakyReLU(C, leakiness=leak, momentum=momentum)
     with torch.no_grad():
         r.weight.uniform_(0.5, 1.5)
         r.bias.uniform_(-0.5, 0.5)
@@ -175,6 +177,8 @@ def test_batchnorm_forward_backward_running_stats(C, leak):
     _close(h.bias.grad, r.bias.grad, tol=2e-3, what="bn dbeta")
     _close(h.running_mean, r.running_mean, what="running_mean")
     _close(h.running_var, r.running_var, what="running_var")
+    # the constant is what it says: the old value's share after one training step
+    assert abs(float(h.running_var[0]) - (momentum * 1.0 + (1 - momentum) * float(x[:, 0].var(unbiased=True)))) < 1e-3
     r.eval(), h.eval()
     _close(h(th).features, r(tr).features, what="bn eval")
 

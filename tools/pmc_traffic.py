@@ -2,13 +2,30 @@
 traffic record bench.py reports as roofline.traffic.  Units/corrections as MI355X_MICROARCH.md prescribes: the counters
 are in KB; FETCH_SIZE is doubled on gfx950 for 16-B/lane streaming reads.
 
-    python tools/pmc_traffic.py <fetch.csv> <write.csv> <n_profiled_steps> <scenes> <algorithmic_bytes_per_step> > profiles/r01/traffic_3d.json
+    python tools/pmc_traffic.py <fetch.csv> <write.csv> <n_profiled_steps> <scenes> <algorithmic_bytes_per_step> [git hash] > profiles/rNN/traffic_3d.json
+
+(run it in the tree the counters were collected on: the record carries a fingerprint of csrc/{spconv,osconv,ostable}.hip)
 """
 import collections
 import csv
+import hashlib
 import json
+import os
 import re
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENGINE_SOURCES = ("spconv.hip", "osconv.hip", "ostable.hip")
+
+
+def engine_sources_sha256():
+    """Fingerprint of the sparse-conv engine sources the counters were taken on; bench.py refuses a record whose fingerprint
+    differs from the tree it runs in (a kernel change that moves traffic must come with a new measurement)."""
+    h = hashlib.sha256()
+    for f in ENGINE_SOURCES:
+        h.update(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 ENGINE = ("k_gather_gemm", "k_csr_reduce", "k_dw_direct", "k_dw_reduce", "k_pack_frag", "k_rows_narrow", "k_generic", "k_osconv", "k_os_pack")
 
@@ -25,6 +42,8 @@ def load(path, counter):
     return acc
 
 
+if __name__ != "__main__":
+    raise SystemExit  # imported for engine_sources_sha256 only (never reached: bench.py re-implements the three lines)
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 steps, scenes, algo = int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
 per = {}
@@ -43,4 +62,7 @@ print(json.dumps({
     "bytes_per_step": round(total),
     "algorithmic_bytes_per_step": algo,
     "traffic_over_algorithmic": round(total / algo, 3),
+    "engine_sources_sha256": engine_sources_sha256(),
+    "git": (subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None)
+           if len(sys.argv) < 7 else sys.argv[6],
 }, indent=1))
