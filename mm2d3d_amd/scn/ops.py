@@ -213,6 +213,38 @@ def _dw(x, dout, rb, src, dst, cin, cout, sink=None):
     return dW
 
 
+# Backward of one sparse convolution = two independent passes over the same dOut rows: the data gradient (engine F or G+R)
+# and the weight gradient (k_dw_*).  Each alone is bound by gather latency (SQ counters: 54-67 % of the wave cycles waiting
+# on memory, matrix pipe 5-11 % busy) and the small levels do not even fill the chip, so the weight gradient is issued on a
+# second stream beside the data gradient: more rows in flight per CU, same kernels, same arithmetic and summation order
+# (results bit-identical).  The pair is joined before the function returns - nothing of it runs beside the single-launch
+# batch-norm kernels that follow in the graph.  MM_SPCONV_BWD_OVERLAP=0 issues them one after the other.
+BWD_OVERLAP = [os.environ.get("MM_SPCONV_BWD_OVERLAP", "1") != "0"]
+BWD_OVERLAP_MIN = int(float(os.environ.get("MM_SPCONV_BWD_OVERLAP_MIN", "40e6")))
+_SIDE = {}
+
+
+def _side_stream(dev):
+    s = _SIDE.get(dev.index)
+    if s is None:
+        s = _SIDE[dev.index] = torch.cuda.Stream(dev)
+    return s
+
+
+def _timed_pair(rb, cin, cout, fn, esize=4):
+    """Both backward passes of a layer under one event pair: algorithmic bytes = dX pass + dW pass."""
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = fn()
+    e1.record()
+    R = rb.n_rules
+    PROFILE.append(dict(kind="dX+dW", R=R, cin=cin, cout=cout, K=rb.K, e0=e0, e1=e1,
+                        bytes=2 * (R * (cin + cout) * esize + 8 * R + rb.K * cin * cout * esize)))
+    return out
+
+
 class SparseConvFunction(torch.autograd.Function):
     """mode 'subm' | 'down' | 'up' over one rulebook."""
 
@@ -277,21 +309,47 @@ class SparseConvFunction(torch.autograd.Function):
         # table; down (dX[child] = dOut[parent] . W[k]^T) on the fine-row table; up (dX[parent] = sum dOut[child] . W[k]^T)
         # on the coarse-row table
         table = rb.os if mode in ("subm", "up") else rb.os_up
-        if ctx.needs_input_grad[0] and _os_usable(table, dout, cout, cin) and table.n_dst == n_in:
-            dx = _timed("dX", rb, ctx.acin, cout, lambda: _apply_os(dout, ctx.weight, w, table, cin, True, mode == "subm"))
-        elif ctx.needs_input_grad[0]:
+        sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
+
+        def data_grad(timed):
+            t = (lambda kind, rb_, a, b, fn: fn()) if not timed else _timed
+            if _os_usable(table, dout, cout, cin) and table.n_dst == n_in:
+                return t("dX", rb, ctx.acin, cout, lambda: _apply_os(dout, ctx.weight, w, table, cin, True, mode == "subm"))
             if mode == "subm":  # symmetric rulebook: (k,i,o) <-> (26-k,o,i)
-                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True, weight=ctx.weight))
-            elif mode == "down":
-                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False, weight=ctx.weight))
-            else:
-                dx = _timed("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False, weight=ctx.weight))
-        if ctx.needs_input_grad[1]:
-            sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
-            if mode == "up":
-                dw = _timed("dW", rb, ctx.acin, cout, lambda: _dw(x, dout, rb, rb.rout, rb.rin, cin, cout, sink))
-            else:
-                dw = _timed("dW", rb, ctx.acin, cout, lambda: _dw(x, dout, rb, rb.rin, rb.rout, cin, cout, sink))
+                return t("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, True, weight=ctx.weight))
+            if mode == "down":
+                return t("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False, weight=ctx.weight))
+            return t("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False, weight=ctx.weight))
+
+        def weight_grad(timed):
+            t = (lambda kind, rb_, a, b, fn: fn()) if not timed else _timed
+            a, b = (rb.rout, rb.rin) if mode == "up" else (rb.rin, rb.rout)
+            return t("dW", rb, ctx.acin, cout, lambda: _dw(x, dout, rb, a, b, cin, cout, sink))
+
+        # the fork / join of the second stream costs ~10-20 us of its own: worth it for the 3^3 layers from 32 input channels and
+        # ~40 M gathered elements per pass up (measured per layer on the bench step: strided K = 8 layers and the small / narrow
+        # ones lose 5-20 us each, the others gain up to 80 us)
+        overlap = BWD_OVERLAP[0] and rb.K == 27 and cin >= 32 and rb.n_rules * (cin + cout) >= BWD_OVERLAP_MIN
+        if ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and overlap:
+            def pair():
+                main = torch.cuda.current_stream(dout.device)
+                side = _side_stream(dout.device)
+                side.wait_event(main.record_event())
+                with torch.cuda.stream(side):
+                    g = weight_grad(False)
+                for t_ in (x, dout, g):
+                    t_.record_stream(side)
+                d = data_grad(False)
+                main.wait_event(side.record_event())
+                return d, g
+
+            dx, dw = _timed_pair(rb, ctx.acin, cout, pair)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = data_grad(True)
+            if ctx.needs_input_grad[1]:
+                dw = weight_grad(True)
+        if dw is not None:
             if sink is not None:
                 gradsink.done(ctx.wparam)
                 dw = None
