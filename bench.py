@@ -122,11 +122,70 @@ def conv_roofline(tm, batch, dev):
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "sparse-conv engines: k_osconv4<*> (fwd, dX of the levels >= 200k rows), k_gather_gemm<*> / k_gather_gemm_s3<*> + "
-                  "k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> + k_dw_reduce (dW)",
+                  "k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> + k_dw_reduce (dW); 'dX+dW' = "
+                  "both backward passes of a 3^3 layer issued on two streams and timed as one interval (bytes of both)",
         "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
         "by_pass": {k: {"GB/s": round(v[0] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else 0.0, "ms": round(v[1], 3), "calls": v[2]}
                     for k, v in by_kind.items()},
     }
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 2:1-sparsity figure is never used)
+GFLOP_2D_FWD_PER_IMAGE = 228.9  # 2 * sum(Cin*Cout*k^2*Hout*Wout) over the convs of the 2D net at 304x480
+
+
+def conv2d_roofline(tm, batch, dev):
+    """MFMA side of the step (north_star: "MFMA utilisation on the 2D GEMMs"): every launch of the 2D convolution entry points
+    (mm_conv2d_3x3s1 = k_conv3x3w/r fwd + dgrad, mm_conv2d_gemm = stems / strided / 1x1 / transposed convs fwd + dgrad,
+    mm_conv2d_wgrad = weight gradients incl. their slab reduction) of one step bracketed by HIP events on the launch stream,
+    against the algorithmic FLOPs of BASELINE.md section 3 (fwd x 3 for fwd + dgrad + wgrad) and the dense bf16 matrix peak."""
+    from mm2d3d_amd import _lib
+
+    L = _lib.lib()
+    names = ("mm_conv2d_3x3s1", "mm_conv2d_gemm", "mm_conv2d_wgrad")
+    rec = {n: [] for n in names}
+    saved = {n: getattr(L, n) for n in names}
+
+    def timed(name, fn):
+        def call(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            rec[name].append((e0, e1))
+            return rc
+        return call
+
+    b = fresh(batch)
+    n_img = b["source"]["img"].shape[0] + b["target"]["img"].shape[0]
+    torch.cuda.synchronize()
+    try:
+        for n in names:
+            setattr(L, n, timed(n, saved[n]))
+        torch.cuda._sleep(int(2.0e9 * 0.25))  # a GPU backlog: the event pairs then bracket kernel execution, not launch cadence
+        tm.fit_step(b)
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(L, n, saved[n])
+    ms = {n: sum(e0.elapsed_time(e1) for e0, e1 in v) for n, v in rec.items()}
+    total = sum(ms.values())
+    tflop = 3 * GFLOP_2D_FWD_PER_IMAGE * n_img / 1e3
+    ach = tflop / (total * 1e-3) if total > 0 else 0.0
+    busy, busy_src = None, None
+    import glob
+
+    for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_sq_step.json")), reverse=True):
+        k = json.load(open(ppath)).get("kernels", {})
+        busy = {name: v["mfma_busy_cycles_per_wave_cycle"] for name, v in k.items() if name.startswith(("k_conv", "k_wgrad"))}
+        busy_src = "offline rocprofv3 --pmc SQ counters, " + os.path.relpath(ppath, ROOT)
+        break
+    return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "algorithmic_tflop_per_step": round(tflop, 3), "conv_set_ms_per_step": round(total, 3),
+            "ms_by_entry_point": {n: round(v, 3) for n, v in ms.items()}, "launches": {n: len(v) for n, v in rec.items()},
+            "kernel": "2D convolution set: k_conv3x3w<*> / k_conv3x3r (3x3 s1 fwd + dgrad), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
+                      "k_wgrad3x3n / k_conv_wgrad2 + k_wgrad_reduce (weight gradients)",
+            "mfma_busy_cycles_per_wave_cycle": busy, "mfma_busy_source": busy_src}
 
 
 def branch_rates(tm, batch, dev, iters=5):
@@ -346,6 +405,7 @@ def main(argv=None):
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c2":
         print(f"[bench] timed region done: {ms:.2f} ms/step; roofline leg ...", file=sys.stderr, flush=True)
         out["roofline"] = conv_roofline(tm, batch, dev)
+        out["roofline_2d"] = conv2d_roofline(tm, batch, dev)
         out["config"]["branch_only_fwd_bwd"] = branch_rates(tm, batch, dev)
         print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline()

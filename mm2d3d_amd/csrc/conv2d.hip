@@ -267,123 +267,10 @@ struct C3P {
   int tiles_y, tiles_x;
 };
 
-template <int BN>
-__global__ __launch_bounds__(256, BN == 64 ? 4 : 2) void k_conv3x3(C3P p) {
-  extern __shared__ __attribute__((aligned(16))) u16 smem[];
-  constexpr int HROWS = 10 * 18;            // halo pixels
-  constexpr int HSZ = 184 * 64;             // elements per halo buffer (rounded up to whole 1-KiB DMA pieces)
-  u16* Hs = smem;                           // [HSZ]        one halo buffer: more resident workgroups hide the DMA latency
-  u16* Bs = smem + HSZ;                     // [2][BN*64]
-  constexpr int NBI = BN / 32;
-  constexpr int TN = BN / 64;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  int t = blockIdx.x;
-  const int tx0 = (t % p.tiles_x) * 16;
-  t /= p.tiles_x;
-  const int ty0 = (t % p.tiles_y) * 8;
-  const int b = t / p.tiles_y;
-  const int n0 = blockIdx.y * BN;
-  const int nchunk = p.Ca >> 6;
-  const int nsteps = nchunk * 9;
-  const int cc = tid & 7, r0 = tid >> 3;
-
-  auto issue_halo = [&](int c, int buf) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int row = r0 + 32 * i;  // halo pixel index (wave-instruction = 8 consecutive halo pixels)
-      if (row < 184) {
-        const int hy = row / 18, hx = row - hy * 18;
-        const int y = ty0 + hy - 1, x = tx0 + hx - 1;
-        const u16* g = (const u16*)g_zero16;
-        if (row < HROWS && y >= 0 && y < p.H && x >= 0 && x < p.W)
-          g = p.A + ((int64_t)(b * p.H + y) * p.W + x) * p.lda + c * 64 + ((cc ^ ((row >> 1) & 7)) << 3);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(Hs + buf * HSZ + (wave * 8 + 32 * i) * 64), 16, 0, 0);
-      }
-    }
-  };
-  auto issue_w = [&](int s, int buf) {
-    const int c = s / 9, tap = s - c * 9;
-#pragma unroll
-    for (int i = 0; i < NBI; i++) {
-      const int row = r0 + 32 * i;
-      const int n = n0 + row;
-      const u16* g = n < p.Cn ? p.Wp + ((int64_t)n * 9 + tap) * p.Ca + c * 64 + ((cc ^ ((row >> 1) & 7)) << 3) : (const u16*)g_zero16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                       (__attribute__((address_space(3))) void*)(Bs + buf * BN * 64 + (wave * 8 + 32 * i) * 64), 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[2][TN];
-#pragma unroll
-  for (int i = 0; i < 2; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  const int fr_ = lane & 31, fh = lane >> 5;
-  // halo row of this lane's two A-fragment pixels at tap (0,0): pixel (py, px) = (4*wm + 2*i + (fr_>>4), fr_&15)
-  int hbase[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) hbase[i] = (4 * wm + 2 * i + (fr_ >> 4)) * 18 + (fr_ & 15);
-
-  issue_halo(0, 0);
-  issue_w(0, 0);
-  for (int s = 0; s < nsteps; s++) {
-    const int c = s / 9, tap = s - c * 9;
-    if (tap == 0 && c > 0) {  // chunk switch: everyone is done with the previous chunk's halo, restage it
-      __syncthreads();
-      issue_halo(c, 0);
-    }
-    __syncthreads();  // vmcnt(0) + barrier: W(s) and halo(c) landed; everyone finished step s-1
-    if (s + 1 < nsteps) issue_w(s + 1, (s + 1) & 1);
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int hoff = p.flip ? (2 - kh) * 18 + (2 - kw) : kh * 18 + kw;
-    const u16* Hb = Hs;
-    const u16* Bb = Bs + (s & 1) * BN * 64;
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      bf16x8 af[2], bf[TN];
-      const int ch = kk * 2 + fh;
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const int row = hbase[i] + hoff;
-        af[i] = *(const bf16x8*)&Hb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
-      }
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int row = wn * (BN / 2) + j * 32 + fr_;
-        bf[j] = *(const bf16x8*)&Bb[row * 64 + ((ch ^ ((row >> 1) & 7)) << 3)];
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-    }
-  }
-
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-#pragma unroll
-    for (int reg = 0; reg < 16; reg++) {
-      const int r32 = (reg & 3) + 8 * (reg >> 2) + 4 * fh;
-      const int y = ty0 + 4 * wm + 2 * i + (r32 >> 4), x = tx0 + (r32 & 15);
-      if (y >= p.H || x >= p.W) continue;
-      const int64_t orow = (int64_t)(b * p.H + y) * p.W + x;
-#pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + fr_;
-        if (n < p.Cn) p.O[orow * p.ldo + n] = f2bf(acc[i][j][reg] + (p.bias ? p.bias[n] : 0.f));
-      }
-    }
-  }
-}
-
-// Persistent variant (the one that runs).  At these layer sizes a 128 px x 64 cout workgroup's MFMA work is ~1 us while
+// Persistent kernel.  (The first-generation kernel - one 128-pixel patch per workgroup, deleted in round 3 - taught this:)
+// At these layer sizes a 128 px x 64 cout workgroup's MFMA work is ~1 us while
 // its fixed costs (first halo from HBM, output stores, dispatch) are several, and every workgroup re-streams the whole
-// weight tensor of its cout block from L2: measured with MFMAs and all streaming switched off, the kernel above still
+// weight tensor of its cout block from L2: measured with MFMAs and all streaming switched off, that kernel still
 // takes 2/3 of its time, and the L2->LDS weight traffic (pixels/128 x |W|) is 3-20x the activation bytes.
 // Here ONE workgroup per CU stays resident and walks a list of (256-pixel tile, BN-cout block) items - half the
 // weight traffic per FLOP, half the LDS-DMA issues per MFMA - with everything software-pipelined ACROSS items and LDS-DMA
@@ -1380,17 +1267,12 @@ int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O
   p.tiles_y = (int)mm_cdiv(H, 8); p.tiles_x = (int)mm_cdiv(W, 16);
   const int64_t nt = (int64_t)B * p.tiles_y * p.tiles_x;
   if (nt == 0) return MM_OK;
-  static bool once = false;
-  const size_t lds64 = (size_t)(184 * 64 + 2 * 64 * 64) * 2;
-  if (!once) {
-    MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds64));
-    once = true;
-  }
-  // 64-wide output-channel blocks everywhere: 39 KB of LDS per workgroup -> 4 workgroups per CU.  Measured: resident
-  // workgroups (DMA-latency hiding) matter more than the halved B-fragment traffic of 128-wide blocks (tools/bench_conv.py).
-  if (Cn % 64 != 0 || Cn > 1024 || ldo % 4 != 0 || ((uintptr_t)O % 8) != 0) {
-    hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)nt, (unsigned)mm_cdiv(Cn, 64)), dim3(256), lds64, s, p);
-  } else {
+  // (round 3: the first-generation one-tile-per-workgroup kernel k_conv3x3<64>, kept as a fallback for output widths that are
+  // not multiples of 64 or pitches that are not multiples of 4, is gone: no layer of the net needs it, and a shape the
+  // persistent kernels cannot take is an error, not a silent slow path)
+  MM_CHECK_ARG(Cn % 64 == 0 && Cn <= 1024 && ldo % 4 == 0 && ((uintptr_t)O % 8) == 0,
+               "conv2d_3x3s1: output channels must be a multiple of 64 (<= 1024), ldo a multiple of 4, O 8-byte aligned (Cn=%d ldo=%d)", Cn, ldo);
+  {
     // 16 x 16 tiles on large maps, 8 x 32 where that wastes fewer out-of-image pixels; 128-cout blocks when Cn allows
     const int64_t px16 = mm_cdiv(H, 16) * mm_cdiv(W, 16), px32 = mm_cdiv(H, 8) * mm_cdiv(W, 32);
     const int tw = px32 < px16 ? 32 : 16;
