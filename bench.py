@@ -353,14 +353,20 @@ def main(argv=None):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # a loader hands the next batch over while the current step runs: fit_step(next_batch=) builds its sparse metadata one step
+    # ahead on the step's own stream (mm2d3d_amd/train.py).  Every timed step does one metadata build, as before.
+    pipeline = os.environ.get("MM_BENCH_PIPELINE", "1") != "0"
+    nxt = fresh(batch)
     for _ in range(a.warmup):
-        tm.fit_step(fresh(batch))
+        cur, nxt = nxt, fresh(batch)
+        tm.fit_step(cur, next_batch=nxt if pipeline else None)
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
-        loss = tm.fit_step(fresh(batch))
+        cur, nxt = nxt, fresh(batch)
+        loss = tm.fit_step(cur, next_batch=nxt if pipeline else None)
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0

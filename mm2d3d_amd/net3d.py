@@ -119,6 +119,11 @@ class Net3DSeg(nn.Module):
         layer = self.net_3d.layer1  # scn.InputLayer
         return scn.prebuild_metadata(data_batch["x"][0], layer.spatial_size, side_stream, after, layer.prebuild_levels)
 
+    def begin_metadata(self, data_batch):
+        """Phase one of a pipelined metadata build for ``data_batch`` (scn.begin_metadata): returns the pending Metadata."""
+        layer = self.net_3d.layer1
+        return scn.begin_metadata(data_batch["x"][0], layer.spatial_size, layer.prebuild_levels)
+
     def forward(self, data_batch):
         coords, feats = data_batch["x"][0], data_batch["x"][1]
         gated, mask_rgb = ops.GateFunction.apply(feats, self.linear_rgb_mask.weight, self.linear_rgb_mask.bias)

@@ -154,7 +154,7 @@ class InputLayer(nn.Module):
         if md is not None and md.n_points == coords.shape[0] and md.spatial_size == S and md.device == dev:
             if md.ready is not None:
                 torch.cuda.current_stream(dev).wait_event(md.ready)
-            lv0 = md.levels[0]
+            lv0 = md.ensure()  # a pipelined build (begin_metadata) may still have its host halves pending
         else:
             md = Metadata(dev, S, self.prebuild_levels, act16=act16())
             lv0 = md.build_levels(coords)
@@ -184,6 +184,22 @@ def prebuild_metadata(coords, spatial_size, side_stream=None, after=None, prebui
         md._coords_keepalive = c  # a converted copy must outlive the side stream's kernels; the caller's own tensor does anyway
     # NOT md -> coords when c is coords: coords -> md -> coords would be a reference cycle, and a step's metadata (hundreds
     # of MB) would wait for a full pass of the cyclic collector instead of dying with the batch
+    coords._mm_metadata = md
+    return md
+
+
+def begin_metadata(coords, spatial_size, prebuild_levels=7):
+    """First phase of a PIPELINED metadata build on the current stream: queues the voxel-dedupe chain of ``coords`` and an
+    asynchronous read-back of the level sizes, attaches the (incomplete) metadata to the tensor and returns it without waiting
+    for the GPU.  ``md.begin_rulebooks()`` (second phase: needs the level sizes on the host) is called later by whoever
+    pipelines the build - mm2d3d_amd/train.py does it one step ahead - and the InputLayer that receives this tensor completes
+    whatever is still pending (``md.ensure()``)."""
+    if not coords.is_cuda:
+        raise RuntimeError("mm2d3d_amd.scn.begin_metadata: coordinates must be on the GPU")
+    if coords.dtype != torch.int64 or not coords.is_contiguous() or coords.shape[1] != 4:
+        raise ValueError("begin_metadata: coordinates must be a contiguous int64 [N, 4] tensor (x, y, z, batch)")
+    md = Metadata(coords.device, int(spatial_size), prebuild_levels, act16=act16())
+    md.begin_levels(coords)
     coords._mm_metadata = md
     return md
 

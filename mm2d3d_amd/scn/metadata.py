@@ -20,6 +20,40 @@ from .._lib import check, ptr, stream
 I32 = torch.int32
 
 
+class _Readback:
+    """A small device -> host copy that does not stall the host when it is issued: the counts go into a persistent pinned
+    buffer by an asynchronous copy on the current stream, followed by an event; ``wait()`` blocks only if the GPU has not
+    reached that point yet.  (``Tensor.cpu()`` waits for everything queued before it, and a fresh ``pin_memory()`` costs
+    milliseconds: the buffers are a per-device ring, reused once their reader has consumed them.)"""
+
+    _ring = {}
+    SLOT = 512  # int32 per slot: 2 * levels + 1 counts, or levels x 37 bucket offsets
+
+    def __init__(self, dev_tensor):
+        n = dev_tensor.numel()
+        if n > self.SLOT:
+            raise ValueError("read-back larger than a staging slot")
+        dev = dev_tensor.device
+        ring = self._ring.setdefault(dev.index, {"free": [], "made": 0})
+        if ring["free"]:
+            self.buf = ring["free"].pop()
+        else:
+            self.buf = torch.empty(self.SLOT, dtype=I32).pin_memory()
+            ring["made"] += 1
+        self.dev_index, self.n, self.shape = dev.index, n, tuple(dev_tensor.shape)
+        self.buf[:n].copy_(dev_tensor.reshape(-1), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev))
+        self._keep = dev_tensor  # the source must stay allocated until the copy has run
+
+    def wait(self):
+        self.event.synchronize()
+        out = self.buf[: self.n].numpy().copy().reshape(self.shape)
+        self._ring[self.dev_index]["free"].append(self.buf)
+        self.buf = self._keep = None
+        return out
+
+
 class Rulebook:
     """k-major rule lists + CSR over destination rows (csrc/spconv.hip header)."""
 
@@ -112,6 +146,8 @@ class Metadata:
         self.ready = None   # event of the stream that built it (prebuild on a side stream)
         self.n_points = 0
         self.split = None
+        self._pending_levels = None     # (read-back, nlev): begin_levels has queued the kernels, finish_levels reads the counts
+        self._pending_rulebooks = None  # (read-back, [(level, subm, down)])
 
     # ------------------------------------------------------------------ active sets
     @classmethod
@@ -165,6 +201,20 @@ class Metadata:
 
     def build_levels(self, coords_i64: torch.Tensor):
         """Dedupe chain: points -> level 0 -> level 1 ... (A.8 i, ii).  One host sync at the end."""
+        self.begin_levels(coords_i64)
+        return self.finish_levels()
+
+    def ensure(self):
+        """Completes whatever a pipelined build (begin_levels / begin_rulebooks, mm2d3d_amd/train.py ``fit_step(next_batch=)``)
+        has left pending.  Returns level 0."""
+        if self._pending_levels is not None:
+            self.finish_levels()
+        if self._pending_rulebooks is not None:
+            self.finish_rulebooks()
+        return self.levels[0]
+
+    def begin_levels(self, coords_i64: torch.Tensor):
+        """Queues the dedupe chain and an asynchronous read-back of the level sizes; nothing here waits for the GPU."""
         L = _lib.lib()
         dev = self.device
         n_pts = self.n_points = coords_i64.shape[0]
@@ -203,7 +253,13 @@ class Metadata:
             self.levels.append(lv)
             prev = lv
             S = max(S // 2, 1)
-        host = counts.cpu().numpy()  # sync #1
+        self._pending_levels = (_Readback(counts), nlev, n_pts, split)
+
+    def finish_levels(self):
+        """Host half of the level build: reads the sizes (blocks only if the GPU has not reached the read-back yet)."""
+        rb_, nlev, n_pts, split = self._pending_levels
+        self._pending_levels = None
+        host = rb_.wait()  # sync #1
         if host[nlev] != 0:
             raise ValueError("InputLayer: coordinates must satisfy 0 <= x,y,z,batch < 65536")
         n_items = n_pts
@@ -294,6 +350,15 @@ class Metadata:
 
     def build_rulebooks(self, levels=None):
         """Submanifold (K=27) rulebook of every level + strided (K=8) rulebook between consecutive levels."""
+        self.begin_rulebooks(levels)
+        self.finish_rulebooks()
+
+    def begin_rulebooks(self, levels=None):
+        """Queues the rulebook / tile-table kernels of the levels and an asynchronous read-back of the bucket offsets."""
+        if self._pending_levels is not None:
+            self.finish_levels()
+        if self._pending_rulebooks is not None:
+            self.finish_rulebooks()
         L = _lib.lib()
         dev = self.device
         levels = [lv for lv in (levels or self.levels) if lv.subm is None]
@@ -322,7 +387,14 @@ class Metadata:
                     check(L.mm_up_neighbors(ptr(lv.coords), lv.n, ptr(c.item2vox), ptr(nbr_up), stream()), "up_neighbors")
                     down.os_up = self._os_table(nbr_up, 8, lv.n)
             pending.append((lv, subm, down))
-        host = offs.cpu().numpy()  # sync #2
+        self._pending_rulebooks = (_Readback(offs), pending)
+
+    def finish_rulebooks(self):
+        if self._pending_rulebooks is None:
+            return
+        rb_, pending = self._pending_rulebooks
+        self._pending_rulebooks = None
+        host = rb_.wait()  # sync #2
         for j, (lv, subm, down) in enumerate(pending):
             for rb, row in ((subm, host[j, :28]), (down, host[j, 28:37])):
                 if rb is None:
@@ -338,6 +410,8 @@ class Metadata:
                 lv.down = down
 
     def subm_rulebook(self, lv: Level) -> Rulebook:
+        if self._pending_rulebooks is not None:
+            self.finish_rulebooks()
         if lv.subm is None:
             self.build_rulebooks()
             if lv.subm is None:
@@ -345,6 +419,8 @@ class Metadata:
         return lv.subm
 
     def down_rulebook(self, lv: Level):
+        if self._pending_rulebooks is not None:
+            self.finish_rulebooks()
         if lv.coarse is None:
             self._extend(lv)
         if lv.down is None:

@@ -56,6 +56,7 @@ class TrainModel(nn.Module):
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
         self._s3d = None
+        self._pipelined = None
         self._opt_factories = optimizer or {}
         self.optimizers, self.schedulers = [], []
         self.reducer = None
@@ -115,7 +116,12 @@ class TrainModel(nn.Module):
         src, trg = batch["source"], batch["target"]
         n2d, n3d = self.modules_name[0], self.modules_name[1]
         if self._can_join(src, trg):
-            both, B = self._join(src, trg)
+            pre = self._pipelined if self._pipelined is not None and self._pipelined["key"] == id(batch) else None
+            self._pipelined = None
+            if pre is not None:  # joined one step ahead by prefetch(): its sparse metadata is already built (or queued)
+                both, B = pre["both"], pre["B"]
+            else:
+                both, B = self._join(src, trg)
             P = src["x"][0].shape[0]  # point rows [0, P) are the source's
             with domains.split(B):
                 dev = both["img"].device
@@ -180,6 +186,35 @@ class TrainModel(nn.Module):
 
     def training_step(self, batch, batch_idx=0):
         return self._generic_step(batch, "train")
+
+    # ------------------------------------------------------------------ sparse metadata one step ahead
+    # The voxel hash / rulebook build of the 3D branch needs two small device -> host read-backs (row counts size the
+    # allocations).  Inside a step each of them stalls the host until the GPU has caught up, the queue drains and the GPU idles
+    # while the host queues the 3D forward (~2 ms of a 41 ms step).  With the NEXT step's batch at hand the build is pipelined on
+    # the step's own stream instead (no second stream: nothing runs beside the single-launch batch norms):
+    #   step t:  [dedupe chain of batch t+1]  2D fwd(t)  3D fwd(t)  losses(t)  [rulebooks of batch t+1]  backward(t)  AdamW(t)
+    # Both read-backs are asynchronous copies into pinned memory; the host reads the level sizes after it has queued the whole
+    # forward of step t (the GPU passed that point long ago) and the bucket offsets in step t+1: it never waits for the GPU.
+    def prefetch(self, batch):
+        """Phase one for the batch of the NEXT ``fit_step`` (pass the same dict object to it)."""
+        self._pipelined = None
+        src, trg = batch["source"], batch["target"]
+        net3d = self.model[self.modules_name[1]]
+        if not (self._can_join(src, trg) and hasattr(net3d, "begin_metadata") and not self.overlap_metadata):
+            return
+        both, B = self._join(src, trg)
+        if both["x"][0].dtype != torch.int64 or both["x"][0].shape[1] != 4:
+            return
+        both["x"][0] = both["x"][0].contiguous()
+        with domains.split(B):
+            md = net3d.begin_metadata(both)
+        self._pipelined = dict(key=id(batch), both=both, B=B, md=md, phase=1)
+
+    def _prefetch_rulebooks(self):
+        pre = self._pipelined
+        if pre is not None and pre["phase"] == 1:
+            pre["md"].begin_rulebooks()  # reads the level sizes (no wait: queued before this step's forward), queues phase two
+            pre["phase"] = 2
 
     # ------------------------------------------------------------------ validation / test (train.py:297-365, 374-458)
     def _iou(self, stage, device, num_classes):
@@ -251,7 +286,9 @@ class TrainModel(nn.Module):
             self.best[k] = ckpt.get(k, self.best[k])
 
     # ------------------------------------------------------------------ what Lightning's loop does around it
-    def fit_step(self, batch):
+    def fit_step(self, batch, next_batch=None):
+        """One optimiser step on ``batch``.  ``next_batch``: the batch of the following call (the very dict that will be passed
+        to it) - its sparse metadata is then built during this step (see ``prefetch``)."""
         if not self.optimizers:
             self.configure_optimizers()
         L = _lib.lib()
@@ -263,7 +300,17 @@ class TrainModel(nn.Module):
             o.zero_grad()
         if self.broadcast_buffers and self.reducer.active:
             self.reducer.broadcast_buffers(self.model.values())  # DDP syncs module buffers from rank 0 before each forward
+        cur = self._pipelined if self._pipelined is not None and self._pipelined["key"] == id(batch) else None
+        if next_batch is not None:
+            if cur is not None:
+                cur["md"].ensure()  # this step's own metadata first (its read-backs are long done)
+            self.prefetch(next_batch)
+            nxt, self._pipelined = self._pipelined, cur
+        else:
+            nxt = None
         loss = self.training_step(batch, self.global_step)
+        self._pipelined = nxt
+        self._prefetch_rulebooks()
         loss.backward()
         self.reducer.finish()
         for o in self.optimizers:

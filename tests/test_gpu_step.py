@@ -342,3 +342,56 @@ def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
     for (k1, v1), (k2, v2) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
         assert k1 == k2 and torch.equal(v1, v2)
     assert t2.best["best_target_iou"] == 0.5
+
+
+def test_metadata_built_one_step_ahead_gives_the_same_steps():
+    """fit_step(batch, next_batch=): the sparse metadata of the next batch is built during the current step (dedupe chain before
+    the forward, rulebooks before the backward, asynchronous read-backs).  Same kernels on the same stream in a different
+    order: losses and parameters after four optimiser steps must be BIT-identical to the in-line build."""
+    import copy
+
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = _dev()
+    torch.manual_seed(3)
+    kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+    n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+    for m in n2.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+
+    def opts():
+        out = {}
+        for k in ("2d_net", "3d_net"):
+            o = Optimizer("adamw", lr=0.001)
+            o.set_scheduler("one_cycle", max_lr=0.005, total_steps=100)
+            out[k] = o
+        return out
+
+    # different scenes per step: a stale or mismatched metadata object would show
+    batches = [{"source": make_batch(5, 2, "nuscenes", (96, 128), device=dev, first_scene=4 * i),
+                "target": make_batch(6, 2, "nuscenes", (96, 128), device=dev, first_scene=4 * i + 2)} for i in range(4)]
+    clone = lambda b: {d: dict(v, x=[v["x"][0], v["x"][1].clone()]) for d, v in b.items()}
+    loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
+    tk = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False)
+    piped = TrainModel({"2d_net": n2, "3d_net": n3}, opts(), loss, dict(tk))
+    plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, opts(), loss, dict(tk))
+    seq = [clone(b) for b in batches]
+    for i in range(4):
+        nxt = seq[i + 1] if i + 1 < 4 else None
+        la = piped.fit_step(seq[i], next_batch=nxt)
+        if nxt is not None:
+            assert piped._pipelined is not None and piped._pipelined["key"] == id(nxt) and piped._pipelined["phase"] == 2
+        lb = plain.fit_step(clone(batches[i]))
+        assert float(la.detach()) == float(lb.detach()), (i, float(la.detach()), float(lb.detach()))
+    torch.cuda.synchronize()
+    for a, b in zip(piped.optimizers, plain.optimizers):
+        for x, y in zip(a._arenas, b._arenas):
+            if x is not None:
+                assert torch.equal(x["p"], y["p"])
