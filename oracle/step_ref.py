@@ -18,14 +18,18 @@ def cross_modal_loss(gt_for_2d, prediction_avg, gt_for_3d, prediction_3d):
     return l2d, l3d
 
 
-def generic_step(sd2d, net3d, batch, class_weights, lambda_xm_src=1.0, lambda_xm_trg=0.1, training=True, dropout_masks=None):
-    """Returns (total loss, dict of the six logged terms).  ``sd2d``: dict of leaf tensors (requires_grad as wanted)."""
+def generic_step(sd2d, net3d, batch, class_weights, lambda_xm_src=1.0, lambda_xm_trg=0.1, training=True, dropout_masks=None,
+                 emulate_bf16=False):
+    """Returns (total loss, dict of the six logged terms).  ``sd2d``: dict of leaf tensors (requires_grad as wanted).
+    ``emulate_bf16``: the 2D branch rounds to bfloat16 where the HIP branch stores bfloat16 (oracle/net2d_ref.py), forward and -
+    through the casts' own backward - the gradients at the same points."""
     w = None if class_weights is None else torch.tensor(class_weights, dtype=torch.float32)
     logs = {}
     terms2d, terms3d = [], []
     for dom, lam in (("source", lambda_xm_src), ("target", lambda_xm_trg)):
         b = batch[dom]
-        p2d, _, _, a2d = net2d_forward(sd2d, b, training=training, dropout_masks=None if dropout_masks is None else dropout_masks[dom])
+        p2d, _, _, a2d = net2d_forward(sd2d, b, training=training, dropout_masks=None if dropout_masks is None else dropout_masks[dom],
+                                       emulate_bf16=emulate_bf16)
         p3d, _, a3d = net3d(b)
         if dom == "source":
             s2 = F.cross_entropy(p2d["seg_logit"], b["seg_label"], weight=w)

@@ -126,6 +126,15 @@ def test_full_step_losses_and_gradients_vs_oracle():
     gpu = {"source": make_batch(5, 1, "nuscenes", (48, 64), device=dev), "target": make_batch(6, 1, "nuscenes", (48, 64), device=dev)}
     ref_total, ref_logs = generic_step(sd2, ref3, cpu, W)
     ref_total.backward()
+    # the same step with the 2D branch rounding to bf16 where the HIP branch stores bf16 (forward values and gradients)
+    import copy
+
+    sd2e = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in sd2.items()}
+    ref3e = copy.deepcopy(ref3)
+    ref3e.zero_grad()
+    cpu_e = {"source": make_batch(5, 1, "nuscenes", (48, 64)), "target": make_batch(6, 1, "nuscenes", (48, 64))}
+    emu_total, emu_logs = generic_step(sd2e, ref3e, cpu_e, W, emulate_bf16=True)
+    emu_total.backward()
     tm = TrainModel({"2d_net": n2.to(dev), "3d_net": n3.to(dev)}, None,
                     Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}]),
                     dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
@@ -145,14 +154,31 @@ def test_full_step_losses_and_gradients_vs_oracle():
         t = g3[name].grad
         worst = max(worst, ((p.grad.cpu() - t).abs().max() / max(1.0, t.abs().max())).item())
     assert worst < 5e-2, worst  # fp32 conditioning ~1e-2 (test_gpu_scn.py) + the bf16 2D logits entering the KL terms
+    # against the bf16-EMULATING oracle what is left is accumulation order and the 1-ulp flips it causes: loss terms ...
+    worst_loss = 0.0
+    for k, v in emu_logs.items():
+        worst_loss = max(worst_loss, abs(tm.last_logs[f"train/{k}"].item() - v.item()) / max(1.0, abs(v.item())))
+    cos_f, cos_e = [], []
     for name, p in n2.named_parameters():
         if p.grad is None:
             continue
-        t = sd2[name].grad
-        # bf16 activations AND bf16 gradients through ~40 layers: per-kernel backward parity is pinned tightly in
-        # test_gpu_conv2d.py / test_gpu_net2d.py; here the composed gradient must point the same way as the fp32 oracle's
-        cos = torch.nn.functional.cosine_similarity(p.grad.cpu().flatten().double(), t.flatten().double(), dim=0).item()
-        assert cos > 0.6 or t.norm() < 1e-2, (name, cos)  # tiny early-layer gradients are the noisiest in bf16
+        t, te = sd2[name].grad, sd2e[name].grad
+        g = p.grad.cpu().flatten().double()
+        cf = torch.nn.functional.cosine_similarity(g, t.flatten().double(), dim=0).item()
+        ce = torch.nn.functional.cosine_similarity(g, te.flatten().double(), dim=0).item()
+        if t.norm() >= 1e-2:  # tiny early-layer gradients are the noisiest in bf16
+            cos_f.append((cf, name))
+            cos_e.append((ce, name))
+    med = lambda v: float(np.median([c for c, _ in v]))
+    print(f"2D gradients of the composed step: cosine vs fp32 oracle min {min(cos_f)[0]:.3f} median {med(cos_f):.3f}; "
+          f"vs bf16-emulating oracle min {min(cos_e)[0]:.3f} median {med(cos_e):.3f}; loss terms vs emulating oracle {worst_loss:.2e}")
+    # ... and the composed 2D gradients (bf16 activations AND bf16 gradients through ~40 layers; per-kernel backward parity is
+    # pinned tightly in test_gpu_conv2d.py / test_gpu_net2d.py).  Measured: cosine min 0.976 / median 1.000 against the emulating
+    # oracle (0.934 / 1.000 against the fp32 oracle; round 2 asserted 0.6); the six loss terms agree with the emulating oracle
+    # to 4.5e-6 - i.e. within north_star's 1e-3 once the storage format is the same on both sides.
+    assert min(cos_f)[0] > 0.85, sorted(cos_f)[:3]
+    assert min(cos_e)[0] > 0.93 and med(cos_e) > 0.99, sorted(cos_e)[:3]
+    assert worst_loss < 1e-4
 
 
 def test_joint_domain_pass_equals_the_two_call_sequence():
