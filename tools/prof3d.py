@@ -17,6 +17,9 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--act16", action="store_true", help="16-bit sparse activations (BASELINE.json configs[4])")
+ap.add_argument("--bench-batch", action="store_true",
+                help="the joint [source | target] point set of bench.py's headline step (8 + 8 augmented NuScenes-shaped scenes, config ids "
+                     "2 / 3): the PMC traffic record then refers to exactly the rule counts bench.py's roofline leg sees")
 a = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -26,8 +29,15 @@ if a.act16:
 
     scn.set_activation_dtype(torch.bfloat16)
 net = Net3DSeg(6, True, dict(in_channels=3, m=16, full_scale=4096, num_planes=7)).to(dev)
-batch = make_batch(2, a.scenes, a.shape, img_hw=(32, 48), device=dev)
-coords, feats = batch["x"]
+if a.bench_batch:
+    src = make_batch(2, 8, "nuscenes", img_hw=(32, 48), device=dev, augment=True)
+    trg = make_batch(3, 8, "nuscenes", img_hw=(32, 48), device=dev, augment=True)
+    ct = trg["x"][0].clone()
+    ct[:, -1] += 8
+    coords, feats = torch.cat([src["x"][0], ct], 0), torch.cat([src["x"][1], trg["x"][1]], 0)
+else:
+    batch = make_batch(2, a.scenes, a.shape, img_hw=(32, 48), device=dev)
+    coords, feats = batch["x"]
 print("points", coords.shape[0])
 
 
@@ -39,6 +49,14 @@ def step():
 
 for _ in range(a.warmup):
     step()
+if not a.fwd_only:  # the algorithmic bytes of one step (SURVEY.md 8d formula over the actual rule counts)
+    from mm2d3d_amd.scn import ops
+
+    ops.PROFILE = []
+    step()
+    torch.cuda.synchronize()
+    print("algorithmic_bytes_per_step", sum(r["bytes"] for r in ops.PROFILE))
+    ops.PROFILE = None
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
