@@ -253,9 +253,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 // ------------------------------------------------------------------------------------------------ 3x3 stride-1 (halo tile)
 // The bulk of the branch's FLOPs are 3x3 stride-1 pad-1 convolutions (and their data gradients, which are the same
 // operation with flipped taps and transposed weights).  k_conv_gemm re-fetches the input tile for each of the 9 taps;
-// here a workgroup owns an 8 x 16 output patch, stages the (8+2) x (16+2) input halo of one 64-channel chunk ONCE
-// (LDS-DMA, double-buffered across chunks) and serves all 9 taps from it - the MFMA A fragments are simply read at
-// shifted halo rows.  Only the weight tiles stream per tap.  Global->LDS traffic per FLOP drops ~2-4x.
+// the kernels below stage the (h+2) x (w+2) input halo of a pixel tile and one 64-channel chunk ONCE (LDS-DMA) and serve
+// all 9 taps from it - the MFMA A fragments are simply read at shifted halo rows.  Only the weight tiles stream per tap.
+// Global->LDS traffic per FLOP drops ~2-4x.
 struct C3P {
   const u16* A;  // [B,H,W,Ca]
   int B, H, W, Ca, lda;

@@ -228,23 +228,38 @@ __global__ __launch_bounds__(T) void k_eval_confusion(const float* __restrict__ 
 
 // ---- AdamW over flat fp32 arenas (torch.optim.AdamW semantics, amsgrad off; same op order as torch's
 // single-tensor path: p*=1-lr*wd; m.lerp_(g,1-b1); v=b2*v+(1-b2)*g*g; p-=step_size*m/(sqrt(v)/sqrt(bc2)+eps))
+template <bool VEC>
 __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float decay, float omb1, float beta2,
                                               float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
   int64_t i = ((int64_t)blockIdx.x * T + threadIdx.x) * 4;
   if (i >= n) return;
+  auto upd = [&](float gj, float& pj, float& mj, float& vj) {
+    const float gi = gj * grad_scale;
+    const float pi = pj * decay;
+    const float mi = mj + omb1 * (gi - mj);
+    const float vi = beta2 * vj + omb2 * gi * gi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pj = pi - step_size * (mi / denom);
+    mj = mi;
+    vj = vi;
+  };
+  if (VEC && i + 4 <= n) {  // 16-byte accesses (host: all four pointers 16-B aligned); same arithmetic per element
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 G = *(const f4*)(g + i);
+    f4 P = *(f4*)(p + i), M = *(f4*)(m + i), V = *(f4*)(v + i);
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    if (i + j >= n) break;
-    float gi = g[i + j] * grad_scale;
-    float pi = p[i + j] * decay;
-    float mi = m[i + j] + omb1 * (gi - m[i + j]);
-    float vi = beta2 * v[i + j] + omb2 * gi * gi;
-    float denom = sqrtf(vi) / bc2_sqrt + eps;
-    p[i + j] = pi - step_size * (mi / denom);
-    m[i + j] = mi;
-    v[i + j] = vi;
+    for (int j = 0; j < 4; j++) {
+      float pj = P[j], mj = M[j], vj = V[j];
+      upd(G[j], pj, mj, vj);
+      P[j] = pj, M[j] = mj, V[j] = vj;
+    }
+    *(f4*)(p + i) = P;
+    *(f4*)(m + i) = M;
+    *(f4*)(v + i) = V;
+    return;
   }
+  for (int j = 0; i + j < n; j++) upd(g[i + j], p[i + j], m[i + j], v[i + j]);
 }
 }  // namespace
 
@@ -351,9 +366,15 @@ int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
   if (n == 0) return MM_OK;
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
-  hipLaunchKernelGGL(k_adamw, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
-                     (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;  // parameter spans may start anywhere
+  if (vec)
+    hipLaunchKernelGGL(k_adamw<true>, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+  else
+    hipLaunchKernelGGL(k_adamw<false>, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
