@@ -75,8 +75,16 @@ class GradAllReducer:
             from . import _lib
 
             keep = 1 if os.environ.get("MM_DDP_BN_FUSED", "0") != "0" else 0
-            _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & keep)
-            _lib.lib().mm_bn_set_fused(_lib.lib().mm_bn_set_fused(0) & keep)
+            was2d = _lib.lib().mm_bn2d_set_fused(0)
+            was3d = _lib.lib().mm_bn_set_fused(0)
+            _lib.lib().mm_bn2d_set_fused(was2d & keep)
+            _lib.lib().mm_bn_set_fused(was3d & keep)
+            if (was2d | was3d) & ~keep and (not dist.is_initialized() or dist.get_rank(process_group) == 0):
+                import sys
+
+                print("[mm2d3d_amd.ddp] data-parallel run: batch norms take the three-kernel path (a grid-barrier launch must not "
+                      "share the GPU with RCCL's kernels); MM_DDP_BN_FUSED=1 keeps the single-launch kernels in the forward direction",
+                      file=sys.stderr, flush=True)
         for opt in optimizers:
             for a in getattr(opt, "_arenas", []):
                 if a is None:
