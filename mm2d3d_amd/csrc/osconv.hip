@@ -105,10 +105,13 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
       const u32x4* wk = p.Wf + ((int64_t)myk * nq * p.ncb_tot + cb0) * FRB + lane;
       // rows without this neighbour read a zero line instead (pointer select: cheaper than zeroing eight loaded values)
       constexpr int ES = BF ? 2 : 4;  // bytes per input element
-      const char* rows[4];
+      // (round 3) global address space kept through the pointer selects: a select between a row pointer and the zero line as
+      // plain `const char*` made every row load a FLAT load (both address paths, both counters)
+      typedef const __attribute__((address_space(1))) char* gptr;
+      gptr rows[4];
 #pragma unroll
       for (int sb = 0; sb < 4; sb++)
-        rows[sb] = ids[sb] >= 0 ? (const char*)p.in + ((int64_t)ids[sb] * p.ld_in + sl * 8) * ES : nullptr;
+        rows[sb] = ids[sb] >= 0 ? (gptr)((const char*)p.in + ((int64_t)ids[sb] * p.ld_in + sl * 8) * ES) : (gptr) nullptr;
       for (int q = 0; q < nq; q++) {
         bf16x8 wt[NCB][NTW];
 #pragma unroll
@@ -119,9 +122,9 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
         f32x4 x[4][BF ? 1 : 2];
 #pragma unroll
         for (int sb = 0; sb < 4; sb++) {  // unconditional loads
-          const char* r = (rows[sb] && in_c) ? rows[sb] + q * 32 * ES : (const char*)g_zero8;
-          x[sb][0] = *(const f32x4*)r;
-          if (!BF) x[sb][BF ? 0 : 1] = *(const f32x4*)(r + 16);
+          gptr r = (rows[sb] && in_c) ? rows[sb] + q * 32 * ES : (gptr)(const char*)g_zero8;
+          x[sb][0] = *(const __attribute__((address_space(1))) f32x4*)r;
+          if (!BF) x[sb][BF ? 0 : 1] = *(const __attribute__((address_space(1))) f32x4*)(r + 16);
         }
 #pragma unroll
         for (int sb = 0; sb < 4; sb++) {

@@ -69,16 +69,17 @@ __global__ __launch_bounds__(256) void k_gather_gemm(const float* __restrict__ i
   const int cb0 = blockIdx.y * NCB;
   const int co_base = cb0 * 16;
   const int nq = (Cin + 15) >> 4;
-  {
-    const f32x4* Wk = (const f32x4*)Wf + ((int64_t)k * nq * ncb_tot + cb0) * 64;
-    f32x4* wl4 = (f32x4*)wl;
-    for (int e = tid; e < nq * NCB * 64; e += 256) {
-      int q = e / (NCB * 64), r = e - q * (NCB * 64);
-      wl4[e] = Wk[(int64_t)q * ncb_tot * 64 + r];
+  const int wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  {  // W[k] slice -> LDS by LDS-DMA, one 1-KiB (q, cb) fragment block per wave instruction, all in flight together
+    const char* Wk = (const char*)((const f32x4*)Wf + ((int64_t)k * nq * ncb_tot + cb0) * 64) + lane * 16;
+    for (int b = wave; b < nq * NCB; b += 4) {
+      const int q = b / NCB, r = b - q * NCB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wk + ((int64_t)q * ncb_tot + r) * 1024),
+                                       (__attribute__((address_space(3))) void*)((char*)wl + b * 1024), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
   for (int g = r_begin + wave * 16; g < r_end; g += 64) {
     const int r = g + rl;
     const bool valid = r < r_end;
@@ -182,6 +183,9 @@ __global__ __launch_bounds__(256) void k_gather_gemm_direct(const float* __restr
 // MM_SPCONV_FP32=1 keeps the plain fp32 engine.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+__device__ __attribute__((aligned(32))) const float g_zero8s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(64))) const float g_zero128[128] = {0.f};  // zero line for absent rules: 16 lanes + up to 4 blocks of 16
+
 template <int NT>
 __device__ inline void split8(const f32x4& a, const f32x4& b, bf16x8 (&t)[NT]) {
   float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -247,7 +251,7 @@ template <int NCB, bool LDSW, int NT>
 __global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict__ in, int ld_in, const int32_t* __restrict__ src,
                                                          const int32_t* __restrict__ dst, float* __restrict__ out, int ld_out,
                                                          const __bf16* __restrict__ Wf, int ncb_tot, int K, int Cin, int tr,
-                                                         KSeg seg) {
+                                                         KSeg seg, int preload) {
   extern __shared__ __attribute__((aligned(16))) char wlds[];  // [nq][NCB][NT][64 lanes][16 B]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
   const int k = find_k(seg, blockIdx.x, K);
@@ -257,27 +261,48 @@ __global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict_
   const int nq = (Cin + 31) >> 5;
   const bf16x8* Wk = (const bf16x8*)Wf + ((int64_t)k * nq * ncb_tot + cb0) * 64 * NT;
   if (LDSW) {
-    bf16x8* w8 = (bf16x8*)wlds;
-    for (int e = tid; e < nq * NCB * 64 * NT; e += 256) {
-      const int q = e / (NCB * 64 * NT), r = e - q * (NCB * 64 * NT);
-      w8[e] = Wk[(int64_t)q * ncb_tot * 64 * NT + r];
+    // W[k] slice -> LDS by LDS-DMA: the fragment blocks ([64 lanes] x 16 B = 1 KiB, one per (q, cb, term)) are exactly what one
+    // wave instruction writes, all of a wave's blocks are in flight together and nothing passes through registers.  (The
+    // round-2 copy loop compiled to load -> s_waitcnt vmcnt(0) -> ds_write per 16-byte piece: up to 19 serial L2 round trips
+    // per workgroup before the first MFMA.)
+    for (int b = wave; b < nq * NCB * NT; b += 4) {
+      const int q = b / (NCB * NT), r = b - q * (NCB * NT);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const char*)Wk + ((int64_t)q * ncb_tot * NT + r) * 1024 + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(wlds + b * 1024), 16, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  for (int g = r_begin + wave * 16; g < r_end; g += 64) {
+  // Round 3: the row loads of a rule group no longer sit inside the channel-chunk loop (one exposed gather latency per 32
+  // channels: 1 + nq dependent round trips per 16 rules, and the SQ counters showed the waves parked 67 % of their cycles).
+  // All chunks of the group are requested at once (NQMAX x 2 sixteen-byte loads in flight per lane, absent chunks read a
+  // zero line), and the source index of the NEXT group is fetched before this group is multiplied.
+  constexpr int NQMAX = 7;  // Cin <= 224
+  int g = r_begin + wave * 16;
+  int sidx_next = (g + rl < r_end) ? src[g + rl] : 0;
+  for (; g < r_end; g += 64) {
     const int r = g + rl;
     const bool valid = r < r_end;
-    const int sidx = valid ? src[r] : 0;
+    const int sidx = sidx_next;
+    if (g + 64 < r_end) sidx_next = (g + 64 + rl < r_end) ? src[g + 64 + rl] : 0;  // uniform branch
     const float* row = in + (int64_t)sidx * ld_in + sl * 8;
+    f32x4 xq[NQMAX][2];
+    const bool pre = preload && nq <= NQMAX;  // uniform (MM_SPCONV_G_PRELOAD=0: the round-2 loop, for A/B runs)
+    if (pre) {
+#pragma unroll
+      for (int q = 0; q < NQMAX; q++) {
+        if (q < nq) {  // uniform
+          typedef const __attribute__((address_space(1))) f32x4* gp4;  // keep the global address space through the select (else: flat loads)
+          const gp4 pq = (valid && q * 32 + sl * 8 < Cin) ? (gp4)(row + q * 32) : (gp4)g_zero8s;  // Cin % 16 == 0: 8 channels in or out together
+          xq[q][0] = pq[0];
+          xq[q][1] = pq[1];
+        }
+      }
+    }
     f32x4 acc[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < nq; q++) {
-      f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-      if (valid && q * 32 + sl * 8 < Cin) {  // Cin % 16 == 0: the 8 channels are inside or outside together
-        x0 = *(const f32x4*)(row + q * 32);
-        x1 = *(const f32x4*)(row + q * 32 + 4);
-      }
+    auto chunk = [&](int q, const f32x4& x0, const f32x4& x1) {
       bf16x8 xt[NT];
       split8<NT>(x0, x1, xt);
 #pragma unroll
@@ -288,6 +313,20 @@ __global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict_
 #pragma unroll
         for (int n = 0; n < NT; n++) wt[n] = w8[n * 64];
         acc[cb] = mfma_split<NT>(wt, xt, acc[cb]);
+      }
+    };
+    if (pre) {
+#pragma unroll
+      for (int q = 0; q < NQMAX; q++)
+        if (q < nq) chunk(q, xq[q][0], xq[q][1]);
+    } else {  // wider than the preload window: one chunk at a time (the round-2 loop)
+      for (int q = 0; q < nq; q++) {
+        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+        if (valid && q * 32 + sl * 8 < Cin) {
+          x0 = *(const f32x4*)(row + q * 32);
+          x1 = *(const f32x4*)(row + q * 32 + 4);
+        }
+        chunk(q, x0, x1);
       }
     }
     if (valid) {
@@ -513,35 +552,73 @@ __global__ __launch_bounds__(256) void k_dw_direct_s3(const E* __restrict__ in, 
   for (int i = 0; i < TI; i++)
 #pragma unroll
     for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int r0 = r_begin + wave * 32; r0 < r_end; r0 += 128) {
-    int si[8], di[8];
+  // Round 3: an iteration of the round-2 loop was two exposed round trips - sixteen dword index loads, a wait, then the value
+  // loads.  The eight rule indices of a lane are contiguous (rules 8 sl .. 8 sl + 7): two 16-byte loads per index array,
+  // and the indices of the NEXT 32-rule group are requested before this group is gathered, split and multiplied.  (Also
+  // tried: unconditional value loads with the absent rules selected to zero afterwards instead of one exec-masked block per
+  // load - the scheduler then hoists the 64-bit address arithmetic of all 48 loads, runs out of registers and issues them
+  // in waited batches of 12: dW 2.14 -> 3.44 ms.  The branchy form keeps one address pair live at a time.)
+  typedef int i32x4 __attribute__((ext_vector_type(4), aligned(4)));  // bucket offsets are arbitrary: dword alignment only
+  auto load_idx = [&](int r0, int (&si)[8], int (&di)[8]) {
+    const int rb = r0 + 8 * sl;
+    if (rb + 8 <= r_end) {  // the usual case: 32 contiguous bytes of each index array (4-byte aligned is enough)
+      const i32x4 s0 = *(const i32x4*)(src + rb), s1 = *(const i32x4*)(src + rb + 4);
+      const i32x4 d0 = *(const i32x4*)(dst + rb), d1 = *(const i32x4*)(dst + rb + 4);
+#pragma unroll
+      for (int t = 0; t < 4; t++) si[t] = s0[t], si[4 + t] = s1[t], di[t] = d0[t], di[4 + t] = d1[t];
+    } else {  // the tail of the chunk
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const int r = rb + t;
+        const bool valid = r < r_end;
+        const int rc = valid ? r : r_end - 1;
+        const int sv = src[rc], dv = dst[rc];
+        si[t] = valid ? sv : -1;
+        di[t] = valid ? dv : 0;
+      }
+    }
+  };
+  int sn[8], dn[8];  // indices of the NEXT group (prefetched)
+  int r0 = r_begin + wave * 32;
+  if (r0 < r_end) load_idx(r0, sn, dn);
+  for (; r0 < r_end; r0 += 128) {
+    // row pointers of the eight rules, once per group (the round-2 loop redid the 64-bit row multiply for every one of the
+    // 8 (TI + TJ) loads, each inside its own exec-masked block: ~6 vector and 4 scalar instructions per loaded dword).  An
+    // absent rule points at a zero line: the loads are unconditional, carry the block as an immediate offset and need no
+    // select afterwards.
+    typedef const __attribute__((address_space(1))) E* gptr;  // global address space kept through the select (else: flat loads)
+    gptr pa[8], pb[8];
 #pragma unroll
     for (int t = 0; t < 8; t++) {
-      const int r = r0 + 8 * sl + t;
-      const bool valid = r < r_end;
-      si[t] = valid ? src[r] : -1;
-      di[t] = valid ? dst[r] : 0;
+      const bool live = sn[t] >= 0;
+      pa[t] = live ? (gptr)(in + (int64_t)sn[t] * ld_in + ci0 * 16 + rl) : (gptr)((const E*)g_zero128 + rl);
+      pb[t] = live ? (gptr)(dout + (int64_t)dn[t] * ld_do + co0 * 16 + rl) : (gptr)((const E*)g_zero128 + rl);
     }
+    if (r0 + 128 < r_end) load_idx(r0 + 128, sn, dn);  // uniform: in flight while this group is gathered, split and multiplied
     bf16x8 at[TI][NT], bt[TJ][NT];
 #pragma unroll
     for (int i = 0; i < TI; i++) {
-      f32x4 v0, v1;
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (ci0 + i < ncib) {  // uniform
 #pragma unroll
-      for (int t = 0; t < 8; t++) {
-        const float x = (si[t] >= 0 && ci0 + i < ncib) ? (float)in[(int64_t)si[t] * ld_in + (ci0 + i) * 16 + rl] : 0.f;
-        if (t < 4) v0[t] = x;
-        else v1[t - 4] = x;
+        for (int t = 0; t < 8; t++) {
+          const float x = (float)pa[t][i * 16];
+          if (t < 4) v0[t] = x;
+          else v1[t - 4] = x;
+        }
       }
       split8<NT>(v0, v1, at[i]);
     }
 #pragma unroll
     for (int j = 0; j < TJ; j++) {
-      f32x4 v0, v1;
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (co0 + j < ncob) {  // uniform
 #pragma unroll
-      for (int t = 0; t < 8; t++) {
-        const float x = (si[t] >= 0 && co0 + j < ncob) ? (float)dout[(int64_t)di[t] * ld_do + (co0 + j) * 16 + rl] : 0.f;
-        if (t < 4) v0[t] = x;
-        else v1[t - 4] = x;
+        for (int t = 0; t < 8; t++) {
+          const float x = (float)pb[t][j * 16];
+          if (t < 4) v0[t] = x;
+          else v1[t - 4] = x;
+        }
       }
       split8<NT>(v0, v1, bt[j]);
     }
@@ -681,13 +758,14 @@ static int split_min_cin(bool dw) {
 template <int N, int NT>
 static int launch_s3(bool small, int nb, int nch, size_t lds, const float* in, int ld_in, const int32_t* src, const int32_t* d, float* tgt,
                      int ld_t, const __bf16* Wf3, int ncb, int K, int Cin, int tr, const KSeg& sg, hipStream_t s) {
+  static const int preload = getenv("MM_SPCONV_G_PRELOAD") ? atoi(getenv("MM_SPCONV_G_PRELOAD")) : 1;
   if (small) {
     hipLaunchKernelGGL((k_gather_gemm_s3<N, false, NT>), dim3(nb, nch), dim3(256), 0, s, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr,
-                       sg);
+                       sg, preload);
   } else {
     if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)k_gather_gemm_s3<N, true, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_gather_gemm_s3<N, true, NT>), dim3(nb, nch), dim3(256), lds, s, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr,
-                       sg);
+                       sg, preload);
   }
   return MM_OK;
 }
@@ -786,7 +864,8 @@ int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int 
       return MM_ERR_UNSUPPORTED;
     }
     const int ncbw = ncb / nch;
-    const bool small = R < 200000;
+    static const int64_t small_r = getenv("MM_SPCONV_SMALL_R") ? atoll(getenv("MM_SPCONV_SMALL_R")) : 0;  // round 3: the LDS-staged form everywhere - with the W slice arriving by LDS-DMA it wins at every size (112->112 on 88k rules: 96 -> 57 us); the unstaged form re-reads the whole slice from L2 per wave
+    const bool small = R < small_r;
     int tr = small ? 64 : TR;
     while (!small && tr > 64 && mm_cdiv(R, tr) * nch < 1024) tr >>= 1;
     KSeg sg;
