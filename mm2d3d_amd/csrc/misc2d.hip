@@ -23,11 +23,11 @@ __device__ inline u16 f2bf(float f) {
 // dst[r][0..C) = src[r][0..C), 16-B vectors (C multiple of 8 elements of 2 bytes)
 __global__ __launch_bounds__(T) void k_copy_rows(const u16* __restrict__ src, int64_t ld_s, u16* __restrict__ dst, int64_t ld_d,
                                                   int64_t N, int C8) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t r = gid / C8;
-  int c = (int)(gid - r * C8);
-  if (r >= N) return;
-  *(uint4*)(dst + r * ld_d + c * 8) = *(const uint4*)(src + r * ld_s + c * 8);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: N * C8 < 2^32)
+  const unsigned r = gid / (unsigned)C8;
+  const int c = (int)(gid - r * (unsigned)C8);
+  if ((int64_t)r >= N) return;
+  *(uint4*)(dst + (int64_t)r * ld_d + c * 8) = *(const uint4*)(src + (int64_t)r * ld_s + c * 8);
 }
 
 // Channel concat / split of up to 4 NHWC bf16 maps in ONE launch: dst[r] = [src0[r] | src1[r] | ...] (SPLIT: the reverse).
@@ -67,14 +67,17 @@ __global__ __launch_bounds__(T) void k_concat(CatP p) {
 __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, int ldx, int B, int H, int W, int C, u16* __restrict__ y,
                                                     unsigned char* __restrict__ idx, int Ho, int Wo) {
   const int C8 = C >> 3;
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * Ho * Wo * C8;
-  if (gid >= total) return;
-  int c8 = (int)(gid % C8);
-  int64_t pix = gid / C8;
-  int ox = (int)(pix % Wo);
-  int64_t t = pix / Wo;
-  int oy = (int)(t % Ho), b = (int)(t / Ho);
+  // 32-bit index arithmetic (host: total < 2^32): three 64-bit div/mod pairs were ~300 instructions per thread, several times
+  // the thread's memory work
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  if ((int64_t)gid >= total) return;
+  const unsigned pixu = gid / (unsigned)C8;
+  const int c8 = (int)(gid - pixu * (unsigned)C8);
+  const unsigned tu = pixu / (unsigned)Wo;
+  const int ox = (int)(pixu - tu * (unsigned)Wo);
+  const int b = (int)(tu / (unsigned)Ho), oy = (int)(tu - (unsigned)b * (unsigned)Ho);
+  const int64_t pix = pixu;
   float best[8];
   unsigned char bi[8];
   bool any = false;
@@ -110,14 +113,15 @@ __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, in
 __global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, const unsigned char* __restrict__ idx, int B, int H,
                                                     int W, int C, int Ho, int Wo, u16* __restrict__ dx) {
   const int C8 = C >> 3;
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * H * W * C8;
-  if (gid >= total) return;
-  int c8 = (int)(gid % C8);
-  int64_t pix = gid / C8;
-  int ix = (int)(pix % W);
-  int64_t t = pix / W;
-  int iy = (int)(t % H), b = (int)(t / H);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: total < 2^32)
+  const int64_t total = (int64_t)B * H * W * C8;
+  if ((int64_t)gid >= total) return;
+  const unsigned pixu = gid / (unsigned)C8;
+  const int c8 = (int)(gid - pixu * (unsigned)C8);
+  const unsigned tu = pixu / (unsigned)W;
+  const int ix = (int)(pixu - tu * (unsigned)W);
+  const int b = (int)(tu / (unsigned)H), iy = (int)(tu - (unsigned)b * (unsigned)H);
+  const int64_t pix = pixu;
   float s[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) s[i] = 0.f;
@@ -232,14 +236,14 @@ __global__ __launch_bounds__(T) void k_head_proj_mfma(const u16* __restrict__ x,
 // 25 reads and the write are coalesced across the wave
 __global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B, int h, int w, int NJ, const float* __restrict__ bias,
                                              float* __restrict__ out) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * h * w * NJ;
-  if (gid >= total) return;
-  int j = (int)(gid % NJ);
-  int64_t t = gid / NJ;
-  int xx = (int)(t % w);
-  t /= w;
-  int yy = (int)(t % h), b = (int)(t / h);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: total < 2^32)
+  const int64_t total = (int64_t)B * h * w * NJ;
+  if ((int64_t)gid >= total) return;
+  const unsigned t1 = gid / (unsigned)NJ;
+  const int j = (int)(gid - t1 * (unsigned)NJ);
+  const unsigned t2 = t1 / (unsigned)w;
+  const int xx = (int)(t1 - t2 * (unsigned)w);
+  const int b = (int)(t2 / (unsigned)h), yy = (int)(t2 - (unsigned)b * (unsigned)h);
   float s = 0.f;
   for (int dy = -2; dy <= 2; dy++) {
     int y2 = yy + dy;
@@ -256,14 +260,14 @@ __global__ __launch_bounds__(T) void k_box5(const float* __restrict__ in, int B,
 // same, 4 maps per thread (NJ % 4 == 0): 16-byte reads, a quarter of the load instructions
 __global__ __launch_bounds__(T) void k_box5_v4(const float* __restrict__ in, int B, int h, int w, int NJ4, const float* __restrict__ bias,
                                                 float* __restrict__ out) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t total = (int64_t)B * h * w * NJ4;
-  if (gid >= total) return;
-  int j4 = (int)(gid % NJ4);
-  int64_t t = gid / NJ4;
-  int xx = (int)(t % w);
-  t /= w;
-  int yy = (int)(t % h), b = (int)(t / h);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: total < 2^32)
+  const int64_t total = (int64_t)B * h * w * NJ4;
+  if ((int64_t)gid >= total) return;
+  const unsigned t1 = gid / (unsigned)NJ4;
+  const int j4 = (int)(gid - t1 * (unsigned)NJ4);
+  const unsigned t2 = t1 / (unsigned)w;
+  const int xx = (int)(t1 - t2 * (unsigned)w);
+  const int b = (int)(t2 / (unsigned)h), yy = (int)(t2 - (unsigned)b * (unsigned)h);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   const int x0 = xx - 2 < 0 ? 0 : xx - 2, x1 = xx + 2 >= w ? w - 1 : xx + 2;
   for (int dy = -2; dy <= 2; dy++) {
@@ -376,6 +380,7 @@ __global__ __launch_bounds__(64) void k_sum_partials_f(const float* __restrict__
 
 static void launch_box5(const float* in, int B, int h, int w, int NJ, const float* bias, float* out, hipStream_t s) {
   int64_t npix = (int64_t)B * h * w;
+  // (the kernels index their threads with 32 bits: the callers' maps are far below 2^32 elements, mm_head_* check it)
   if (NJ % 4 == 0 && ((uintptr_t)in % 16) == 0 && ((uintptr_t)out % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0))
     hipLaunchKernelGGL(k_box5_v4, dim3((unsigned)mm_cdiv(npix * (NJ / 4), T)), dim3(T), 0, s, in, B, h, w, NJ / 4, bias, out);
   else
@@ -389,6 +394,7 @@ int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, in
   MM_CHECK_ARG(C % 8 == 0 && ld_s % 8 == 0 && ld_d % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
                "copy_rows: C and pitches must be multiples of 8 elements");
   if (N == 0) return MM_OK;
+  MM_CHECK_ARG(N * (C / 8) < (1ll << 32) - 4096, "copy_rows: too many elements for 32-bit thread indices");
   hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)mm_cdiv(N * (C / 8), T)), dim3(T), 0, s, (const u16*)src, ld_s, (u16*)dst, ld_d, N, C / 8);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -422,6 +428,7 @@ int mm_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void
   MM_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, "maxpool: C and the input pitch must be multiples of 8");
   int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   if (total == 0) return MM_OK;
+  MM_CHECK_ARG(total < (1ll << 32) - 4096, "maxpool: too many elements for 32-bit thread indices");
   hipLaunchKernelGGL(k_maxpool_fwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)x, ldx, B, H, W, C, (u16*)y,
                      (unsigned char*)idx, Ho, Wo);
   MM_LAUNCH_CHECK();
@@ -433,6 +440,7 @@ int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, in
   MM_CHECK_ARG(C % 8 == 0, "maxpool: C must be a multiple of 8");
   int64_t total = (int64_t)B * H * W * (C / 8);
   if (total == 0) return MM_OK;
+  MM_CHECK_ARG(total < (1ll << 32) - 4096, "maxpool: too many elements for 32-bit thread indices");
   hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)dy, (const unsigned char*)idx, B, H, W,
                      C, Ho, Wo, (u16*)dx);
   MM_LAUNCH_CHECK();
@@ -471,6 +479,7 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   else if (NJ <= 20) MM_HEAD_PROJ(20);
   else MM_HEAD_PROJ(32);
 #undef MM_HEAD_PROJ
+  MM_CHECK_ARG((int64_t)B * h * w * NJ < (1ll << 32) - 4096, "head: too many elements for 32-bit thread indices");
   launch_box5(z, B, h, w, NJ, bias, out, s);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -494,6 +503,7 @@ int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
   float* dz = (float*)ws;
   float* partial = (float*)((char*)ws + zb);
   int64_t npix = (int64_t)B * h * w;
+  MM_CHECK_ARG(npix * NJ < (1ll << 32) - 4096, "head: too many elements for 32-bit thread indices");
   if (npix) launch_box5(dout, B, h, w, NJ, nullptr, dz, s);
 #define MM_HEAD_BWD(MJ)                                                                                                          \
   hipLaunchKernelGGL(k_head_bwd<MJ>, dim3(nblk), dim3(T), (size_t)(T / 64) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, \

@@ -76,9 +76,10 @@ __global__ __launch_bounds__(T) void k_seg_mean(const float* __restrict__ feats,
                                                  const int32_t* __restrict__ csr_off,
                                                  const int32_t* __restrict__ csr_items, int64_t n_vox, int mean,
                                                  float* __restrict__ out, int ld_o) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t v = gid / C;
-  int c = (int)(gid - v * C);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: n_vox * C < 2^32)
+  const unsigned vu = gid / (unsigned)C;
+  const int c = (int)(gid - vu * (unsigned)C);
+  const int64_t v = vu;
   if (v >= n_vox) return;
   int a = csr_off[v], b = csr_off[v + 1];
   float s = 0.f;
@@ -90,9 +91,10 @@ __global__ __launch_bounds__(T) void k_seg_mean(const float* __restrict__ feats,
 __global__ __launch_bounds__(T) void k_row_gather(const float* __restrict__ vox, int ld_v, int C,
                                                    const int32_t* __restrict__ p2v, const int32_t* __restrict__ csr_off,
                                                    int div_count, int64_t N, float* __restrict__ out, int ld_o) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t p = gid / C;
-  int c = (int)(gid - p * C);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: N * C < 2^32)
+  const unsigned pu = gid / (unsigned)C;
+  const int c = (int)(gid - pu * (unsigned)C);
+  const int64_t p = pu;
   if (p >= N) return;
   int v = p2v[p];
   float x = 0.f;
@@ -107,9 +109,10 @@ __global__ __launch_bounds__(T) void k_row_gather(const float* __restrict__ vox,
 __global__ __launch_bounds__(T) void k_linear_fwd(const float* __restrict__ x, int ld_x, int64_t N, int Cin, int Cout,
                                                    const float* __restrict__ w, const float* __restrict__ b,
                                                    float* __restrict__ y, int ld_y) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t n = gid / Cout;
-  int co = (int)(gid - n * Cout);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: N * Cout < 2^32)
+  const unsigned nu = gid / (unsigned)Cout;
+  const int co = (int)(gid - nu * (unsigned)Cout);
+  const int64_t n = nu;
   if (n >= N) return;
   float acc = b ? b[co] : 0.f;
   for (int ci = 0; ci < Cin; ci++) acc = fmaf(x[n * ld_x + ci], w[co * Cin + ci], acc);
@@ -120,9 +123,10 @@ __global__ __launch_bounds__(T) void k_linear_fwd(const float* __restrict__ x, i
 __global__ __launch_bounds__(T) void k_linear_bwd_x(const float* __restrict__ dy, int ld_dy, int64_t N, int Cin, int Cout,
                                                      const float* __restrict__ w, float* __restrict__ dx, int ld_dx,
                                                      int accumulate) {
-  int64_t gid = (int64_t)blockIdx.x * T + threadIdx.x;
-  int64_t n = gid / Cin;
-  int ci = (int)(gid - n * Cin);
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: N * Cin < 2^32)
+  const unsigned nu = gid / (unsigned)Cin;
+  const int ci = (int)(gid - nu * (unsigned)Cin);
+  const int64_t n = nu;
   if (n >= N) return;
   float acc = 0.f;
   for (int co = 0; co < Cout; co++) acc = fmaf(dy[n * ld_dy + co], w[co * Cin + ci], acc);
@@ -320,6 +324,7 @@ int mm_gate_bwd(const float* x, const float* mask, const float* dy, int64_t N, i
 int mm_segment_reduce(const float* feats, int ld_f, int C, const int32_t* csr_off, const int32_t* csr_items, int64_t n_vox,
                       int mean, float* out, int ld_o, hipStream_t s) {
   if (n_vox == 0) return MM_OK;
+  MM_CHECK_ARG((int64_t)(n_vox * C) < (1ll << 32) - 4096, "k_seg_mean: too many elements for 32-bit thread indices");
   hipLaunchKernelGGL(k_seg_mean, dim3((unsigned)mm_cdiv(n_vox * C, T)), dim3(T), 0, s, feats, ld_f, C, csr_off, csr_items, n_vox,
                      mean, out, ld_o);
   MM_LAUNCH_CHECK();
@@ -330,6 +335,7 @@ int mm_segment_reduce(const float* feats, int ld_f, int C, const int32_t* csr_of
 int mm_row_gather(const float* vox, int ld_v, int C, const int32_t* p2v, const int32_t* csr_off, int div_count, int64_t N,
                   float* out, int ld_o, hipStream_t s) {
   if (N == 0) return MM_OK;
+  MM_CHECK_ARG((int64_t)(N * C) < (1ll << 32) - 4096, "k_row_gather: too many elements for 32-bit thread indices");
   hipLaunchKernelGGL(k_row_gather, dim3((unsigned)mm_cdiv(N * C, T)), dim3(T), 0, s, vox, ld_v, C, p2v, csr_off, div_count, N,
                      out, ld_o);
   MM_LAUNCH_CHECK();
@@ -344,6 +350,7 @@ int mm_linear_fwd(const float* x, int ld_x, int64_t N, int Cin, int Cout, const 
     MM_LAUNCH_CHECK();
     return MM_OK;
   }
+  MM_CHECK_ARG((int64_t)(N * Cout) < (1ll << 32) - 4096, "k_linear_fwd: too many elements for 32-bit thread indices");
   hipLaunchKernelGGL(k_linear_fwd, dim3((unsigned)mm_cdiv(N * Cout, T)), dim3(T), 0, s, x, ld_x, N, Cin, Cout, w, b, y, ld_y);
   MM_LAUNCH_CHECK();
   return MM_OK;
@@ -361,6 +368,7 @@ int mm_linear_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t 
     if (fast && ld_dx % 4 == 0 && ((uintptr_t)dx % 16) == 0)
       hipLaunchKernelGGL(k_linear16_bwd_x, dim3((unsigned)mm_cdiv(N, T)), dim3(T), 0, s, dy, ld_dy, N, Cout, w, dx, ld_dx, accumulate_dx);
     else
+      MM_CHECK_ARG((int64_t)(N * Cin) < (1ll << 32) - 4096, "k_linear_bwd_x: too many elements for 32-bit thread indices");
       hipLaunchKernelGGL(k_linear_bwd_x, dim3((unsigned)mm_cdiv(N * Cin, T)), dim3(T), 0, s, dy, ld_dy, N, Cin, Cout, w, dx, ld_dx,
                          accumulate_dx);
   }
