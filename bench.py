@@ -92,22 +92,33 @@ def _engine_step(tm, batch, overlap):
 def conv_roofline(tm, batch, dev):
     """Sparse-conv engine kernels against SURVEY.md 8d's algorithmic bytes.
 
-    ``achieved`` / ``frac`` follow the contract's per-kernel definition: every engine call of one step timed ALONE (HIP events on
+    ``achieved`` / ``frac`` follow the contract's per-kernel definition: every engine call of a step timed ALONE (median over three
+    profiled steps per call; HIP events on
     the launch stream, the second stream of the backward switched off for this step, so that a kernel's interval is its own
     duration and agrees with a serial rocprofv3 kernel trace, profiles/rNN/bench_n1_serial_kernel_stats.csv).  The training
     step itself issues the weight gradient of the large 3^3 layers on a second stream beside the data gradient
     (mm2d3d_amd/scn/ops.py): ``backward_overlapped`` reports the same accounting over those joint intervals - what the step
     experiences; under concurrency the per-kernel durations of a kernel trace are longer than either figure (time sharing)."""
-    rec = _engine_step(tm, batch, overlap=False)
-    rec_ov = _engine_step(tm, batch, overlap=True)
+    def profiled(overlap, reps=3):
+        """``reps`` profiled steps; every call's time = the median of its ``reps`` measurements (one step's event times scatter
+        by a few per cent with whatever else the step's other kernels left in the caches)."""
+        runs = [_engine_step(tm, batch, overlap) for _ in range(reps)]
+        rec = runs[0]
+        for i, r in enumerate(rec):
+            ts = sorted(run[i]["e0"].elapsed_time(run[i]["e1"]) for run in runs if len(run) == len(rec))
+            r["ms"] = ts[len(ts) // 2]
+        return rec
+
+    rec = profiled(False)
+    rec_ov = profiled(True)
     alg_bytes = sum(r["bytes"] for r in rec)
-    ms = sum(r["e0"].elapsed_time(r["e1"]) for r in rec)
-    ms_ov = sum(r["e0"].elapsed_time(r["e1"]) for r in rec_ov)
+    ms = sum(r["ms"] for r in rec)
+    ms_ov = sum(r["ms"] for r in rec_ov)
     by_kind = {}
     for r in rec:
         k = by_kind.setdefault(r["kind"], [0.0, 0.0, 0])
         k[0] += r["bytes"]
-        k[1] += r["e0"].elapsed_time(r["e1"])
+        k[1] += r["ms"]
         k[2] += 1
     ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     ach_ov = alg_bytes / (ms_ov * 1e-3) / 1e9 if ms_ov > 0 else 0.0
@@ -137,7 +148,7 @@ def conv_roofline(tm, batch, dev):
     if os.environ.get("MM_BENCH_LAYERS"):
         which = rec_ov if os.environ["MM_BENCH_LAYERS"] == "overlap" else rec
         for r in which:
-            t = r["e0"].elapsed_time(r["e1"])
+            t = r["ms"]
             print(f"[layer] {r['kind']:3s} K={r['K']:2d} R={r['R']:8d} {r['cin']:3d}->{r['cout']:3d} {t*1e3:8.1f} us "
                   f"{r['bytes']/t/1e6:8.1f} GB/s  {2*r['R']*r['cin']*r['cout']/t/1e9:6.1f} TF/s", file=sys.stderr)
     return {

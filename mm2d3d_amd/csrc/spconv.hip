@@ -289,15 +289,16 @@ __global__ __launch_bounds__(256) void k_gather_gemm_s3(const float* __restrict_
     f32x4 xq[NQMAX][2];
     const bool pre = preload && nq <= NQMAX;  // uniform (MM_SPCONV_G_PRELOAD=0: the round-2 loop, for A/B runs)
     if (pre) {
+      // no branch per chunk: with one, the compiler moved every chunk's loads down next to that chunk's multiply again; a chunk
+      // beyond Cin (or an absent rule) reads the zero line - a data select, so all loads issue back to back
 #pragma unroll
       for (int q = 0; q < NQMAX; q++) {
-        if (q < nq) {  // uniform
-          typedef const __attribute__((address_space(1))) f32x4* gp4;  // keep the global address space through the select (else: flat loads)
-          const gp4 pq = (valid && q * 32 + sl * 8 < Cin) ? (gp4)(row + q * 32) : (gp4)g_zero8s;  // Cin % 16 == 0: 8 channels in or out together
-          xq[q][0] = pq[0];
-          xq[q][1] = pq[1];
-        }
+        typedef const __attribute__((address_space(1))) f32x4* gp4;  // keep the global address space through the select (else: flat loads)
+        const gp4 pq = (valid && q * 32 + sl * 8 < Cin) ? (gp4)(row + q * 32) : (gp4)g_zero8s;  // Cin % 16 == 0: 8 channels in or out together
+        xq[q][0] = pq[0];
+        xq[q][1] = pq[1];
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
     f32x4 acc[NCB];
 #pragma unroll
