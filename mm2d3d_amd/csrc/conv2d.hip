@@ -76,11 +76,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   for (int i = 0; i < 4; i++) {
     int64_t m = m0 + r0 + 32 * i;
     if (m < M) {
-      int gx = (int)(m % p.Wg);
-      int64_t t = m / p.Wg;
-      ay[i] = (int)(t % p.Hg);
-      ab[i] = (int)(t / p.Hg);
-      ax[i] = gx;
+      // 32-bit index arithmetic (host: M < 2^31).  Round 3: the 64-bit div / mod pairs of this decode and of the epilogue's were
+      // ~1,000 instructions per thread - for the short-K launches (stems, 1x1) more than the kernel's whole MFMA loop
+      const unsigned mu = (unsigned)m, t = mu / (unsigned)p.Wg;
+      ax[i] = (int)(mu - t * (unsigned)p.Wg);
+      ab[i] = (int)(t / (unsigned)p.Hg);
+      ay[i] = (int)(t - (unsigned)ab[i] * (unsigned)p.Hg);
     } else {
       ab[i] = -1;
       ay[i] = ax[i] = 0;
@@ -207,9 +208,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
     if (m >= M) continue;
     int64_t orow = m;
     if (p.so != 1 || ooy || oox || p.Ho != p.Hg || p.Wo != p.Wg) {
-      int gx = (int)(m % p.Wg);
-      int64_t t = m / p.Wg;
-      int gy = (int)(t % p.Hg), b = (int)(t / p.Hg);
+      const unsigned mu = (unsigned)m, t = mu / (unsigned)p.Wg;
+      const int gx = (int)(mu - t * (unsigned)p.Wg);
+      const int b = (int)(t / (unsigned)p.Hg), gy = (int)(t - (unsigned)b * (unsigned)p.Hg);
       orow = ((int64_t)b * p.Ho + gy * p.so + ooy) * p.Wo + gx * p.so + oox;
     }
 #pragma unroll
@@ -1183,12 +1184,12 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc_bf16(const float* __restri
 // filter become ONE 128-B tap of the implicit GEMM (conv2d.py StemConvFn): 1 tap for the depth image, 4 for RGB.
 __global__ __launch_bounds__(256) void k_stem_prep(const float* __restrict__ in, int B, int C, int H, int W, int pad, int Hb, int Wb,
                                                     int R, u16* __restrict__ out) {
-  int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int64_t total = (int64_t)B * Hb * Wb;
-  if (gid >= total) return;
-  int x = (int)(gid % Wb);
-  int64_t t = gid / Wb;
-  int y = (int)(t % Hb), b = (int)(t / Hb);
+  const unsigned gid = blockIdx.x * 256u + threadIdx.x;  // 32-bit index arithmetic (host: total < 2^32)
+  const int64_t total = (int64_t)B * Hb * Wb;
+  if ((int64_t)gid >= total) return;
+  const unsigned t = gid / (unsigned)Wb;
+  const int x = (int)(gid - t * (unsigned)Wb);
+  const int b = (int)(t / (unsigned)Hb), y = (int)(t - (unsigned)b * (unsigned)Hb);
   u16 v[8];
 #pragma unroll
   for (int sl = 0; sl < 8; sl++) {
@@ -1199,7 +1200,7 @@ __global__ __launch_bounds__(256) void k_stem_prep(const float* __restrict__ in,
   unsigned w[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) w[i] = (unsigned)v[2 * i] | ((unsigned)v[2 * i + 1] << 16);
-  *(uint4*)(out + gid * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+  *(uint4*)(out + (int64_t)gid * 8) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 int fill_taps(ConvP* p, const int* ty, const int* tx, int nt) {
@@ -1234,6 +1235,7 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
   }
   const int64_t M = (int64_t)B * Hg * Wg;
   if (M == 0) return MM_OK;
+  MM_CHECK_ARG(M < (1ll << 31), "conv2d_gemm: too many output pixels for 32-bit pixel indices");
   // Short K (1x1 layers, the stems, the transposed convolutions: <= 4 steps of 64 channels) with 64 output channels: these
   // launches are bound by load latency, not by MFMA time; one stage buffer (24 KB) lets five workgroups share a CU instead of
   // three, which hides more of it than the one-step prefetch did (18240-tile stems 269 -> 231 us, 4560x4 transposed conv 441 -> 385).

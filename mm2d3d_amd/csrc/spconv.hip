@@ -392,10 +392,21 @@ __global__ __launch_bounds__(256) void k_csr_reduce(const float* __restrict__ tm
   // four rules at a time: the four positions, then the four tmp rows, are independent loads (a rule-by-rule loop is a chain
   // of two dependent memory round trips per rule); rules beyond the row's last one re-read it and are not added.  The sum
   // stays in ascending rule order = ascending k.
+  // (round 3) the positions of the next four rules are requested before the current four tmp rows are added: one exposed round
+  // trip per iteration instead of two (positions, then rows)
+  int posn[4];
+  if (a < b) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) posn[j] = csr_pos[a + j < b ? a + j : b - 1];
+  }
   for (int e = a; e < b; e += 4) {
     int pos[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) pos[j] = csr_pos[e + j < b ? e + j : b - 1];
+    for (int j = 0; j < 4; j++) pos[j] = posn[j];
+    if (e + 4 < b) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) posn[j] = csr_pos[e + 4 + j < b ? e + 4 + j : b - 1];
+    }
     f32x4 v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) v[j] = *(const f32x4*)(tmp + (int64_t)pos[j] * ld_tmp + c4 * 4);
