@@ -97,9 +97,9 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const E* __restrict__ x, int ld
   const int64_t r0 = gbase + (int64_t)lb * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < gbase + Ng ? r0 + rows_per_block : gbase + Ng;
   if (slot < rs) {
-    for (int64_t r = r0 + slot; r < r1; r += rs) {
-      float xv[VEC];
-      ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+    // four rows (statistics) / two rows (backward reductions) per trip, all loads issued before any value is used (round 3: the one-row loop was one exposed round trip per
+    // row and thread); rows accumulate in the same order as before: bit-identical
+    auto row_acc = [&](const float (&xv)[VEC], const float (&dv)[VEC]) {
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
@@ -107,8 +107,6 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const E* __restrict__ x, int ld
           b[i] = fmaf(xv[i], xv[i], b[i]);
         }
       } else {
-        float dv[VEC];
-        ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
 #pragma unroll
         for (int i = 0; i < VEC; i++) {
           float xh = (xv[i] - m[i]) * is[i];
@@ -118,6 +116,25 @@ __global__ __launch_bounds__(T) void k_bn_reduce(const E* __restrict__ x, int ld
           b[i] = fmaf(g, xh, b[i]);
         }
       }
+    };
+    constexpr int U = MODE == 1 ? 2 : 4;
+    int64_t r = r0 + slot;
+    for (; r + (U - 1) * (int64_t)rs < r1; r += U * (int64_t)rs) {
+      float xv[U][VEC], dv[U][VEC];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int64_t ru = r + (int64_t)u * rs;
+        ldv<VEC>(x + ru * ld_x + cv * VEC, xv[u]);
+        if (MODE == 1) ldv<VEC>(dy + ru * ld_dy + cv * VEC, dv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) row_acc(xv[u], dv[u]);
+    }
+    for (; r < r1; r += rs) {
+      float xv[VEC], dv[VEC];
+      ldv<VEC>(x + r * ld_x + cv * VEC, xv);
+      if (MODE == 1) ldv<VEC>(dy + r * ld_dy + cv * VEC, dv);
+      row_acc(xv, dv);
     }
   }
   // reduce over row slots through LDS, one vector lane at a time

@@ -28,6 +28,14 @@ __device__ inline void ld8(const u16* p, float (&v)[8]) {
     v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
   }
 }
+__device__ inline void cvt8(const uint4& t, float (&v)[8]) {
+  const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    v[2 * i] = __uint_as_float(w[i] << 16);
+    v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+  }
+}
 __device__ inline void st8(u16* p, const float (&v)[8]) {
   unsigned w[4];
 #pragma unroll
@@ -73,9 +81,12 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
   const int64_t r0 = gbase + (int64_t)lb * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < gbase + Ng ? r0 + rows_per_block : gbase + Ng;
   if (slot < rs) {
-    for (int64_t r = r0 + slot; r < r1; r += rs) {
+    // Four rows (forward statistics) / two rows (backward reductions) per trip with all their loads issued before any is consumed (round 3: the one-row loop compiled to
+    // load -> s_waitcnt vmcnt(0) -> accumulate, one exposed round trip per row and thread).  The rows are accumulated in the
+    // same order as before: results are bit-identical.
+    auto row_acc = [&](const uint4& tx, const uint4& td, const uint4& t2, const uint4& ty) {
       float xv[8];
-      ld8(x + r * ld_x + cv * 8, xv);
+      cvt8(tx, xv);
       if (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < 8; i++) a[i] += xv[i];
@@ -87,14 +98,14 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
         }
       } else {
         float dv[8], yv[8];
-        ld8(dy + r * ld_dy + cv * 8, dv);
+        cvt8(td, dv);
         if (dy2) {  // second gradient contribution of this map (residual / concat consumer), summed here instead of by an add kernel
           float d2[8];
-          ld8(dy2 + r * ld_dy2 + cv * 8, d2);
+          cvt8(t2, d2);
 #pragma unroll
           for (int i = 0; i < 8; i++) dv[i] += d2[i];
         }
-        if (relu && !remask) ld8(yout + r * ld_y + cv * 8, yv);
+        if (relu && !remask) cvt8(ty, yv);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           if (remask) yv[i] = fmaf(xv[i], sc[i], sh[i]);
@@ -103,6 +114,29 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
           b[i] = fmaf(g, (xv[i] - m[i]) * is[i], b[i]);
         }
       }
+    };
+    const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+    constexpr int U = MODE == 1 ? 2 : 4;  // the backward reduction has up to four tensors per row: two rows keep the occupancy
+    int64_t r = r0 + slot;
+    for (; r + (U - 1) * (int64_t)rs < r1; r += U * (int64_t)rs) {
+      uint4 tx[U], td[U], t2[U], ty[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int64_t ru = r + (int64_t)u * rs;
+        tx[u] = *(const uint4*)(x + ru * ld_x + cv * 8);
+        td[u] = MODE == 1 ? *(const uint4*)(dy + ru * ld_dy + cv * 8) : z4;
+        t2[u] = (MODE == 1 && dy2) ? *(const uint4*)(dy2 + ru * ld_dy2 + cv * 8) : z4;
+        ty[u] = (MODE == 1 && relu && !remask) ? *(const uint4*)(yout + ru * ld_y + cv * 8) : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) row_acc(tx[u], td[u], t2[u], ty[u]);
+    }
+    for (; r < r1; r += rs) {
+      const uint4 tx = *(const uint4*)(x + r * ld_x + cv * 8);
+      const uint4 td = MODE == 1 ? *(const uint4*)(dy + r * ld_dy + cv * 8) : z4;
+      const uint4 t2 = (MODE == 1 && dy2) ? *(const uint4*)(dy2 + r * ld_dy2 + cv * 8) : z4;
+      const uint4 ty = (MODE == 1 && relu && !remask) ? *(const uint4*)(yout + r * ld_y + cv * 8) : z4;
+      row_acc(tx, td, t2, ty);
     }
   }
   // per-thread fp32 partials cover <= rows_per_block/rs rows (a few hundred); block and grid combination in fp64
