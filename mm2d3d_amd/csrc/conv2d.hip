@@ -1139,8 +1139,9 @@ __global__ __launch_bounds__(256) void k_pack_weights_batch(const int64_t* __res
     else hi = mid - 1;
   }
   const int64_t* d = desc + (int64_t)lo * 11;
-  const float* in = (const float*)d[0];
-  u16* out = (u16*)d[1];
+  // pointers that come out of an integer table are generic: say that they are global (else: flat loads / stores)
+  const __attribute__((address_space(1))) float* in = (const __attribute__((address_space(1))) float*)d[0];
+  __attribute__((address_space(1))) u16* out = (__attribute__((address_space(1))) u16*)d[1];
   const unsigned N = (unsigned)d[3], T = (unsigned)d[4], K = (unsigned)d[5];
   const int64_t sz = d[6], sn = d[7], st = d[8], sk = d[9];
   const unsigned ne = (unsigned)(d[2] * d[3] * d[4] * d[5]);  // < 2^31: checked where the table is built
