@@ -109,8 +109,24 @@ def conv_roofline(tm, batch, dev):
             r["ms"] = ts[len(ts) // 2]
         return rec
 
+    def event_pair_overhead_us(n=64):
+        """What an EMPTY event pair on a busy queue measures (median): the part of every bracket that is not kernel time.
+        Reported next to ``frac``, never subtracted from it."""
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(2.0e9 * 0.02))
+        pairs = []
+        for _ in range(n):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            pairs.append((e0, e1))
+        torch.cuda.synchronize()
+        ts = sorted(a.elapsed_time(b) for a, b in pairs)
+        return ts[len(ts) // 2] * 1e3
+
     rec = profiled(False)
     rec_ov = profiled(True)
+    pair_us = event_pair_overhead_us()
     alg_bytes = sum(r["bytes"] for r in rec)
     ms = sum(r["ms"] for r in rec)
     ms_ov = sum(r["ms"] for r in rec_ov)
@@ -155,8 +171,9 @@ def conv_roofline(tm, batch, dev):
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "sparse-conv engines, each call timed alone: k_osconv4<*> (fwd, dX of the levels >= 200k rows), k_gather_gemm<*> / "
-                  "k_gather_gemm_s3<*> + k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> + k_dw_reduce (dW)",
+                  "k_gather_gemm_s3<*> + k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> per layer + ONE k_dw_reduce_batch per backward (dW)",
         "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
+        "event_pair_overhead_us": round(pair_us, 2),
         "by_pass": {k: {"GB/s": round(v[0] / (v[1] * 1e-3) / 1e9, 1) if v[1] > 0 else 0.0, "ms": round(v[1], 3), "calls": v[2]}
                     for k, v in by_kind.items()},
         "backward_overlapped": {

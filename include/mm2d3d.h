@@ -173,6 +173,19 @@ int mm_spconv_os_apply_bf16(const void* in, int ld_in, int Cin, void* out, int l
 int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
                       const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
+/* The weight gradient in two calls: mm_spconv_dw_partial writes the partial slabs of ONE layer (fp32 rows, or bf16 rows when
+ * bf16 != 0) into ``partial`` (mm_spconv_dw_ws_bytes; must stay untouched until the reduce) and the 33 slab offsets of the
+ * layer into ``blk_start_host``; mm_spconv_dw_reduce_batch sums the slabs of n layers in ONE launch.  descs_dev: n rows of
+ * mm_spconv_dw_desc_bytes() bytes {const float* partial; float* dW; int32 ne = Cin*Cout, K, accumulate, blk_first;
+ * int32 blk_start[33]}, blk_first = sum of mm_spconv_dw_reduce_blocks(ne, K) over the preceding rows, total_blocks = that sum over all rows.
+ * Bit-identical to mm_spconv_dw (same slabs, same order).  Replaces the per-layer tail of scn's ConvolutionFunction /
+ * SubmanifoldConvolutionFunction backward (reference call sites scn_unet.py:43-52,68-77,114). */
+int mm_spconv_dw_partial(int bf16, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+                         const int32_t* dst, const int32_t* offsets_host, int K, void* partial, size_t partial_bytes,
+                         int32_t* blk_start_host, mm_stream_t stream);
+int mm_spconv_dw_desc_bytes(void);
+int64_t mm_spconv_dw_reduce_blocks(int ne, int K);
+int mm_spconv_dw_reduce_batch(const void* descs_dev, int n, int64_t total_blocks, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
  * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */

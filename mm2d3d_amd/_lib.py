@@ -56,6 +56,10 @@ _PROTOS = {
     "mm_spconv_os_pack_batch_bf16": (i32, [vp, i32, i64, vp]),
     "mm_spconv_os_apply_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp]),
     "mm_spconv_dw_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_spconv_dw_partial": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, sz, vp, vp]),
+    "mm_spconv_dw_desc_bytes": (i32, []),
+    "mm_spconv_dw_reduce_blocks": (i64, [i32, i32]),
+    "mm_spconv_dw_reduce_batch": (i32, [vp, i32, i64, vp]),
     "mm_bn_fwd_train_bf16": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval_bf16": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
     "mm_bn_bwd_bf16": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),

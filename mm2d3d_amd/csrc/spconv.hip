@@ -722,6 +722,73 @@ __global__ __launch_bounds__(256) void k_dw_reduce(const float* __restrict__ par
   }
 }
 
+// k_dw_reduce for every layer of a backward pass in one launch (mm_spconv_dw_reduce_batch): a workgroup finds its layer by
+// its block index, then does exactly what k_dw_reduce does for (32 elements, kernel offset k) - same slices, same fp64 sums.
+struct DwRedD {
+  const float* partial;
+  float* dW;
+  int32_t ne, K, accumulate, blk_first;
+  int32_t blk_start[MAXK + 1];
+};
+
+// Work per thread instead of threads per element (the first form - k_dw_reduce's 8 slices x 32 elements per workgroup - was
+// 100k workgroups of five loads per thread: 149 us for ~200 MB, bound by workgroup dispatch): a thread owns VEC consecutive
+// elements of one kernel offset and walks ALL its slabs with eight loads in flight, keeping k_dw_reduce's eight slice sums
+// (slab i of the offset goes to slice i mod 8) in eight accumulators, then adds them in slice order: the same fp64 sums in the
+// same order, no LDS, no barrier.
+__host__ __device__ inline int dw_red_vec(int ne) { return (ne & 3) ? 1 : 4; }
+__host__ __device__ inline int dw_red_blocks_k(int ne) { const int v = dw_red_vec(ne); return (ne / v + 255) >> 8; }
+
+template <int VEC>
+__device__ inline void dw_reduce_thread(const DwRedD& d, int k, int g) {
+  const int ne = d.ne;
+  const int e = g * VEC;
+  if (e >= ne) return;
+  typedef float fv __attribute__((ext_vector_type(VEC)));
+  const float* __restrict__ base = d.partial + e;
+  const int begin = d.blk_start[k], end = d.blk_start[k + 1];
+  double acc[8][VEC];
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int c = 0; c < VEC; c++) acc[i][c] = 0.0;
+  int s = begin;
+  for (; s + 8 <= end; s += 8) {
+    fv v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = *(const fv*)(base + (int64_t)(s + i) * ne);
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+      for (int c = 0; c < VEC; c++) acc[i][c] += (double)v[i][c];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++)  // the last, partial round of slices
+    if (s + i < end) {
+      const fv v = *(const fv*)(base + (int64_t)(s + i) * ne);
+#pragma unroll
+      for (int c = 0; c < VEC; c++) acc[i][c] += (double)v[c];
+    }
+  float* o = d.dW + (int64_t)k * ne + e;
+#pragma unroll
+  for (int c = 0; c < VEC; c++) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) t += acc[i][c];
+    o[c] = d.accumulate ? o[c] + (float)t : (float)t;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_dw_reduce_batch(const DwRedD* __restrict__ descs, int n) {
+  int li = 0;
+  while (li + 1 < n && (int)blockIdx.x >= descs[li + 1].blk_first) li++;  // uniform; n is a few dozen
+  const DwRedD& d = descs[li];
+  const int nbk = dw_red_blocks_k(d.ne);
+  const int b = blockIdx.x - d.blk_first, k = b / nbk, g = (b - k * nbk) * 256 + threadIdx.x;
+  if (dw_red_vec(d.ne) == 4) dw_reduce_thread<4>(d, k, g);
+  else dw_reduce_thread<1>(d, k, g);
+}
+
 int make_seg(const int32_t* offsets_host, int K, int rules_per_block, KSeg* seg) {
   int nb = 0;
   for (int k = 0; k < K; k++) {
@@ -987,6 +1054,65 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
                                 unique_dst, W, w_kstride, s_ci, s_co, kflip, nullptr, ws, ws_bytes, s);
 }
 
+}  // extern "C"
+
+namespace {
+
+// the partial slabs of one layer: partial[slab b][ci][co], slab b = rules [chunk b) of kernel offset find_k(b)
+int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+               const int32_t* dst, const int32_t* offsets_host, int K, void* ws, size_t ws_bytes, KSeg* seg_out, hipStream_t s) {
+  MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0, "spconv_dw: bad shape");
+  MM_CHECK_ARG(!bf || (Cin % 16 == 0 && Cout % 16 == 0), "spconv_dw_bf16: channels must be multiples of 16");
+  KSeg& seg = *seg_out;
+  const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
+  int nb = make_seg(offsets_host, K, chunk, &seg);
+  const int ne = Cin * Cout;
+  if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
+    mm_set_error("spconv_dw: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  float* partial = (float*)ws;
+  if (nb == 0) return MM_OK;
+  const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
+  if (mfma_ok) {
+    const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
+    const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
+    const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
+    const int nt = bf ? -1 : (Cin >= split_min_cin(true) ? split_terms() : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
+#define DWCASE(I, J)                                                                                                          \
+  if (ti == I && tj == J) {                                                                                                   \
+    if (nt == -1)                                                                                                             \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, __bf16>), dim3(nb, ny), dim3(256), lds, s, (const __bf16*)in, ld_in,        \
+                         (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                            \
+    else if (nt == 3)                                                                                                         \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 3>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, \
+                         ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                                                 \
+    else if (nt == 2)                                                                                                         \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 2>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, \
+                         ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                                                 \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((k_dw_direct<I, J>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout,   \
+                         ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                                                 \
+  }
+    DWCASE(1, 1) DWCASE(1, 2) DWCASE(1, 3) DWCASE(1, 4) DWCASE(2, 1) DWCASE(2, 2) DWCASE(2, 3) DWCASE(2, 4)
+    DWCASE(3, 1) DWCASE(3, 2) DWCASE(3, 3) DWCASE(3, 4) DWCASE(4, 1) DWCASE(4, 2) DWCASE(4, 3) DWCASE(4, 4)
+#undef DWCASE
+  } else {
+    size_t lds = (size_t)64 * (Cin + Cout) * sizeof(float);
+    MM_CHECK_ARG(lds <= 150 * 1024, "spconv_dw: channels too wide for the generic kernel");
+    if (lds > 64 * 1024)
+      MM_HIP(hipFuncSetAttribute((const void*)k_dw_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_dw_generic, dim3(nb), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, ld_do, src, dst, Cin,
+                       Cout, K, seg, partial);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout) {
   KSeg seg;
   int nb = make_seg(offsets_host, K, dw_chunk(offsets_host[K], Cin, Cout), &seg);
@@ -997,47 +1123,11 @@ size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Co
 int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_do, int Cout, const int32_t* src,
                  const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
                  size_t ws_bytes, hipStream_t s) {
-  MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0, "spconv_dw: bad shape");
   KSeg seg;
-  const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
-  int nb = make_seg(offsets_host, K, chunk, &seg);
+  int rc = dw_partial(0, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
+  if (rc != MM_OK) return rc;
   const int ne = Cin * Cout;
-  if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
-    mm_set_error("spconv_dw: workspace too small");
-    return MM_ERR_WORKSPACE;
-  }
-  float* partial = (float*)ws;
-  if (nb > 0) {
-    const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
-    if (mfma_ok) {
-      const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
-      const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
-      const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
-      const int nt = Cin >= split_min_cin(true) ? split_terms() : 0;  // matrix-rate-bound widths, as in mm_spconv_apply
-#define DWCASE(I, J)                                                                                                  \
-  if (ti == I && tj == J) {                                                                                           \
-    if (nt == 3)                                                                                                      \
-      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 3>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, \
-                         Cout, K, seg, chunk, partial);                                                               \
-    else if (nt == 2)                                                                                                 \
-      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 2>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, \
-                         Cout, K, seg, chunk, partial);                                                               \
-    else                                                                                                              \
-      hipLaunchKernelGGL((k_dw_direct<I, J>), dim3(nb, ny), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, \
-                         K, seg, chunk, partial);                                                                     \
-  }
-      DWCASE(1, 1) DWCASE(1, 2) DWCASE(1, 3) DWCASE(1, 4) DWCASE(2, 1) DWCASE(2, 2) DWCASE(2, 3) DWCASE(2, 4)
-      DWCASE(3, 1) DWCASE(3, 2) DWCASE(3, 3) DWCASE(3, 4) DWCASE(4, 1) DWCASE(4, 2) DWCASE(4, 3) DWCASE(4, 4)
-#undef DWCASE
-    } else {
-      size_t lds = (size_t)64 * (Cin + Cout) * sizeof(float);
-      MM_CHECK_ARG(lds <= 150 * 1024, "spconv_dw: channels too wide for the generic kernel");
-      if (lds > 64 * 1024)
-        MM_HIP(hipFuncSetAttribute((const void*)k_dw_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_dw_generic, dim3(nb), dim3(256), lds, s, in, ld_in, dout, ld_do, src, dst, Cin, Cout, K, seg, partial);
-    }
-  }
-  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, (const float*)ws, ne, K, seg, dW, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -1046,29 +1136,40 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
 int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
                       const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
                       size_t ws_bytes, hipStream_t s) {
-  MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && Cin % 16 == 0 && Cout % 16 == 0, "spconv_dw_bf16: channels must be multiples of 16");
   KSeg seg;
-  const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
-  int nb = make_seg(offsets_host, K, chunk, &seg);
+  int rc = dw_partial(1, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
+  if (rc != MM_OK) return rc;
   const int ne = Cin * Cout;
-  if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
-    mm_set_error("spconv_dw_bf16: workspace too small");
-    return MM_ERR_WORKSPACE;
-  }
-  float* partial = (float*)ws;
-  if (nb > 0) {
-    const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
-    const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
-    const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
-#define DWB(I, J)                                                                                                          \
-  if (ti == I && tj == J)                                                                                                  \
-    hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, __bf16>), dim3(nb, ny), dim3(256), lds, s, (const __bf16*)in, ld_in,        \
-                       (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);
-    DWB(1, 1) DWB(1, 2) DWB(1, 3) DWB(1, 4) DWB(2, 1) DWB(2, 2) DWB(2, 3) DWB(2, 4)
-    DWB(3, 1) DWB(3, 2) DWB(3, 3) DWB(3, 4) DWB(4, 1) DWB(4, 2) DWB(4, 3) DWB(4, 4)
-#undef DWB
-  }
-  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, partial, ne, K, seg, dW, accumulate);
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, (const float*)ws, ne, K, seg, dW, accumulate);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// The weight gradient in two calls (round 3): the partial slabs of a layer now, the slab sums of EVERY layer of a backward
+// pass later in one launch (mm_spconv_dw_reduce_batch) - 26 small reduce launches and as many dependent-launch gaps per step
+// become one.  ``partial`` (mm_spconv_dw_ws_bytes) must stay untouched until the batched reduce has run; ``blk_start_host``
+// receives the MAXK + 1 = 33 slab offsets per kernel offset that the reduce needs (a row of its descriptor table).
+// bf16 != 0: in / dout are bf16 rows.  Same kernels, same slabs, same summation order as mm_spconv_dw: bit-identical.
+int mm_spconv_dw_partial(int bf16, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+                         const int32_t* dst, const int32_t* offsets_host, int K, void* partial, size_t partial_bytes,
+                         int32_t* blk_start_host, hipStream_t s) {
+  MM_CHECK_ARG(blk_start_host != nullptr, "spconv_dw_partial: no descriptor row");
+  KSeg seg;
+  int rc = dw_partial(bf16, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, partial, partial_bytes, &seg, s);
+  if (rc != MM_OK) return rc;
+  for (int k = 0; k <= MAXK; k++) blk_start_host[k] = seg.blk_start[k];
+  return MM_OK;
+}
+
+int mm_spconv_dw_desc_bytes(void) { return (int)sizeof(DwRedD); }
+int64_t mm_spconv_dw_reduce_blocks(int ne, int K) { return (int64_t)dw_red_blocks_k(ne) * K; }
+
+// descs (device): n rows of DwRedD {partial, dW, ne, K, accumulate, blk_first, blk_start[33]}; blk_first = prefix sum of
+// mm_spconv_dw_reduce_blocks(ne, K) over the preceding rows, total_blocks = the sum over all rows.
+int mm_spconv_dw_reduce_batch(const void* descs_dev, int n, int64_t total_blocks, hipStream_t s) {
+  MM_CHECK_ARG(n >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "spconv_dw_reduce_batch: bad table");
+  if (n == 0 || total_blocks == 0) return MM_OK;
+  hipLaunchKernelGGL(k_dw_reduce_batch, dim3((unsigned)total_blocks), dim3(256), 0, s, (const DwRedD*)descs_dev, n);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -4,6 +4,8 @@ from __future__ import annotations
 import os
 import weakref
 
+import numpy as np
+
 import torch
 
 from .. import _lib, gradsink
@@ -213,6 +215,91 @@ def _dw(x, dout, rb, src, dst, cin, cout, sink=None):
     return dW
 
 
+# The weight gradient of a layer is a "partial slabs" kernel plus a small slab-sum kernel (csrc/spconv.hip).  With a gradient
+# sink the slab sums of ALL layers of a backward pass are deferred into one launch (k_dw_reduce_batch): 26 launches of ~9 us,
+# each behind a dependent-launch gap, become one.  The sums run when the last sparse convolution that went forward with a sink
+# has issued its slabs (so a data-parallel run still gets the 3D gradients while the 2D backward is running), at the latest in
+# an end-of-backward callback of the autograd engine.  Same slabs, same summation order: bit-identical with the per-layer form.
+DW_BATCH = [os.environ.get("MM_SPCONV_DW_BATCH", "1") != "0"]
+
+
+class _DwBatch:
+    def __init__(self):
+        self.expected = 0  # forward calls with a sink whose backward has not run yet (early trigger only, see flush)
+        self.items = []    # (partial, sink, ne, K, blk_start row, param)
+        self.cb_queued = False
+        self.row_ints = None
+
+    def rows(self):
+        if self.row_ints is None:
+            self.row_ints = (int(_lib.lib().mm_spconv_dw_desc_bytes()) - 32) // 4
+        return self.row_ints
+
+    def add(self, partial, sink, ne, K, row, param):
+        self.items.append((partial, sink, ne, K, row, param))
+        if not self.cb_queued:
+            self.cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        self.expected -= 1
+        if self.expected == 0:
+            self.flush()
+
+    def _end_of_backward(self):
+        self.cb_queued = False
+        self.expected = 0  # heals a forward that never saw its backward
+        self.flush()
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        L = _lib.lib()
+        n, nr = len(items), self.rows()
+        tab = np.zeros((n, 8 + nr), dtype=np.int32)  # {int64 partial, int64 dW, int32 ne, K, accumulate, blk_first, blk_start[nr]}
+        ptrs = tab[:, :4].view(np.int64)
+        first = 0
+        for i, (partial, sink, ne, K, row, _) in enumerate(items):
+            ptrs[i, 0], ptrs[i, 1] = partial.data_ptr(), sink.data_ptr()
+            tab[i, 4:8] = (ne, K, 1, first)
+            tab[i, 8:] = row
+            first += int(L.mm_spconv_dw_reduce_blocks(ne, K))
+        dev = items[0][0].device
+        descs = torch.from_numpy(tab.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+
+        def run():
+            check(L.mm_spconv_dw_reduce_batch(ptr(descs), n, first, stream()), "spconv_dw_reduce_batch")
+
+        if PROFILE is None:
+            run()
+        else:  # the roofline leg charges the slab sums to the dW passes: time without bytes of its own
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run()
+            e1.record()
+            PROFILE.append(dict(kind="dW", R=0, cin=0, cout=0, K=0, e0=e0, e1=e1, bytes=0))
+        for it in items:
+            gradsink.done(it[5])
+
+
+_DWB = _DwBatch()
+
+
+def _dw_partial(x, dout, rb, src, dst, cin, cout, sink, param, bf16, partial=None):
+    """The slabs of one layer now, their sum with every other layer's later (``_DwBatch``)."""
+    L = _lib.lib()
+    nbytes = int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout))
+    if partial is None:
+        partial = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    row = np.empty(_DWB.rows(), dtype=np.int32)
+    check(L.mm_spconv_dw_partial(1 if bf16 else 0, ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst),
+                                 rb.offsets_ptr, rb.K, ptr(partial), nbytes, row.ctypes.data, stream()), "spconv_dw_partial")
+    return partial, row
+
+
+def _dw_slab_buffer(x, rb, cin, cout):
+    return torch.empty(int(_lib.lib().mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), dtype=torch.uint8, device=x.device)
+
+
 # Backward of one sparse convolution = two independent passes over the same dOut rows: the data gradient (engine F or G+R)
 # and the weight gradient (k_dw_*).  Each alone is bound by gather latency (SQ counters: 54-67 % of the wave cycles waiting
 # on memory, matrix pipe 5-11 % busy) and the small levels do not even fill the chip, so the weight gradient is issued on a
@@ -269,6 +356,9 @@ class SparseConvFunction(torch.autograd.Function):
             ctx.weight = weight
             ctx.wparam = weight if (weight.dtype == F32 and weight.is_contiguous()
                                     and gradsink.claim(ctx, weight, ctx.needs_input_grad[1])) else None
+            ctx.dw_batched = ctx.wparam is not None and DW_BATCH[0]
+            if ctx.dw_batched:
+                _DWB.expected += 1
             return out
         if _os_usable(table, x, cin, cout) and table.n_dst == n_out:
             out = _timed("fwd", rb, acin, cout, lambda: _apply_os(x, weight, w, table, cout, False, False))
@@ -281,6 +371,9 @@ class SparseConvFunction(torch.autograd.Function):
         ctx.weight = weight
         ctx.wparam = weight if (weight.dtype == F32 and weight.is_contiguous()
                                 and gradsink.claim(ctx, weight, ctx.needs_input_grad[1])) else None
+        ctx.dw_batched = ctx.wparam is not None and DW_BATCH[0]
+        if ctx.dw_batched:
+            _DWB.expected += 1
         return out
 
     @staticmethod
@@ -297,6 +390,10 @@ class SparseConvFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 sink = ctx.wparam._mm_sink if ctx.wparam is not None else None
                 a, b = (rb.rout, rb.rin) if mode == "up" else (rb.rin, rb.rout)
+                if ctx.dw_batched:
+                    pr = _timed("dW", rb, cin, cout, lambda: _dw_partial(x, dout, rb, a, b, cin, cout, sink, ctx.wparam, True), 2)
+                    _DWB.add(pr[0], sink, cin * cout, rb.K, pr[1], ctx.wparam)
+                    return dx, None, None, None, None, None, None
                 dw = _timed("dW", rb, cin, cout, lambda: _dw_bf16(x, dout, rb, a, b, cin, cout, sink), 2)
                 if sink is not None:
                     gradsink.done(ctx.wparam)
@@ -321,9 +418,13 @@ class SparseConvFunction(torch.autograd.Function):
                 return t("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rout, rb.rin, n_in, cin, True, True, False, weight=ctx.weight))
             return t("dX", rb, cin, cout, lambda: _apply(dout, w, rb, rb.rin, rb.rout, n_in, cin, False, True, False, weight=ctx.weight))
 
-        def weight_grad(timed):
+        batched = ctx.dw_batched and ctx.needs_input_grad[1]
+
+        def weight_grad(timed, slabs=None):
             t = (lambda kind, rb_, a, b, fn: fn()) if not timed else _timed
             a, b = (rb.rout, rb.rin) if mode == "up" else (rb.rin, rb.rout)
+            if batched:  # slabs now, their sum with every other layer's in one launch (_DwBatch)
+                return t("dW", rb, ctx.acin, cout, lambda: _dw_partial(x, dout, rb, a, b, cin, cout, sink, ctx.wparam, False, slabs))
             return t("dW", rb, ctx.acin, cout, lambda: _dw(x, dout, rb, a, b, cin, cout, sink))
 
         # the fork / join of the second stream costs ~10-20 us of its own: worth it for the 3^3 layers from 32 input channels and
@@ -334,10 +435,12 @@ class SparseConvFunction(torch.autograd.Function):
             def pair():
                 main = torch.cuda.current_stream(dout.device)
                 side = _side_stream(dout.device)
+                # the slab buffer of the deferred form lives until the batched sum on the MAIN stream: allocate it there
+                slabs = _dw_slab_buffer(x, rb, cin, cout) if batched else None
                 side.wait_event(main.record_event())
                 with torch.cuda.stream(side):
-                    g = weight_grad(False)
-                for t_ in (x, dout, g):
+                    g = weight_grad(False, slabs)
+                for t_ in (x, dout) + (() if batched else (g,)):
                     t_.record_stream(side)
                 d = data_grad(False)
                 main.wait_event(side.record_event())
@@ -350,7 +453,10 @@ class SparseConvFunction(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dw = weight_grad(True)
         if dw is not None:
-            if sink is not None:
+            if batched:
+                _DWB.add(dw[0], sink, cin * cout, rb.K, dw[1], ctx.wparam)
+                dw = None
+            elif sink is not None:
                 gradsink.done(ctx.wparam)
                 dw = None
             else:

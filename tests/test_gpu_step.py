@@ -328,6 +328,57 @@ def test_gradient_sinks_equal_autograd_accumulation():
             assert sum(a["touched"]) >= len(a["params"]) - 6
 
 
+def test_deferred_sparse_weight_gradient_sums_equal_per_layer_sums():
+    """scn.ops._DwBatch: the slab sums of every sparse layer of a backward pass in ONE launch (mm_spconv_dw_reduce_batch) give
+    bit for bit the gradient arena of the per-layer launches (mm_spconv_dw), fp32 rows and 16-bit rows."""
+    import copy
+
+    from mm2d3d_amd import scn
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.scn import ops
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = _dev()
+    kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+    W = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]
+    mk = lambda: {"source": make_batch(5, 2, "nuscenes", (48, 64), device=dev), "target": make_batch(6, 2, "nuscenes", (48, 64), device=dev)}
+    loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
+    prev = ops.DW_BATCH[0]
+    try:
+        for act in (None, torch.bfloat16):
+            torch.manual_seed(0)
+            n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+            for m in n2.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.p = 0.0
+            arenas = []
+            for batched in (True, False):
+                ops.DW_BATCH[0] = batched
+                a2, a3 = copy.deepcopy(n2), copy.deepcopy(n3)
+                opts = {k: Optimizer("adamw", lr=1e-3) for k in ("2d_net", "3d_net")}
+                kwargs = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1)
+                kwargs["sparse_activations"] = "bf16" if act is not None else "fp32"
+                tm = TrainModel({"2d_net": a2, "3d_net": a3}, opts, loss, kwargs)
+                tm.configure_optimizers()
+                for o in tm.optimizers:
+                    o.zero_grad()
+                tm.training_step(mk()).backward()
+                torch.cuda.synchronize()
+                assert ops._DWB.items == [] and ops._DWB.expected == 0
+                arenas.append({n: p._mm_sink.clone() for n, p in a3.named_parameters() if hasattr(p, "_mm_sink")})
+                assert all(p._mm_pending == 0 for p in a3.parameters() if hasattr(p, "_mm_sink"))
+            assert len(arenas[0]) > 50
+            for n in arenas[0]:
+                assert torch.equal(arenas[0][n], arenas[1][n]), (act, n)
+    finally:
+        ops.DW_BATCH[0] = prev
+        scn.set_activation_dtype(torch.float32)
+
+
 def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
     from mm2d3d_amd.metrics import SegIoU
 
