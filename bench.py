@@ -34,7 +34,7 @@ NET3D_KW = dict(in_channels=3, m=16, block_reps=1, residual_blocks=False, full_s
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def build_trainer(dev, total_steps=49047, num_classes=6, class_weights=None):
+def build_trainer(dev, total_steps=49047, num_classes=6, class_weights=None, train_kwargs=None):
     from mm2d3d_amd.losses import Loss
     from mm2d3d_amd.net2d import Net2DSeg
     from mm2d3d_amd.net3d import Net3DSeg
@@ -50,7 +50,7 @@ def build_trainer(dev, total_steps=49047, num_classes=6, class_weights=None):
         opts[k] = o
     loss = Loss([{"name": "cross_entropy", "weight": 1.0, "target": "segmentation",
                   "args": {"weight": class_weights if class_weights is not None else CLASS_WEIGHTS}}])
-    tm = TrainModel(nets, opts, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
+    tm = TrainModel(nets, opts, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, **(train_kwargs or {})))
     tm.configure_optimizers()
     return tm
 
@@ -349,6 +349,8 @@ def main(argv=None):
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes; "
                          "c5 = configs[4]: 10k-pt vKITTI-shaped source + KITTI-shaped target, 8/GPU, 16-bit sparse activations")
+    ap.add_argument("--sparse-act", default="bf16", choices=["bf16", "fp16"],
+                    help="--workload c5: kind of the 16-bit sparse rows (fp16 = IEEE half + loss scaling)")
     a = ap.parse_args(argv)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -387,11 +389,9 @@ def main(argv=None):
     elif a.workload == "c5":
         # source = KITTI-shaped sweeps downsampled to 10,000 points (datasets/virtual_kitti_semantic_kitti.yaml:27),
         # target = full KITTI-shaped scans; sparse rows in bf16 between the stem and the OutputLayer (fp32 accumulation)
-        from mm2d3d_amd import scn
-
-        scn.set_activation_dtype(torch.bfloat16)
+        # (--sparse-act fp16: IEEE fp16 rows + the device-resident loss scale of mm2d3d_amd/amp.py)
         shape, ncls, B, down_src = "kitti", 6, a.scenes, 10000
-        tm = build_trainer(dev)
+        tm = build_trainer(dev, train_kwargs={"sparse_activations": a.sparse_act})
     else:
         shape, ncls, B = "nuscenes", 6, a.scenes
         tm = build_trainer(dev)
@@ -459,7 +459,9 @@ def main(argv=None):
         out["config"]["workload"] = ("BASELINE.json configs[4] shape: source = KITTI-shaped sweeps downsampled to 10,000 pts, target = KITTI-shaped "
                                      "121,600-pt scans, 480x302, sparse rows bf16 between the stem and the OutputLayer, fp32 accumulation "
                                      "(not the headline)")
-        out["dtype"] = "bf16 MFMA, fp32 accumulate (2D branch) + bf16 sparse activations / fp32 accumulate and statistics (3D branch)"
+        out["dtype"] = (f"bf16 MFMA, fp32 accumulate (2D branch) + {a.sparse_act} sparse activations / fp32 accumulate and statistics "
+                        "(3D branch)" + (", loss scale 65536 on the device (GradScaler semantics)" if a.sparse_act == "fp16" else ""))
+        out["config"]["workload"] = out["config"]["workload"].replace("sparse rows bf16", f"sparse rows {a.sparse_act}")
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c5":
         out["roofline"] = conv_roofline(tm, batch, dev)
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c2":

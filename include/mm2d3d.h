@@ -173,8 +173,21 @@ int mm_spconv_os_apply_bf16(const void* in, int ld_in, int Cin, void* out, int l
 int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
                       const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
-/* The weight gradient in two calls: mm_spconv_dw_partial writes the partial slabs of ONE layer (fp32 rows, or bf16 rows when
- * bf16 != 0) into ``partial`` (mm_spconv_dw_ws_bytes; must stay untouched until the reduce) and the 33 slab offsets of the
+/* The fp16 kind of the 16-bit activation mode (BASELINE.json configs[4] "fp16 activations"; the reference trains with
+ * ``precision: 16`` = fp16 autocast + GradScaler, train.yaml:11): the sparse rows are IEEE fp16, the weights one fp16 term per
+ * element (fragment sizes: mm_spconv_os_pack_bytes_bf16), products on v_mfma_f32_16x16x32_f16, accumulation fp32 in
+ * ascending k.  Gradient rows need loss scaling (mm2d3d_amd/amp.py). */
+int mm_spconv_os_pack_f16(const float* W, int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin, int Cout, void* Wf,
+                          mm_stream_t stream);
+int mm_spconv_os_pack_batch_f16(const int64_t* descs_dev, int n_desc, int64_t total_blocks, mm_stream_t stream);
+int mm_spconv_os_apply_f16(const void* in, int ld_in, int Cin, void* out, int ld_out, int Cout, const void* Wf, int K,
+                           const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
+                           mm_stream_t stream);
+int mm_spconv_dw_f16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+                     const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                     size_t ws_bytes, mm_stream_t stream);
+/* The weight gradient in two calls: mm_spconv_dw_partial writes the partial slabs of ONE layer (fp32 rows; bf16 rows when
+ * bf16 == 1, IEEE fp16 rows when bf16 == 2) into ``partial`` (mm_spconv_dw_ws_bytes; must stay untouched until the reduce) and the 33 slab offsets of the
  * layer into ``blk_start_host``; mm_spconv_dw_reduce_batch sums the slabs of n layers in ONE launch.  descs_dev: n rows of
  * mm_spconv_dw_desc_bytes() bytes {const float* partial; float* dW; int32 ne = Cin*Cout, K, accumulate, blk_first;
  * int32 blk_start[33]}, blk_first = sum of mm_spconv_dw_reduce_blocks(ne, K) over the preceding rows, total_blocks = that sum over all rows.
@@ -220,6 +233,16 @@ int mm_bn_fwd_eval_bf16(const void* x, int ld_x, int64_t N, int C, const float* 
 int mm_bn_bwd_bf16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
                    const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
                    float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* ... and over IEEE fp16 rows (the fp16 kind of the 16-bit activation mode: train.yaml:11 ``precision: 16``) */
+int mm_bn_fwd_train_f16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
+                        float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn_fwd_eval_f16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                       const float* running_mean, const float* running_var, float eps, float leak, void* y, int ld_y,
+                       mm_stream_t stream);
+int mm_bn_bwd_f16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+                  const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
+                  float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- per-point rows (csrc/point.hip) */
 size_t mm_point_ws_bytes(int Cin, int Cout);
@@ -270,6 +293,18 @@ int mm_eval_confusion(const float* logits2d, int ld2, const float* logits3d, int
 /* torch.optim.AdamW update over flat fp32 arenas (EXP/train.py:627-636); step counts from 1; g is multiplied by grad_scale */
 int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int64_t step, double grad_scale, mm_stream_t stream);
+/* Loss-scaled steps (the fp16 kind of the 16-bit activation mode; torch.cuda.amp.GradScaler semantics as driven by the
+ * reference's ``precision: 16`` trainer, train.yaml:11) WITHOUT a read-back: scale, non-finite flag, clean-step tracker and
+ * step counter live on the device.  mm_grad_nonfinite: found_dev[0] = 1 if any gradient is inf / nan (the caller zeroes it);
+ * mm_amp_prepare: the coefficients of one parameter group's update (mm_amp_coef_bytes bytes) incl. 1 / scale and "skip";
+ * mm_adamw_step_dev: mm_adamw_step with those coefficients, a no-op when skip is set; mm_amp_update: GradScaler.update(). */
+int mm_grad_nonfinite(const float* g, int64_t n, int* found_dev, mm_stream_t stream);
+int mm_amp_coef_bytes(void);
+int mm_amp_prepare(const float* scale_dev, const int* found_dev, int64_t* step_dev, int advance, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, double grad_scale, void* coef_dev, mm_stream_t stream);
+int mm_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const void* coef_dev, mm_stream_t stream);
+int mm_amp_update(float* scale_dev, int* tracker_dev, const int* found_dev, int nfound, double growth, double backoff, int interval,
+                  mm_stream_t stream);
 
 /* ---------------------------------------------------------------- dense 2D convolutions (csrc/conv2d.hip)
  * torch.nn.Conv2d / ConvTranspose2d of EXP/2d_net/backbones.py:43-65 and EXP/2d_net/model.py:64-82,104-123.

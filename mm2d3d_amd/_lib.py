@@ -56,6 +56,10 @@ _PROTOS = {
     "mm_spconv_os_pack_batch_bf16": (i32, [vp, i32, i64, vp]),
     "mm_spconv_os_apply_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp]),
     "mm_spconv_dw_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_spconv_os_pack_f16": (i32, [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "mm_spconv_os_pack_batch_f16": (i32, [vp, i32, i64, vp]),
+    "mm_spconv_os_apply_f16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp]),
+    "mm_spconv_dw_f16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
     "mm_spconv_dw_partial": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, sz, vp, vp]),
     "mm_spconv_dw_desc_bytes": (i32, []),
     "mm_spconv_dw_reduce_blocks": (i64, [i32, i32]),
@@ -63,6 +67,9 @@ _PROTOS = {
     "mm_bn_fwd_train_bf16": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval_bf16": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
     "mm_bn_bwd_bf16": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn_fwd_train_f16": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn_fwd_eval_f16": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
+    "mm_bn_bwd_f16": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_bn_ws_bytes": (sz, [i32]),
     "mm_bn_fwd_train": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
@@ -84,6 +91,11 @@ _PROTOS = {
     "mm_lift_scatter_runs": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp]),
     "mm_eval_confusion": (i32, [vp, i32, vp, i32, vp, i64, i32, i64, vp, vp]),
     "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp]),
+    "mm_grad_nonfinite": (i32, [vp, i64, vp, vp]),
+    "mm_amp_coef_bytes": (i32, []),
+    "mm_amp_prepare": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, vp, vp]),
+    "mm_adamw_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
+    "mm_amp_update": (i32, [vp, vp, vp, i32, f64, f64, i32, vp]),
     "mm_conv2d_gemm": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp,
                              vp, i32, i64, i32, vp, vp]),
     "mm_conv2d_3x3s1": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp]),

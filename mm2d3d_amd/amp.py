@@ -1,0 +1,86 @@
+"""Loss scaling for the fp16 kind of the 16-bit activation mode.
+
+The reference trains with ``precision: 16`` (/root/reference/.../config/train.yaml:11): Lightning's native-AMP plugin, i.e. fp16
+autocast + ``torch.cuda.amp.GradScaler`` (init_scale 65536, growth_factor 2, backoff_factor 0.5, growth_interval 2000; an
+optimiser whose gradients hold an inf / nan skips its step, ``update()`` then halves the scale, 2000 clean steps double it).
+IEEE fp16 gradient rows need that scale (bf16 rows do not: the default 16-bit kind here), so ``GradScaler`` below restates
+those semantics for :class:`mm2d3d_amd.optimizers.FlatAdamW` - with the scale, the non-finite flags, the clean-step tracker and
+the optimisers' step counters RESIDENT ON THE DEVICE (csrc/loss.hip k_grad_nonfinite / k_amp_prepare / k_adamw<., true> /
+k_amp_update): a skipped step costs no read-back, the host never waits for the GPU.
+
+    scaler = GradScaler(device)
+    (loss * scaler.scale_tensor).backward()          # or scaler.scale(loss).backward()
+    for o in optimizers: scaler.step(o, grad_scale)  # checks o's gradient arenas, updates unless non-finite
+    scaler.update()
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+
+class GradScaler:
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        if growth_factor <= 1.0 or not (0.0 < backoff_factor < 1.0) or growth_interval < 1:
+            raise ValueError("GradScaler: growth_factor > 1, 0 < backoff_factor < 1, growth_interval >= 1")
+        self.enabled = bool(enabled)
+        self.device = torch.device(device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+        self.scale_tensor = torch.full((1,), float(init_scale), dtype=torch.float32, device=self.device)
+        self._tracker = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._found = {}   # id(optimizer) -> int32[1] flag of the current step
+        self._steps = {}   # id(optimizer) -> int64[1] device step counter (advances only on steps that are taken)
+        self._coef = {}    # id(optimizer) -> uint8 coefficient rows, one per parameter group
+
+    def scale(self, loss):
+        return loss * self.scale_tensor.to(loss.dtype) if self.enabled else loss
+
+    def _state(self, opt):
+        k = id(opt)
+        if k not in self._found:
+            nb = int(_lib.lib().mm_amp_coef_bytes())
+            self._found[k] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            self._steps[k] = torch.full((1,), int(getattr(opt, "_step", 0)), dtype=torch.int64, device=self.device)
+            self._coef[k] = torch.zeros((max(1, len(opt.param_groups)), nb), dtype=torch.uint8, device=self.device)
+        return self._found[k], self._steps[k], self._coef[k]
+
+    def step(self, opt, grad_scale: float = 1.0):
+        """``opt.step()`` on the unscaled gradients unless one of them is inf / nan (decided and applied on the device)."""
+        if not self.enabled:
+            return opt.step(grad_scale=grad_scale)
+        if not hasattr(opt, "step_scaled"):
+            raise TypeError("GradScaler.step: the optimiser must be a FlatAdamW (adamw); other optimisers have no device-side skip")
+        found, steps, coef = self._state(opt)
+        found.zero_()
+        L = _lib.lib()
+        for g in opt.grad_arenas():
+            check(L.mm_grad_nonfinite(ptr(g), g.numel(), ptr(found), stream()), "grad_nonfinite")
+        opt.step_scaled(self.scale_tensor, found, steps, coef, grad_scale)
+
+    def update(self):
+        if not self.enabled or not self._found:
+            return
+        L = _lib.lib()
+        flags = torch.cat(list(self._found.values())) if len(self._found) > 1 else next(iter(self._found.values()))
+        check(L.mm_amp_update(ptr(self.scale_tensor), ptr(self._tracker), ptr(flags), flags.numel(), self.growth_factor,
+                              self.backoff_factor, self.growth_interval, stream()), "amp_update")
+
+    # host views (each one a read-back: logging / tests / checkpoints only)
+    def get_scale(self):
+        return float(self.scale_tensor.item())
+
+    def steps_taken(self, opt):
+        return int(self._state(opt)[1].item())
+
+    def state_dict(self):
+        return {"scale": self.get_scale(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval, "_growth_tracker": int(self._tracker.item())}
+
+    def load_state_dict(self, sd):
+        self.scale_tensor.fill_(float(sd["scale"]))
+        self._tracker.fill_(int(sd.get("_growth_tracker", 0)))
+        self.growth_factor = float(sd.get("growth_factor", self.growth_factor))
+        self.backoff_factor = float(sd.get("backoff_factor", self.backoff_factor))
+        self.growth_interval = int(sd.get("growth_interval", self.growth_interval))

@@ -42,6 +42,26 @@ __device__ inline void stv(__bf16* p, const float (&v)[VEC]) {
   }
 }
 
+// IEEE fp16 rows (the fp16 kind of the 16-bit activation mode)
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ inline void ldv(const _Float16* p, float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    f16x4 t = *(const f16x4*)p;
+    v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+  } else {
+    v[0] = (float)*p;
+  }
+}
+template <int VEC>
+__device__ inline void stv(_Float16* p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) {
+    *(f16x4*)p = f16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+  } else {
+    *p = (_Float16)v[0];
+  }
+}
+
 template <int VEC>
 __device__ inline void ldv(const float* p, float (&v)[VEC]) {
   if constexpr (VEC == 4) {
@@ -790,6 +810,25 @@ int mm_bn_bwd_bf16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N
                    float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   return bn_bwd<__bf16>((const __bf16*)x, ld_x, (const __bf16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
                         (__bf16*)dx, ld_dx, dweight, dbias, accumulate, ws, ws_bytes, s);
+}
+
+// ... and over IEEE fp16 rows
+int mm_bn_fwd_train_f16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+                        float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
+                        float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
+  return bn_fwd_train<_Float16>((const _Float16*)x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak,
+                                (_Float16*)y, ld_y, save_mean, save_invstd, ws, ws_bytes, s);
+}
+int mm_bn_fwd_eval_f16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
+                       const float* running_mean, const float* running_var, float eps, float leak, void* y, int ld_y,
+                       hipStream_t s) {
+  return bn_fwd_eval<_Float16>((const _Float16*)x, ld_x, N, C, weight, bias, running_mean, running_var, eps, leak, (_Float16*)y, ld_y, s);
+}
+int mm_bn_bwd_f16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+                  const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
+                  float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  return bn_bwd<_Float16>((const _Float16*)x, ld_x, (const _Float16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
+                          (_Float16*)dx, ld_dx, dweight, dbias, accumulate, ws, ws_bytes, s);
 }
 
 }  // extern "C"

@@ -131,15 +131,16 @@ __device__ inline void fused_wave_sums(const double* partial, int b0, int b1, in
   q = fused_wave_sum((vq[0] + vq[1]) + (vq[2] + vq[3]));
 }
 
-// Grid barrier (every workgroup of the launch is resident, see the header).  The last workgroup to arrive resets the counter
-// and advances the release word from flag_old to flag_old + 1; the others poll the release word.
+// Grid barrier (every workgroup of the launch is resident, see the header).  The last workgroup to arrive (its increment wraps
+// the counter to 0) advances the release word from flag_old to flag_old + 1; the others poll the release word.
 __device__ inline void fused_barrier(unsigned* sync, unsigned G, unsigned flag_old) {
   stores_acked();   // this thread's xcd_store()s have reached the coherence point
   __syncthreads();  // ... and so have the whole workgroup's
   if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(&sync[0], 1u);
+    // wrapping increment: the G-th arrival (old value G - 1) sets the counter back to 0 in the same atomic - the separate
+    // reset (an atomicExch whose return the release had to wait for) was one more round trip to the coherence point per barrier
+    const unsigned t = atomicInc(&sync[0], G - 1u);
     if (t == G - 1) {
-      atomicExch(&sync[0], 0u);  // returns, i.e. has completed, before the release below; nobody arrives again before it
       xcd_store(&sync[FUSED_FLAG], flag_old + 1u);
     } else {
       const unsigned long long t0 = wall_clock64();

@@ -228,10 +228,24 @@ __global__ __launch_bounds__(T) void k_eval_confusion(const float* __restrict__ 
 
 // ---- AdamW over flat fp32 arenas (torch.optim.AdamW semantics, amsgrad off; same op order as torch's
 // single-tensor path: p*=1-lr*wd; m.lerp_(g,1-b1); v=b2*v+(1-b2)*g*g; p-=step_size*m/(sqrt(v)/sqrt(bc2)+eps))
-template <bool VEC>
+// Loss-scaled training (mm2d3d_amd/amp.py, the fp16 kind of the 16-bit activation mode): the coefficients of an update live
+// on the DEVICE, written by k_amp_prepare from the device-resident loss scale, non-finite flag and step counter, so that a
+// skipped step (torch.cuda.amp.GradScaler semantics) needs no read-back: DEV = true reads them, and returns when skip is set.
+struct AmpCoef {
+  float decay, omb1, beta2, omb2, eps, step_size, bc2_sqrt, grad_scale;
+  int skip, pad;
+};
+
+template <bool VEC, bool DEV = false>
 __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float decay, float omb1, float beta2,
-                                              float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale) {
+                                              float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale,
+                                              const AmpCoef* __restrict__ dc = nullptr) {
+  if (DEV) {
+    if (dc->skip) return;  // uniform
+    decay = dc->decay, omb1 = dc->omb1, beta2 = dc->beta2, omb2 = dc->omb2, eps = dc->eps, step_size = dc->step_size;
+    bc2_sqrt = dc->bc2_sqrt, grad_scale = dc->grad_scale;
+  }
   int64_t i = ((int64_t)blockIdx.x * T + threadIdx.x) * 4;
   if (i >= n) return;
   auto upd = [&](float gj, float& pj, float& mj, float& vj) {
@@ -260,6 +274,55 @@ __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float*
     return;
   }
   for (int j = 0; i + j < n; j++) upd(g[i + j], p[i + j], m[i + j], v[i + j]);
+}
+
+// found[0] |= any element of g is inf / nan (benign race: every writer stores 1)
+__global__ __launch_bounds__(T) void k_grad_nonfinite(const float* __restrict__ g, int64_t n, int* __restrict__ found) {
+  const int64_t stride = (int64_t)gridDim.x * T * 4;
+  bool bad = false;
+  for (int64_t i = ((int64_t)blockIdx.x * T + threadIdx.x) * 4; i < n; i += stride) {
+    if (i + 4 <= n && (((uintptr_t)(g + i)) & 15) == 0) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 G = *(const f4*)(g + i);
+#pragma unroll
+      for (int j = 0; j < 4; j++) bad |= !(fabsf(G[j]) <= 3.402823466e38f);
+    } else {
+      for (int j = 0; j < 4 && i + j < n; j++) bad |= !(fabsf(g[i + j]) <= 3.402823466e38f);
+    }
+  }
+  if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) found[0] = 1;
+}
+
+// one thread: the update coefficients of one parameter group from the device state.  t = *step + 1 is the step this update
+// would be; it is committed to *step only when the step is taken and ``advance`` is set (first group of an optimiser).
+__global__ void k_amp_prepare(const float* __restrict__ scale, const int* __restrict__ found, long long* __restrict__ step, int advance,
+                              double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                              AmpCoef* __restrict__ out) {
+  const int skip = found[0] != 0;
+  const long long t = step[0] + (advance ? 1 : 0);
+  if (!skip && advance) step[0] = t;
+  const double tt = (double)(t > 0 ? t : 1);
+  const double bc1 = 1.0 - pow(beta1, tt), bc2 = 1.0 - pow(beta2, tt);
+  AmpCoef c;
+  c.decay = (float)(1.0 - lr * weight_decay), c.omb1 = (float)(1.0 - beta1), c.beta2 = (float)beta2, c.omb2 = (float)(1.0 - beta2);
+  c.eps = (float)eps, c.step_size = (float)(lr / bc1), c.bc2_sqrt = (float)sqrt(bc2);
+  c.grad_scale = (float)(grad_scale / (double)scale[0]);
+  c.skip = skip, c.pad = 0;
+  *out = c;
+}
+
+// GradScaler.update(): found -> scale *= backoff, tracker = 0; else tracker += 1 and scale *= growth every ``interval`` clean steps
+__global__ void k_amp_update(float* __restrict__ scale, int* __restrict__ tracker, const int* __restrict__ found, int nfound,
+                             float growth, float backoff, int interval) {
+  int any = 0;
+  for (int i = 0; i < nfound; i++) any |= found[i];
+  if (any) {
+    scale[0] *= backoff;
+    tracker[0] = 0;
+  } else if (++tracker[0] >= interval) {
+    scale[0] *= growth;
+    tracker[0] = 0;
+  }
 }
 }  // namespace
 
@@ -375,6 +438,50 @@ int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
     hipLaunchKernelGGL(k_adamw<false>, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                        (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// ---- loss-scaled steps (torch.cuda.amp.GradScaler semantics without a read-back; mm2d3d_amd/amp.py)
+int mm_grad_nonfinite(const float* g, int64_t n, int* found_dev, hipStream_t s) {
+  if (n == 0) return MM_OK;
+  int64_t nb = mm_cdiv(n, (int64_t)T * 4);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(k_grad_nonfinite, dim3((unsigned)nb), dim3(T), 0, s, g, n, found_dev);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_amp_coef_bytes(void) { return (int)sizeof(AmpCoef); }
+
+int mm_amp_prepare(const float* scale_dev, const int* found_dev, int64_t* step_dev, int advance, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, double grad_scale, void* coef_dev, hipStream_t s) {
+  MM_CHECK_ARG(scale_dev && found_dev && step_dev && coef_dev, "amp_prepare: null argument");
+  hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(1), 0, s, scale_dev, found_dev, (long long*)step_dev, advance, lr, beta1, beta2, eps,
+                     weight_decay, grad_scale, (AmpCoef*)coef_dev);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// mm_adamw_step with the coefficients of mm_amp_prepare (a step whose coefficients say "skip" leaves p, m, v untouched)
+int mm_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const void* coef_dev, hipStream_t s) {
+  MM_CHECK_ARG(coef_dev != nullptr, "adamw_step_dev: no coefficients");
+  if (n == 0) return MM_OK;
+  const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL((k_adamw<true, true>), dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n, 0.f, 0.f, 0.f, 0.f,
+                       0.f, 0.f, 0.f, 0.f, (const AmpCoef*)coef_dev);
+  else
+    hipLaunchKernelGGL((k_adamw<false, true>), dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n, 0.f, 0.f, 0.f, 0.f,
+                       0.f, 0.f, 0.f, 0.f, (const AmpCoef*)coef_dev);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int mm_amp_update(float* scale_dev, int* tracker_dev, const int* found_dev, int nfound, double growth, double backoff, int interval,
+                  hipStream_t s) {
+  MM_CHECK_ARG(scale_dev && tracker_dev && found_dev && nfound >= 0 && interval >= 1, "amp_update: bad arguments");
+  hipLaunchKernelGGL(k_amp_update, dim3(1), dim3(1), 0, s, scale_dev, tracker_dev, found_dev, nfound, (float)growth, (float)backoff, interval);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -25,6 +25,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -68,10 +69,12 @@ __device__ inline void split3(const f32x4& a, const f32x4& b, bf16x8 (&t)[3]) {
 // then publishes its four partial sub-block results in LDS; after one barrier wave w adds the four partials of sub-block w
 // in wave order = ascending k (canonical order A.8 iv; bit-identical to "tmp[rule] then CSR reduce") into its final
 // accumulators.  Two barriers per FOUR offsets and no dependent-latency chain longer than one offset's q loop.
-// BF: the 16-bit activation mode - rows are bf16 (in and out), the weights one bf16 term per
-// element ([K][nq][ncb][64 lanes] x 16 B fragments), one MFMA per block and no operand splitting; accumulation stays fp32.
-template <int NCB, bool BF>
+// MODE 1 / 2: the 16-bit activation modes - rows are bf16 / IEEE fp16 (in and out), the weights one
+// 16-bit term per element ([K][nq][ncb][64 lanes] x 16 B fragments), one MFMA per block (v_mfma_f32_16x16x32_bf16 / _f16) and no
+// operand splitting; accumulation stays fp32.  MODE 0: fp32 rows, three-term split.
+template <int NCB, int MODE>
 __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
+  constexpr bool BF = MODE != 0;
   constexpr int NW = 4, MT = 64;
   constexpr int NTW = BF ? 1 : 3;             // bf16 terms per weight
   constexpr int FRB = NTW * 1024 / 16;        // 16-B pieces per (k, q, cb) fragment block
@@ -129,11 +132,18 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
 #pragma unroll
         for (int sb = 0; sb < 4; sb++) {
           if (pres[sb]) {
-            if constexpr (BF) {
+            if constexpr (MODE == 1) {
               const bf16x8 xb = __builtin_bit_cast(bf16x8, x[sb][0]);
 #pragma unroll
               for (int cb = 0; cb < NCB; cb++)
                 accP[sb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wt[cb][0], xb, accP[sb][cb], 0, 0, 0);
+              continue;
+            }
+            if constexpr (MODE == 2) {
+              const f16x8 xb = __builtin_bit_cast(f16x8, x[sb][0]);
+#pragma unroll
+              for (int cb = 0; cb < NCB; cb++)
+                accP[sb][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wt[cb][0]), xb, accP[sb][cb], 0, 0, 0);
               continue;
             }
             bf16x8 xt[3];
@@ -168,11 +178,11 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
   const int d = p.dst[j0 + wave * 16];
   if (d >= 0) {
     if constexpr (BF) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-      __bf16* o = (__bf16*)p.out + (int64_t)d * p.ld_out + cb0 * 16 + sl * 4;
+      typedef std::conditional_t<MODE == 1, __bf16, _Float16> H;
+      typedef H hx4 __attribute__((ext_vector_type(4)));
+      H* o = (H*)p.out + (int64_t)d * p.ld_out + cb0 * 16 + sl * 4;
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++)
-        *(bf16x4*)(o + cb * 16) = bf16x4{(__bf16)acc[cb].x, (__bf16)acc[cb].y, (__bf16)acc[cb].z, (__bf16)acc[cb].w};
+      for (int cb = 0; cb < NCB; cb++) *(hx4*)(o + cb * 16) = hx4{(H)acc[cb].x, (H)acc[cb].y, (H)acc[cb].z, (H)acc[cb].w};
     } else {
       float* o = p.out + (int64_t)d * p.ld_out + cb0 * 16 + sl * 4;
 #pragma unroll
@@ -192,7 +202,7 @@ struct PackD {  // 12 x int64: the layout of the device descriptor table of mm_s
 // bytes of a weight row when co is the fast axis), split, and stored as ONE 16-byte piece per term (the first version wrote
 // 2-byte pieces 1 KB apart, one thread per element: 63 us per step for 16 MB of fragments; this form is bound by the 11 MB
 // of weights it reads)
-template <int NT>
+template <int NT, typename H = __bf16>
 __device__ inline void pack_one(const PackD& d, int64_t e) {
   const int64_t total = d.K * d.nq * d.ncb * 64;
   if (e >= total) return;
@@ -210,36 +220,38 @@ __device__ inline void pack_one(const PackD& d, int64_t e) {
     const int ci = 32 * q + 8 * (lane >> 4) + j;
     r[j] = (ci < d.Cin && co < d.Cout) ? wsrc[(int64_t)ci * d.s_ci] : 0.f;
   }
-  bf16x8* o = (bf16x8*)((__bf16*)d.Wf + blk * (512 * NT)) + lane;
+  typedef H hx8 __attribute__((ext_vector_type(8)));
+  hx8* o = (hx8*)((H*)d.Wf + blk * (512 * NT)) + lane;
 #pragma unroll
   for (int n = 0; n < NT; n++) {
-    bf16x8 h;
+    hx8 h;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      h[j] = (__bf16)r[j];
+      h[j] = (H)r[j];
       r[j] -= (float)h[j];
     }
     o[n * 64] = h;
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void k_os_pack(PackD d) { pack_one<NT>(d, (int64_t)blockIdx.x * 256 + threadIdx.x); }
+template <int NT, typename H = __bf16>
+__global__ __launch_bounds__(256) void k_os_pack(PackD d) { pack_one<NT, H>(d, (int64_t)blockIdx.x * 256 + threadIdx.x); }
 
-template <int NT>
+template <int NT, typename H = __bf16>
 __global__ __launch_bounds__(256) void k_os_pack_batch(const PackD* __restrict__ descs, int n) {
   int i = 0;
   while (i + 1 < n && (int64_t)blockIdx.x >= descs[i].blk_end) i++;
   const PackD d = descs[i];
   const int64_t blk0 = i ? descs[i - 1].blk_end : 0;
-  pack_one<NT>(d, ((int64_t)blockIdx.x - blk0) * 256 + threadIdx.x);
+  pack_one<NT, H>(d, ((int64_t)blockIdx.x - blk0) * 256 + threadIdx.x);
 }
 
 template <int NCB>
 int launch_os4(const OsP& p, int64_t n_tiles, int nchunk, int bf, hipStream_t s) {
   constexpr int LDSB = 4 * 4 * NCB * 1024;
-  if (bf) hipLaunchKernelGGL((k_osconv4<NCB, true>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
-  else hipLaunchKernelGGL((k_osconv4<NCB, false>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
+  if (bf == 2) hipLaunchKernelGGL((k_osconv4<NCB, 2>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
+  else if (bf) hipLaunchKernelGGL((k_osconv4<NCB, 1>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
+  else hipLaunchKernelGGL((k_osconv4<NCB, 0>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
   return MM_OK;
 }
 
@@ -282,6 +294,21 @@ int mm_spconv_os_pack_bf16(const float* W, int64_t w_kstride, int s_ci, int s_co
 int mm_spconv_os_pack_batch_bf16(const int64_t* descs_dev, int n_desc, int64_t total_blocks, hipStream_t s) {
   MM_CHECK_ARG(descs_dev && n_desc > 0 && total_blocks > 0, "spconv_os_pack_batch_bf16: bad arguments");
   hipLaunchKernelGGL(k_os_pack_batch<1>, dim3((unsigned)total_blocks), dim3(256), 0, s, (const PackD*)descs_dev, n_desc);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+// the same with one IEEE fp16 term per weight (fragment sizes as mm_spconv_os_pack_bytes_bf16)
+int mm_spconv_os_pack_f16(const float* W, int64_t w_kstride, int s_ci, int s_co, int kflip, int K, int Cin, int Cout, void* Wf,
+                          hipStream_t s) {
+  MM_CHECK_ARG(K > 0 && K <= 32 && Cin > 0 && Cout > 0 && W && Wf, "spconv_os_pack_f16: bad arguments");
+  PackD d{(int64_t)W, (int64_t)Wf, K, Cin, Cout, (Cin + 31) / 32, (Cout + 15) / 16, w_kstride, s_ci, s_co, kflip, 0};
+  hipLaunchKernelGGL((k_os_pack<1, _Float16>), dim3((unsigned)mm_spconv_os_pack_blocks(K, Cin, Cout)), dim3(256), 0, s, d);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+int mm_spconv_os_pack_batch_f16(const int64_t* descs_dev, int n_desc, int64_t total_blocks, hipStream_t s) {
+  MM_CHECK_ARG(descs_dev && n_desc > 0 && total_blocks > 0, "spconv_os_pack_batch_f16: bad arguments");
+  hipLaunchKernelGGL((k_os_pack_batch<1, _Float16>), dim3((unsigned)total_blocks), dim3(256), 0, s, (const PackD*)descs_dev, n_desc);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -354,6 +381,12 @@ int mm_spconv_os_apply_bf16(const void* in, int ld_in, int Cin, void* out, int l
                             const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
                             hipStream_t s) {
   return os_apply(1, in, ld_in, Cin, out, ld_out, Cout, Wf, K, dst, nbrp, tmask, n_tiles, tile_rows, s);
+}
+// the same over IEEE fp16 rows, Wf from mm_spconv_os_pack(_batch)_f16 (v_mfma_f32_16x16x32_f16)
+int mm_spconv_os_apply_f16(const void* in, int ld_in, int Cin, void* out, int ld_out, int Cout, const void* Wf, int K,
+                           const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
+                           hipStream_t s) {
+  return os_apply(2, in, ld_in, Cin, out, ld_out, Cout, Wf, K, dst, nbrp, tmask, n_tiles, tile_rows, s);
 }
 
 }  // extern "C"

@@ -202,6 +202,17 @@ __device__ inline void split8(const f32x4& a, const f32x4& b, bf16x8 (&t)[NT]) {
 }
 
 // acc += x . w from the split terms (a: MFMA A operand, b: MFMA B operand), largest products last is not needed: fp32 adds
+// IEEE fp16 rows (16-bit activation mode, fp16 kind): the values ARE fp16, one exact term, v_mfma_f32_16x16x32_f16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NT>
+__device__ inline void split8(const f32x4& a, const f32x4& b, f16x8 (&t)[NT]) {
+  static_assert(NT == 1, "fp16 rows take one term");
+  t[0] = f16x8{(_Float16)a.x, (_Float16)a.y, (_Float16)a.z, (_Float16)a.w, (_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+}
+template <int NT>
+__device__ inline f32x4 mfma_split(const f16x8 (&a)[NT], const f16x8 (&b)[NT], f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], acc, 0, 0, 0);
+}
 template <int NT>
 __device__ inline f32x4 mfma_split(const bf16x8 (&a)[NT], const bf16x8 (&b)[NT], f32x4 acc) {
   if constexpr (NT == 1) {
@@ -609,7 +620,8 @@ __global__ __launch_bounds__(256) void k_dw_direct_s3(const E* __restrict__ in, 
       pb[t] = live ? (gptr)(dout + (int64_t)dn[t] * ld_do + co0 * 16 + rl) : (gptr)((const E*)g_zero128 + rl);
     }
     if (r0 + 128 < r_end) load_idx(r0 + 128, sn, dn);  // uniform: in flight while this group is gathered, split and multiplied
-    bf16x8 at[TI][NT], bt[TJ][NT];
+    typedef std::conditional_t<std::is_same_v<E, _Float16>, f16x8, bf16x8> HV;
+    HV at[TI][NT], bt[TJ][NT];
 #pragma unroll
     for (int i = 0; i < TI; i++) {
       f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
@@ -1062,7 +1074,8 @@ namespace {
 int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
                const int32_t* dst, const int32_t* offsets_host, int K, void* ws, size_t ws_bytes, KSeg* seg_out, hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0, "spconv_dw: bad shape");
-  MM_CHECK_ARG(!bf || (Cin % 16 == 0 && Cout % 16 == 0), "spconv_dw_bf16: channels must be multiples of 16");
+  MM_CHECK_ARG(bf >= 0 && bf <= 2, "spconv_dw: row kind must be 0 (fp32), 1 (bf16) or 2 (fp16)");
+  MM_CHECK_ARG(!bf || (Cin % 16 == 0 && Cout % 16 == 0), "spconv_dw (16-bit rows): channels must be multiples of 16");
   KSeg& seg = *seg_out;
   const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
   int nb = make_seg(offsets_host, K, chunk, &seg);
@@ -1078,12 +1091,15 @@ int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int
     const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
     const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
     const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
-    const int nt = bf ? -1 : (Cin >= split_min_cin(true) ? split_terms() : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
+    const int nt = bf ? -bf : (Cin >= split_min_cin(true) ? split_terms() : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
 #define DWCASE(I, J)                                                                                                          \
   if (ti == I && tj == J) {                                                                                                   \
     if (nt == -1)                                                                                                             \
       hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, __bf16>), dim3(nb, ny), dim3(256), lds, s, (const __bf16*)in, ld_in,        \
                          (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                            \
+    else if (nt == -2)                                                                                                        \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, _Float16>), dim3(nb, ny), dim3(256), lds, s, (const _Float16*)in, ld_in,    \
+                         (const _Float16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                          \
     else if (nt == 3)                                                                                                         \
       hipLaunchKernelGGL((k_dw_direct_s3<I, J, 3>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, \
                          ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                                                 \
@@ -1145,11 +1161,24 @@ int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int 
   return MM_OK;
 }
 
+// the same over IEEE fp16 rows
+int mm_spconv_dw_f16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+                     const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+  KSeg seg;
+  int rc = dw_partial(2, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
+  if (rc != MM_OK) return rc;
+  const int ne = Cin * Cout;
+  hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, (const float*)ws, ne, K, seg, dW, accumulate);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
 // The weight gradient in two calls (round 3): the partial slabs of a layer now, the slab sums of EVERY layer of a backward
 // pass later in one launch (mm_spconv_dw_reduce_batch) - 26 small reduce launches and as many dependent-launch gaps per step
 // become one.  ``partial`` (mm_spconv_dw_ws_bytes) must stay untouched until the batched reduce has run; ``blk_start_host``
 // receives the MAXK + 1 = 33 slab offsets per kernel offset that the reduce needs (a row of its descriptor table).
-// bf16 != 0: in / dout are bf16 rows.  Same kernels, same slabs, same summation order as mm_spconv_dw: bit-identical.
+// bf16 = 1 / 2: in / dout are bf16 / IEEE fp16 rows.  Same kernels, same slabs, same summation order as mm_spconv_dw: bit-identical.
 int mm_spconv_dw_partial(int bf16, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
                          const int32_t* dst, const int32_t* offsets_host, int K, void* partial, size_t partial_bytes,
                          int32_t* blk_start_host, hipStream_t s) {

@@ -106,25 +106,57 @@ class FlatAdamW(optim.Optimizer):
             if a is None:
                 continue
             b1, b2 = group["betas"]
-            # parameters that took part in no backward keep weights and moments (torch skips grad=None params)
-            ranges, cur = [], None
-            for t, (lo, hi) in zip(a["touched"], a["spans"]):
-                if t:
-                    cur = [lo, hi] if cur is None else [cur[0], hi]
-                elif cur is not None:
-                    ranges.append(cur)
-                    cur = None
-            if cur is not None:
-                ranges.append(cur)
-            for lo, hi in ranges:
+            for lo, hi in self._touched_ranges(a):
                 check(L.mm_adamw_step(ptr(a["p"][lo:hi]), ptr(a["g"][lo:hi]), ptr(a["m"][lo:hi]), ptr(a["v"][lo:hi]), hi - lo,
                                       float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                                       float(group["weight_decay"]), self._step, float(grad_scale), stream()), "adamw_step")
         return loss
 
+    @torch.no_grad()
+    def step_scaled(self, scale_dev, found_dev, step_dev, coef_dev, grad_scale: float = 1.0):
+        """The update of ``step`` under a device-resident loss scale (mm2d3d_amd/amp.py): gradients are multiplied by
+        ``grad_scale / scale``, and nothing is updated when ``found_dev`` says a gradient is inf / nan - decided on the device,
+        the step counter of the bias corrections (``step_dev``) advances only when the step is taken."""
+        if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
+            raise RuntimeError("FlatAdamW.step_scaled: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
+        L = _lib.lib()
+        self._dev_step = step_dev
+        self._opt_called = True  # what torch's lr schedulers look at to tell "step() before scheduler.step()"
+        from . import conv2d as _c2d
+
+        _c2d.PARAM_EPOCH[0] += 1
+        first = True
+        for gi, (group, a) in enumerate(zip(self.param_groups, self._arenas)):
+            if a is None:
+                continue
+            b1, b2 = group["betas"]
+            check(L.mm_amp_prepare(ptr(scale_dev), ptr(found_dev), ptr(step_dev), 1 if first else 0, float(group["lr"]), float(b1),
+                                   float(b2), float(group["eps"]), float(group["weight_decay"]), float(grad_scale),
+                                   ptr(coef_dev[gi]), stream()), "amp_prepare")
+            first = False
+            for lo, hi in self._touched_ranges(a):
+                check(L.mm_adamw_step_dev(ptr(a["p"][lo:hi]), ptr(a["g"][lo:hi]), ptr(a["m"][lo:hi]), ptr(a["v"][lo:hi]), hi - lo,
+                                          ptr(coef_dev[gi]), stream()), "adamw_step_dev")
+
+    @staticmethod
+    def _touched_ranges(a):
+        """Parameters that took part in no backward keep weights and moments (torch skips grad=None params)."""
+        ranges, cur = [], None
+        for t, (lo, hi) in zip(a["touched"], a["spans"]):
+            if t:
+                cur = [lo, hi] if cur is None else [cur[0], hi]
+            elif cur is not None:
+                ranges.append(cur)
+                cur = None
+        if cur is not None:
+            ranges.append(cur)
+        return ranges
+
     def state_dict(self):
         sd = super().state_dict()
         sd["flat"] = [None if a is None else dict(m=a["m"].clone(), v=a["v"].clone()) for a in self._arenas]
+        if getattr(self, "_dev_step", None) is not None:  # loss-scaled training: the device counter is the truth (skipped steps)
+            self._step = int(self._dev_step.item())
         sd["step"] = self._step
         return sd
 

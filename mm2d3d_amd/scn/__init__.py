@@ -34,14 +34,16 @@ PAD_NARROW_STEM = [True]
 
 
 def set_activation_dtype(dtype):
-    """torch.float32 (the reference's behaviour) or torch.bfloat16."""
-    if dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError("activation dtype must be float32 or bfloat16")
+    """torch.float32 (the reference's behaviour), torch.bfloat16, or torch.float16 (IEEE fp16 rows: the wording of
+    BASELINE.json configs[4] and the reference's ``precision: 16``; gradient rows then need a loss scale, mm2d3d_amd/amp.py -
+    ``TrainModel`` installs one with ``train_kwargs["sparse_activations"] = "fp16"``)."""
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError("activation dtype must be float32, bfloat16 or float16")
     ACTIVATION_DTYPE[0] = dtype
 
 
 def act16():
-    return ACTIVATION_DTYPE[0] == torch.bfloat16
+    return ACTIVATION_DTYPE[0] in (torch.bfloat16, torch.float16)
 
 
 class SparseConvNetTensor:
@@ -245,8 +247,8 @@ class SubmanifoldConvolution(_ConvBase):
         rb = x.metadata.subm_rulebook(lv)
         feats = x.features
         wide = self.nIn % 16 == 0 and self.nOut % 16 == 0
-        if act16() and wide and feats.dtype != torch.bfloat16:
-            feats = feats.to(torch.bfloat16)
+        if act16() and wide and feats.dtype != ACTIVATION_DTYPE[0]:
+            feats = feats.to(ACTIVATION_DTYPE[0])
         weight = self.weight
         if (self.nIn < 16 and self.nOut % 16 == 0 and rb.os is not None and ops.OS_ENABLED and feats.dtype == torch.float32
                 and PAD_NARROW_STEM[0]):
@@ -256,8 +258,8 @@ class SubmanifoldConvolution(_ConvBase):
             feats = torch.nn.functional.pad(feats, (0, 16 - self.nIn))
             weight = torch.nn.functional.pad(weight, (0, 0, 0, 16 - self.nIn))
         f = ops.SparseConvFunction.apply(feats, weight, rb, "subm", lv.n, lv.n, self.nIn)
-        if act16() and f.dtype != torch.bfloat16:  # the 3-channel stem runs in fp32; its output enters the 16-bit region
-            f = f.to(torch.bfloat16)
+        if act16() and f.dtype != ACTIVATION_DTYPE[0]:  # the 3-channel stem runs in fp32; its output enters the 16-bit region
+            f = f.to(ACTIVATION_DTYPE[0])
         return x._with(self._bias(f))
 
     def __repr__(self):
@@ -335,7 +337,7 @@ class BatchNormalization(nn.Module):
     def forward(self, x):
         parts = x._parts if x._features is None else None
         if (parts is not None and self.weight is not None and all(t.is_cuda and t.shape[1] % 4 == 0 and t.dtype == parts[0].dtype
-                                                                   and t.dtype in (torch.float32, torch.bfloat16) for t in parts)):
+                                                                   and t.dtype in (torch.float32, torch.bfloat16, torch.float16) for t in parts)):
             f = ops.BatchNormActJoinFunction.apply(self.weight, self.bias, self.running_mean, self.running_var, self.training,
                                                    float(self.eps), float(self.momentum), float(self.leakiness),
                                                    getattr(x.level, "seg_rows", None), *parts)

@@ -132,14 +132,18 @@ class _OsPacks:
             self.table = torch.tensor(rows, dtype=torch.int64).to(ents[0]["buf"].device)
             self.total_blocks = blk
             self.dirty = False
-        check((L.mm_spconv_os_pack_batch_bf16 if self.bf16 else L.mm_spconv_os_pack_batch)(ptr(self.table), len(ents), self.total_blocks,
-                                                                                        stream()), "spconv_os_pack_batch")
+        pack = {False: L.mm_spconv_os_pack_batch, True: L.mm_spconv_os_pack_batch_bf16, "f16": L.mm_spconv_os_pack_batch_f16}[self.bf16]
+        check(pack(ptr(self.table), len(ents), self.total_blocks, stream()), "spconv_os_pack_batch")
         for e in ents:
             e["key"] = self._key(e["owner"]())
 
 
 class _OsPacksBf16(_OsPacks):
     bf16 = True
+
+
+class _OsPacksF16(_OsPacks):
+    bf16 = "f16"  # one IEEE fp16 term per weight (same fragment sizes as the bf16 kind)
 
 
 _OS_PACKS = {}  # (device index, bf16) -> _OsPacks
@@ -151,11 +155,14 @@ def _os_fragments(weight, w_kcc, transpose, kflip, bf16=False):
     L = _lib.lib()
     K, cw_in, cw_out = w_kcc.shape
     if isinstance(weight, torch.nn.Parameter) and weight.dtype == F32 and weight.is_contiguous() and weight.data_ptr() == w_kcc.data_ptr():
-        reg = _OS_PACKS.setdefault((weight.device.index, bf16), _OsPacksBf16() if bf16 else _OsPacks())
+        reg = _OS_PACKS.get((weight.device.index, bf16))
+        if reg is None:
+            reg = _OS_PACKS[(weight.device.index, bf16)] = {False: _OsPacks, True: _OsPacksBf16, "f16": _OsPacksF16}[bf16]()
         return reg.get(weight, K, cw_in, cw_out, bool(transpose), bool(kflip))
     cin, cout = (cw_out, cw_in) if transpose else (cw_in, cw_out)
     s_ci, s_co = (1, cw_out) if transpose else (cw_out, 1)
-    nbytes, pack = (L.mm_spconv_os_pack_bytes_bf16, L.mm_spconv_os_pack_bf16) if bf16 else (L.mm_spconv_os_pack_bytes, L.mm_spconv_os_pack)
+    nbytes, pack = {False: (L.mm_spconv_os_pack_bytes, L.mm_spconv_os_pack), True: (L.mm_spconv_os_pack_bytes_bf16, L.mm_spconv_os_pack_bf16),
+                    "f16": (L.mm_spconv_os_pack_bytes_bf16, L.mm_spconv_os_pack_f16)}[bf16]
     buf = torch.empty(int(nbytes(K, cin, cout)), dtype=torch.uint8, device=w_kcc.device)
     check(pack(ptr(w_kcc), cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, K, cin, cout, ptr(buf), stream()), "spconv_os_pack")
     return buf
@@ -177,19 +184,24 @@ def _apply_os(x, weight, w_kcc, table, cout, transpose, kflip):
 
 
 BF16 = torch.bfloat16
+F16 = torch.float16
+H16 = (BF16, F16)  # the two kinds of 16-bit rows
 
 
 def _apply_os_bf16(x, weight, w_kcc, table, cout, transpose, kflip):
-    """16-bit activation mode: bf16 rows in, bf16 rows out, fp32 accumulation over the offsets in ascending k."""
+    """16-bit activation mode: bf16 (or IEEE fp16) rows in, rows of the same kind out, fp32 accumulation over the offsets in
+    ascending k."""
     L = _lib.lib()
     if table is None:
         raise RuntimeError("16-bit activation mode: the level has no output-stationary table (build the metadata with act16=True)")
     if x.shape[1] % 16 or cout % 16 or x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
         raise RuntimeError("16-bit activation mode: channel counts must be multiples of 16 and rows 16-byte aligned")
-    Wf = _os_fragments(weight, w_kcc, transpose, kflip, bf16=True)
-    out = torch.empty((table.n_dst, cout), dtype=BF16, device=x.device)
-    check(L.mm_spconv_os_apply_bf16(ptr(x), x.stride(0), x.shape[1], ptr(out), cout, cout, ptr(Wf), table.K, ptr(table.dst),
-                                    ptr(table.nbrp), ptr(table.tmask), table.n_tiles, table.tile_rows, stream()), "spconv_os_apply_bf16")
+    f16 = x.dtype == F16
+    Wf = _os_fragments(weight, w_kcc, transpose, kflip, bf16="f16" if f16 else True)
+    out = torch.empty((table.n_dst, cout), dtype=x.dtype, device=x.device)
+    check((L.mm_spconv_os_apply_f16 if f16 else L.mm_spconv_os_apply_bf16)(
+        ptr(x), x.stride(0), x.shape[1], ptr(out), cout, cout, ptr(Wf), table.K, ptr(table.dst), ptr(table.nbrp), ptr(table.tmask),
+        table.n_tiles, table.tile_rows, stream()), "spconv_os_apply_16")
     return out
 
 
@@ -197,8 +209,9 @@ def _dw_bf16(x, dout, rb, src, dst, cin, cout, sink=None):
     L = _lib.lib()
     dW = sink if sink is not None else torch.empty((rb.K, cin, cout), dtype=F32, device=x.device)
     ws = _lib.workspace.get(int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), x.device)
-    check(L.mm_spconv_dw_bf16(ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
-                              ptr(dW), 0 if sink is None else 1, ptr(ws), ws.numel(), stream()), "spconv_dw_bf16")
+    check((L.mm_spconv_dw_f16 if x.dtype == F16 else L.mm_spconv_dw_bf16)(
+        ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
+        ptr(dW), 0 if sink is None else 1, ptr(ws), ws.numel(), stream()), "spconv_dw_16")
     return dW
 
 
@@ -291,7 +304,7 @@ def _dw_partial(x, dout, rb, src, dst, cin, cout, sink, param, bf16, partial=Non
     if partial is None:
         partial = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     row = np.empty(_DWB.rows(), dtype=np.int32)
-    check(L.mm_spconv_dw_partial(1 if bf16 else 0, ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst),
+    check(L.mm_spconv_dw_partial((2 if x.dtype == F16 else 1) if bf16 else 0, ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst),
                                  rb.offsets_ptr, rb.K, ptr(partial), nbytes, row.ctypes.data, stream()), "spconv_dw_partial")
     return partial, row
 
@@ -339,7 +352,7 @@ class SparseConvFunction(torch.autograd.Function):
     def forward(ctx, x, weight, rb, mode, n_in, n_out, account_cin=None):
         """``account_cin``: input channels the roofline accounting charges (the zero-padded 3-channel stem is charged as 3)."""
         _lib.require_cuda(x, "features")
-        act16 = x.dtype == BF16  # 16-bit activation mode (SURVEY.md section 8d C5): bf16 rows, fp32 accumulation
+        act16 = x.dtype in H16  # 16-bit activation mode (SURVEY.md section 8d C5): bf16 / fp16 rows, fp32 accumulation
         x = _c(x) if act16 else _c(x.to(F32))
         w = _c(weight.reshape(weight.shape[0], weight.shape[-2], weight.shape[-1]).to(F32))
         cout = w.shape[2]
@@ -383,7 +396,7 @@ class SparseConvFunction(torch.autograd.Function):
         cin, cout = w.shape[1], w.shape[2]
         dx = dw = None
         if ctx.act16:
-            dout = _c(dout.to(BF16))
+            dout = _c(dout.to(x.dtype))
             if ctx.needs_input_grad[0]:
                 table = rb.os if mode in ("subm", "up") else rb.os_up
                 dx = _timed("dX", rb, cin, cout, lambda: _apply_os_bf16(dout, ctx.weight, w, table, cin, True, mode == "subm"), 2)
@@ -467,7 +480,8 @@ def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, 
     """bf16 rows.  With a plain ReLU (leak 0) the rows ARE an NHWC bf16 map of N pixels: the BatchNorm2d entry points apply
     (same statistics groups, pitches, fp32 parameters) and bring the single-launch kernels of csrc/bn2d.hip; torch's momentum
     convention is 1 - scn's keep fraction.  Other leak values take the row kernels of csrc/bn.hip."""
-    if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0:
+    f16 = x.dtype == F16  # IEEE fp16 rows: the row kernels of csrc/bn.hip (the BatchNorm2d kernels unpack bf16 bit patterns)
+    if not f16 and leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0:
         if training:
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
             check(L.mm_bn2d_fwd_train(x_ptr(x), ldx, None, c, N, Ns, c, w, b, rm, rv, None, eps, 1.0 - momentum, 1, y, ldy, ptr(st[0]),
@@ -477,25 +491,37 @@ def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, 
         return
     if training:
         ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
-        check(L.mm_bn_fwd_train_bf16(x_ptr(x), ldx, N, Ns, c, w, b, rm, rv, eps, momentum, leak, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws),
-                                     ws.numel(), stream()), "bn_fwd_train")
+        check((L.mm_bn_fwd_train_f16 if f16 else L.mm_bn_fwd_train_bf16)(
+            x_ptr(x), ldx, N, Ns, c, w, b, rm, rv, eps, momentum, leak, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws), ws.numel(), stream()),
+            "bn_fwd_train")
     else:
-        check(L.mm_bn_fwd_eval_bf16(x_ptr(x), ldx, N, c, w, b, rm, rv, eps, leak, y, ldy, stream()), "bn_fwd_eval")
+        check((L.mm_bn_fwd_eval_f16 if f16 else L.mm_bn_fwd_eval_bf16)(x_ptr(x), ldx, N, c, w, b, rm, rv, eps, leak, y, ldy, stream()),
+              "bn_fwd_eval")
 
 
 def _bn16_bwd(L, x, ldx, dy, lddy, N, Ns, c, w, b, st, leak, dx, dwt, dbt, acc):
-    if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and lddy % 8 == 0:
+    f16 = x.dtype == F16
+    if not f16 and leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and lddy % 8 == 0:
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
         check(L.mm_bn2d_bwd(x_ptr(x), ldx, dy, lddy, None, 0, None, c, 1, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), ptr(dx), c, None, c, dwt, dbt,
                             acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
         return
     ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
-    check(L.mm_bn_bwd_bf16(x_ptr(x), ldx, dy, lddy, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), leak, ptr(dx), c, dwt, dbt, acc, ptr(ws), ws.numel(),
-                           stream()), "bn_bwd")
+    check((L.mm_bn_bwd_f16 if f16 else L.mm_bn_bwd_bf16)(x_ptr(x), ldx, dy, lddy, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), leak, ptr(dx), c,
+                                                         dwt, dbt, acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
 
 
 def x_ptr(x):
     return x if isinstance(x, int) else ptr(x)
+
+
+def _bn_entry(L, dtype):
+    """(forward training, forward eval, backward) row kernels of csrc/bn.hip for fp32 / bf16 / IEEE fp16 rows."""
+    if dtype == BF16:
+        return L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16, L.mm_bn_bwd_bf16
+    if dtype == F16:
+        return L.mm_bn_fwd_train_f16, L.mm_bn_fwd_eval_f16, L.mm_bn_bwd_f16
+    return L.mm_bn_fwd_train, L.mm_bn_fwd_eval, L.mm_bn_bwd
 
 
 class BatchNormActFunction(torch.autograd.Function):
@@ -503,10 +529,10 @@ class BatchNormActFunction(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, training, eps, momentum, leak, seg_rows=None):
         _lib.require_cuda(x, "features")
         L = _lib.lib()
-        act16 = x.dtype == BF16
+        act16 = x.dtype in H16
         x = _c(x) if act16 else _c(x.to(F32))
         ctx.act16 = act16
-        fwd_train, fwd_eval = (L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16) if act16 else (L.mm_bn_fwd_train, L.mm_bn_fwd_eval)
+        fwd_train, fwd_eval = _bn_entry(L, x.dtype)[:2]
         N, C = x.shape
         y = torch.empty_like(x)
         if training:
@@ -549,7 +575,7 @@ class BatchNormActFunction(torch.autograd.Function):
             raise RuntimeError("BatchNorm backward in eval mode is not part of the hot path")
         L = _lib.lib()
         x, weight, bias, stats = ctx.saved_tensors
-        dy = _c(dy.to(BF16 if ctx.act16 else F32))
+        dy = _c(dy.to(x.dtype if ctx.act16 else F32))
         N, C = x.shape
         dx = torch.empty_like(x)
         ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
@@ -564,13 +590,8 @@ class BatchNormActFunction(torch.autograd.Function):
         if ctx.act16 and weight is not None:
             _bn16_bwd(L, x, C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), stats, ctx.leak, dx, ptr(dwt), ptr(dbt), acc)
         else:
-            check(
-                L.mm_bn_bwd(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
-                            ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()) if not ctx.act16 else
-                L.mm_bn_bwd_bf16(ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak, ptr(dx), C,
-                                 ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
-                "bn_bwd",
-            )
+            check(_bn_entry(L, x.dtype)[2](ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak,
+                                           ptr(dx), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
         if ctx.sinks is not None:
             gradsink.done(wp)
             gradsink.done(bp)
@@ -586,12 +607,12 @@ class BatchNormActJoinFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, weight, bias, running_mean, running_var, training, eps, momentum, leak, seg_rows, *xs):
         L = _lib.lib()
-        act16 = xs[0].dtype == BF16
+        act16 = xs[0].dtype in H16
         xs = [_c(x) if act16 else _c(x.to(F32)) for x in xs]
         for x in xs:
             _lib.require_cuda(x, "features")
         es = 2 if act16 else 4
-        fwd_train, fwd_eval = (L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16) if act16 else (L.mm_bn_fwd_train, L.mm_bn_fwd_eval)
+        fwd_train, fwd_eval = _bn_entry(L, xs[0].dtype)[:2]
         N = xs[0].shape[0]
         widths = [x.shape[1] for x in xs]
         C = sum(widths)
@@ -631,7 +652,7 @@ class BatchNormActJoinFunction(torch.autograd.Function):
         weight, bias = ctx.saved_tensors[:2]
         stats, xs = ctx.saved_tensors[2 : 2 + n], ctx.saved_tensors[2 + n :]
         es = 2 if ctx.act16 else 4
-        dy = _c(dy.to(BF16 if ctx.act16 else F32))
+        dy = _c(dy.to(xs[0].dtype if ctx.act16 else F32))
         N, C = dy.shape
         if ctx.sinks is not None:
             wp, bp = ctx.sinks
@@ -641,7 +662,7 @@ class BatchNormActJoinFunction(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=dy.device)
             db = dbt = torch.empty(C, dtype=F32, device=dy.device)
             acc = 0
-        bwd = L.mm_bn_bwd_bf16 if ctx.act16 else L.mm_bn_bwd
+        bwd = _bn_entry(L, xs[0].dtype)[2]
         dxs, off = [], 0
         for x, st, c in zip(xs, stats, ctx.widths):
             dx = torch.empty_like(x)

@@ -51,7 +51,14 @@ class TrainModel(nn.Module):
         if "sparse_activations" in train_kwargs:
             from . import scn
 
-            scn.set_activation_dtype(torch.bfloat16 if str(train_kwargs["sparse_activations"]) in ("bf16", "16") else torch.float32)
+            kind = str(train_kwargs["sparse_activations"])
+            scn.set_activation_dtype({"bf16": torch.bfloat16, "16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16,
+                                      "half": torch.float16}.get(kind, torch.float32))
+        # IEEE fp16 rows: gradients need the loss scale of the reference's ``precision: 16`` trainer (Lightning native AMP =
+        # torch.cuda.amp.GradScaler); mm2d3d_amd/amp.py keeps its state on the device.  ``loss_scale: False`` switches it off,
+        # a dict passes GradScaler arguments (init_scale, growth_interval, ...).
+        self._scaler_cfg = train_kwargs.get("loss_scale", str(train_kwargs.get("sparse_activations", "")) in ("fp16", "f16", "half"))
+        self.scaler = None
         self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
@@ -311,13 +318,24 @@ class TrainModel(nn.Module):
         loss = self.training_step(batch, self.global_step)
         self._pipelined = nxt
         self._prefetch_rulebooks()
-        loss.backward()
-        self.reducer.finish()
-        for o in self.optimizers:
-            if hasattr(o, "grad_arenas"):
-                o.step(grad_scale=self.reducer.grad_scale)
-            else:
-                o.step()
+        if self._scaler_cfg and self.scaler is None:
+            from .amp import GradScaler
+
+            self.scaler = GradScaler(loss.device, **(self._scaler_cfg if isinstance(self._scaler_cfg, dict) else {}))
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()
+            self.reducer.finish()
+            for o in self.optimizers:
+                self.scaler.step(o, self.reducer.grad_scale)
+            self.scaler.update()
+        else:
+            loss.backward()
+            self.reducer.finish()
+            for o in self.optimizers:
+                if hasattr(o, "grad_arenas"):
+                    o.step(grad_scale=self.reducer.grad_scale)
+                else:
+                    o.step()
         for s in self.schedulers:
             if s is not None:
                 s.step()

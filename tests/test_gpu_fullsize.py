@@ -252,11 +252,14 @@ def test_full_joint_step_at_bench_size(workload):
         assert torch.equal(n3.linear.weight.grad, g1)
 
 
-def test_full_joint_step_at_bench_size_c5_16bit_rows():
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_full_joint_step_at_bench_size_c5_16bit_rows(kind):
     """BASELINE.json configs[4] at its bench size: 8 source scans downsampled to 10,000 points + 8 KITTI-shaped target scans
-    (121,600 points), 480x302, sparse rows stored in 16 bits (`bench.py --workload c5`).  The joint [source | target] pass
-    must give the losses of the literal two-call sequence; the step is repeatable bit for bit; three optimiser steps on the
-    fixed batch lower the loss and stay finite."""
+    (121,600 points), 480x302, sparse rows stored in 16 bits (`bench.py --workload c5 [--sparse-act fp16]`).  The joint
+    [source | target] pass must give the losses of the literal two-call sequence; the step is repeatable bit for bit; three
+    optimiser steps on the fixed batch lower the loss and stay finite.  fp16: IEEE half rows ("fp16 activations", the
+    reference's ``precision: 16``) under the device-resident loss scale (mm2d3d_amd/amp.py), which must still stand at its
+    initial 65536 after the four steps (no overflow on this workload) with every step taken."""
     import copy
 
     from mm2d3d_amd import scn
@@ -269,7 +272,7 @@ def test_full_joint_step_at_bench_size_c5_16bit_rows():
 
     dev = _dev()
     torch.manual_seed(0)
-    scn.set_activation_dtype(torch.bfloat16)
+    scn.set_activation_dtype(torch.bfloat16 if kind == "bf16" else torch.float16)
     try:
         kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
         n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
@@ -292,7 +295,7 @@ def test_full_joint_step_at_bench_size_c5_16bit_rows():
             o = Optimizer("adamw", lr=0.001)
             o.set_scheduler("one_cycle", max_lr=0.005, total_steps=1000)
             opts[k] = o
-        one = TrainModel({"2d_net": n2, "3d_net": n3}, opts, loss, dict(tk, gc_freeze=False))
+        one = TrainModel({"2d_net": n2, "3d_net": n3}, opts, loss, dict(tk, gc_freeze=False, sparse_activations=kind))
         two = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(tk, joint_domains=False))
         t1 = one.training_step(mk())
         logs1 = {k: float(v) for k, v in one.last_logs.items()}
@@ -306,6 +309,11 @@ def test_full_joint_step_at_bench_size_c5_16bit_rows():
         del t1, t2, t3, two
         losses = [float(one.fit_step(mk())) for _ in range(4)]
         assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+        if kind == "fp16":
+            assert one.scaler is not None and one.scaler.get_scale() == 65536.0
+            assert [one.scaler.steps_taken(o) for o in one.optimizers] == [4, 4]
+        else:
+            assert one.scaler is None
     finally:
         scn.set_activation_dtype(torch.float32)
 

@@ -348,12 +348,14 @@ def test_net3d_forward_backward_vs_oracle(residual, engine):
 # section 7, last bullet), so there is no reference behaviour to match: the tolerances below are this mode's own, stated
 # against the fp32 oracle on the SAME bf16-rounded operands (operator tests: what is left is the bf16 rounding of the
 # output rows, 2^-9) and against the fp32 network (network test).
-@pytest.fixture
-def act16_mode():
+# Both kinds of 16-bit rows: bf16 (no loss scale needed) and IEEE fp16 (BASELINE.json configs[4]'s wording, the reference's
+# ``precision: 16``; 2^-11 rounding instead of 2^-8, so every bf16 bound below holds with room).
+@pytest.fixture(params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def act16_mode(request):
     from mm2d3d_amd import scn
 
-    scn.set_activation_dtype(torch.bfloat16)
-    yield
+    scn.set_activation_dtype(request.param)
+    yield request.param
     scn.set_activation_dtype(torch.float32)
 
 
@@ -374,7 +376,7 @@ def test_act16_conv_ops_forward_backward(cin, cout, act16_mode):
     keys = scn_ref.pack_keys(coords.numpy())
     _, first = scn_ref.first_occurrence_ids(keys)
     rlv = scn_ref.Level(coords.numpy()[first], 32)
-    bf = lambda t: t.to(torch.bfloat16)
+    bf = lambda t: t.to(act16_mode)
     for mode in ("subm", "down", "up"):
         if mode == "subm":
             rb, rrb, n_in, n_out, K, tr = lv.subm, scn_ref.subm_rulebook(rlv), lv.n, lv.n, 27, False
@@ -389,9 +391,9 @@ def test_act16_conv_ops_forward_backward(cin, cout, act16_mode):
         xh = x.to(dev).requires_grad_(True)
         wh = w.to(dev).requires_grad_(True)
         y = ops.SparseConvFunction.apply(xh, wh, rb, mode, n_in, n_out)
-        assert y.dtype == torch.bfloat16
+        assert y.dtype == act16_mode
         y.backward(g.to(dev))
-        assert xh.grad.dtype == torch.bfloat16 and wh.grad.dtype == torch.float32
+        assert xh.grad.dtype == act16_mode and wh.grad.dtype == torch.float32
         xr = x.double().requires_grad_(True)
         wr = bf(w).double().reshape(K, cin, cout).requires_grad_(True)  # the kernels use one bf16 term per weight
         yr = scn_ref.rule_conv(xr, wr, rrb, n_out, transpose_roles=tr)
@@ -410,7 +412,7 @@ def test_act16_batchnorm(act16_mode):
     dev = _dev()
     torch.manual_seed(3)
     C, N = 48, 3000
-    x = (torch.randn(N, C) * 2 + 0.5).to(torch.bfloat16)
+    x = (torch.randn(N, C) * 2 + 0.5).to(act16_mode)
     bn = scn.BatchNormReLU(C).to(dev)
     ref = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1).double()
     with torch.no_grad():
@@ -421,10 +423,10 @@ def test_act16_batchnorm(act16_mode):
     xh = x.to(dev).requires_grad_(True)
     t = scn.SparseConvNetTensor(xh, None, 32, None)
     y = bn(t).features
-    assert y.dtype == torch.bfloat16
+    assert y.dtype == act16_mode
     xr = x.double().requires_grad_(True)
     yr = torch.relu(ref(xr))
-    g = torch.randn(N, C).to(torch.bfloat16)
+    g = torch.randn(N, C).to(act16_mode)
     y.backward(g.to(dev))
     yr.backward(g.double())
     _close(y.float(), yr, tol=4e-3, what="bn16 fwd")
@@ -450,11 +452,12 @@ def test_act16_net3d_vs_fp32(act16_mode):
     net32 = copy.deepcopy(net16)
     coords, feats = batch["x"]
     w = torch.randn(coords.shape[0], 6, device=dev)
+    S = 256.0 if act16_mode == torch.float16 else 1.0  # fp16 gradient rows: a loss scale (cosines do not depend on it)
     p16, _, a16 = net16({"x": [coords.to(dev), feats.clone().to(dev)]})
-    (p16["seg_logit"] * w).sum().backward()
+    ((p16["seg_logit"] * w).sum() * S).backward()
     scn.set_activation_dtype(torch.float32)
     p32, _, a32 = net32({"x": [coords.to(dev), feats.clone().to(dev)]})
-    (p32["seg_logit"] * w).sum().backward()
+    ((p32["seg_logit"] * w).sum() * S).backward()
     assert p16["seg_logit"].dtype == torch.float32
     _close(p16["seg_logit"], p32["seg_logit"], tol=3e-2, what="act16 logits vs fp32 logits")
     cos = []
@@ -491,12 +494,14 @@ def test_act16_net3d_vs_16bit_emulating_oracle(act16_mode):
     hip.to(dev)
     coords, feats = batch["x"]
     w = torch.randn(coords.shape[0], 6)
+    # IEEE fp16 gradient rows need a loss scale (mm2d3d_amd/amp.py in training); the same factor on both sides here
+    S = 256.0 if act16_mode == torch.float16 else 1.0
     ph, _, ah = hip({"x": [coords.to(dev), feats.clone().to(dev)]})
-    (ph["seg_logit"] * w.to(dev)).sum().add((ah["seg_logit_point"] * w.to(dev)).sum()).backward()
-    scn_ref.EMULATE16[0] = torch.bfloat16
+    ((ph["seg_logit"] * w.to(dev)).sum().add((ah["seg_logit_point"] * w.to(dev)).sum()) * S).backward()
+    scn_ref.EMULATE16[0] = act16_mode
     try:
         pr, _, ar = ref({"x": [coords, feats.clone()]})
-        (pr["seg_logit"] * w).sum().add((ar["seg_logit_point"] * w).sum()).backward()
+        ((pr["seg_logit"] * w).sum().add((ar["seg_logit_point"] * w).sum()) * S).backward()
     finally:
         scn_ref.EMULATE16[0] = None
     p32, _, _ = ref32({"x": [coords, feats.clone()]})

@@ -379,6 +379,75 @@ def test_deferred_sparse_weight_gradient_sums_equal_per_layer_sums():
         scn.set_activation_dtype(torch.float32)
 
 
+def test_grad_scaler_semantics_on_the_device():
+    """mm2d3d_amd/amp.py restates torch.cuda.amp.GradScaler (what the reference's ``precision: 16`` trainer drives) with its state
+    on the device: (1) a clean step applies exactly the update of ``step(grad_scale=1/scale)``; (2) a gradient holding an
+    inf / nan leaves parameters, moments and the bias-correction step counter untouched and halves the scale; (3)
+    ``growth_interval`` clean steps double it; (4) an optimiser with clean gradients still steps when another one overflowed."""
+    from mm2d3d_amd.amp import GradScaler
+    from mm2d3d_amd.optimizers import FlatAdamW
+
+    dev = _dev()
+    torch.manual_seed(0)
+    mk = lambda: [torch.nn.Parameter(torch.randn(37, 5, device=dev)), torch.nn.Parameter(torch.randn(1001, device=dev))]
+    pa, pb, pc = mk(), mk(), mk()
+    for q, r, t in zip(pa, pb, pc):
+        r.data.copy_(q.data)
+        t.data.copy_(q.data)
+    oa, ob, oc = (FlatAdamW(p, lr=1e-2, weight_decay=0.01) for p in (pa, pb, pc))
+    sc = GradScaler(dev, init_scale=1024.0, growth_interval=2)
+    g = [torch.randn_like(q) for q in pa]
+
+    def load(opt, params, mult, poison=None):
+        opt.zero_grad()
+        for q, gg in zip(params, g):
+            q.grad.copy_(gg * mult)
+        if poison is not None:
+            params[1].grad[17] = poison
+        opt.mark_all_touched()
+
+    # (1) clean step == the plain update on unscaled gradients
+    load(oa, pa, 1024.0)
+    load(ob, pb, 1024.0)
+    sc.step(oa)
+    sc.update()
+    ob.step(grad_scale=1.0 / 1024.0)
+    for q, r in zip(pa, pb):
+        assert torch.allclose(q, r, rtol=0, atol=1e-7), float((q - r).abs().max())
+    assert sc.steps_taken(oa) == 1 and sc.get_scale() == 1024.0
+    # (2) overflow: nothing moves, the scale halves, the step counter stays; (4) the other optimiser steps
+    keep = [q.detach().clone() for q in pa]
+    m0 = oa._arenas[0]["m"].clone()
+    for poison in (float("inf"), float("nan")):
+        load(oa, pa, 1024.0, poison)
+        load(oc, pc, sc.get_scale())
+        before_c = [q.detach().clone() for q in pc]
+        sc.step(oa)
+        sc.step(oc)
+        sc.update()
+        for q, k in zip(pa, keep):
+            assert torch.equal(q, k)
+        assert torch.equal(oa._arenas[0]["m"], m0)
+        assert any(not torch.equal(q, k) for q, k in zip(pc, before_c))
+    assert sc.steps_taken(oa) == 1 and sc.steps_taken(oc) == 2
+    assert sc.get_scale() == 256.0
+    # (3) two clean steps (growth_interval) double the scale; the bias corrections continue from step 2
+    for i in range(2):
+        load(oa, pa, sc.get_scale())
+        load(ob, pb, 1.0)
+        sc.step(oa)
+        sc.update()
+        ob.step()
+        for q, r in zip(pa, pb):
+            assert torch.allclose(q, r, rtol=0, atol=2e-7), (i, float((q - r).abs().max()))
+    assert sc.get_scale() == 512.0 and sc.steps_taken(oa) == 3
+    assert oa.state_dict()["step"] == 3
+    sd = sc.state_dict()
+    sc2 = GradScaler(dev)
+    sc2.load_state_dict(sd)
+    assert sc2.get_scale() == 512.0 and sc2.growth_interval == 2
+
+
 def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
     from mm2d3d_amd.metrics import SegIoU
 
