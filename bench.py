@@ -349,6 +349,8 @@ def main(argv=None):
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes; "
                          "c5 = configs[4]: 10k-pt vKITTI-shaped source + KITTI-shaped target, 8/GPU, 16-bit sparse activations")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
+                    help="16-bit storage format of the 2D maps: bf16 (default) or IEEE fp16 + loss scale (the reference's precision: 16)")
     ap.add_argument("--sparse-act", default="bf16", choices=["bf16", "fp16"],
                     help="--workload c5: kind of the 16-bit sparse rows (fp16 = IEEE half + loss scaling)")
     a = ap.parse_args(argv)
@@ -385,16 +387,16 @@ def main(argv=None):
     down_src = 0
     if a.workload == "c4":
         shape, ncls, B = "kitti", 10, (a.scenes if a.scenes != 8 else 4)
-        tm = build_trainer(dev, num_classes=10, class_weights=[1.0] * 10)
+        tm = build_trainer(dev, num_classes=10, class_weights=[1.0] * 10, train_kwargs={"precision": a.precision})
     elif a.workload == "c5":
         # source = KITTI-shaped sweeps downsampled to 10,000 points (datasets/virtual_kitti_semantic_kitti.yaml:27),
         # target = full KITTI-shaped scans; sparse rows in bf16 between the stem and the OutputLayer (fp32 accumulation)
         # (--sparse-act fp16: IEEE fp16 rows + the device-resident loss scale of mm2d3d_amd/amp.py)
         shape, ncls, B, down_src = "kitti", 6, a.scenes, 10000
-        tm = build_trainer(dev, train_kwargs={"sparse_activations": a.sparse_act})
+        tm = build_trainer(dev, train_kwargs={"sparse_activations": a.sparse_act, "precision": a.precision})
     else:
         shape, ncls, B = "nuscenes", 6, a.scenes
-        tm = build_trainer(dev)
+        tm = build_trainer(dev, train_kwargs={"precision": a.precision})
     cid = {"c2": (2, 3), "c4": (4, 5), "c5": (6, 7)}[a.workload]
     batch = {
         "source": make_batch(cid[0], B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True, downsample=down_src),
@@ -453,13 +455,17 @@ def main(argv=None):
             "allreduce_bytes_per_step": st["bytes"], "allreduce_buckets_per_step": st["buckets"],
             "buckets_launched_before_finish": st["early"],  # sent from backward hooks, i.e. overlapped with the rest of backward
         })
+    if a.precision == "fp16":
+        out["dtype"] = out["dtype"].replace("bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP)",
+                                            "fp16 MFMA, fp32 accumulate, loss scale 65536 on the device (2D branch: IEEE fp16 maps, "
+                                            "as the reference's fp16 AMP)")
     if a.workload == "c4":
         out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
     if a.workload == "c5":
         out["config"]["workload"] = ("BASELINE.json configs[4] shape: source = KITTI-shaped sweeps downsampled to 10,000 pts, target = KITTI-shaped "
                                      "121,600-pt scans, 480x302, sparse rows bf16 between the stem and the OutputLayer, fp32 accumulation "
                                      "(not the headline)")
-        out["dtype"] = (f"bf16 MFMA, fp32 accumulate (2D branch) + {a.sparse_act} sparse activations / fp32 accumulate and statistics "
+        out["dtype"] = (f"{a.precision} MFMA, fp32 accumulate (2D branch) + {a.sparse_act} sparse activations / fp32 accumulate and statistics "
                         "(3D branch)" + (", loss scale 65536 on the device (GradScaler semantics)" if a.sparse_act == "fp16" else ""))
         out["config"]["workload"] = out["config"]["workload"].replace("sparse rows bf16", f"sparse rows {a.sparse_act}")
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c5":

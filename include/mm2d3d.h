@@ -390,6 +390,51 @@ int mm_conv2d_f32_wgrad(const float* G, int B, int Hg, int Wg, int Cg, int ldG, 
                         int64_t w_sx, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_colsum_f32(const float* x, int ld, int64_t N, int C, float* out, int accumulate, mm_stream_t stream);
 
+
+/* ---------------------------------------------------------------- the dense 2D kernels over IEEE fp16 maps
+ * The reference's 2D branch runs under ``precision: 16`` = fp16 autocast + GradScaler (config/run/train.yaml:11).  The kernels of
+ * csrc/conv2d.hip, bn2d.hip and misc2d.hip are built a second time with IEEE fp16 as the 16-bit storage format
+ * (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16; csrc/h16.h) and exported under the suffix _f16: same arguments, same
+ * semantics, "bf16" in the descriptions above reads "fp16".  The switches and the fault word are per build
+ * (mm_bn2d_set_fused_f16, mm_bn2d_fused_fault_f16).  mm_copy_rows_bf16 / mm_concat_bf16 move 2-byte elements and serve both.
+ * Gradient maps in fp16 need the loss scale of mm2d3d_amd/amp.py (mm_grad_nonfinite ... mm_amp_update below). */
+int mm_conv2d_gemm_f16(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
+                   int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
+                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, mm_stream_t stream);
+int mm_conv2d_3x3s1_f16(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
+                    const float* bias, int flip, mm_stream_t stream);
+size_t mm_conv2d_wgrad_ws_bytes_f16(int64_t M, int Cn, int Ck, int ntaps);
+int mm_conv2d_wgrad_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
+                    int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
+                    int64_t sk, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_stem_prep_f16(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, mm_stream_t stream);
+int mm_pack_weights_f16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st,
+                         int64_t sk, mm_stream_t stream);
+int mm_pack_weights_f16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, mm_stream_t stream);
+int mm_bn2d_fused_fault_f16(void);
+int mm_bn2d_set_fused_f16(int mask);
+size_t mm_bn2d_ws_bytes_f16(int C);
+int mm_bn2d_fwd_train_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+                      const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                      float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
+                      size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_fwd_eval_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
+                     const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
+                     int ld_y, mm_stream_t stream);
+int mm_bn2d_bwd_f16(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y,
+                int relu, int64_t N, int64_t Ns, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
+                int ld_dx, void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
+                mm_stream_t stream);
+int mm_colsum_f16(const void* x, int ld_x, int64_t N, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
+                   mm_stream_t stream);
+int mm_maxpool3x3s2_fwd_f16(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, mm_stream_t stream);
+int mm_maxpool3x3s2_bwd_f16(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, mm_stream_t stream);
+size_t mm_head_ws_bytes_f16(int B, int h, int w, int Hp, int Wp, int C, int NJ);
+int mm_head_fwd_f16(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias,
+                int NJ, float* out, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_head_bwd_f16(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ,
+                const float* dout, void* dx, float* dWj, void* ws, size_t ws_bytes, mm_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -133,6 +133,32 @@ class HipLibraryMissing(RuntimeError):
     pass
 
 
+# the dense 2D kernels built for IEEE fp16 storage (csrc/h16.h): same prototypes under the suffix _f16
+H16_2D = {
+    "mm_conv2d_gemm": "mm_conv2d_gemm_f16",
+    "mm_conv2d_3x3s1": "mm_conv2d_3x3s1_f16",
+    "mm_conv2d_wgrad_ws_bytes": "mm_conv2d_wgrad_ws_bytes_f16",
+    "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",
+    "mm_stem_prep": "mm_stem_prep_f16",
+    "mm_pack_weights_bf16": "mm_pack_weights_f16",
+    "mm_pack_weights_bf16_batch": "mm_pack_weights_f16_batch",
+    "mm_bn2d_fused_fault": "mm_bn2d_fused_fault_f16",
+    "mm_bn2d_set_fused": "mm_bn2d_set_fused_f16",
+    "mm_bn2d_ws_bytes": "mm_bn2d_ws_bytes_f16",
+    "mm_bn2d_fwd_train": "mm_bn2d_fwd_train_f16",
+    "mm_bn2d_fwd_eval": "mm_bn2d_fwd_eval_f16",
+    "mm_bn2d_bwd": "mm_bn2d_bwd_f16",
+    "mm_colsum_bf16": "mm_colsum_f16",
+    "mm_maxpool3x3s2_fwd": "mm_maxpool3x3s2_fwd_f16",
+    "mm_maxpool3x3s2_bwd": "mm_maxpool3x3s2_bwd_f16",
+    "mm_head_ws_bytes": "mm_head_ws_bytes_f16",
+    "mm_head_fwd": "mm_head_fwd_f16",
+    "mm_head_bwd": "mm_head_bwd_f16",
+}
+for _a, _b in H16_2D.items():
+    _PROTOS[_b] = _PROTOS[_a]
+
+
 def build(verbose: bool = False) -> str:
     """Compile every .hip source for gfx950 into the in-tree shared library (hipcc cross-compiles without a GPU)."""
     r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=not verbose, text=True)
@@ -155,6 +181,19 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def bn2d_set_fused(mask: int) -> int:
+    """mm_bn2d_set_fused for BOTH builds of csrc/bn2d.hip (bf16 and IEEE fp16 storage keep separate switches); returns the previous
+    mask of the bf16 build (the two are always set together through this function)."""
+    l = lib()
+    l.mm_bn2d_set_fused_f16(mask)
+    return int(l.mm_bn2d_set_fused(mask))
+
+
+def bn2d_fused_fault() -> int:
+    l = lib()
+    return int(l.mm_bn2d_fused_fault()) | int(l.mm_bn2d_fused_fault_f16())
 
 
 def exported_symbols():

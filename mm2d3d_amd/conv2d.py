@@ -15,15 +15,45 @@ import torch
 from . import _lib, gradsink
 from ._lib import check, ptr, stream
 
-BF16 = torch.bfloat16
 CL = torch.channels_last
+
+# Storage format of the 2D maps and of the packed weights: bfloat16 (default) or IEEE float16 - the reference's ``precision: 16`` is
+# fp16 autocast + GradScaler (config/run/train.yaml:11).  The kernels exist in both builds (csrc/h16.h: entry points suffixed
+# _f16, same arguments); fp16 gradient maps need the loss scale of mm2d3d_amd/amp.py, which TrainModel installs with
+# ``train_kwargs["precision"] = "fp16"``.
+HALF = [torch.bfloat16]
+
+
+def set_half(dtype):
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("the 16-bit storage format of the 2D branch is torch.bfloat16 or torch.float16")
+    HALF[0] = dtype
+
+
+class _Lib2d:
+    """The C-ABI library with the dense 2D entry points resolved for the current storage format."""
+
+    def __getattr__(self, name):
+        L = _lib.lib()
+        if HALF[0] == torch.float16:
+            alt = _lib.H16_2D.get(name)
+            if alt is not None:
+                return getattr(L, alt)
+        return getattr(L, name)
+
+
+_LIB2D = _Lib2d()
+
+
+def lib2d():
+    return _LIB2D
 
 
 def nhwc_pitch(x):
     """(tensor, pitch in elements) of an NHWC bf16 map that may be a channel slice of a wider NHWC buffer (pitch > C):
     the decoder's concat buffers are filled in place by their producers and read through such views."""
-    if x.dtype != BF16:
-        x = x.to(BF16)
+    if x.dtype != HALF[0]:
+        x = x.to(HALF[0])
     B, C, H, W = x.shape
     s0, s1, s2, s3 = x.stride()
     if s1 == 1 and s3 >= C and s3 % 8 == 0 and s2 == W * s3 and s0 == H * W * s3 and x.data_ptr() % 16 == 0:
@@ -36,8 +66,8 @@ def _arr(v):
 
 
 def as_nhwc_bf16(x):
-    if x.dtype != BF16:
-        x = x.to(BF16)
+    if x.dtype != HALF[0]:
+        x = x.to(HALF[0])
     if not x.is_contiguous(memory_format=CL):
         x = x.contiguous(memory_format=CL)
     return x
@@ -92,7 +122,7 @@ class _PackRegistry:
                 blk += e.nblk
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.table_n, self.total_blocks = len(rows), blk
-        check(_lib.lib().mm_pack_weights_bf16_batch(ptr(self.table), self.table_n, self.total_blocks, stream()), "pack_weights_batch")
+        check(lib2d().mm_pack_weights_bf16_batch(ptr(self.table), self.table_n, self.total_blocks, stream()), "pack_weights_batch")
         ep = PARAM_EPOCH[0]
         for e in self.entries:
             o = e.owner()
@@ -107,16 +137,17 @@ def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
     (torch in-place ops bump ``_version``; the fused AdamW kernel bumps PARAM_EPOCH): both forward passes of a step and
     both backward passes share one pack, and all stale packs of a device are refreshed together."""
     if owner is None:
-        out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
-        check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
+        out = torch.empty(Z * N * T * K, dtype=HALF[0], device=w.device)
+        check(lib2d().mm_pack_weights_bf16(ptr(w), ptr(out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
         return out
     key = (owner._version, PARAM_EPOCH[0], owner.data_ptr())
     cache = owner.__dict__.setdefault("_mm_packs", {})
+    kind = (kind, HALF[0])  # a pack holds one storage format
     e = cache.get(kind)
     if e is not None:
         if e.key == key:
             return e.out
-        reg = _REGISTRIES[w.device.index]
+        reg = _REGISTRIES[(w.device.index, HALF[0])]
         reg.repack_all(w.device)
         e = cache.get(kind)
         if e is not None and e.key == key:
@@ -124,22 +155,22 @@ def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
     # first use (or the parameter moved): pack this one and register it
     e = _PackEntry()
     e.owner, e.kind = weakref.ref(owner), kind
-    e.out = torch.empty(Z * N * T * K, dtype=BF16, device=w.device)
+    e.out = torch.empty(Z * N * T * K, dtype=HALF[0], device=w.device)
     e.in_ptr = (w.data_ptr(), owner.data_ptr())
     e.args = (Z, N, T, K, sz, sn, st, sk)
     if Z * N * T * K >= 1 << 31:
         raise ValueError("conv2d: a weight of 2^31 or more elements cannot be packed")
     e.nblk = (Z * N * T * K + 4095) // 4096  # MM_PACK_CHUNK of csrc/conv2d.hip
-    check(_lib.lib().mm_pack_weights_bf16(ptr(w), ptr(e.out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
+    check(lib2d().mm_pack_weights_bf16(ptr(w), ptr(e.out), Z, N, T, K, sz, sn, st, sk, stream()), "pack_weights")
     e.key = key
     cache[kind] = e
-    _REGISTRIES.setdefault(w.device.index, _PackRegistry()).entries.append(e)
+    _REGISTRIES.setdefault((w.device.index, HALF[0]), _PackRegistry()).entries.append(e)
     return e.out
 
 
 def _bias_grad(dy):
     """dy.sum((0, 2, 3)) of an NHWC bf16 gradient in one pass (fp64 combination), fp32 result."""
-    L = _lib.lib()
+    L = lib2d()
     Bn, C, H, W = dy.shape
     out = torch.empty(C, dtype=torch.float32, device=dy.device)
     ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), dy.device)
@@ -150,14 +181,14 @@ def _bias_grad(dy):
 
 def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None, lda=None):
     check(
-        _lib.lib().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, lda or Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
+        lib2d().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, lda or Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
                                   Hg, Wg, so, 0, 0, sa, fr, len(ty), _arr(ty), _arr(tx), ptr(Wp), nz, wz, zpar, ptr(bias), stream()),
         "conv2d_gemm",
     )
 
 
 def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk, accumulate=0, ldx=None, ldy=None):
-    L = _lib.lib()
+    L = lib2d()
     ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * Hg * Wg, Cn, Ck, len(ty))), X.device)
     check(
         L.mm_conv2d_wgrad(ptr(X), Bn, Hi, Wi, Ck, ldx or Ck, ptr(dY), Hg, Wg, Cn, ldy or Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(dW), sn, st, sk,
@@ -185,12 +216,12 @@ class Conv2dFn(torch.autograd.Function):
         w = weight.detach().float().contiguous()
         T = KH * KW
         Wp = _pack(w, 1, Cout, T, Cin, 0, Cin * T, 1, T, weight, "fwd")  # [co][t][ci]
-        y = torch.empty((Bn, Cout, Ho, Wo), dtype=BF16, device=x.device, memory_format=CL)
+        y = torch.empty((Bn, Cout, Ho, Wo), dtype=HALF[0], device=x.device, memory_format=CL)
         ty = [kh - padding for kh in range(KH) for _ in range(KW)]
         tx = [kw - padding for _ in range(KH) for kw in range(KW)]
         b = bias.detach().float().contiguous() if bias is not None else None
         if (KH, KW, stride, padding) == (3, 3, 1, 1):  # halo-tile kernel: input patch staged once for all 9 taps
-            check(_lib.lib().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0, stream()),
+            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0, stream()),
                   "conv2d_3x3s1")
         else:
             _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b, lda=ldx)
@@ -214,9 +245,9 @@ class Conv2dFn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T, ctx.wowner, "dgrad")  # [ci][t][co]
-            dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
+            dx = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x.device, memory_format=CL)
             if (KH, KW, stride, padding) == (3, 3, 1, 1):
-                check(_lib.lib().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),
+                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),
                       "conv2d_3x3s1")
             else:
                 ty = [padding - kh for kh in range(KH) for _ in range(KW)]
@@ -250,7 +281,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         w = weight.detach().float().contiguous()  # [ci][co][a][b]
         Wp = _pack(w, 4, Cout, 1, Cin, 1, 4, 0, Cout * 4, weight, "tfwd")  # [z=(a,b)][co][ci]
         ctx.wowner = weight
-        y = torch.empty((Bn, Cout, 2 * H, 2 * W), dtype=BF16, device=x.device, memory_format=CL)
+        y = torch.empty((Bn, Cout, 2 * H, 2 * W), dtype=HALF[0], device=x.device, memory_format=CL)
         b = bias.detach().float().contiguous() if bias is not None else None
         _gemm(x, Bn, H, W, Cin, y, 2 * H, 2 * W, Cout, H, W, 2, 1, 1, [0], [0], Wp, nz=4, wz=Cout * Cin, zpar=1, bias=b)
         ctx.save_for_backward(x, w)
@@ -267,7 +298,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         ty, tx = [0, 0, 1, 1], [0, 1, 0, 1]
         if ctx.needs_input_grad[0]:
             Wd = _pack(w, 1, Cin, 4, Cout, 0, Cout * 4, 1, 4, ctx.wowner, "tdgrad")  # [ci][t=(a,b)][co]
-            dx = torch.empty((Bn, Cin, H, W), dtype=BF16, device=x.device, memory_format=CL)
+            dx = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x.device, memory_format=CL)
             _gemm(dy, Bn, 2 * H, 2 * W, Cout, dx, H, W, Cin, H, W, 1, 2, 1, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
@@ -316,18 +347,18 @@ class StemConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, weight):
         _lib.require_cuda(img, "img")
-        L = _lib.lib()
+        L = lib2d()
         img = img.float().contiguous()
         Bn, C, H, W = img.shape
         Cout, _, KH, KW = weight.shape
         assert (KH, KW) == (7, 7) and C <= 8 and Cout % 64 == 0
         R, T, flat, valid, src = _stem_index(C, img.device)
         Hb, Wb = H + 6 + 8, W + 6 + 2  # rows: taps reach R*T - 1 <= 7 rows further; cols: the 8-pixel window of the last column
-        xb = torch.empty((Bn, Hb, Wb, 8), dtype=BF16, device=img.device)
+        xb = torch.empty((Bn, Hb, Wb, 8), dtype=HALF[0], device=img.device)
         check(L.mm_stem_prep(ptr(img), Bn, C, H, W, 3, Hb, Wb, R, ptr(xb), stream()), "stem_prep")
         w = weight.detach().float().reshape(Cout, C * 49)
-        Wp = torch.cat([w, w.new_zeros((Cout, 1))], 1).index_select(1, flat).to(BF16).contiguous()  # [co][t][kw8][slot]
-        y = torch.empty((Bn, Cout, H, W), dtype=BF16, device=img.device, memory_format=CL)
+        Wp = torch.cat([w, w.new_zeros((Cout, 1))], 1).index_select(1, flat).to(HALF[0]).contiguous()  # [co][t][kw8][slot]
+        y = torch.empty((Bn, Cout, H, W), dtype=HALF[0], device=img.device, memory_format=CL)
         ty = [t * R for t in range(T)]
         # virtual activation: pixel pitch (lda) 8, 64 channels, Wi = Wb - 7 valid window starts; output (y,x) reads row y + t*R at x
         check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, T, _arr(ty),
@@ -338,7 +369,7 @@ class StemConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        L = _lib.lib()
+        L = lib2d()
         (xb,) = ctx.saved_tensors
         Bn, C, H, W, Cout, Hb, Wb, wshape = ctx.dims
         R, T, flat, valid, src = _stem_index(C, dy.device)

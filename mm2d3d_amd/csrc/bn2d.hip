@@ -7,33 +7,27 @@
 #include "fused_bn.h"
 
 
-typedef unsigned short u16;
+#include "h16.h"  // bf16 (default) or IEEE fp16 (-DMM_ACT_FP16) storage: this file is built once for each
 
 namespace {
 constexpr int T = 256;
 constexpr int MAX_PART = 2048;
 
-__device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
-__device__ inline u16 f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
-}
 __device__ inline void ld8(const u16* p, float (&v)[8]) {
   uint4 t = *(const uint4*)p;
   unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    v[2 * i] = __uint_as_float(w[i] << 16);
-    v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    v[2 * i] = h_lo(w[i]);
+    v[2 * i + 1] = h_hi(w[i]);
   }
 }
 __device__ inline void cvt8(const uint4& t, float (&v)[8]) {
   const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    v[2 * i] = __uint_as_float(w[i] << 16);
-    v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    v[2 * i] = h_lo(w[i]);
+    v[2 * i + 1] = h_hi(w[i]);
   }
 }
 __device__ inline void st8(u16* p, const float (&v)[8]) {
@@ -346,8 +340,8 @@ __device__ inline void unpack8(const u32x4 t, float (&v)[8]) {
   const unsigned w[4] = {t.x, t.y, t.z, t.w};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    v[2 * i] = __uint_as_float(w[i] << 16);
-    v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+    v[2 * i] = h_lo(w[i]);
+    v[2 * i + 1] = h_hi(w[i]);
   }
 }
 __device__ inline u32x4 pack8(const float (&v)[8]) {
@@ -692,15 +686,15 @@ extern "C" {
 
 // Selects the single-launch training kernels per direction: bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd (default 3, or the
 // value of the environment variable MM_BN2D_FUSED); 0 = always the reduce / finalize / apply kernels.  Returns the previous mask.
-int mm_bn2d_fused_fault(void) { return fused_fault_poll(); }
+int MM_SYM(mm_bn2d_fused_fault)(void) { return fused_fault_poll(); }
 
-int mm_bn2d_set_fused(int mask) {
+int MM_SYM(mm_bn2d_set_fused)(int mask) {
   const int prev = fused_mask("MM_BN2D_FUSED");
   g_fused_enabled = mask & 3;
   return prev;
 }
 
-size_t mm_bn2d_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
+size_t MM_SYM(mm_bn2d_ws_bytes)(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 
 // block counts of the two statistics groups (rows [0,Ns) and [Ns,N)); Ns == N or Ns == 0: a single group
 static void split_blocks(int64_t N, int64_t& Ns, int C, bool stats, int& b0, int& b1) {
@@ -722,7 +716,7 @@ static void split_blocks(int64_t N, int64_t& Ns, int C, bool stats, int& b0, int
 // Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source and target halves of a jointly
 // batched step, train.py:186-292 calls the net once per domain); Ns = N (or 0) is the ordinary single-batch case.
 // save_mean / save_invstd: fp32 [G][C], G = 2 when split.
-int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+int MM_SYM(mm_bn2d_fwd_train)(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                       hipStream_t s) {
@@ -773,7 +767,7 @@ int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_
   return MM_OK;
 }
 
-int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
+int MM_SYM(mm_bn2d_fwd_eval)(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
                      const float* running_mean, const float* running_var, float eps, int relu, void* y, int ld_y, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0, "bn2d: C must be a multiple of 8");
   if (N == 0) return MM_OK;
@@ -788,7 +782,7 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
 // dy2 != NULL: the incoming gradient is dy + dy2 (the map had two consumers; summed here in fp32 instead of by an add kernel).
 // yout == NULL with relu != 0 (only valid when the forward had no residual input): the ReLU mask is recomputed from x,
 // weight, bias and the saved statistics instead of reading the output map.
-int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y, int relu,
+int MM_SYM(mm_bn2d_bwd)(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y, int relu,
                 int64_t N, int64_t Ns, int C,
                 const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
                 float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -852,7 +846,7 @@ int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* 
 }
 
 // out[c] (+)= sum over the N rows of x[:, c]  (conv bias gradient: torch's dy.sum((0, 2, 3)))
-int mm_colsum_bf16(const void* x, int ld_x, int64_t N, int C, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+int MM_H(mm_colsum)(const void* x, int ld_x, int64_t N, int C, float* out, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0, "colsum: C must be a multiple of 8, <= 2048");
   if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
     mm_set_error("colsum: workspace too small");

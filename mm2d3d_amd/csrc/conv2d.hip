@@ -16,11 +16,11 @@
 #include <hip/hip_bf16.h>
 
 #include "common.h"
+#include "h16.h"  // bf16 (default) or IEEE fp16 (-DMM_ACT_FP16) storage: this file is built once for each
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef h16x8 bf16x8;  // a 16-byte MFMA fragment of eight stored elements (the name predates the fp16 build)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned short u16;
 
 namespace {
 
@@ -46,12 +46,6 @@ struct ConvP {
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
 
-__device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
-__device__ inline u16 f2bf(float f) {  // round to nearest even (inputs are finite)
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
-}
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
@@ -194,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; j++) acc[i][j] = MM_MFMA_32x32x16(bf[j], af[i], acc[i][j]);
     }
   }
 
@@ -496,7 +490,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);  // D[cout][pixel]
+            acc[i][j] = MM_MFMA_32x32x16(bf[j], af[i], acc[i][j]);  // D[cout][pixel]
       }
       slot = slot + BSZB == RW * BSZB ? 0 : slot + BSZB;
     }
@@ -646,7 +640,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
         for (int i = 0; i < 2; i++) af[i] = *(const bf16x8*)(lds + ((aoff[i][tap] + hb) ^ (kk << 5)));
         const bf16x8 bf = *(const bf16x8*)(lds + ((boff ^ (kk << 5)) + tap * BSZB));
 #pragma unroll
-        for (int i = 0; i < 2; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[i], acc[i], 0, 0, 0);  // D[cout][pixel]
+        for (int i = 0; i < 2; i++) acc[i] = MM_MFMA_32x32x16(bf, af[i], acc[i]);  // D[cout][pixel]
       }
     }
     int b, ty0, tx0;
@@ -797,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
 #pragma unroll
       for (int i = 0; i < NTN; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; j++) acc[i][j] = MM_MFMA_32x32x16(af[i], bf[j], acc[i][j]);
     }
   }
   float* P = p.partial + (int64_t)blockIdx.x * p.Cn * p.ntaps * p.Ck;
@@ -1026,8 +1020,8 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
         if (py >= 0 && py < 8) {
 #pragma unroll
           for (int kw = 0; kw < 3; kw++)
-            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(Au[py & 3], Aw[py & 3]), frag(Bu[cur][kw], Bw[cur][kw]),
-                                                                       acc[kh * 3 + kw], 0, 0, 0);
+            acc[kh * 3 + kw] = MM_MFMA_32x32x16(frag(Au[py & 3], Aw[py & 3]), frag(Bu[cur][kw], Bw[cur][kw]),
+                                                                       acc[kh * 3 + kw]);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1219,7 +1213,7 @@ int fill_taps(ConvP* p, const int* ty, const int* tx, int nt) {
 extern "C" {
 
 // Generic implicit GEMM (see ConvP).  ty/tx: host arrays of ntaps tap offsets.
-int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
+int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, hipStream_t s) {
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
@@ -1261,7 +1255,7 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
 }
 
 // 3x3, stride 1, pad 1 convolution (flip = 0) or its data gradient (flip = 1; Wp packed as [ci][tap][co]).  NHWC bf16.
-int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp, const float* bias,
+int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp, const float* bias,
                     int flip, hipStream_t s) {
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0, "conv2d_3x3s1: bad shape");
   C3P p;
@@ -1327,7 +1321,7 @@ static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
   return c;
 }
 
-size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps) {
+size_t MM_SYM(mm_conv2d_wgrad_ws_bytes)(int64_t M, int Cn, int Ck, int ntaps) {
   int64_t c = wgrad_chunk(M, Cn, Ck, ntaps);
   size_t a = (size_t)mm_cdiv(M, c) * Cn * ntaps * Ck * sizeof(float);
   if (ntaps == 9) {  // halo variant: at most ceil(1536 / tiles) + 1 pixel splits
@@ -1339,7 +1333,7 @@ size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps) {
 }
 
 // dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k];   base grid = dY pixels (B,Hg,Wg), src = (gy*sa+ty, gx*sa+tx)
-int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
                     int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st, int64_t sk,
                     int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(Ck % 64 == 0 && Cn % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ntaps <= MAXT, "conv2d_wgrad: bad shape");
@@ -1414,7 +1408,7 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
   return MM_OK;
 }
 
-int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, hipStream_t s) {
+int MM_SYM(mm_stem_prep)(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, hipStream_t s) {
   MM_CHECK_ARG(C >= 1 && C <= 8 && R >= 1 && R * C <= 8 && Hb >= H + pad && Wb >= W + pad, "stem_prep: bad shape");
   int64_t total = (int64_t)B * Hb * Wb;
   if (total == 0) return MM_OK;
@@ -1423,7 +1417,7 @@ int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, i
   return MM_OK;
 }
 
-int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st, int64_t sk,
+int MM_H(mm_pack_weights)(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st, int64_t sk,
                          hipStream_t s) {
   int64_t ne = (int64_t)Z * N * T * K;
   if (ne == 0) return MM_OK;
@@ -1434,7 +1428,7 @@ int mm_pack_weights_bf16(const float* in, void* out, int Z, int N, int T, int K,
 
 // desc (device): ndesc rows of 11 int64 {in, out, Z, N, T, K, sz, sn, st, sk, first_block}, first_block = prefix sum of
 // ceil(Z*N*T*K / 4096) over the preceding rows (Z*N*T*K < 2^31 per row); total_blocks = the sum over all rows.
-int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, hipStream_t s) {
+int MM_H2(mm_pack_weights, _batch)(const int64_t* desc, int ndesc, int64_t total_blocks, hipStream_t s) {
   MM_CHECK_ARG(ndesc >= 0 && total_blocks >= 0 && total_blocks < (1ll << 31), "pack_weights_batch: bad table");
   if (ndesc == 0 || total_blocks == 0) return MM_OK;
   hipLaunchKernelGGL(k_pack_weights_batch, dim3((unsigned)total_blocks), dim3(256), 0, s, desc, ndesc);

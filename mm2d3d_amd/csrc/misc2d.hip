@@ -7,18 +7,12 @@
 // the bias is added after the filter, which is exact for count_include_pad=True zero padding.
 #include "common.h"
 
-typedef unsigned short u16;
+#include "h16.h"  // bf16 (default) or IEEE fp16 (-DMM_ACT_FP16) storage: this file is built once for each
 
 namespace {
 constexpr int T = 256;
 constexpr int MAXJ = 32;
 
-__device__ inline float bf2f(u16 v) { return __uint_as_float((unsigned)v << 16); }
-__device__ inline u16 f2bf(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (u16)(u >> 16);
-}
 
 // dst[r][0..C) = src[r][0..C), 16-B vectors (C multiple of 8 elements of 2 bytes)
 __global__ __launch_bounds__(T) void k_copy_rows(const u16* __restrict__ src, int64_t ld_s, u16* __restrict__ dst, int64_t ld_d,
@@ -91,7 +85,7 @@ __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, in
       unsigned wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int i = 0; i < 8; i++) {
-        float f = __uint_as_float((i & 1) ? (wv[i >> 1] & 0xFFFF0000u) : (wv[i >> 1] << 16));
+        float f = (i & 1) ? h_hi(wv[i >> 1]) : h_lo(wv[i >> 1]);
         if (!any || f > best[i]) {
           best[i] = f;
           bi[i] = (unsigned char)(kh * 3 + kw);
@@ -140,7 +134,7 @@ __global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, c
       const unsigned tap = (unsigned)(kh * 3 + kw);
 #pragma unroll
       for (int i = 0; i < 8; i++)
-        if (((iw >> (8 * i)) & 0xFFull) == tap) s[i] += __uint_as_float((i & 1) ? (wv[i >> 1] & 0xFFFF0000u) : (wv[i >> 1] << 16));
+        if (((iw >> (8 * i)) & 0xFFull) == tap) s[i] += (i & 1) ? h_hi(wv[i >> 1]) : h_lo(wv[i >> 1]);
     }
   }
   unsigned ow[4];
@@ -170,8 +164,8 @@ __global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int 
     float xv[8];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      xv[2 * i] = __uint_as_float(wv[i] << 16);
-      xv[2 * i + 1] = __uint_as_float(wv[i] & 0xFFFF0000u);
+      xv[2 * i] = h_lo(wv[i]);
+      xv[2 * i + 1] = h_hi(wv[i]);
     }
 #pragma unroll
     for (int j = 0; j < MJ; j++)
@@ -189,7 +183,7 @@ __global__ __launch_bounds__(T) void k_head_proj(const u16* __restrict__ x, int 
 // x is bf16 already, the fp32 weights enter as two bf16 terms (hi + lo: 2^-17 relative), so this is the fp32-weight
 // product to fp32 accumulation noise.  A lane loads 16 B of one pixel row per MFMA (whole 128-B rows per 4 lanes) and
 // stores 4 consecutive outputs of its pixel (16 B): a pure streaming kernel.
-typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef h16x8 hbf16x8;
 typedef float hf32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(T) void k_head_proj_mfma(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w,
                                                        const float* __restrict__ Wj, int NJ, float* __restrict__ z, int groups) {
@@ -200,9 +194,9 @@ __global__ __launch_bounds__(T) void k_head_proj_mfma(const u16* __restrict__ x,
 #pragma unroll
     for (int t = 0; t < 8; t++) {
       const float v = jl < NJ ? Wj[jl * 64 + 32 * half + 8 * sl + t] : 0.f;
-      const __bf16 hh = (__bf16)v;
+      const h16 hh = (h16)v;
       wh[half][t] = hh;
-      wl[half][t] = (__bf16)(v - (float)hh);
+      wl[half][t] = (h16)(v - (float)hh);
     }
   const unsigned total = (unsigned)B * h * w;
   const int gw = (blockIdx.x * (T / 64) + (threadIdx.x >> 6));  // global wave index
@@ -217,10 +211,10 @@ __global__ __launch_bounds__(T) void k_head_proj_mfma(const u16* __restrict__ x,
     if (ok) v0 = *(const uint4*)row, v1 = *(const uint4*)(row + 32);
     const hbf16x8 x0 = __builtin_bit_cast(hbf16x8, v0), x1 = __builtin_bit_cast(hbf16x8, v1);
     hf32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[0], x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[1], x1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[0], x0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[1], x1, acc, 0, 0, 0);
+    acc = MM_MFMA_16x16x32(wl[0], x0, acc);
+    acc = MM_MFMA_16x16x32(wl[1], x1, acc);
+    acc = MM_MFMA_16x16x32(wh[0], x0, acc);
+    acc = MM_MFMA_16x16x32(wh[1], x1, acc);
     if (ok) {  // D row 4*sl + r = output j, column jl = pixel
       float* o = z + (int64_t)pix * NJ + 4 * sl;
       if (4 * sl + 3 < NJ && (NJ & 3) == 0) *(hf32x4*)o = acc;
@@ -331,8 +325,7 @@ __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int H
       if (pp >= p1) break;
       float o[4] = {0.f, 0.f, 0.f, 0.f};
       if (in[u]) {
-        const float xv[4] = {__uint_as_float(xv2[u].x << 16), __uint_as_float(xv2[u].x & 0xFFFF0000u), __uint_as_float(xv2[u].y << 16),
-                             __uint_as_float(xv2[u].y & 0xFFFF0000u)};
+        const float xv[4] = {h_lo(xv2[u].x), h_hi(xv2[u].x), h_lo(xv2[u].y), h_hi(xv2[u].y)};
 #pragma unroll
         for (int j = 0; j < MJ; j++)
           if (j < NJ) {
@@ -389,6 +382,7 @@ static void launch_box5(const float* in, int B, int h, int w, int NJ, const floa
 
 extern "C" {
 
+#ifndef MM_ACT_FP16  // the copies move 2-byte elements whatever they encode: one build serves both storage formats
 // strided 2-byte-element row copy (channel concat / split of NHWC tensors); C multiple of 8
 int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, int64_t N, int C, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0 && ld_s % 8 == 0 && ld_d % 8 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
@@ -422,8 +416,9 @@ int mm_concat_bf16(void* const* parts, const int* channels, int nparts, void* wi
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
+#endif  // MM_ACT_FP16
 
-int mm_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, hipStream_t s) {
+int MM_SYM(mm_maxpool3x3s2_fwd)(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, hipStream_t s) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   MM_CHECK_ARG(C % 8 == 0 && ldx % 8 == 0 && ldx >= C, "maxpool: C and the input pitch must be multiples of 8");
   int64_t total = (int64_t)B * Ho * Wo * (C / 8);
@@ -435,7 +430,7 @@ int mm_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void
   return MM_OK;
 }
 
-int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, hipStream_t s) {
+int MM_SYM(mm_maxpool3x3s2_bwd)(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, hipStream_t s) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   MM_CHECK_ARG(C % 8 == 0, "maxpool: C must be a multiple of 8");
   int64_t total = (int64_t)B * H * W * (C / 8);
@@ -447,14 +442,14 @@ int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, in
   return MM_OK;
 }
 
-size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ) {
+size_t MM_SYM(mm_head_ws_bytes)(int B, int h, int w, int Hp, int Wp, int C, int NJ) {
   size_t z = mm_align((size_t)B * h * w * NJ * sizeof(float));
   size_t part = mm_align((size_t)8192 * NJ * C * sizeof(float));
   return z + part + 256;
 }
 
 // out [B,h,w,NJ] fp32 (NHWC) = box5x5( x[.., :h, :w, :] . Wj^T ) + bias      (x: NHWC bf16 [B,Hp,Wp,C] with pitch ld)
-int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias, int NJ,
+int MM_SYM(mm_head_fwd)(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias, int NJ,
                 float* out, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C % 8 == 0 && (size_t)NJ * C * 4 <= 60 * 1024, "head: bad NJ/C");
   size_t zb = mm_align((size_t)B * h * w * NJ * sizeof(float));
@@ -486,7 +481,7 @@ int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int 
 }
 
 // dout [B,h,w,NJ] fp32 (NHWC) -> dx NHWC bf16 [B,Hp,Wp,C] (zero outside h x w), dWj [NJ,C]
-int mm_head_bwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ, const float* dout,
+int MM_SYM(mm_head_bwd)(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, int NJ, const float* dout,
                 void* dx, float* dWj, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(NJ > 0 && NJ <= MAXJ && C == 64, "head_bwd: C must be 64");
   MM_CHECK_ARG((int64_t)B * Hp * Wp < (1ll << 31), "head_bwd: too many pixels");

@@ -75,9 +75,9 @@ class GradAllReducer:
             from . import _lib
 
             keep = 1 if os.environ.get("MM_DDP_BN_FUSED", "0") != "0" else 0
-            was2d = _lib.lib().mm_bn2d_set_fused(0)
+            was2d = _lib.bn2d_set_fused(0)
             was3d = _lib.lib().mm_bn_set_fused(0)
-            _lib.lib().mm_bn2d_set_fused(was2d & keep)
+            _lib.bn2d_set_fused(was2d & keep)
             _lib.lib().mm_bn_set_fused(was3d & keep)
             if (was2d | was3d) & ~keep and (not dist.is_initialized() or dist.get_rank(process_group) == 0):
                 import sys

@@ -22,7 +22,6 @@ from . import conv2d as _c2d
 from . import conv2d_f32 as _c2f
 from ._lib import check, ptr, stream
 
-BF16 = torch.bfloat16
 CL = torch.channels_last
 F32 = torch.float32
 
@@ -34,9 +33,22 @@ PRECISION = [16]
 
 
 def set_precision(bits):
+    """16 / "bf16": bf16 maps on the MFMA kernels (default); "fp16": IEEE fp16 maps on the same kernels built for fp16 (the
+    reference's ``precision: 16`` is fp16 autocast + GradScaler: 11 significand bits instead of 8, and a loss scale for the
+    gradient maps - mm2d3d_amd/amp.py); 32: the exact-fp32 2D branch."""
+    if bits in ("fp16", "f16", "half"):
+        PRECISION[0] = 16
+        _c2d.set_half(torch.float16)
+        return
+    if bits in ("bf16", "16"):
+        bits = 16
+    if bits in ("32",):
+        bits = 32
     if bits not in (16, 32):
-        raise ValueError("precision must be 16 (bf16 MFMA) or 32 (exact fp32)")
+        raise ValueError('precision must be 16 / "bf16" (bf16 MFMA), "fp16" (IEEE fp16 MFMA + loss scale) or 32 (exact fp32)')
     PRECISION[0] = bits
+    if bits == 16:
+        _c2d.set_half(torch.bfloat16)
 
 
 def fp32_mode():
@@ -97,7 +109,7 @@ class _BN2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None, out=None, handoff=None,
                 res_handoff=None):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         ctx.handoff, ctx.res_handoff = handoff, res_handoff
         x, ldx = _c2d.nhwc_pitch(x)
         B, C, H, W = x.shape
@@ -110,10 +122,10 @@ class _BN2dFn(torch.autograd.Function):
         if out is not None:
             dst = out[0].detach()
             y, ldy = _c2d.nhwc_pitch(dst)
-            if y.data_ptr() != dst.data_ptr() or tuple(y.shape) != tuple(x.shape) or y.dtype != BF16:
+            if y.data_ptr() != dst.data_ptr() or tuple(y.shape) != tuple(x.shape) or y.dtype != _c2d.HALF[0]:
                 raise ValueError("BatchNorm2d(out=): destination must be an NHWC bf16 channel slice of the output's shape")
         else:
-            y, ldy = torch.empty((B, C, H, W), dtype=BF16, device=x.device, memory_format=CL), C
+            y, ldy = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x.device, memory_format=CL), C
         if training:
             nf = domains.current()  # jointly batched domains keep their own batch statistics
             Ns = nf * H * W if (nf is not None and 0 < nf < B) else N
@@ -138,7 +150,7 @@ class _BN2dFn(torch.autograd.Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise RuntimeError("BatchNorm2d backward in eval mode is not part of the hot path")
-        L = _lib.lib()
+        L = _c2d.lib2d()
         x, y, weight, stats, bias = ctx.saved_tensors
         dy, lddy = _c2d.nhwc_pitch(dy)
         dy2, lddy2 = None, 0
@@ -152,7 +164,7 @@ class _BN2dFn(torch.autograd.Function):
         ldx, ldy = ctx.lds
         B, C, H, W = x.shape
         N = B * H * W
-        dx = torch.empty((B, C, H, W), dtype=BF16, device=x.device, memory_format=CL)
+        dx = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
         dres = torch.empty_like(dx) if ctx.has_res else None
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
         if ctx.sinks is not None:  # dgamma / dbeta accumulate straight into the optimiser's gradient arena
@@ -218,11 +230,11 @@ class ReLU(nn.ReLU):
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         x, ldx = _c2d.nhwc_pitch(x)
         B, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-        y = torch.empty((B, C, Ho, Wo), dtype=BF16, device=x.device, memory_format=CL)
+        y = torch.empty((B, C, Ho, Wo), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
         idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
         check(L.mm_maxpool3x3s2_fwd(ptr(x), ldx, B, H, W, C, ptr(y), ptr(idx), stream()), "maxpool_fwd")
         ctx.save_for_backward(idx)
@@ -231,11 +243,11 @@ class _MaxPoolFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         (idx,) = ctx.saved_tensors
         B, C, H, W = ctx.shape
         dy = _c2d.as_nhwc_bf16(dy)
-        dx = torch.empty((B, C, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+        dx = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=dy.device, memory_format=CL)
         check(L.mm_maxpool3x3s2_bwd(ptr(dy), ptr(idx), B, H, W, C, ptr(dx), stream()), "maxpool_bwd")
         return dx
 
@@ -261,12 +273,12 @@ class Dropout(nn.Dropout):
 class _CatFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         xs = [_c2d.as_nhwc_bf16(x) for x in xs]
         B, _, H, W = xs[0].shape
         cs = [x.shape[1] for x in xs]
         Ct = sum(cs)
-        out = torch.empty((B, Ct, H, W), dtype=BF16, device=xs[0].device, memory_format=CL)
+        out = torch.empty((B, Ct, H, W), dtype=_c2d.HALF[0], device=xs[0].device, memory_format=CL)
         n = len(xs)
         check(L.mm_concat_bf16((ctypes.c_void_p * n)(*[x.data_ptr() for x in xs]), (ctypes.c_int * n)(*cs), n, ptr(out), B * H * W, 0,
                                stream()), "concat")
@@ -275,10 +287,10 @@ class _CatFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         dy = _c2d.as_nhwc_bf16(dy)
         B, Ct, H, W = dy.shape
-        outs = [torch.empty((B, c, H, W), dtype=BF16, device=dy.device, memory_format=CL) for c in ctx.cs]
+        outs = [torch.empty((B, c, H, W), dtype=_c2d.HALF[0], device=dy.device, memory_format=CL) for c in ctx.cs]
         n = len(outs)
         check(L.mm_concat_bf16((ctypes.c_void_p * n)(*[g.data_ptr() for g in outs]), (ctypes.c_int * n)(*ctx.cs), n, ptr(dy), B * H * W, 1,
                                stream()), "split")
@@ -319,7 +331,7 @@ class CatBuffer:
     """Pre-allocated NHWC bf16 concat buffer whose channel slices are handed to the producers as destinations."""
 
     def __init__(self, B, channels, H, W, device):
-        self.buf = torch.empty((B, sum(channels), H, W), dtype=BF16, device=device, memory_format=CL)
+        self.buf = torch.empty((B, sum(channels), H, W), dtype=_c2d.HALF[0], device=device, memory_format=CL)
         self.channels = list(channels)
         self.parts = [None] * len(channels)
         self.shared = [False] * len(channels)
@@ -356,7 +368,7 @@ class _HeadsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, h, w, w1, b1, w2, b2):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         x = _c2d.as_nhwc_bf16(x)
         B, C, Hp, Wp = x.shape
         nc = w1.shape[0]
@@ -372,7 +384,7 @@ class _HeadsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d1, d2):
-        L = _lib.lib()
+        L = _c2d.lib2d()
         x, Wj = ctx.saved_tensors
         h, w, nc, wshape = ctx.dims
         B, C, Hp, Wp = x.shape

@@ -480,14 +480,16 @@ def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, 
     """bf16 rows.  With a plain ReLU (leak 0) the rows ARE an NHWC bf16 map of N pixels: the BatchNorm2d entry points apply
     (same statistics groups, pitches, fp32 parameters) and bring the single-launch kernels of csrc/bn2d.hip; torch's momentum
     convention is 1 - scn's keep fraction.  Other leak values take the row kernels of csrc/bn.hip."""
-    f16 = x.dtype == F16  # IEEE fp16 rows: the row kernels of csrc/bn.hip (the BatchNorm2d kernels unpack bf16 bit patterns)
-    if not f16 and leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0:
+    f16 = x.dtype == F16  # IEEE fp16 rows: the fp16 build of the BatchNorm2d kernels (csrc/h16.h), or the fp16 row kernels of bn.hip
+    if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0:
         if training:
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
-            check(L.mm_bn2d_fwd_train(x_ptr(x), ldx, None, c, N, Ns, c, w, b, rm, rv, None, eps, 1.0 - momentum, 1, y, ldy, ptr(st[0]),
-                                      ptr(st[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
+            check((L.mm_bn2d_fwd_train_f16 if f16 else L.mm_bn2d_fwd_train)(
+                x_ptr(x), ldx, None, c, N, Ns, c, w, b, rm, rv, None, eps, 1.0 - momentum, 1, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws),
+                ws.numel(), stream()), "bn2d_fwd_train")
         else:
-            check(L.mm_bn2d_fwd_eval(x_ptr(x), ldx, None, c, N, c, w, b, rm, rv, eps, 1, y, ldy, stream()), "bn2d_fwd_eval")
+            check((L.mm_bn2d_fwd_eval_f16 if f16 else L.mm_bn2d_fwd_eval)(x_ptr(x), ldx, None, c, N, c, w, b, rm, rv, eps, 1, y, ldy,
+                                                                          stream()), "bn2d_fwd_eval")
         return
     if training:
         ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
@@ -501,10 +503,10 @@ def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, 
 
 def _bn16_bwd(L, x, ldx, dy, lddy, N, Ns, c, w, b, st, leak, dx, dwt, dbt, acc):
     f16 = x.dtype == F16
-    if not f16 and leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and lddy % 8 == 0:
+    if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and lddy % 8 == 0:
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
-        check(L.mm_bn2d_bwd(x_ptr(x), ldx, dy, lddy, None, 0, None, c, 1, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), ptr(dx), c, None, c, dwt, dbt,
-                            acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
+        check((L.mm_bn2d_bwd_f16 if f16 else L.mm_bn2d_bwd)(x_ptr(x), ldx, dy, lddy, None, 0, None, c, 1, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]),
+                                                            ptr(dx), c, None, c, dwt, dbt, acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
         return
     ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
     check((L.mm_bn_bwd_f16 if f16 else L.mm_bn_bwd_bf16)(x_ptr(x), ldx, dy, lddy, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), leak, ptr(dx), c,

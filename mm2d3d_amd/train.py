@@ -42,12 +42,14 @@ class TrainModel(nn.Module):
         # path: 43.7 ms per step against 44.1 ms without the side stream, for 7 GB more reserved memory.  Off by default.
         self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "0") != "0"))
         # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
-        # path), 32 = the exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
+        # path), "fp16" = the same kernels over IEEE fp16 maps + loss scale (what the reference's 16 literally is), 32 = the
+        # exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
         # branch in bf16 (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so the default is fp32.
         if "precision" in train_kwargs:
             from . import nn2d
 
-            nn2d.set_precision(int(train_kwargs["precision"]))
+            pv = train_kwargs["precision"]
+            nn2d.set_precision(pv if isinstance(pv, str) and not pv.isdigit() else int(pv))
         if "sparse_activations" in train_kwargs:
             from . import scn
 
@@ -57,7 +59,9 @@ class TrainModel(nn.Module):
         # IEEE fp16 rows: gradients need the loss scale of the reference's ``precision: 16`` trainer (Lightning native AMP =
         # torch.cuda.amp.GradScaler); mm2d3d_amd/amp.py keeps its state on the device.  ``loss_scale: False`` switches it off,
         # a dict passes GradScaler arguments (init_scale, growth_interval, ...).
-        self._scaler_cfg = train_kwargs.get("loss_scale", str(train_kwargs.get("sparse_activations", "")) in ("fp16", "f16", "half"))
+        fp16_names = ("fp16", "f16", "half")
+        self._scaler_cfg = train_kwargs.get("loss_scale", str(train_kwargs.get("sparse_activations", "")) in fp16_names
+                                            or str(train_kwargs.get("precision", "")) in fp16_names)
         self.scaler = None
         self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
@@ -138,7 +142,7 @@ class TrainModel(nn.Module):
                     self._side = torch.cuda.Stream(dev)
                     from . import _lib
 
-                    _lib.lib().mm_bn2d_set_fused(_lib.lib().mm_bn2d_set_fused(0) & 2)  # no grid barrier beside the side stream
+                    _lib.bn2d_set_fused(_lib.bn2d_set_fused(0) & 2)  # no grid barrier beside the side stream
                 p2d, _, _, aux2d = self(both, model_name=n2d)
                 # the 2D branch is queued: build the voxel hash / rulebooks of the 3D branch on a side stream while the GPU
                 # works through it (the build's two host read-backs would otherwise drain the queue)
@@ -153,7 +157,7 @@ class TrainModel(nn.Module):
                         # stream's workgroups (csrc/bn2d.hip): three-kernel path while the branches share the GPU
                         from . import _lib
 
-                        _lib.lib().mm_bn2d_set_fused(0)
+                        _lib.bn2d_set_fused(0)
                         _lib.lib().mm_bn_set_fused(0)
                     main = torch.cuda.current_stream(dev)
                     self._s3d.wait_event(step_start)
@@ -299,7 +303,7 @@ class TrainModel(nn.Module):
         if not self.optimizers:
             self.configure_optimizers()
         L = _lib.lib()
-        if L.mm_bn2d_fused_fault() | L.mm_bn_fused_fault():  # a read of pinned host memory; set by a kernel of an EARLIER step
+        if _lib.bn2d_fused_fault() | L.mm_bn_fused_fault():  # a read of pinned host memory; set by a kernel of an EARLIER step
             raise RuntimeError("a single-launch batch-norm kernel of an earlier step gave up at its grid barrier (its grid shared the GPU "
                                "with another process or a spin-waiting kernel): that step's results are invalid - restore the last "
                                "checkpoint; the process now uses the three-kernel batch norms")

@@ -21,7 +21,10 @@ _EMULATE = [False]
 
 
 def _q(t):
-    return t.bfloat16().float() if _EMULATE[0] else t
+    e = _EMULATE[0]
+    if not e:
+        return t
+    return t.to(torch.bfloat16 if e is True else e).float()  # True = bfloat16; torch.float16 for the fp16 build of the kernels
 
 
 def _bn(sd, pre, x, training, stats_out=None):
@@ -81,7 +84,7 @@ def lift(seg, img_indices):
 
 def net2d_forward(sd, data_batch, training=False, stats_out=None, dropout_masks=None, emulate_bf16=False):
     old = _EMULATE[0]
-    _EMULATE[0] = bool(emulate_bf16)
+    _EMULATE[0] = emulate_bf16 if isinstance(emulate_bf16, torch.dtype) else bool(emulate_bf16)
     try:
         return _net2d_forward(sd, data_batch, training, stats_out, dropout_masks)
     finally:

@@ -448,6 +448,53 @@ def test_grad_scaler_semantics_on_the_device():
     assert sc2.get_scale() == 512.0 and sc2.growth_interval == 2
 
 
+def test_training_steps_with_fp16_maps_and_rows_under_the_loss_scale():
+    """``precision: "fp16"`` + ``sparse_activations: "fp16"``: both branches store IEEE fp16 (the reference's ``precision: 16``),
+    the step runs under the device-resident GradScaler.  First-step losses agree with the bf16 configuration of the same
+    weights within the storage formats' rounding; six steps on a fixed batch stay finite, lower the loss, take every step and
+    leave the scale at 65536."""
+    import copy
+
+    from mm2d3d_amd import nn2d, scn
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = _dev()
+    torch.manual_seed(0)
+    kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+    W = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]
+    n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+    for m in n2.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+    mk = lambda: {"source": make_batch(5, 2, "nuscenes", (48, 64), device=dev), "target": make_batch(6, 2, "nuscenes", (48, 64), device=dev)}
+    loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
+    try:
+        ref = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, precision=16,
+                                                                             sparse_activations="bf16"))
+        l_bf = float(ref.training_step(mk()))
+        opts = {k: Optimizer("adamw", lr=1e-3) for k in ("2d_net", "3d_net")}
+        tm = TrainModel({"2d_net": n2, "3d_net": n3}, opts, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, precision="fp16",
+                                                                     sparse_activations="fp16", gc_freeze=False))
+        assert nn2d._c2d.HALF[0] == torch.float16 and scn.ACTIVATION_DTYPE[0] == torch.float16
+        l_fp = float(tm.training_step(mk()))
+        assert abs(l_fp - l_bf) < 2e-2 * max(1.0, abs(l_bf)), (l_fp, l_bf)
+        losses = [float(tm.fit_step(mk())) for _ in range(6)]
+        assert all(np.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+        assert tm.scaler is not None and tm.scaler.get_scale() == 65536.0
+        assert [tm.scaler.steps_taken(o) for o in tm.optimizers] == [6, 6]
+        for p in list(n2.parameters()) + list(n3.parameters()):
+            assert bool(torch.isfinite(p).all())
+    finally:
+        nn2d.set_precision(16)
+        scn.set_activation_dtype(torch.float32)
+
+
 def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
     from mm2d3d_amd.metrics import SegIoU
 
