@@ -19,6 +19,7 @@ PROFILE = None
 
 
 PROFILE_LEAD_CYCLES = 0  # bench.py: GPU spin (clock cycles) queued before the first timed call of a step
+PROFILE_KEEP_CALLS = False  # bench.py: keep every engine call (closure + operands) of the profiled step for a back-to-back replay
 
 
 def _timed(kind, rb, cin, cout, fn, esize=4):
@@ -34,7 +35,7 @@ def _timed(kind, rb, cin, cout, fn, esize=4):
     e1.record()
     R = rb.n_rules
     PROFILE.append(dict(kind=kind, R=R, cin=cin, cout=cout, K=rb.K, e0=e0, e1=e1,
-                        bytes=R * (cin + cout) * esize + 8 * R + rb.K * cin * cout * esize))
+                        bytes=R * (cin + cout) * esize + 8 * R + rb.K * cin * cout * esize, fn=fn if PROFILE_KEEP_CALLS else None))
     return out
 
 
@@ -289,7 +290,9 @@ class _DwBatch:
             e0.record()
             run()
             e1.record()
-            PROFILE.append(dict(kind="dW", R=0, cin=0, cout=0, K=0, e0=e0, e1=e1, bytes=0))
+            keep = items  # the replay reads the same slabs
+            PROFILE.append(dict(kind="dW", R=0, cin=0, cout=0, K=0, e0=e0, e1=e1, bytes=0,
+                                fn=(lambda: (keep, run())[1]) if PROFILE_KEEP_CALLS else None))
         for it in items:
             gradsink.done(it[5])
 
