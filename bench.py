@@ -230,6 +230,7 @@ def conv_roofline(tm, batch, dev):
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 2:1-sparsity figure is never used)
 GFLOP_2D_FWD_PER_IMAGE = 228.9  # 2 * sum(Cin*Cout*k^2*Hout*Wout) over the convs of the 2D net at 304x480
+GFLOP_2D_FWD_BY_IMAGE = {(302, 480): 228.9, (225, 400): 150.6}  # padded to 304x480 / 240x400
 
 
 def conv2d_roofline(tm, batch, dev):
@@ -268,7 +269,8 @@ def conv2d_roofline(tm, batch, dev):
             setattr(L, n, saved[n])
     ms = {n: sum(e0.elapsed_time(e1) for e0, e1 in v) for n, v in rec.items()}
     total = sum(ms.values())
-    tflop = 3 * GFLOP_2D_FWD_PER_IMAGE * n_img / 1e3
+    hw = tuple(int(v) for v in batch["source"]["img"].shape[2:])
+    tflop = 3 * GFLOP_2D_FWD_BY_IMAGE.get(hw, GFLOP_2D_FWD_PER_IMAGE * hw[0] * hw[1] / (302 * 480)) * n_img / 1e3
     ach = tflop / (total * 1e-3) if total > 0 else 0.0
     busy, busy_src = None, None
     import glob
@@ -393,6 +395,9 @@ def main(argv=None):
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 = BASELINE.json configs[1] (headline); c4 = configs[3]: KITTI-shaped 121,600-pt scans, 4/GPU, 10 classes; "
                          "c5 = configs[4]: 10k-pt vKITTI-shaped source + KITTI-shaped target, 8/GPU, 16-bit sparse activations")
+    ap.add_argument("--image", default="480x302", choices=["480x302", "400x225"],
+                    help="camera image W x H: BASELINE.json's 480x302 (headline) or the reference's own NuScenes YAML size 400x225 "
+                         "(config/datasets/nuscenes_usa_singapore.yaml:26; SURVEY.md 8d asks for both)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
                     help="16-bit storage format of the 2D maps: bf16 (default) or IEEE fp16 + loss scale (the reference's precision: 16)")
     ap.add_argument("--sparse-act", default="bf16", choices=["bf16", "fp16"],
@@ -442,9 +447,10 @@ def main(argv=None):
         shape, ncls, B = "nuscenes", 6, a.scenes
         tm = build_trainer(dev, train_kwargs={"precision": a.precision})
     cid = {"c2": (2, 3), "c4": (4, 5), "c5": (6, 7)}[a.workload]
+    IMG_HW = (302, 480) if a.image == "480x302" else (225, 400)
     batch = {
-        "source": make_batch(cid[0], B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True, downsample=down_src),
-        "target": make_batch(cid[1], B, shape, (302, 480), ncls, rank=rank, device=dev, augment=True),
+        "source": make_batch(cid[0], B, shape, IMG_HW, ncls, rank=rank, device=dev, augment=True, downsample=down_src),
+        "target": make_batch(cid[1], B, shape, IMG_HW, ncls, rank=rank, device=dev, augment=True),
     }
     n_pts = batch["source"]["x"][0].shape[0] + batch["target"]["x"][0].shape[0]
 
@@ -503,6 +509,8 @@ def main(argv=None):
         out["dtype"] = out["dtype"].replace("bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP)",
                                             "fp16 MFMA, fp32 accumulate, loss scale 65536 on the device (2D branch: IEEE fp16 maps, "
                                             "as the reference's fp16 AMP)")
+    if a.image != "480x302":
+        out["config"]["workload"] = out["config"]["workload"].replace("480x302", a.image) + f" [image {a.image}: the reference YAML's size, not the headline]"
     if a.workload == "c4":
         out["config"]["workload"] = "BASELINE.json configs[3] shape: KITTI-shaped 64x1900 sweeps (121,600 pts), 480x302, 10 classes (not the headline)"
     if a.workload == "c5":

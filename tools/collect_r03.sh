@@ -23,5 +23,6 @@ cp $O/kstats_serial/ks_kernel_stats.csv $O/bench_n1_serial_kernel_stats.csv 2>/d
 python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2>/dev/null; python bench.py --workload c5 --steps 10 --warmup 3 > $O/bench_c5.json 2>/dev/null
 python bench.py --workload c5 --sparse-act fp16 --precision fp16 --steps 10 --warmup 3 > $O/bench_c5_fp16.json 2>/dev/null
 python bench.py --precision fp16 --steps 20 --warmup 5 --no-extras > $O/bench_n1_fp16.json 2>/dev/null
+python bench.py --image 400x225 --steps 15 --warmup 4 > $O/bench_n1_image_400x225.json 2>/dev/null
 rm -rf $O/kstats/*trace* $O/kstats_serial/*trace* $O/pmc_fetch/*trace* $O/pmc_write/*trace* 2>/dev/null
 ls -la $O | tail -24
