@@ -30,6 +30,7 @@ class GradScaler:
         self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
         self.scale_tensor = torch.full((1,), float(init_scale), dtype=torch.float32, device=self.device)
         self._tracker = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._flags = torch.zeros(16, dtype=torch.int32, device=self.device)  # one non-finite flag per optimiser (views below)
         self._found = {}   # id(optimizer) -> int32[1] flag of the current step
         self._steps = {}   # id(optimizer) -> int64[1] device step counter (advances only on steps that are taken)
         self._coef = {}    # id(optimizer) -> uint8 coefficient rows, one per parameter group
@@ -41,7 +42,9 @@ class GradScaler:
         k = id(opt)
         if k not in self._found:
             nb = int(_lib.lib().mm_amp_coef_bytes())
-            self._found[k] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            if len(self._found) >= self._flags.numel():
+                raise RuntimeError("GradScaler: more than 16 optimisers")
+            self._found[k] = self._flags[len(self._found) : len(self._found) + 1]
             self._steps[k] = torch.full((1,), int(getattr(opt, "_step", 0)), dtype=torch.int64, device=self.device)
             self._coef[k] = torch.zeros((max(1, len(opt.param_groups)), nb), dtype=torch.uint8, device=self.device)
         return self._found[k], self._steps[k], self._coef[k]
@@ -63,7 +66,7 @@ class GradScaler:
         if not self.enabled or not self._found:
             return
         L = _lib.lib()
-        flags = torch.cat(list(self._found.values())) if len(self._found) > 1 else next(iter(self._found.values()))
+        flags = self._flags[: len(self._found)]  # the optimisers' flags are consecutive views of one buffer
         check(L.mm_amp_update(ptr(self.scale_tensor), ptr(self._tracker), ptr(flags), flags.numel(), self.growth_factor,
                               self.backoff_factor, self.growth_interval, stream()), "amp_update")
 

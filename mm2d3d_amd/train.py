@@ -275,7 +275,9 @@ class TrainModel(nn.Module):
         return {"state_dict": {f"model.{k}": v for k, v in self.model.state_dict().items()},
                 "optimizer_states": [o.state_dict() for o in self.optimizers],
                 "lr_schedulers": [s.state_dict() if s is not None else None for s in self.schedulers],
-                "global_step": self.global_step, **self.best}
+                "global_step": self.global_step, **self.best,
+                # Lightning's key for the GradScaler of a ``precision: 16`` run
+                **({"native_amp_scaling_state": self.scaler.state_dict()} if self.scaler is not None else {})}
 
     def load_checkpoint(self, ckpt):
         self.model.load_state_dict({k[len("model."):]: v for k, v in ckpt["state_dict"].items()})
@@ -293,6 +295,10 @@ class TrainModel(nn.Module):
             if s is not None and sd is not None:
                 s.load_state_dict(sd)
         self.global_step = ckpt.get("global_step", 0)
+        # the loss scale resumes where it was; the scaler itself is rebuilt by the next fit_step (its device step counters start
+        # from the optimisers' restored step counts)
+        self._scaler_state = ckpt.get("native_amp_scaling_state")
+        self.scaler = None
         for k in self.best:
             self.best[k] = ckpt.get(k, self.best[k])
 
@@ -326,6 +332,9 @@ class TrainModel(nn.Module):
             from .amp import GradScaler
 
             self.scaler = GradScaler(loss.device, **(self._scaler_cfg if isinstance(self._scaler_cfg, dict) else {}))
+            if getattr(self, "_scaler_state", None):
+                self.scaler.load_state_dict(self._scaler_state)
+                self._scaler_state = None
         if self.scaler is not None:
             self.scaler.scale(loss).backward()
             self.reducer.finish()

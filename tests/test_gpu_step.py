@@ -490,6 +490,13 @@ def test_training_steps_with_fp16_maps_and_rows_under_the_loss_scale():
         assert [tm.scaler.steps_taken(o) for o in tm.optimizers] == [6, 6]
         for p in list(n2.parameters()) + list(n3.parameters()):
             assert bool(torch.isfinite(p).all())
+        # checkpoint round trip: the loss scale travels under Lightning's key, the step counters resume from the optimisers'
+        ck = tm.checkpoint()
+        assert ck["native_amp_scaling_state"]["scale"] == 65536.0 and [sd["step"] for sd in ck["optimizer_states"]] == [6, 6]
+        ck["native_amp_scaling_state"]["scale"] = 1024.0
+        tm.load_checkpoint(ck)
+        assert np.isfinite(float(tm.fit_step(mk())))
+        assert tm.scaler.get_scale() == 1024.0 and [tm.scaler.steps_taken(o) for o in tm.optimizers] == [7, 7]
     finally:
         nn2d.set_precision(16)
         scn.set_activation_dtype(torch.float32)
