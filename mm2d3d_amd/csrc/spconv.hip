@@ -1046,10 +1046,38 @@ int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int 
 
 static inline int dw_tile(int n) { return (n + ((n + 3) / 4) - 1) / ((n + 3) / 4); }  // balanced split, <= 4
 
+// Channel tile (ti x tj blocks of 16) of one dW workgroup.  A rule's input row is gathered once per OUTPUT-channel tile and
+// its gradient row once per INPUT-channel tile - with 4-byte gathers, the instructions that bound the kernel.  Up to 4 x 4
+// blocks every tile shape keeps three or more workgroups per CU; on the wide layers (more than four blocks on a side) the
+// balanced <= 4 split gathers 2 - 2.3x the minimum (160 -> 80: 42 block gathers per rule against 15), so there (round 3) the tile
+// may grow to 6 blocks on a side, at most 25 accumulator blocks (5 x 5: 155 VGPRs + 100 AGPRs, still two workgroups per CU like
+// 4 x 4): the shape with the fewest gathers per rule is taken, the smaller area on a tie (160 -> 80: 5 x 5, 20 gathers).
+// Measured per layer on the bench step (same box, us): 96->48 169 -> 126, 160->80 227 -> 139, 192->96 107 -> 91, 80->80 141 -> 86;
+// rule lists below ~200k rules (the strided layers of the coarse levels) lose 3-5 us each with the fewer, fatter workgroups and
+// keep the <= 4 split.  Element sums and their order do not depend on the tile shape.
+constexpr int DW_WIDE_MIN_RULES = 200000;
+static void dw_tiles(int nci, int nco, bool wide_ok, int* ti, int* tj) {
+  *ti = dw_tile(nci), *tj = dw_tile(nco);
+  static const bool wide = !(getenv("MM_DW_WIDE") && atoi(getenv("MM_DW_WIDE")) == 0);
+  if (!wide || !wide_ok || (nci <= 4 && nco <= 4)) return;
+  int best = (int)(mm_cdiv(nci, *ti) * mm_cdiv(nco, *tj)) * (*ti + *tj), area = *ti * *tj;
+  for (int a = 1; a <= nci; a++) {
+    const int i = (int)mm_cdiv(nci, a);
+    if (i > 6) continue;
+    for (int b = 1; b <= nco; b++) {
+      const int j = (int)mm_cdiv(nco, b);
+      if (j > 6 || i * j > 25 || (i <= 4 && j <= 4)) continue;
+      const int cost = a * b * (i + j);
+      if (cost < best || (cost == best && i * j < area)) best = cost, area = i * j, *ti = i, *tj = j;
+    }
+  }
+}
+
 // rules per workgroup for dW: aim at ~1024 workgroups, 16-rule granularity
-static int dw_chunk(int64_t R, int Cin, int Cout) {
+static int dw_chunk(int64_t R, int Cin, int Cout, bool wide_ok) {
   if (Cin % 16 || Cout % 16) return TRW;
-  int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
+  int ti, tj;
+  dw_tiles(Cin / 16, Cout / 16, wide_ok, &ti, &tj);
   int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
   int64_t c = mm_cdiv(R, 1024 / ny > 0 ? 1024 / ny : 1);
   c = mm_cdiv(c, 16) * 16;
@@ -1077,7 +1105,10 @@ int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int
   MM_CHECK_ARG(bf >= 0 && bf <= 2, "spconv_dw: row kind must be 0 (fp32), 1 (bf16) or 2 (fp16)");
   MM_CHECK_ARG(!bf || (Cin % 16 == 0 && Cout % 16 == 0), "spconv_dw (16-bit rows): channels must be multiples of 16");
   KSeg& seg = *seg_out;
-  const int chunk = dw_chunk(offsets_host[K], Cin, Cout);
+  const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
+  const int nt = bf ? -bf : (mfma_ok && Cin >= split_min_cin(true) ? split_terms() : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
+  const bool wide_ok = nt != 0 && offsets_host[K] >= DW_WIDE_MIN_RULES;  // the wide tiles exist for the split / 16-bit kernels
+  const int chunk = dw_chunk(offsets_host[K], Cin, Cout, wide_ok);
   int nb = make_seg(offsets_host, K, chunk, &seg);
   const int ne = Cin * Cout;
   if ((size_t)(nb > 0 ? nb : 1) * ne * sizeof(float) > ws_bytes) {
@@ -1086,12 +1117,11 @@ int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int
   }
   float* partial = (float*)ws;
   if (nb == 0) return MM_OK;
-  const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
   if (mfma_ok) {
-    const int ti = dw_tile(Cin / 16), tj = dw_tile(Cout / 16);
+    int ti, tj;
+    dw_tiles(Cin / 16, Cout / 16, wide_ok, &ti, &tj);
     const int ny = (int)(mm_cdiv(Cin / 16, ti) * mm_cdiv(Cout / 16, tj));
     const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
-    const int nt = bf ? -bf : (Cin >= split_min_cin(true) ? split_terms() : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
 #define DWCASE(I, J)                                                                                                          \
   if (ti == I && tj == J) {                                                                                                   \
     if (nt == -1)                                                                                                             \
@@ -1113,6 +1143,30 @@ int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int
     DWCASE(1, 1) DWCASE(1, 2) DWCASE(1, 3) DWCASE(1, 4) DWCASE(2, 1) DWCASE(2, 2) DWCASE(2, 3) DWCASE(2, 4)
     DWCASE(3, 1) DWCASE(3, 2) DWCASE(3, 3) DWCASE(3, 4) DWCASE(4, 1) DWCASE(4, 2) DWCASE(4, 3) DWCASE(4, 4)
 #undef DWCASE
+    // the wide tiles (split / 16-bit kernels only); more than 64 KB of LDS for the cross-wave sums from 22 blocks up
+#define DWWIDE(I, J)                                                                                                          \
+  if (ti == I && tj == J) {                                                                                                   \
+    if (nt == -1) {                                                                                                           \
+      if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)k_dw_direct_s3<I, J, 1, __bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, __bf16>), dim3(nb, ny), dim3(256), lds, s, (const __bf16*)in, ld_in,        \
+                         (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                            \
+    } else if (nt == -2) {                                                                                                    \
+      if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)k_dw_direct_s3<I, J, 1, _Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, _Float16>), dim3(nb, ny), dim3(256), lds, s, (const _Float16*)in, ld_in,    \
+                         (const _Float16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                          \
+    } else if (nt == 3) {                                                                                                     \
+      if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)k_dw_direct_s3<I, J, 3, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 3>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, \
+                         ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                                                 \
+    } else {                                                                                                                  \
+      if (lds > 64 * 1024) MM_HIP(hipFuncSetAttribute((const void*)k_dw_direct_s3<I, J, 2, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      hipLaunchKernelGGL((k_dw_direct_s3<I, J, 2>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, \
+                         ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                                                 \
+    }                                                                                                                         \
+  }
+    DWWIDE(5, 1) DWWIDE(5, 2) DWWIDE(5, 3) DWWIDE(5, 4) DWWIDE(5, 5) DWWIDE(6, 1) DWWIDE(6, 2) DWWIDE(6, 3) DWWIDE(6, 4)
+    DWWIDE(1, 5) DWWIDE(2, 5) DWWIDE(3, 5) DWWIDE(4, 5) DWWIDE(1, 6) DWWIDE(2, 6) DWWIDE(3, 6) DWWIDE(4, 6)
+#undef DWWIDE
   } else {
     size_t lds = (size_t)64 * (Cin + Cout) * sizeof(float);
     MM_CHECK_ARG(lds <= 150 * 1024, "spconv_dw: channels too wide for the generic kernel");
@@ -1131,7 +1185,9 @@ extern "C" {
 
 size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout) {
   KSeg seg;
-  int nb = make_seg(offsets_host, K, dw_chunk(offsets_host[K], Cin, Cout), &seg);
+  int nb = make_seg(offsets_host, K, dw_chunk(offsets_host[K], Cin, Cout, true), &seg);
+  const int nb2 = make_seg(offsets_host, K, dw_chunk(offsets_host[K], Cin, Cout, false), &seg);  // plain-fp32 kernels: <= 4 x 4 tiles
+  if (nb2 > nb) nb = nb2;
   return mm_align((size_t)(nb > 0 ? nb : 1) * Cin * Cout * sizeof(float)) + 256;
 }
 
