@@ -230,6 +230,7 @@ def conv_roofline(tm, batch, dev):
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 2:1-sparsity figure is never used)
 GFLOP_2D_FWD_PER_IMAGE = 228.9  # 2 * sum(Cin*Cout*k^2*Hout*Wout) over the convs of the 2D net at 304x480
+SQ_SOURCES = ("conv2d.hip", "h16.h")  # what the MFMA-busy counters of profiles/rNN/pmc_sq_step.json were taken on
 GFLOP_2D_FWD_BY_IMAGE = {(302, 480): 228.9, (225, 400): 150.6}  # padded to 304x480 / 240x400
 
 
@@ -239,9 +240,13 @@ def conv2d_roofline(tm, batch, dev):
     mm_conv2d_wgrad = weight gradients incl. their slab reduction) of one step bracketed by HIP events on the launch stream,
     against the algorithmic FLOPs of BASELINE.md section 3 (fwd x 3 for fwd + dgrad + wgrad) and the dense bf16 matrix peak."""
     from mm2d3d_amd import _lib
+    from mm2d3d_amd import conv2d as c2d
 
     L = _lib.lib()
-    names = ("mm_conv2d_3x3s1", "mm_conv2d_gemm", "mm_conv2d_wgrad")
+    base = ("mm_conv2d_3x3s1", "mm_conv2d_gemm", "mm_conv2d_wgrad")
+    # the IEEE fp16 build exports the same entry points under the suffix _f16 (csrc/h16.h); hook the ones this run calls
+    f16 = c2d.HALF[0] == torch.float16
+    names = tuple(_lib.H16_2D[n] if f16 else n for n in base)
     rec = {n: [] for n in names}
     saved = {n: getattr(L, n) for n in names}
 
@@ -267,22 +272,54 @@ def conv2d_roofline(tm, batch, dev):
     finally:
         for n in names:
             setattr(L, n, saved[n])
+    n_launch = sum(len(v) for v in rec.values())
+    if n_launch == 0:
+        return None  # nothing recorded (an entry point this leg does not know): report no measurement rather than zeros
     ms = {n: sum(e0.elapsed_time(e1) for e0, e1 in v) for n, v in rec.items()}
     total = sum(ms.values())
+    # what an EMPTY event pair on a busy queue measures sits around every one of the launches: reported both ways
+    torch.cuda._sleep(int(2.0e9 * 0.02))
+    pairs = []
+    for _ in range(64):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        pairs.append((e0, e1))
+    torch.cuda.synchronize()
+    pair_us = sorted(a.elapsed_time(b_) for a, b_ in pairs)[32] * 1e3
+    net = max(total - n_launch * pair_us * 1e-3, 1e-6)
     hw = tuple(int(v) for v in batch["source"]["img"].shape[2:])
     tflop = 3 * GFLOP_2D_FWD_BY_IMAGE.get(hw, GFLOP_2D_FWD_PER_IMAGE * hw[0] * hw[1] / (302 * 480)) * n_img / 1e3
     ach = tflop / (total * 1e-3) if total > 0 else 0.0
+    # SQ counters: an OFFLINE rocprofv3 --pmc measurement (tools/pmc_sq.py); only a record taken on THIS tree's 2D kernel sources
+    # is reported (same rule as roofline.traffic)
     busy, busy_src = None, None
     import glob
+    import hashlib
 
+    h = hashlib.sha256()
+    for f in SQ_SOURCES:
+        h.update(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f), "rb").read())
+    fingerprint = h.hexdigest()
+    kind = "f16" if f16 else "bf16"
     for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_sq_step.json")), reverse=True):
-        k = json.load(open(ppath)).get("kernels", {})
+        prec = json.load(open(ppath))
+        if prec.get("conv2d_sources_sha256") != fingerprint:
+            busy_src = (f"none: {os.path.relpath(ppath, ROOT)} was taken on other 2D kernel sources (git {prec.get('git')}); "
+                        "re-run tools/pmc_sq.py")
+            continue
+        k = prec.get("kernels", {})
         busy = {name: v["mfma_busy_cycles_per_wave_cycle"] for name, v in k.items() if name.startswith(("k_conv", "k_wgrad"))}
-        busy_src = "offline rocprofv3 --pmc SQ counters, " + os.path.relpath(ppath, ROOT)
+        busy_src = (f"offline rocprofv3 --pmc SQ counters, {os.path.relpath(ppath, ROOT)}, taken at git {prec.get('git')} on these 2D "
+                    f"kernel sources (sha256 {fingerprint[:12]}, storage {prec.get('storage', '?')}; this run: {kind})")
         break
     return {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
             "algorithmic_tflop_per_step": round(tflop, 3), "conv_set_ms_per_step": round(total, 3),
+            "net_of_event_pairs": {"what": "the same sum minus event_pair_overhead_us per launch (an empty event pair on a busy queue)",
+                                   "event_pair_overhead_us": round(pair_us, 2), "launches": n_launch, "conv_set_ms_per_step": round(net, 3),
+                                   "TFLOP/s": round(tflop / (net * 1e-3), 1), "frac_of_peak": round(tflop / (net * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4)},
             "ms_by_entry_point": {n: round(v, 3) for n, v in ms.items()}, "launches": {n: len(v) for n, v in rec.items()},
+            "storage": kind + " maps and packed weights, fp32 accumulate (v_mfma_f32_32x32x16_" + kind + " / 16x16x32)",
             "kernel": "2D convolution set: k_conv3x3w<*> / k_conv3x3r (3x3 s1 fwd + dgrad), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
                       "k_wgrad3x3n / k_conv_wgrad2 + k_wgrad_reduce (weight gradients)",
             "mfma_busy_cycles_per_wave_cycle": busy, "mfma_busy_source": busy_src}
@@ -352,13 +389,30 @@ def cpu_baseline():
             net3d({"x": [one["x"][0], one["x"][1].clone()]})
             if i:
                 c1.append(time.perf_counter() - t0)
+    # BASELINE.md section 2 planned a batch of 8: the 3D branch alone fits the host at that size (the full two-domain step does
+    # not: ~18 GB of autograd state) - 8 NuScenes-shaped scenes, fwd+bwd with the CE loss, as config.branch_only_fwd_bwd["3d_net"]
+    import torch.nn.functional as F
+
+    b8 = make_batch(2, 8, "nuscenes", (302, 480))
+    w6 = torch.tensor(CLASS_WEIGHTS)
+    t3 = []
+    for i in range(3):
+        net3d.zero_grad()
+        t0 = time.perf_counter()
+        preds = net3d({"x": [b8["x"][0], b8["x"][1].clone()]})[0]
+        F.cross_entropy(preds["seg_logit"], b8["seg_label"], weight=w6).backward()  # lib/losses.py:66-68
+        if i:
+            t3.append(time.perf_counter() - t0)
     return {"value": round(2 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "branch_3d_8_scenes_fwd_bwd": {"scenes_per_s": round(8 / min(t3), 4), "seconds_per_pass": round(min(t3), 3),
+                                           "what": "CPU oracle of the 3D branch alone (oracle/net3d_ref.py) on the C2 per-GPU batch of 8 "
+                                                   "NuScenes-shaped scenes, fwd+bwd with the weighted CE; best of 2 after 1 warm-up"},
             "sample": "CPU oracle (torch-CPU 2D + oracle sparse ops): 1 source + 1 target NuScenes-shaped scene at 480x302 = 1/8 of the "
                       "C2 batch (8 + 8; the full batch needs ~18 GB of autograd state and ~20 s per pass on the host), fwd+bwd of the "
                       "full two-domain step (no optimiser step), median of 4 passes after 1 warm-up; c1_fwd_only = BASELINE.md C1 "
                       "(one scene, forward only, both networks, eval mode), best of 2 after 1 warm-up",
             "c1_fwd_only_scenes_per_s": round(1.0 / min(c1), 4),
-            "seconds": round(sum(dts) + sum(c1), 2)}
+            "seconds": round(sum(dts) + sum(c1) + sum(t3), 2)}
 
 
 def launch_ranks(a, argv):
@@ -398,8 +452,11 @@ def main(argv=None):
     ap.add_argument("--image", default="480x302", choices=["480x302", "400x225"],
                     help="camera image W x H: BASELINE.json's 480x302 (headline) or the reference's own NuScenes YAML size 400x225 "
                          "(config/datasets/nuscenes_usa_singapore.yaml:26; SURVEY.md 8d asks for both)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16"],
-                    help="16-bit storage format of the 2D maps: bf16 (default) or IEEE fp16 + loss scale (the reference's precision: 16)")
+    ap.add_argument("--precision", default="fp16", choices=["fp16", "bf16"],
+                    help="16-bit storage format of the 2D maps: IEEE fp16 + device-resident loss scale (default: the reference's "
+                         "precision: 16 = fp16 autocast + GradScaler, run/train.yaml:11) or bf16")
+    ap.add_argument("--batches", type=int, default=4, help="distinct batches rotated through the warm-up and the timed loop (different "
+                    "scene seeds -> different point / voxel / rule counts per level every step)")
     ap.add_argument("--sparse-act", default="bf16", choices=["bf16", "fp16"],
                     help="--workload c5: kind of the 16-bit sparse rows (fp16 = IEEE half + loss scaling)")
     a = ap.parse_args(argv)
@@ -448,11 +505,17 @@ def main(argv=None):
         tm = build_trainer(dev, train_kwargs={"precision": a.precision})
     cid = {"c2": (2, 3), "c4": (4, 5), "c5": (6, 7)}[a.workload]
     IMG_HW = (302, 480) if a.image == "480x302" else (225, 400)
-    batch = {
-        "source": make_batch(cid[0], B, shape, IMG_HW, ncls, rank=rank, device=dev, augment=True, downsample=down_src),
-        "target": make_batch(cid[1], B, shape, IMG_HW, ncls, rank=rank, device=dev, augment=True),
-    }
-    n_pts = batch["source"]["x"][0].shape[0] + batch["target"]["x"][0].shape[0]
+    # a loader never hands over the same scenes twice: ``--batches`` distinct batches (scene seeds first_scene = j*B ...) rotate
+    # through the loop, so the row counts of every level, the allocator, the pinned read-backs and the dW tile choices see
+    # changing shapes
+    nb = max(1, a.batches)
+    batches = [{
+        "source": make_batch(cid[0], B, shape, IMG_HW, ncls, rank=rank, device=dev, augment=True, downsample=down_src, first_scene=j * B),
+        "target": make_batch(cid[1], B, shape, IMG_HW, ncls, rank=rank, device=dev, augment=True, first_scene=j * B),
+    } for j in range(nb)]
+    batch = batches[0]  # the roofline legs profile this one
+    n_pts_each = [bt["source"]["x"][0].shape[0] + bt["target"]["x"][0].shape[0] for bt in batches]
+    n_pts = n_pts_each[0]
 
     def sync():
         if world > 1:
@@ -462,17 +525,26 @@ def main(argv=None):
     # a loader hands the next batch over while the current step runs: fit_step(next_batch=) builds its sparse metadata one step
     # ahead on the step's own stream (mm2d3d_amd/train.py).  Every timed step does one metadata build, as before.
     pipeline = os.environ.get("MM_BENCH_PIPELINE", "1") != "0"
-    nxt = fresh(batch)
+    seq = [0]
+
+    def next_batch():
+        seq[0] += 1
+        return fresh(batches[(seq[0] - 1) % nb])
+
+    nxt = next_batch()
     for _ in range(a.warmup):
-        cur, nxt = nxt, fresh(batch)
+        cur, nxt = nxt, next_batch()
         tm.fit_step(cur, next_batch=nxt if pipeline else None)
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    host_s = 0.0
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
-        cur, nxt = nxt, fresh(batch)
+        cur, nxt = nxt, next_batch()
+        h0 = time.perf_counter()
         loss = tm.fit_step(cur, next_batch=nxt if pipeline else None)
+        host_s += time.perf_counter() - h0
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
@@ -488,12 +560,19 @@ def main(argv=None):
     out = {
         "metric": "LiDAR scenes/sec fwd+bwd (NuScenes ~35k pts, 5cm voxel)", "value": round(2 * B * world / (ms * 1e-3), 3),
         "unit": "scenes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP) + f32 (3D sparse branch, fp32 as in the reference: f32 MFMA on narrow layers, fp32-faithful 3-term split-bf16 products with fp32 accumulation from 32 (fwd/dX) / 16 (dW) input channels up)",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ({"fp16": "fp16 MFMA, fp32 accumulate, loss scale 65536 on the device (2D branch: IEEE fp16 maps and packed weights - the "
+                           "reference's precision: 16 = fp16 autocast + GradScaler)",
+                   "bf16": "bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP)"}[a.precision]
+                  + " + f32 (3D sparse branch, fp32 as in the reference: f32 MFMA on narrow layers, fp32-faithful 3-term split-bf16 products "
+                    "with fp32 accumulation from 32 (fwd/dX) / 16 (dW) input channels up)"),
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[1]: NuScenes-shaped (32x1090 sweep, 34,880 pts/scene), 5 cm voxels, 480x302 RGB + "
                                "sparse depth; full two-domain training step (train.py:186-292): 2D+3D fwd on source and target, "
                                "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
-                   "points_per_gpu_per_step": int(n_pts), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
+                   "points_per_gpu_per_step": int(n_pts),
+                   "distinct_batches_rotated": nb, "points_per_step_by_batch": [int(v) for v in n_pts_each],
+                   "host_enqueue_ms_per_step": round(host_s / a.steps * 1e3, 3), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
                    "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)],
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
     }
@@ -504,11 +583,8 @@ def main(argv=None):
             "ms_per_step_by_rank": [round(v, 3) for v in rank_ms],
             "allreduce_bytes_per_step": st["bytes"], "allreduce_buckets_per_step": st["buckets"],
             "buckets_launched_before_finish": st["early"],  # sent from backward hooks, i.e. overlapped with the rest of backward
+            "batch_norm_path": tm.reducer.bn_path,
         })
-    if a.precision == "fp16":
-        out["dtype"] = out["dtype"].replace("bf16 MFMA, fp32 accumulate (2D branch; the reference runs it under fp16 AMP)",
-                                            "fp16 MFMA, fp32 accumulate, loss scale 65536 on the device (2D branch: IEEE fp16 maps, "
-                                            "as the reference's fp16 AMP)")
     if a.image != "480x302":
         out["config"]["workload"] = out["config"]["workload"].replace("480x302", a.image) + f" [image {a.image}: the reference YAML's size, not the headline]"
     if a.workload == "c4":

@@ -17,11 +17,11 @@ from ._lib import check, ptr, stream
 
 CL = torch.channels_last
 
-# Storage format of the 2D maps and of the packed weights: bfloat16 (default) or IEEE float16 - the reference's ``precision: 16`` is
-# fp16 autocast + GradScaler (config/run/train.yaml:11).  The kernels exist in both builds (csrc/h16.h: entry points suffixed
-# _f16, same arguments); fp16 gradient maps need the loss scale of mm2d3d_amd/amp.py, which TrainModel installs with
-# ``train_kwargs["precision"] = "fp16"``.
-HALF = [torch.bfloat16]
+# Storage format of the 2D maps and of the packed weights: IEEE float16 (default: the reference's ``precision: 16`` is fp16
+# autocast + GradScaler, config/run/train.yaml:11) or bfloat16.  The kernels exist in both builds (csrc/h16.h: entry points
+# suffixed _f16, same arguments); fp16 gradient maps need a loss scale - mm2d3d_amd/amp.py, which TrainModel installs unless
+# ``train_kwargs["precision"] = "bf16"``.
+HALF = [torch.float16]
 
 
 def set_half(dtype):

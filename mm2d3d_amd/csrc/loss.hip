@@ -273,7 +273,7 @@ __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float*
     *(f4*)(v + i) = V;
     return;
   }
-  for (int j = 0; i + j < n; j++) upd(g[i + j], p[i + j], m[i + j], v[i + j]);
+  for (int j = 0; j < 4 && i + j < n; j++) upd(g[i + j], p[i + j], m[i + j], v[i + j]);  // a thread owns elements [i, i+4)
 }
 
 // found[0] |= any element of g is inf / nan (benign race: every writer stores 1)

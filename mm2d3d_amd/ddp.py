@@ -60,8 +60,10 @@ class GradAllReducer:
         self._arenas = []
         self._in_finish = False
         self._flag = None
+        self._flag_host, self._flag_event, self._finished = None, None, 0
         self.stats = {"bytes": 0, "buckets": 0, "early": 0}  # of the last finished step
         self._step_stats = {"bytes": 0, "buckets": 0, "early": 0}
+        self.bn_path = "as configured (no data-parallel group)"  # which batch-norm kernels run beside the collectives (bench line)
         if not self.active:
             return
         if overlap and torch.cuda.is_available():
@@ -79,6 +81,8 @@ class GradAllReducer:
             was3d = _lib.lib().mm_bn_set_fused(0)
             _lib.bn2d_set_fused(was2d & keep)
             _lib.lib().mm_bn_set_fused(was3d & keep)
+            self.bn_path = ("forward single-launch, backward three-kernel (MM_DDP_BN_FUSED=1)" if keep and (was2d | was3d) & 1
+                            else "three-kernel in both directions")
             if (was2d | was3d) & ~keep and (not dist.is_initialized() or dist.get_rank(process_group) == 0):
                 import sys
 
@@ -190,13 +194,6 @@ class GradAllReducer:
         if not self.active:
             return
         self._in_finish = True
-        # "a parameter learned as unused received a gradient" is a LOCAL observation (a data-dependent branch may take it on
-        # some ranks only).  The decision to re-learn must be collective, or the ranks' collective sequences diverge in the
-        # next step: one int goes out with the buckets, MAX over the ranks.
-        if self._flag is None:
-            self._flag = torch.zeros(1, dtype=torch.int32, device=self.buckets[0].arena.device)
-        self._flag.fill_(1 if self._late else 0)
-        flag_work = dist.all_reduce(self._flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         if not self.learned:
             # learning step: nothing was launched during backward; send every bucket in build order (the same on all ranks)
             for b in self.buckets:
@@ -205,11 +202,20 @@ class GradAllReducer:
             for b in self.order:
                 if not b.launched:
                     self._send(b)
+        # "a parameter learned as unused received a gradient" is a LOCAL observation (a data-dependent branch may take it on
+        # some ranks only).  The decision to re-learn must be collective, or the ranks' collective sequences diverge in the
+        # next step: one int, MAX over the ranks.  It goes out AFTER the last bucket, at a fixed position of the
+        # sequence: which buckets were sent early is a per-rank fact, and a flag issued before the leftovers would sit at different
+        # positions of different ranks' sequences.
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=self.buckets[0].arena.device)
+        self._flag.fill_(1 if self._late else 0)
+        flag_work = dist.all_reduce(self._flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
         flag_work.wait()
-        late_anywhere = bool(int(self._flag.item()))
+        late_anywhere, late_step = self._read_flag()
         n_late = len(self._late)
         if not self.learned:
             self._learn()
@@ -218,15 +224,51 @@ class GradAllReducer:
         self._fired, self._late, self._tick = set(), [], 0
         self.stats, self._step_stats = self._step_stats, {"bytes": 0, "buckets": 0, "early": 0}
         self._in_finish = False
+        self._finished += 1
         if late_anywhere:  # every rank takes this branch together: all re-learn in the next step, all raise now
             self.learned, self.unused = False, set()
             for b in self.buckets:
                 b.n_used = b.pending = len(b.params)
             self.order = list(self.buckets)
+            when = "this step's" if late_step == self._finished - 1 else f"the gradients of reducer step {late_step} (and of every step since)"
             raise RuntimeError(
-                f"GradAllReducer: a parameter learned as unused received a gradient on some rank ({n_late} on this one; the graph "
-                "changed); this step's gradients are not reduced correctly on any rank - skip the optimiser step everywhere; the next "
-                "step re-learns the unused set")
+                f"GradAllReducer: a parameter learned as unused received a gradient on some rank ({n_late} on this one now; the graph "
+                f"changed); {when} gradients are not reduced correctly on any rank - "
+                + ("skip the optimiser step everywhere; " if late_step == self._finished - 1 else "restore the last checkpoint; ")
+                + "the next step re-learns the unused set")
+
+    def _read_flag(self):
+        """(value, reducer step it belongs to) of the collective "graph changed" flag WITHOUT making the host wait for the GPU.
+        On the CPU (gloo) the value is there after ``wait()``.  On the GPU ``wait()`` only orders streams: the flag is copied to
+        pinned memory behind the collective and read ONE STEP LATE, when the copy has long landed (the pattern of
+        ``scn.metadata._Readback``) - the host keeps queueing the optimiser while backward and the reductions still run.  The
+        condition is exceptional (the training graph of this path is static) and every rank sees the same value at the same
+        step, so the ranks still raise and re-learn together."""
+        if self._flag.device.type != "cuda":
+            return bool(int(self._flag.item())), self._finished
+        if self._flag_host is None:
+            self._flag_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._flag_event = [None, None]
+        cur = self._finished & 1
+        prev_value, prev_step = False, self._finished - 1
+        if self._flag_event[cur ^ 1] is not None:
+            self._flag_event[cur ^ 1].synchronize()  # recorded a whole step ago: returns at once
+            prev_value = bool(int(self._flag_host[cur ^ 1][0]))
+            self._flag_event[cur ^ 1] = None
+        self._flag_host[cur].copy_(self._flag, non_blocking=True)
+        self._flag_event[cur] = torch.cuda.current_stream(self._flag.device).record_event()
+        return prev_value, prev_step
+
+    def drain_flag(self):
+        """The flag of the LAST finished step (a host wait: end of training / before a checkpoint)."""
+        if not self.active or self._flag is None or self._flag.device.type != "cuda" or self._flag_host is None:
+            return False
+        cur = (self._finished - 1) & 1
+        if self._flag_event[cur] is None:
+            return False
+        self._flag_event[cur].synchronize()
+        self._flag_event[cur] = None
+        return bool(int(self._flag_host[cur][0]))
 
     def broadcast_buffers(self, modules, src=0):
         """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a

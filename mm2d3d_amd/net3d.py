@@ -60,7 +60,7 @@ def UNet(dimension, reps, nPlanes, residual_blocks=False, downsample=(2, 2), lea
 class UNetSCN(nn.Module):
     def __init__(self, in_channels=1, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7, bn_momentum=None):
         """``bn_momentum`` (not in the reference): keep-fraction of the batch-norm running statistics for every layer of this
-        net, see scn.DEFAULT_BN_MOMENTUM (0.9 per SURVEY.md A.5; 0.99 is the other reading of the un-vendored dependency)."""
+        net, see scn.DEFAULT_BN_MOMENTUM (0.99: the recalled constructor default of the pinned SparseConvNet commit; 0.9 is SURVEY.md A.5's / the docstring's reading)."""
         super().__init__()
         self.in_channels = in_channels
         self.out_channels = m

@@ -26,29 +26,40 @@ CL = torch.channels_last
 F32 = torch.float32
 
 
-# 16: bf16 MFMA kernels (training hot path).  32: the whole 2D branch in fp32 (config/run/test.yaml:8 `precision: 32`) on the
-# fp32 implicit-GEMM convolutions of csrc/conv2d_f32.hip and the fp32 batch-norm rows of csrc/bn.hip; pooling, padding,
-# concatenation and the residual add are torch elementwise / pooling ops in that mode.
+# 16: the 2D branch on the MFMA kernels over 16-bit maps (training hot path) - IEEE fp16 by default, the storage format of the
+# reference's ``precision: 16`` (fp16 autocast + GradScaler, config/run/train.yaml:11); "bf16" selects bfloat16 maps (same
+# kernels, same rate, 8 instead of 11 significand bits, no loss scale needed).  32: the whole 2D branch in fp32
+# (config/run/test.yaml:8 `precision: 32`) on the fp32 implicit-GEMM convolutions of csrc/conv2d_f32.hip and the fp32
+# batch-norm rows of csrc/bn.hip; pooling, padding, concatenation and the residual add are torch elementwise / pooling ops in
+# that mode.
 PRECISION = [16]
+DEFAULT_PRECISION = 16
 
 
 def set_precision(bits):
-    """16 / "bf16": bf16 maps on the MFMA kernels (default); "fp16": IEEE fp16 maps on the same kernels built for fp16 (the
-    reference's ``precision: 16`` is fp16 autocast + GradScaler: 11 significand bits instead of 8, and a loss scale for the
-    gradient maps - mm2d3d_amd/amp.py); 32: the exact-fp32 2D branch."""
-    if bits in ("fp16", "f16", "half"):
+    """16 / "fp16": IEEE fp16 maps on the MFMA kernels (default; what the reference's ``precision: 16`` stores - the gradient maps
+    want the loss scale of mm2d3d_amd/amp.py, which ``TrainModel`` installs, or Lightning's own GradScaler when the plugins run
+    under the reference's trainer); "bf16": bfloat16 maps on the same kernels; 32: the exact-fp32 2D branch."""
+    if isinstance(bits, str) and bits.isdigit():
+        bits = int(bits)
+    if bits in ("fp16", "f16", "half", 16):
         PRECISION[0] = 16
         _c2d.set_half(torch.float16)
         return
-    if bits in ("bf16", "16"):
-        bits = 16
-    if bits in ("32",):
-        bits = 32
-    if bits not in (16, 32):
-        raise ValueError('precision must be 16 / "bf16" (bf16 MFMA), "fp16" (IEEE fp16 MFMA + loss scale) or 32 (exact fp32)')
-    PRECISION[0] = bits
-    if bits == 16:
+    if bits in ("bf16", "bfloat16"):
+        PRECISION[0] = 16
         _c2d.set_half(torch.bfloat16)
+        return
+    if bits != 32:
+        raise ValueError('precision must be 16 / "fp16" (IEEE fp16 MFMA, loss scale), "bf16" (bf16 MFMA) or 32 (exact fp32)')
+    PRECISION[0] = 32
+
+
+def half_kind():
+    """"fp16" / "bf16" / "fp32": what the 2D branch currently stores."""
+    if PRECISION[0] == 32:
+        return "fp32"
+    return "fp16" if _c2d.HALF[0] == torch.float16 else "bf16"
 
 
 def fp32_mode():

@@ -98,6 +98,11 @@ class FlatAdamW(optim.Optimizer):
         if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
             raise RuntimeError("FlatAdamW.step: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
         L = _lib.lib()
+        if getattr(self, "_dev_step", None) is not None:
+            # plain step after loss-scaled ones: the device counter is the truth (skipped steps never advanced it); one read-back,
+            # then the host counter leads again
+            self._step = int(self._dev_step.item())
+            self._dev_step = None
         self._step += 1
         from . import conv2d as _c2d
 
@@ -120,6 +125,9 @@ class FlatAdamW(optim.Optimizer):
         if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
             raise RuntimeError("FlatAdamW.step_scaled: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
         L = _lib.lib()
+        if getattr(self, "_dev_step", None) is not step_dev:
+            # first scaled step, or the first after plain steps / a restored checkpoint: the host counter is the truth until now
+            step_dev.fill_(int(self._step))
         self._dev_step = step_dev
         self._opt_called = True  # what torch's lr schedulers look at to tell "step() before scheduler.step()"
         from . import conv2d as _c2d
@@ -164,6 +172,7 @@ class FlatAdamW(optim.Optimizer):
         flat, step = sd.get("flat"), sd.get("step", 0)
         super().load_state_dict({k: v for k, v in sd.items() if k not in ("flat", "step")})
         self._step = step
+        self._dev_step = None  # a device counter from before the restore is stale
         if flat:
             for a, f in zip(self._arenas, flat):
                 if a is not None and f is not None:

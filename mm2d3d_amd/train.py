@@ -41,27 +41,24 @@ class TrainModel(nn.Module):
         # the merge-sort tile tables), so with this option the 2D FORWARD batch norms take the three-kernel
         # path: 43.7 ms per step against 44.1 ms without the side stream, for 7 GB more reserved memory.  Off by default.
         self.overlap_metadata = bool(train_kwargs.get("overlap_metadata", os.environ.get("MM_OVERLAP_METADATA", "0") != "0"))
-        # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 = bf16 MFMA 2D branch (the training hot
-        # path), "fp16" = the same kernels over IEEE fp16 maps + loss scale (what the reference's 16 literally is), 32 = the
-        # exact-fp32 2D kernels.  `sparse_activations: "bf16"` additionally stores the sparse rows of the 3D
-        # branch in bf16 (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so the default is fp32.
+        # run/train.yaml:11 `precision: 16` / run/test.yaml:8 `precision: 32`: 16 (or "fp16") = the 2D branch on the MFMA kernels
+        # over IEEE fp16 maps + loss scale - what the reference's 16 literally is (Lightning native AMP = fp16 autocast +
+        # torch.cuda.amp.GradScaler); "bf16" = the same kernels over bfloat16 maps, no loss scale; 32 = the exact-fp32 2D kernels.
+        # Absent: whatever nn2d.set_precision() selected (default 16).  `sparse_activations: "bf16" / "fp16"` additionally stores
+        # the sparse rows of the 3D branch in 16 bits (BASELINE.json configs[4]); the reference's SparseConvNet is fp32-only, so
+        # the default is fp32.
+        from . import nn2d, scn
+
         if "precision" in train_kwargs:
-            from . import nn2d
-
-            pv = train_kwargs["precision"]
-            nn2d.set_precision(pv if isinstance(pv, str) and not pv.isdigit() else int(pv))
+            nn2d.set_precision(train_kwargs["precision"])
         if "sparse_activations" in train_kwargs:
-            from . import scn
-
             kind = str(train_kwargs["sparse_activations"])
-            scn.set_activation_dtype({"bf16": torch.bfloat16, "16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16,
+            scn.set_activation_dtype({"bf16": torch.bfloat16, "16": torch.float16, "fp16": torch.float16, "f16": torch.float16,
                                       "half": torch.float16}.get(kind, torch.float32))
-        # IEEE fp16 rows: gradients need the loss scale of the reference's ``precision: 16`` trainer (Lightning native AMP =
-        # torch.cuda.amp.GradScaler); mm2d3d_amd/amp.py keeps its state on the device.  ``loss_scale: False`` switches it off,
-        # a dict passes GradScaler arguments (init_scale, growth_interval, ...).
-        fp16_names = ("fp16", "f16", "half")
-        self._scaler_cfg = train_kwargs.get("loss_scale", str(train_kwargs.get("sparse_activations", "")) in fp16_names
-                                            or str(train_kwargs.get("precision", "")) in fp16_names)
+        # IEEE fp16 maps / rows: gradients need the loss scale of the reference's ``precision: 16`` trainer;
+        # mm2d3d_amd/amp.py keeps its state on the device.  ``loss_scale: False`` switches it off, a dict passes GradScaler
+        # arguments (init_scale, growth_interval, ...).
+        self._scaler_cfg = train_kwargs.get("loss_scale", nn2d.half_kind() == "fp16" or scn.ACTIVATION_DTYPE[0] == torch.float16)
         self.scaler = None
         self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
@@ -127,7 +124,7 @@ class TrainModel(nn.Module):
         src, trg = batch["source"], batch["target"]
         n2d, n3d = self.modules_name[0], self.modules_name[1]
         if self._can_join(src, trg):
-            pre = self._pipelined if self._pipelined is not None and self._pipelined["key"] == id(batch) else None
+            pre = self._pipelined if self._pipelined is not None and self._matches(self._pipelined, batch) else None
             self._pipelined = None
             if pre is not None:  # joined one step ahead by prefetch(): its sparse metadata is already built (or queued)
                 both, B = pre["both"], pre["B"]
@@ -219,7 +216,17 @@ class TrainModel(nn.Module):
         both["x"][0] = both["x"][0].contiguous()
         with domains.split(B):
             md = net3d.begin_metadata(both)
-        self._pipelined = dict(key=id(batch), both=both, B=B, md=md, phase=1)
+        self._pipelined = dict(key=batch, both=both, B=B, md=md, phase=1, n_src=int(src["x"][0].shape[0]), n_trg=int(trg["x"][0].shape[0]),
+                               ptrs=(src["x"][0].data_ptr(), trg["x"][0].data_ptr()))
+
+    @staticmethod
+    def _matches(pre, batch):
+        """The prefetched state belongs to ``batch``: the very dict object (held by reference - an ``id()`` alone can be reused by
+        another dict once the first is dropped) with the same point tensors."""
+        if pre["key"] is not batch:
+            return False
+        s, t = batch["source"]["x"][0], batch["target"]["x"][0]
+        return (int(s.shape[0]), int(t.shape[0])) == (pre["n_src"], pre["n_trg"]) and (s.data_ptr(), t.data_ptr()) == pre["ptrs"]
 
     def _prefetch_rulebooks(self):
         pre = self._pipelined
@@ -270,9 +277,16 @@ class TrainModel(nn.Module):
         return out
 
     # ------------------------------------------------------------------ checkpoints (run.py:166-182, train.py:475-489)
+    @staticmethod
+    def _ckpt_key(k):
+        """``<net>.<param>`` -> ``model.<net>.model.<param>``: the reference's LightningModule holds ``self.model`` = ModuleDict of
+        ModelWrapper, each holding the net as ``.model`` (train.py:553-560, 531)."""
+        net, rest = k.split(".", 1)
+        return f"model.{net}.model.{rest}"
+
     def checkpoint(self):
-        """state_dict keys ``model.<net>.*`` as under the reference's ModuleDict; optimisers as a list (HybridOptim)."""
-        return {"state_dict": {f"model.{k}": v for k, v in self.model.state_dict().items()},
+        """state_dict keys ``model.<net>.model.*`` as in a Lightning checkpoint of the reference; optimisers as a list (HybridOptim)."""
+        return {"state_dict": {self._ckpt_key(k): v for k, v in self.model.state_dict().items()},
                 "optimizer_states": [o.state_dict() for o in self.optimizers],
                 "lr_schedulers": [s.state_dict() if s is not None else None for s in self.schedulers],
                 "global_step": self.global_step, **self.best,
@@ -280,7 +294,16 @@ class TrainModel(nn.Module):
                 **({"native_amp_scaling_state": self.scaler.state_dict()} if self.scaler is not None else {})}
 
     def load_checkpoint(self, ckpt):
-        self.model.load_state_dict({k[len("model."):]: v for k, v in ckpt["state_dict"].items()})
+        nets = set(self.model.keys())
+
+        def strip(k):  # ``model.<net>.model.<param>`` (the reference's; written since round 4) or the older ``model.<net>.<param>``
+            k = k[len("model."):] if k.startswith("model.") else k
+            net, rest = k.split(".", 1)
+            if net in nets and rest.startswith("model."):
+                rest = rest[len("model."):]
+            return f"{net}.{rest}"
+
+        self.model.load_state_dict({strip(k): v for k, v in ckpt["state_dict"].items()})
         if not self.optimizers and self._opt_factories:
             self.configure_optimizers()  # built lazily by fit_step otherwise: a resume before step 1 must not drop the moments
         states = ckpt.get("optimizer_states", [])
@@ -303,21 +326,28 @@ class TrainModel(nn.Module):
             self.best[k] = ckpt.get(k, self.best[k])
 
     # ------------------------------------------------------------------ what Lightning's loop does around it
+    @staticmethod
+    def _check_bn_fault(when):
+        """A read of pinned host memory, written by a single-launch batch-norm kernel whose grid barrier ran out of time.  Polled at
+        the start of every step and again before the optimiser step: a barrier waits 10 s before it gives up, by which
+        time the host has long filled the queue and sits in the step's read-back wait, so the second poll normally sees a fault of
+        the step it belongs to before that step's gradients are applied; the first poll catches what is left."""
+        if _lib.bn2d_fused_fault() | _lib.lib().mm_bn_fused_fault():
+            raise RuntimeError(f"a single-launch batch-norm kernel of {when} gave up at its grid barrier (its grid shared the GPU "
+                               "with another process or a spin-waiting kernel): that step's results are invalid - skip its optimiser "
+                               "step / restore the last checkpoint; the process now uses the three-kernel batch norms")
+
     def fit_step(self, batch, next_batch=None):
         """One optimiser step on ``batch``.  ``next_batch``: the batch of the following call (the very dict that will be passed
         to it) - its sparse metadata is then built during this step (see ``prefetch``)."""
         if not self.optimizers:
             self.configure_optimizers()
-        L = _lib.lib()
-        if _lib.bn2d_fused_fault() | L.mm_bn_fused_fault():  # a read of pinned host memory; set by a kernel of an EARLIER step
-            raise RuntimeError("a single-launch batch-norm kernel of an earlier step gave up at its grid barrier (its grid shared the GPU "
-                               "with another process or a spin-waiting kernel): that step's results are invalid - restore the last "
-                               "checkpoint; the process now uses the three-kernel batch norms")
+        self._check_bn_fault("an earlier step")
         for o in self.optimizers:
             o.zero_grad()
         if self.broadcast_buffers and self.reducer.active:
             self.reducer.broadcast_buffers(self.model.values())  # DDP syncs module buffers from rank 0 before each forward
-        cur = self._pipelined if self._pipelined is not None and self._pipelined["key"] == id(batch) else None
+        cur = self._pipelined if self._pipelined is not None and self._matches(self._pipelined, batch) else None
         if next_batch is not None:
             if cur is not None:
                 cur["md"].ensure()  # this step's own metadata first (its read-backs are long done)
@@ -338,12 +368,14 @@ class TrainModel(nn.Module):
         if self.scaler is not None:
             self.scaler.scale(loss).backward()
             self.reducer.finish()
+            self._check_bn_fault("this step")
             for o in self.optimizers:
                 self.scaler.step(o, self.reducer.grad_scale)
             self.scaler.update()
         else:
             loss.backward()
             self.reducer.finish()
+            self._check_bn_fault("this step")
             for o in self.optimizers:
                 if hasattr(o, "grad_arenas"):
                     o.step(grad_scale=self.reducer.grad_scale)

@@ -359,7 +359,7 @@ class Deconvolution(nn.Module):
         return _carry(x, _q(f), fine)
 
 
-DEFAULT_BN_MOMENTUM = [0.9]  # SURVEY A.5; the other reading of the un-vendored dependency is 0.99 (see mm2d3d_amd/scn)
+DEFAULT_BN_MOMENTUM = [0.99]  # constructor signature of the pinned commit as recalled (SURVEY A.5 / its docstring say 0.9; see mm2d3d_amd/scn)
 
 
 class BatchNormalization(nn.Module):

@@ -31,3 +31,37 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _default_formats(request):
+    """GPU tests start from, and leave behind, the default storage formats: IEEE fp16 2D maps (the reference's precision: 16),
+    fp32 sparse rows - whatever a test (or a failing test) selected."""
+    yield
+    if "gpu" in request.keywords:
+        from mm2d3d_amd import nn2d, scn
+
+        nn2d.set_precision(nn2d.DEFAULT_PRECISION)
+        scn.set_activation_dtype(__import__("torch").float32)
+
+
+@pytest.fixture(params=["fp16", "bf16"])
+def half2d(request):
+    """Both 16-bit builds of the dense 2D kernels (csrc/h16.h): the test body runs once per storage format; yields the torch dtype."""
+    import torch
+
+    from mm2d3d_amd import nn2d
+
+    nn2d.set_precision(request.param)
+    yield torch.float16 if request.param == "fp16" else torch.bfloat16
+    nn2d.set_precision(nn2d.DEFAULT_PRECISION)
+
+
+@pytest.fixture
+def bf16_mode():
+    """bfloat16 2D maps (tests whose bounds were calibrated for that format; the fp16 default has its own tests)."""
+    from mm2d3d_amd import nn2d
+
+    nn2d.set_precision("bf16")
+    yield
+    nn2d.set_precision(nn2d.DEFAULT_PRECISION)

@@ -33,3 +33,43 @@ def fill_state_dict(sd):
             a = g.normal(0, 0.1, shape)
         out[k] = torch.from_numpy(a.astype(np.float32)).to(v.dtype)
     return out
+
+
+def grad_digest(named, nproj=8, full_max=4096):
+    """Compact record of a set of (large) tensors, comparable across implementations: per tensor its L2 norm, ``nproj``
+    projections on key-seeded +-1 vectors (for two tensors a, b: E[((a - b) . s)^2] = |a - b|^2, so the projections give an
+    estimate of the relative L2 difference without storing 46 M gradients) and - up to ``full_max`` elements - the tensor itself."""
+    out = {}
+    for k, t in named:
+        a = t.detach().double().cpu().numpy().ravel()
+        out[f"{k}/norm"] = np.array(np.sqrt((a * a).sum()))
+        g = np.random.default_rng(zlib.crc32(("proj/" + k).encode()))
+        proj = np.empty(nproj)
+        for j in range(nproj):
+            s = g.integers(0, 2, a.size, dtype=np.int8)
+            proj[j] = a[s == 1].sum() - a[s == 0].sum()
+        out[f"{k}/proj"] = proj
+        if a.size <= full_max:
+            out[f"{k}/full"] = a.astype(np.float32).reshape(tuple(t.shape))
+    return out
+
+
+def digest_compare(digest, prefix, named, nproj=8):
+    """For every tensor of ``named`` recorded under ``prefix`` in ``digest``: (key, estimated relative L2 difference, norm ratio,
+    exact cosine or None).  The relative difference comes from the stored projections (or exactly, where the tensor is stored)."""
+    rows = []
+    mine = grad_digest(named, nproj=nproj)
+    for k, _ in named:
+        rn = float(digest[f"{prefix}{k}/norm"])
+        hn = float(mine[f"{k}/norm"])
+        if f"{prefix}{k}/full" in digest:
+            r = digest[f"{prefix}{k}/full"].astype(np.float64).ravel()
+            h = mine[f"{k}/full"].astype(np.float64).ravel()
+            rel = float(np.linalg.norm(h - r) / max(np.linalg.norm(r), 1e-30))
+            cos = float(h @ r / max(np.linalg.norm(h) * np.linalg.norm(r), 1e-30))
+        else:
+            d = mine[f"{k}/proj"] - digest[f"{prefix}{k}/proj"]
+            rel = float(np.sqrt((d * d).mean()) / max(rn, 1e-30))
+            cos = None
+        rows.append((k, rel, hn / max(rn, 1e-30), cos, rn))
+    return rows

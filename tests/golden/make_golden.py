@@ -118,10 +118,20 @@ def wiring_case():
         coords = np.concatenate([coords, coords[:40]], 0)  # duplicates
         feats = g.standard_normal((len(coords), 3)).astype(np.float32)
         net.train()
-        y = net([torch.from_numpy(coords), torch.from_numpy(feats)])
+        for k, v in net.state_dict().items():
+            out[f"{tag}/sd0/{k}"] = v.clone().numpy()  # BEFORE the forward: the initial running statistics
+        ft = torch.from_numpy(feats).requires_grad_(True)
+        y = net([torch.from_numpy(coords), ft])
         out[f"{tag}/coords"], out[f"{tag}/feats"], out[f"{tag}/out"] = coords, feats, y.detach().numpy()
         for k, v in net.state_dict().items():
             out[f"{tag}/sd/{k}"] = v.numpy()  # AFTER the forward: running stats included
+        # backward of a fixed linear functional through the reference's composition (VERDICT r3 missing #3): input and
+        # weight gradients
+        wlin = g.standard_normal(tuple(y.shape)).astype(np.float32)
+        (y * torch.from_numpy(wlin)).sum().backward()
+        out[f"{tag}/wlin"], out[f"{tag}/dfeats"] = wlin, ft.grad.numpy()
+        for k, p_ in net.named_parameters():
+            out[f"{tag}/grad/{k}"] = p_.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "wiring_unet.npz"), **out)
     del sys.modules["sparseconvnet"]
 
@@ -235,6 +245,31 @@ def wiring_case_2d():
                 out[f"{tag}/seg_logit_2d"] = preds["seg_logit_2d"].numpy()
                 out[f"{tag}/segm_last"] = segm_last.numpy()
                 out[f"{tag}/seg_logit_avg_2d"] = aux["seg_logit_avg_2d"].numpy()
+            if not frozen:
+                # train mode (batch statistics, dropout p = 0 for determinism), backward of a fixed linear functional of the two
+                # point-logit outputs: updated running statistics + a digest of every weight gradient (fill.grad_digest)
+                from fill import grad_digest
+
+                net.train()
+                for m in net.modules():
+                    if isinstance(m, torch.nn.Dropout):
+                        m.p = 0.0
+                preds, segm_last, _, aux = net({"img": torch.from_numpy(img), "depth": torch.from_numpy(depth), "img_indices": idx})
+                w1 = g.standard_normal(tuple(preds["seg_logit"].shape)).astype(np.float32)
+                w2 = g.standard_normal(tuple(aux["seg_logit_avg"].shape)).astype(np.float32)
+                ((preds["seg_logit"] * torch.from_numpy(w1)).sum() + (aux["seg_logit_avg"] * torch.from_numpy(w2)).sum()).backward()
+                out["train/w1"], out["train/w2"] = w1, w2
+                out["train/seg_logit"] = preds["seg_logit"].detach().numpy()
+                out["train/seg_logit_avg"] = aux["seg_logit_avg"].detach().numpy()
+                out["train/segm_last"] = segm_last.detach().numpy()
+                for k, v in net.state_dict().items():
+                    if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+                        out[f"train/sd/{k}"] = v.numpy()
+                out["train/grad_keys"] = np.array([k for k, p_ in net.named_parameters() if p_.grad is not None])
+                out["train/nograd_keys"] = np.array([k for k, p_ in net.named_parameters() if p_.grad is None])
+                for k, v in grad_digest([(k, p_.grad) for k, p_ in net.named_parameters() if p_.grad is not None]).items():
+                    out[f"train/grad/{k}"] = v
+                net.eval()
             out[f"{tag}/keys"] = np.array(sorted(net.state_dict().keys()))
             out[f"{tag}/shapes"] = np.array([str(tuple(net.state_dict()[k].shape)) for k in sorted(net.state_dict())])
         np.savez_compressed(os.path.join(HERE, "wiring_net2d.npz"), **out)
@@ -269,3 +304,115 @@ def pselab_case():
 if __name__ == "__main__":
     pselab_case()
     print("pseudo-label fixture written")
+
+
+def step_case():
+    """The reference's OWN training step: ``TrainModel._generic_step`` and ``cross_modal_loss`` (train.py:157-184, 186-292),
+    imported unchanged, over the reference's own 2d_net / 3d_net plugins (loaded by bare name through its ModelWrapper,
+    train.py:508-568) and its own Loss registry.  Stand-ins, in this process only, for what the image lacks:
+    ``pytorch_lightning.LightningModule`` -> an nn.Module with ``log_dict`` recording what is logged, ``global_step`` = 1 (step 0
+    draws a figure from ``preds_3d_fe["confidence"]``, a key the USA_SING 3d_net never sets: SURVEY.md section 2.1);
+    ``torchmetrics.JaccardIndex`` and ``lib.utils.visualize`` (matplotlib / plyfile) -> inert stubs, never called by the step;
+    ``torchvision`` -> the ResNet34 stand-in above; ``sparseconvnet`` -> oracle/scn_ref.py (the dependency is un-vendored).
+    Pins the composition of row a17 against the reference's source: which logits feed which KL term, the detach, the lambda
+    weights, the six logged keys, the summed loss - and every parameter gradient of that loss (digest)."""
+    import importlib
+    import types
+
+    import torch.nn as nn
+    from fill import fill_state_dict, grad_digest
+
+    from mm2d3d_amd.synthetic import collate, make_scene
+    from oracle import scn_ref
+
+    logged = {}
+
+    class LightningModule(nn.Module):
+        global_step = 1
+        current_epoch = 0
+        loggers = [None, None]
+        device = torch.device("cpu")
+
+        def log_dict(self, d, **kw):
+            logged.update({k: float(v.detach()) for k, v in d.items()})
+
+        def log(self, k, v, **kw):
+            logged[k] = float(v)
+
+    pl = types.ModuleType("pytorch_lightning")
+    pl.LightningModule = LightningModule
+    tmx = types.ModuleType("torchmetrics")
+    tmx.JaccardIndex = type("JaccardIndex", (nn.Module,), {"__init__": lambda self, *a, **k: nn.Module.__init__(self),
+                                                           "reset": lambda self: None})
+    viz = types.ModuleType("lib.utils.visualize")
+    viz.draw_points_image_labels_with_confidence = lambda *a, **k: None
+    mods = dict(_torchvision_standin())
+    mods.update({"pytorch_lightning": pl, "torchmetrics": tmx, "lib.utils.visualize": viz, "sparseconvnet": scn_ref})
+    sys.modules.update(mods)
+    exp = "/root/reference/experiments_USA_SING/rgbd_rgbxyz_sigmoid_for_rgb"
+    sys.path.insert(0, exp)
+    try:
+        for stale in ("2d_net", "2d_net.model", "2d_net.backbones", "3d_net", "3d_net.model", "3d_net.scn_unet", "train"):
+            sys.modules.pop(stale, None)
+        ref_train = importlib.import_module("train")
+        weights = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]  # config.yaml:45
+        loss = RefLoss([{"name": "cross_entropy", "weight": 1.0, "target": "segmentation", "args": {"weight": weights}}])
+        kw3d = dict(in_channels=3, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7)  # config.yaml:22-29
+        tm = ref_train.TrainModel(
+            model_modules=["2d_net", "3d_net"], optimizer=None, loss=loss,
+            train_kwargs={"class_names": [str(i) for i in range(6)], "class_palette": [[0, 0, 0]] * 6, "lambda_xm_src": 1.0,
+                          "lambda_xm_trg": 0.1},  # config.yaml:105-106
+            model_kwargs={"2d_net": {"num_classes": 6, "pretrained": False},
+                          "3d_net": {"num_classes": 6, "dual_head": True, "backbone_3d_kwargs": kw3d}})
+        tm.model.load_state_dict(fill_state_dict(tm.model.state_dict()))
+        tm.train()
+        for m in tm.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        # 2 + 2 NuScenes-shaped scenes, 1,500 points each, 46 x 62 images (not multiples of 16: the reference binds `segm_last`
+        # only on the padded path, 2d_net/model.py:126-129)
+        batch = {"source": collate([make_scene(91000 + i, "nuscenes", (46, 62), 6, downsample=1500) for i in range(2)]),
+                 "target": collate([make_scene(92000 + i, "nuscenes", (46, 62), 6, downsample=1500) for i in range(2)])}
+        out = {}
+        for dom, b in batch.items():
+            out[f"{dom}/coords"], out[f"{dom}/feats"] = b["x"][0].numpy(), b["x"][1].numpy().copy()
+            out[f"{dom}/img"], out[f"{dom}/depth"], out[f"{dom}/seg_label"] = b["img"].numpy(), b["depth"].numpy(), b["seg_label"].numpy()
+            for i, ix in enumerate(b["img_indices"]):
+                out[f"{dom}/idx{i}"] = ix
+        # 3d_net/model.py:46-48 multiplies the features IN PLACE after nn.Linear has saved them for its weight gradient: in fp32
+        # autograd refuses that backward (the reference only ever trains under fp16 autocast, where Linear saves its own fp16 copy,
+        # run/train.yaml:11).  Saving every tensor as a copy gives fp32 autograd what autocast gives the reference: the linear
+        # layer's weight gradient sees the UNGATED features.  The reference source stays unchanged.
+        with torch.autograd.graph.saved_tensors_hooks(lambda t: t.clone(), lambda t: t):
+            total = tm._generic_step(batch, "train")
+        total.backward()
+        out["total"] = np.array(float(total.detach()))
+        out["log_keys"] = np.array(list(logged.keys()))
+        out["log_values"] = np.array([logged[k] for k in logged])
+        # cross_modal_loss on its own (train.py:157-184): four random logit sets
+        g = torch.Generator().manual_seed(5)
+        a, b_, c, d = (torch.randn(211, 6, generator=g) * 2 for _ in range(4))
+        l2d, l3d = tm.cross_modal_loss(a, b_, c, d)
+        out["xm/args"] = torch.stack([a, b_, c, d]).numpy()
+        out["xm/values"] = np.array([float(l2d), float(l3d)])
+        sd = tm.state_dict()
+        out["state_dict_keys"] = np.array(sorted(sd.keys()))  # "model.2d_net.model.*" / "model.3d_net.model.*"
+        for k, v in sd.items():
+            if k.endswith(("running_mean", "running_var")):
+                out[f"sd/{k}"] = v.numpy()
+        named = [(k, p_.grad) for k, p_ in tm.named_parameters() if p_.grad is not None]
+        out["grad_keys"] = np.array([k for k, _ in named])
+        out["nograd_keys"] = np.array([k for k, p_ in tm.named_parameters() if p_.grad is None])
+        for k, v in grad_digest(named).items():
+            out[f"grad/{k}"] = v
+        np.savez_compressed(os.path.join(HERE, "step_ref.npz"), **out)
+        print("step fixture:", {k: round(v, 6) for k, v in logged.items()}, "total", float(total.detach()))
+    finally:
+        sys.path.remove(exp)
+        for k in list(mods) + ["train", "2d_net", "2d_net.model", "2d_net.backbones", "3d_net", "3d_net.model", "3d_net.scn_unet"]:
+            sys.modules.pop(k, None)
+
+
+if __name__ == "__main__":
+    step_case()
+    print("step fixture written")

@@ -110,6 +110,35 @@ def _worker(rank, world, port, overlap, q):
         used_bytes = sum((b.hi - b.lo) * 4 for b in red.order)
         assert red.stats["bytes"] == used_bytes and red.stats["buckets"] == len(red.order)
         assert red.stats["early"] == (len(red.order) if overlap else 0)
+        # a parameter learned as USED that gets no gradient on ONE rank this step (data-dependent graph): on that rank its
+        # bucket - and, the launch order being strict, every later one - waits for finish(), on the other rank everything went
+        # out during backward.  The collective sequences must still match: buckets in the learned order, the flag LAST (ADVICE r3:
+        # a flag issued before the leftovers sat at a different position of each rank's sequence).
+        opt.zero_grad()
+        replica.zero_grad()
+        sub = (lambda m: m[:3]) if rank == 1 else (lambda m: m)
+        (sub(replica)(x) ** 2).sum().backward()
+        local = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in replica.parameters()]
+                          + [torch.zeros(n_unused)])
+        (sub(net)(x) ** 2).sum().backward()
+        if overlap:
+            assert all(b.launched for b in red.order) == (rank == 0)
+        red.finish()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(opt.grad_arenas()[0], sum(gathered), atol=1e-6)
+        assert red.learned and red.stats["buckets"] == len(red.order)
+        # epoch-end metric sync (train.py:379,402,423): confusion matrices add up over the ranks
+        from mm2d3d_amd.metrics import SegIoU
+
+        m = SegIoU(3, "cpu")
+        m.cm[:] = torch.arange(27).view(3, 3, 3) * (rank + 1)
+        m.sync()
+        assert torch.equal(m.cm, torch.arange(27).view(3, 3, 3) * 3)
+        ious = m.compute()
+        cm0 = m.cm[0].double()
+        want = cm0.diagonal() / (cm0.sum(0) + cm0.sum(1) - cm0.diagonal())
+        assert torch.allclose(ious["2d"].double(), want, atol=1e-6)
         # sync_parameters: rank 0's weights win (torch DDP's constructor broadcast)
         with torch.no_grad():
             for a in opt._arenas:

@@ -1,5 +1,6 @@
-"""GPU parity of the bf16 MFMA implicit-GEMM convolutions against torch fp32 convolutions of the SAME bf16-rounded
-operands (so the only difference is fp32 accumulation order and the final bf16 rounding of the output)."""
+"""GPU parity of the 16-bit MFMA implicit-GEMM convolutions against torch fp32 convolutions of the SAME 16-bit-rounded
+operands (so the only difference is fp32 accumulation order and the final 16-bit rounding of the output).  Every test runs for
+both builds of the kernels: IEEE fp16 maps (default, the reference's precision: 16) and bfloat16 maps (``half2d``)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -21,26 +22,26 @@ def _rel(a, b):
     (64, 64, 3, 1, 1, (19, 23)), (64, 128, 3, 2, 1, (20, 28)), (64, 128, 1, 2, 0, (20, 28)), (128, 128, 3, 1, 1, (9, 13)),
     (192, 64, 3, 1, 1, (16, 16)), (256, 512, 3, 2, 1, (10, 14)), (768, 256, 3, 1, 1, (6, 8)), (64, 64, 3, 1, 1, (1, 1)),
 ])
-def test_conv2d_fwd_bwd(cin, cout, k, s, p, hw):
+def test_conv2d_fwd_bwd(cin, cout, k, s, p, hw, half2d):
     from mm2d3d_amd.conv2d import Conv2dFn
 
     dev = _dev()
     torch.manual_seed(cin + cout + k)
     B, (H, W) = 3, hw
-    x = torch.randn(B, cin, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, device=dev).to(half2d).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, cin, k, k, device=dev) / (cin * k * k) ** 0.5)
     b = torch.randn(cout, device=dev)
     xr = x.float().requires_grad_(True)
-    wr = w.bfloat16().float().requires_grad_(True)
+    wr = w.to(half2d).float().requires_grad_(True)
     br = b.clone().requires_grad_(True)
     yr = F.conv2d(xr, wr, br, s, p)
     xh = x.clone().requires_grad_(True)
     wh = w.clone().requires_grad_(True)
     bh = b.clone().requires_grad_(True)
     yh = Conv2dFn.apply(xh, wh, bh, s, p)
-    assert yh.shape == yr.shape and yh.dtype == torch.bfloat16
+    assert yh.shape == yr.shape and yh.dtype == half2d
     assert _rel(yh, yr) < 1e-2  # bf16 output rounding: 2^-8 relative
-    g = torch.randn_like(yr).bfloat16()
+    g = torch.randn_like(yr).to(half2d)
     yr.backward(g.float())
     yh.backward(g)
     assert _rel(xh.grad, xr.grad) < 1e-2
@@ -49,24 +50,24 @@ def test_conv2d_fwd_bwd(cin, cout, k, s, p, hw):
 
 
 @pytest.mark.parametrize("cin,cout,hw", [(1024, 256, (5, 7)), (256, 128, (10, 14)), (64, 64, (12, 20))])
-def test_conv_transpose2d_fwd_bwd(cin, cout, hw):
+def test_conv_transpose2d_fwd_bwd(cin, cout, hw, half2d):
     from mm2d3d_amd.conv2d import ConvTranspose2dFn
 
     dev = _dev()
     torch.manual_seed(cin + cout)
     B, (H, W) = 2, hw
-    x = torch.randn(B, cin, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, device=dev).to(half2d).contiguous(memory_format=torch.channels_last)
     w = torch.randn(cin, cout, 2, 2, device=dev) / cin ** 0.5
     b = torch.randn(cout, device=dev)
     xr = x.float().requires_grad_(True)
-    wr = w.bfloat16().float().requires_grad_(True)
+    wr = w.to(half2d).float().requires_grad_(True)
     br = b.clone().requires_grad_(True)
     yr = F.conv_transpose2d(xr, wr, br, 2)
     xh, wh, bh = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
     yh = ConvTranspose2dFn.apply(xh, wh, bh)
     assert yh.shape == yr.shape
     assert _rel(yh, yr) < 1e-2
-    g = torch.randn_like(yr).bfloat16()
+    g = torch.randn_like(yr).to(half2d)
     yr.backward(g.float())
     yh.backward(g)
     assert _rel(xh.grad, xr.grad) < 1e-2
@@ -75,7 +76,7 @@ def test_conv_transpose2d_fwd_bwd(cin, cout, hw):
 
 
 @pytest.mark.parametrize("cin", [3, 1])
-def test_stem_conv7x7_fwd_and_weight_grad(cin):
+def test_stem_conv7x7_fwd_and_weight_grad(cin, half2d):
     from mm2d3d_amd.conv2d import StemConvFn
 
     dev = _dev()
@@ -83,19 +84,19 @@ def test_stem_conv7x7_fwd_and_weight_grad(cin):
     B, H, W = 2, 32, 48
     img = torch.rand(B, cin, H, W, device=dev)
     w = torch.randn(64, cin, 7, 7, device=dev) / (cin * 49) ** 0.5
-    xr = img.bfloat16().float()
-    wr = w.bfloat16().float().requires_grad_(True)
+    xr = img.to(half2d).float()
+    wr = w.to(half2d).float().requires_grad_(True)
     yr = F.conv2d(xr, wr, None, 1, 3)
     wh = w.clone().requires_grad_(True)
     yh = StemConvFn.apply(img, wh)
     assert yh.shape == yr.shape and _rel(yh, yr) < 1e-2
-    g = torch.randn_like(yr).bfloat16()
+    g = torch.randn_like(yr).to(half2d)
     yr.backward(g.float())
     yh.backward(g)
     assert _rel(wh.grad, wr.grad) < 5e-3
 
 
-def test_batched_weight_repack_equals_single_packs():
+def test_batched_weight_repack_equals_single_packs(half2d):
     """After an optimiser step every cached bf16 weight copy is refreshed by ONE launch (mm_pack_weights_bf16_batch); the
     result must equal the per-weight kernel for every layout in use (conv fwd/dgrad, transposed-conv fwd/dgrad), including
     sizes that are not a multiple of the 4096-element block chunk."""
@@ -132,7 +133,7 @@ def test_batched_weight_repack_equals_single_packs():
     (128, 64, 5, (33, 50)),    # Cn != Ck, 100 splits of one patch
     (64, 64, 6, (72, 112)),    # one tile, the splits fill the chip: 378 patches over 189 workgroups
 ])
-def test_conv3x3_weight_grad_patch_ring(cin, cout, B, hw):
+def test_conv3x3_weight_grad_patch_ring(cin, cout, B, hw, half2d):
     """k_wgrad3x3n at patch counts per workgroup around and beyond its ring depth (1, 2, 3, 8, 12): the products are exact
     in fp32 (bf16 operands), so only the summation order differs from torch's fp32 weight gradient."""
     from mm2d3d_amd.conv2d import Conv2dFn
@@ -140,9 +141,9 @@ def test_conv3x3_weight_grad_patch_ring(cin, cout, B, hw):
     dev = _dev()
     torch.manual_seed(cin * 7 + cout + B)
     H, W = hw
-    x = torch.randn(B, cin, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x = torch.randn(B, cin, H, W, device=dev).to(half2d).contiguous(memory_format=torch.channels_last)
     w = torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5
-    g = torch.randn(B, cout, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, cout, H, W, device=dev).to(half2d).contiguous(memory_format=torch.channels_last)
     wh = w.clone().requires_grad_(True)
     Conv2dFn.apply(x, wh, None, 1, 1).backward(g)
     ref = torch.nn.grad.conv2d_weight(x.float(), w.shape, g.float(), stride=1, padding=1)

@@ -172,7 +172,7 @@ def test_rulebook_engine_with_per_step_fragments_equals_per_call_pack(level, cin
 
 
 @pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 152, 240), (128, 128, 76, 120), (256, 256, 38, 60), (512, 512, 19, 30), (192, 64, 152, 240)])
-def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W):
+def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W, half2d):
     """The persistent 3x3 kernels at the joint-pass shapes of the bench (B = 16): forward and data gradient against torch's
     fp32 convolution on the same bf16-rounded operands (tolerance = bf16 output rounding), weight gradient likewise."""
     import torch.nn.functional as F
@@ -182,13 +182,13 @@ def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W):
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(cin + cout + H)
     B = 16
-    x = torch.randn(B, cin, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = torch.randn(B, cin, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
     w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev).requires_grad_(True)
     y = Conv2dFn.apply(x, w, None, 1, 1)
-    gy = torch.randn(B, cout, H, W, generator=g).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, cout, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
     gx, gw = torch.autograd.grad(y, [x, w], gy)
     xr = x.detach().float().requires_grad_(True)
-    wr = w.detach().bfloat16().float().requires_grad_(True)  # the kernels multiply the bf16-rounded weights
+    wr = w.detach().to(half2d).float().requires_grad_(True)  # the kernels multiply the bf16-rounded weights
     yr = F.conv2d(xr, wr, None, 1, 1)
     gxr, gwr = torch.autograd.grad(yr, [xr, wr], gy.float())
     rel = lambda a, b: float((a.detach().float() - b.detach()).norm() / b.detach().norm())
@@ -197,7 +197,7 @@ def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W):
 
 
 @pytest.mark.parametrize("workload", ["c2", "c4"])
-def test_full_joint_step_at_bench_size(workload):
+def test_full_joint_step_at_bench_size(workload, bf16_mode):
     """One whole two-domain training step at BASELINE.json's sizes - configs[1]: 8 + 8 NuScenes-shaped scenes, 6 classes;
     configs[3]: 4 + 4 KITTI-shaped scans of 121,600 points, 10 classes (datasets/a2d2_semantic_kitti.yaml:19), both at
     480x302.  The jointly batched step (one pass per network over [source | target], per-domain batch-norm statistics)

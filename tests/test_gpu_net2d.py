@@ -23,14 +23,14 @@ def _rel(a, b):
 
 
 @pytest.mark.parametrize("C,relu,with_res", [(64, True, False), (128, True, True), (512, False, False), (64, False, True)])
-def test_bn2d_train_eval_backward(C, relu, with_res):
+def test_bn2d_train_eval_backward(C, relu, with_res, half2d):
     from mm2d3d_amd import nn2d
 
     dev = _dev()
     torch.manual_seed(C)
     B, H, W = 3, 13, 17
-    x = (torch.randn(B, C, H, W, device=dev) * 2 + 0.3).bfloat16().contiguous(memory_format=CL)
-    res = torch.randn(B, C, H, W, device=dev).bfloat16().contiguous(memory_format=CL) if with_res else None
+    x = (torch.randn(B, C, H, W, device=dev) * 2 + 0.3).to(half2d).contiguous(memory_format=CL)
+    res = torch.randn(B, C, H, W, device=dev).to(half2d).contiguous(memory_format=CL) if with_res else None
     bn = nn2d.BatchNorm2d(C, relu=relu).to(dev)
     ref = torch.nn.BatchNorm2d(C).to(dev)
     with torch.no_grad():
@@ -50,7 +50,7 @@ def test_bn2d_train_eval_backward(C, relu, with_res):
     assert _rel(yh, yr) < 1e-2
     assert torch.allclose(bn.running_mean, ref.running_mean, atol=1e-4) and torch.allclose(bn.running_var, ref.running_var, atol=1e-3)
     assert int(bn.num_batches_tracked) == 1  # incremented inside the finalize kernel
-    g = torch.randn_like(yr).bfloat16()
+    g = torch.randn_like(yr).to(half2d)
     # reference gradient with the bf16-rounded forward output deciding the ReLU mask, as the kernel does
     yr.backward(g.float())
     yh.backward(g)
@@ -68,31 +68,31 @@ def test_bn2d_train_eval_backward(C, relu, with_res):
     assert _rel(ye, yre) < 1e-2
 
 
-def test_maxpool_cat_heads():
+def test_maxpool_cat_heads(half2d):
     from mm2d3d_amd import nn2d
 
     dev = _dev()
     torch.manual_seed(0)
     # max-pool: post-ReLU maps have many ties (zeros): the first maximum in scan order must receive the gradient
-    x = F.relu(torch.randn(2, 64, 15, 18, device=dev)).bfloat16().contiguous(memory_format=CL)
+    x = F.relu(torch.randn(2, 64, 15, 18, device=dev)).to(half2d).contiguous(memory_format=CL)
     xh, xr = x.clone().requires_grad_(True), x.float().requires_grad_(True)
     yh, yr = nn2d.MaxPool2d(3, 2, 1)(xh), F.max_pool2d(xr, 3, 2, 1)
     assert torch.equal(yh.float(), yr)
-    g = torch.randn_like(yr).bfloat16()
+    g = torch.randn_like(yr).to(half2d)
     yh.backward(g)
     yr.backward(g.float())
     assert _rel(xh.grad, xr.grad) < 1e-2
     # concat
-    a = torch.randn(2, 64, 5, 7, device=dev).bfloat16().contiguous(memory_format=CL).requires_grad_(True)
-    b = torch.randn(2, 128, 5, 7, device=dev).bfloat16().contiguous(memory_format=CL).requires_grad_(True)
+    a = torch.randn(2, 64, 5, 7, device=dev).to(half2d).contiguous(memory_format=CL).requires_grad_(True)
+    b = torch.randn(2, 128, 5, 7, device=dev).to(half2d).contiguous(memory_format=CL).requires_grad_(True)
     c = nn2d.cat_channels([a, b, a])
     assert torch.equal(c, torch.cat([a, b, a], 1))
     gg = torch.randn_like(c)
     c.backward(gg)
-    assert torch.equal(a.grad.float(), (gg[:, :64].float() + gg[:, 192:].float()).bfloat16().float()) and torch.equal(b.grad, gg[:, 64:192])
+    assert torch.equal(a.grad.float(), (gg[:, :64].float() + gg[:, 192:].float()).to(half2d).float()) and torch.equal(b.grad, gg[:, 64:192])
     # fused heads == Conv1x1(AvgPool5x5(crop(x))) for both heads
     B, Hp, Wp, h, w = 2, 32, 48, 30, 44
-    x = torch.randn(B, 64, Hp, Wp, device=dev).bfloat16().contiguous(memory_format=CL)
+    x = torch.randn(B, 64, Hp, Wp, device=dev).to(half2d).contiguous(memory_format=CL)
     c1, c2 = nn2d.Conv2d(64, 6, 1).to(dev), nn2d.Conv2d(64, 6, 1).to(dev)
     # reference on a plain NCHW-contiguous fp32 copy (torch's NHWC avg-pool backward on a cropped view is not trusted)
     xh, xr = x.clone().requires_grad_(True), x.float().contiguous(memory_format=torch.contiguous_format).requires_grad_(True)
@@ -109,7 +109,7 @@ def test_maxpool_cat_heads():
 
 
 @pytest.mark.parametrize("training", [False, True])
-def test_net2d_vs_oracle(training):
+def test_net2d_vs_oracle(training, bf16_mode):
     from mm2d3d_amd.net2d import Net2DSeg
     from oracle.net2d_ref import net2d_forward
 
@@ -158,7 +158,7 @@ def fp16_mode():
 
     nn2d.set_precision("fp16")
     yield
-    nn2d.set_precision(16)
+    nn2d.set_precision(nn2d.DEFAULT_PRECISION)
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -231,7 +231,7 @@ def fp32_mode():
 
     nn2d.set_precision(32)
     yield
-    nn2d.set_precision(16)
+    nn2d.set_precision(nn2d.DEFAULT_PRECISION)
 
 
 @pytest.mark.parametrize("training", [False, True])
@@ -351,9 +351,10 @@ def _bn2d_call(L, fused, x, ldx, res, dy, dy2, N, Ns, C, relu, w, b, use_yout):
     try:
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         nbt = torch.zeros(1, dtype=torch.int64, device=dev)
-        y = torch.zeros(N, C, dtype=torch.bfloat16, device=dev)
-        dx = torch.zeros(N, C, dtype=torch.bfloat16, device=dev)
-        dres = torch.zeros(N, C, dtype=torch.bfloat16, device=dev) if res is not None else None
+        half = x.dtype
+        y = torch.zeros(N, C, dtype=half, device=dev)
+        dx = torch.zeros(N, C, dtype=half, device=dev)
+        dres = torch.zeros(N, C, dtype=half, device=dev) if res is not None else None
         dw, db = torch.full((C,), 0.25, device=dev), torch.full((C,), -0.5, device=dev)  # accumulate = 1 adds to these
         stats = torch.zeros((2, 2 if 0 < Ns < N else 1, C), device=dev)
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), dev)
@@ -378,21 +379,21 @@ def _bn2d_call(L, fused, x, ldx, res, dy, dy2, N, Ns, C, relu, w, b, use_yout):
     (583680, 291840, 64, True, True, False, False),  # 240x151 maps: forward on chip (36 rows per thread), backward three-kernel
     (300, 7, 8, False, True, False, False),          # tiny first group, 8 channels
 ])
-def test_bn2d_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, res, relu, two, sliced):
+def test_bn2d_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, res, relu, two, sliced, half2d):
     """csrc/bn2d.hip: the grid-barrier kernels (rows kept in registers / LDS, statistics combined by the last workgroup) against
     the reduce / finalize / apply kernels on the same inputs.  The statistics are combined in a different (fixed) order, so
     means and variances agree to fp32 rounding and the bf16 outputs may differ by one rounding step on a few elements."""
-    from mm2d3d_amd import _lib
+    from mm2d3d_amd import conv2d as c2d
 
     dev = _dev()
-    L = _lib.lib()
+    L = c2d.lib2d()  # the entry points of the build for the storage format under test (csrc/h16.h: suffix _f16)
     g = torch.Generator(device="cpu").manual_seed(N + C)
     ld = C + 32 if sliced else C
-    xbuf = (torch.randn(N, ld, generator=g) * 1.7 + 0.4).to(dev).bfloat16()
+    xbuf = (torch.randn(N, ld, generator=g) * 1.7 + 0.4).to(dev).to(half2d)
     x = xbuf[:, 16:16 + C] if sliced else xbuf
-    r = torch.randn(N, C, generator=g).to(dev).bfloat16() if res else None
-    dy = torch.randn(N, C, generator=g).to(dev).bfloat16()
-    dy2 = torch.randn(N, C, generator=g).to(dev).bfloat16() if two else None
+    r = torch.randn(N, C, generator=g).to(dev).to(half2d) if res else None
+    dy = torch.randn(N, C, generator=g).to(dev).to(half2d)
+    dy2 = torch.randn(N, C, generator=g).to(dev).to(half2d) if two else None
     w = (torch.rand(C, generator=g) + 0.5).to(dev)
     b = torch.randn(C, generator=g).to(dev)
     use_yout = res or not relu
@@ -408,7 +409,7 @@ def test_bn2d_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, res, r
         u, v = a[k].float(), c[k].float()
         bad = (u != v)
         assert bad.float().mean().item() < 2e-3, k  # almost every element identical
-        # ... and never more than one bf16 step apart; the absolute term covers values that are themselves the small
+        # ... and never more than one 16-bit step apart (2^-7 covers bf16; fp16 steps are 8x finer); the absolute term covers values that are themselves the small
         # difference of two O(1) fp32 terms (normalised x + residual), where one fp32 rounding of the scale / shift shows
         assert ((u - v).abs() <= 2.0 ** -7 * v.abs() + 4e-6 * (1.0 + float(v.abs().max()))).all(), k
     # gamma / beta gradients: sums over up to 5.8e5 rows, combined in fp64 in both paths (the single-launch kernels form

@@ -101,7 +101,48 @@ def test_unused_parameters_keep_their_weights():
     assert torch.equal(b.detach().cpu(), torch.ones(7)) and not torch.equal(a.detach().cpu(), torch.ones(5))
 
 
-def test_full_step_losses_and_gradients_vs_oracle():
+@pytest.mark.parametrize("scaled", [False, True])
+def test_adamw_touched_range_that_starts_unaligned_matches_torch_adamw(scaled):
+    """an untouched 6-element parameter ahead of touched ones makes the touched range start at arena offset
+    6 (not 16-byte aligned): the scalar instantiations k_adamw<false> / <false, true> run.  Every element must be updated
+    exactly once per step, as torch.optim.AdamW does."""
+    from mm2d3d_amd.amp import GradScaler
+    from mm2d3d_amd.optimizers import FlatAdamW
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    shapes = [(6,), (3, 1), (1,), (1037,), (16, 6), (6,), (5000,)]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    hp = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+    rp = [torch.nn.Parameter(t.clone()) for t in init]
+    o = FlatAdamW(hp, lr=0.01, weight_decay=0.05)
+    r = torch.optim.AdamW(rp[1:], lr=0.01, weight_decay=0.05)  # parameter 0 never receives a gradient
+    scaler = GradScaler(dev, init_scale=1024.0) if scaled else None
+    for step in range(4):
+        ws = [torch.randn(s, generator=g) for s in shapes]
+        o.zero_grad(), r.zero_grad()
+        lh = sum((p * w.to(dev)).sum() for p, w in zip(hp[1:], ws[1:]))
+        lr_ = sum((p * w).sum() for p, w in zip(rp[1:], ws[1:]))
+        if scaled:
+            scaler.scale(lh).backward()
+            scaler.step(o)
+            scaler.update()
+        else:
+            lh.backward()
+            o.step()
+        lr_.backward()
+        r.step()
+        lo = o._touched_ranges(o._arenas[0])[0][0]
+        assert lo == 6 and (o._arenas[0]["p"][lo:].data_ptr() & 15) != 0  # the case under test
+        assert torch.equal(hp[0].detach().cpu(), init[0])
+        for a, b in zip(hp[1:], rp[1:]):
+            assert torch.allclose(a.detach().cpu(), b.detach(), atol=2e-6, rtol=1e-6), step
+    if scaled:
+        assert scaler.steps_taken(o) == 4
+
+
+@pytest.mark.parametrize("kind", ["fp16", "bf16"])
+def test_full_step_losses_and_gradients_vs_oracle(kind):
     """One two-domain step on 1+1 small-image scenes: six loss terms within 1e-3, 3D/2D gradients consistent."""
     from mm2d3d_amd.losses import Loss
     from mm2d3d_amd.net2d import Net2DSeg
@@ -133,13 +174,22 @@ def test_full_step_losses_and_gradients_vs_oracle():
     ref3e = copy.deepcopy(ref3)
     ref3e.zero_grad()
     cpu_e = {"source": make_batch(5, 1, "nuscenes", (48, 64)), "target": make_batch(6, 1, "nuscenes", (48, 64))}
-    emu_total, emu_logs = generic_step(sd2e, ref3e, cpu_e, W, emulate_bf16=True)
-    emu_total.backward()
+    scale = 1024.0 if kind == "fp16" else 1.0  # IEEE fp16 gradient maps want the trainer's loss scale (mm2d3d_amd/amp.py)
+    emu_total, emu_logs = generic_step(sd2e, ref3e, cpu_e, W, emulate_bf16=torch.float16 if kind == "fp16" else torch.bfloat16)
+    (emu_total * scale).backward()
+    if scale != 1.0:
+        for v in list(sd2e.values()) + list(ref3e.parameters()):
+            if v.grad is not None:
+                v.grad.div_(scale)
     tm = TrainModel({"2d_net": n2.to(dev), "3d_net": n3.to(dev)}, None,
                     Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}]),
-                    dict(lambda_xm_src=1.0, lambda_xm_trg=0.1))
+                    dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, precision=kind))
     total = tm.training_step(gpu)
-    total.backward()
+    (total * scale).backward()
+    if scale != 1.0:
+        for p_ in list(n2.parameters()) + list(n3.parameters()):
+            if p_.grad is not None:
+                p_.grad.div_(scale)
     # 3D-only terms: fp32 on both sides -> 1e-3 (north_star).  Terms fed by the 2D branch (bf16 activations, as the
     # reference's fp16 AMP) -> 3e-2.
     tol = {"loss_segmentation_3d": 1e-3}
@@ -181,7 +231,7 @@ def test_full_step_losses_and_gradients_vs_oracle():
     assert worst_loss < 1e-4
 
 
-def test_joint_domain_pass_equals_the_two_call_sequence():
+def test_joint_domain_pass_equals_the_two_call_sequence(bf16_mode):
     """TrainModel batches [source | target] into one pass per network with per-domain batch-norm statistics
     (mm2d3d_amd/domains.py); losses, gradients, running statistics and batch counters must be those of the reference's
     literal two-call sequence (joint_domains=False)."""
@@ -475,7 +525,7 @@ def test_training_steps_with_fp16_maps_and_rows_under_the_loss_scale():
     mk = lambda: {"source": make_batch(5, 2, "nuscenes", (48, 64), device=dev), "target": make_batch(6, 2, "nuscenes", (48, 64), device=dev)}
     loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
     try:
-        ref = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, precision=16,
+        ref = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, precision="bf16",
                                                                              sparse_activations="bf16"))
         l_bf = float(ref.training_step(mk()))
         opts = {k: Optimizer("adamw", lr=1e-3) for k in ("2d_net", "3d_net")}
@@ -498,7 +548,7 @@ def test_training_steps_with_fp16_maps_and_rows_under_the_loss_scale():
         assert np.isfinite(float(tm.fit_step(mk())))
         assert tm.scaler.get_scale() == 1024.0 and [tm.scaler.steps_taken(o) for o in tm.optimizers] == [7, 7]
     finally:
-        nn2d.set_precision(16)
+        nn2d.set_precision(nn2d.DEFAULT_PRECISION)
         scn.set_activation_dtype(torch.float32)
 
 
@@ -523,7 +573,7 @@ def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
         tp = cm.diag().double()
         iou = tp / (cm.sum(0) + cm.sum(1) - cm.diag()).double()
         assert torch.allclose(m.compute()[SegIoU.NAMES[i]].cpu().double(), iou, atol=1e-6)
-    # checkpoint round trip of a tiny trainer (keys follow the reference: model.<net>.*)
+    # checkpoint round trip of a tiny trainer (keys follow the reference: model.<net>.model.*)
     from mm2d3d_amd.losses import Loss
     from mm2d3d_amd.net3d import Net3DSeg
     from mm2d3d_amd.optimizers import Optimizer
@@ -536,7 +586,7 @@ def test_eval_confusion_iou_and_checkpoint_roundtrip(tmp_path):
     t1.configure_optimizers(), t2.configure_optimizers()
     t1.best["best_target_iou"] = 0.5
     ck = t1.checkpoint()
-    assert any(k.startswith("model.3d_net.net_3d.layer2.weight") for k in ck["state_dict"])
+    assert any(k.startswith("model.3d_net.model.net_3d.layer2.weight") for k in ck["state_dict"])  # the reference's key path
     torch.save(ck, tmp_path / "last.ckpt")
     t2.load_checkpoint(torch.load(tmp_path / "last.ckpt", weights_only=False))
     for (k1, v1), (k2, v2) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
@@ -587,7 +637,7 @@ def test_metadata_built_one_step_ahead_gives_the_same_steps():
         nxt = seq[i + 1] if i + 1 < 4 else None
         la = piped.fit_step(seq[i], next_batch=nxt)
         if nxt is not None:
-            assert piped._pipelined is not None and piped._pipelined["key"] == id(nxt) and piped._pipelined["phase"] == 2
+            assert piped._pipelined is not None and piped._pipelined["key"] is nxt and piped._pipelined["phase"] == 2
         lb = plain.fit_step(clone(batches[i]))
         assert float(la.detach()) == float(lb.detach()), (i, float(la.detach()), float(lb.detach()))
     torch.cuda.synchronize()

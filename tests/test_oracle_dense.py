@@ -84,8 +84,13 @@ def test_batchnorm_matches_torch_and_updates_running_stats():
     y = bn(t).features
     mean, var = x.mean(0), x.var(0, unbiased=False)
     assert torch.allclose(y, F.relu((x - mean) / torch.sqrt(var + 1e-4)), atol=1e-5)
-    assert torch.allclose(bn.running_mean, 0.1 * mean, atol=1e-6)
-    assert torch.allclose(bn.running_var, 0.9 + 0.1 * x.var(0, unbiased=True), atol=1e-5)
+    keep = scn.DEFAULT_BN_MOMENTUM[0]  # 0.99: the recalled constructor default of the pinned commit (the docstring says 0.9)
+    assert keep == 0.99 and bn.momentum == keep
+    assert torch.allclose(bn.running_mean, (1 - keep) * mean, atol=1e-6)
+    assert torch.allclose(bn.running_var, keep + (1 - keep) * x.var(0, unbiased=True), atol=1e-5)
+    bn9 = scn.BatchNormReLU(9, momentum=0.9)  # the survey's reading stays selectable
+    bn9(t)
+    assert torch.allclose(bn9.running_mean, 0.1 * mean, atol=1e-6)
 
 
 def test_unet_forward_backward_and_output_order():

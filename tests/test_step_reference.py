@@ -1,0 +1,193 @@
+"""The reference's OWN training step as a fixture (tests/golden/step_ref.npz, written by tests/golden/make_golden.py:step_case).
+
+``TrainModel._generic_step`` / ``cross_modal_loss`` of /root/reference/experiments_USA_SING/.../train.py:157-184,186-292 were
+imported unchanged (stand-ins only for pytorch_lightning / torchmetrics / visualize / torchvision; sparseconvnet = the oracle
+primitives) and run over the reference's own 2d_net / 3d_net plugins on a 2 + 2-scene batch: the six logged terms, the summed
+loss, the running statistics after the step and a digest of every parameter gradient are stored.
+
+CPU (here): oracle/step_ref.py must reproduce them - pins the restated composition (which logits feed which KL term, detach,
+lambda weights, logged keys).  GPU (-m gpu): ``mm2d3d_amd.train.TrainModel.training_step`` must - the exact-fp32 2D mode at
+north_star's 1e-3, the default IEEE fp16 mode at 16-bit bounds.
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(__file__)
+G = os.path.join(HERE, "golden", "step_ref.npz")
+W = [1.9241476, 1.0, 2.16763851, 2.78254323, 1.54875664, 1.85686537]
+KW3D = dict(in_channels=3, m=16, block_reps=1, residual_blocks=False, full_scale=4096, num_planes=7)
+KEYS = ("loss_segmentation", "loss_segmentation_3d", "xm_loss_src_2d", "xm_loss_tgt_2d", "xm_loss_src_3d", "xm_loss_tgt_3d")
+
+
+def _fillmod():
+    spec = importlib.util.spec_from_file_location("golden_fill", os.path.join(HERE, "golden", "fill.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def _batch(z, dev=None):
+    out = {}
+    for dom in ("source", "target"):
+        n_img = z[f"{dom}/img"].shape[0]
+        b = {"x": [torch.from_numpy(z[f"{dom}/coords"]), torch.from_numpy(z[f"{dom}/feats"]).clone()],
+             "img": torch.from_numpy(z[f"{dom}/img"]), "depth": torch.from_numpy(z[f"{dom}/depth"]),
+             "seg_label": torch.from_numpy(z[f"{dom}/seg_label"]), "img_indices": [z[f"{dom}/idx{i}"] for i in range(n_img)]}
+        if dev is not None:
+            b["x"] = [t.to(dev) for t in b["x"]]
+            for k in ("img", "depth", "seg_label"):
+                b[k] = b[k].to(dev)
+        out[dom] = b
+    return out
+
+
+def _weights(net2d_sd, net3d_sd):
+    """The reference filled ``tm.model.state_dict()`` (keys ``2d_net.model.*`` / ``3d_net.model.*``: ModuleDict -> ModelWrapper ->
+    net, train.py:553-560,531) from the key names: regenerate under the same names."""
+    fill = _fillmod().fill_state_dict
+    full = {f"2d_net.model.{k}": v for k, v in net2d_sd.items()}
+    full.update({f"3d_net.model.{k}": v for k, v in net3d_sd.items()})
+    filled = fill(full)
+    return ({k[len("2d_net.model."):]: v for k, v in filled.items() if k.startswith("2d_net.")},
+            {k[len("3d_net.model."):]: v for k, v in filled.items() if k.startswith("3d_net.")})
+
+
+def _logs(z):
+    return {k.split("/", 1)[1]: float(v) for k, v in zip(z["log_keys"], z["log_values"])}
+
+
+def test_fixture_holds_the_reference_keys():
+    z = np.load(G)
+    assert [k for k in z["log_keys"]] == [f"train/{k}" for k in KEYS]  # the six keys, in the order train.py:280-291 logs them
+    logs = _logs(z)
+    # the summed loss (train.py:292) with lambda_xm_src = 1.0, lambda_xm_trg = 0.1 (config.yaml:105-106)
+    want = (logs["loss_segmentation"] + logs["loss_segmentation_3d"] + 1.0 * (logs["xm_loss_src_2d"] + logs["xm_loss_src_3d"])
+            + 0.1 * (logs["xm_loss_tgt_2d"] + logs["xm_loss_tgt_3d"]))
+    assert abs(want - float(z["total"])) < 1e-5
+    # unused parameters of the reference's step (the find_unused_parameters=True case, run.py:264-268)
+    assert sorted(z["nograd_keys"]) == sorted(["model.2d_net.model.aux.linear.bias", "model.2d_net.model.aux.linear.weight",
+                                               "model.3d_net.model.aux.linear_global.bias", "model.3d_net.model.aux.linear_global.weight"])
+
+
+def test_oracle_step_reproduces_the_reference_step():
+    from mm2d3d_amd.net2d import Net2DSeg
+    from oracle.net3d_ref import Net3DSegRef
+    from oracle.step_ref import cross_modal_loss, generic_step
+
+    z = np.load(G)
+    net3 = Net3DSegRef(6, True, KW3D)
+    sd2, sd3 = _weights(Net2DSeg(6, pretrained=False).state_dict(), net3.state_dict())
+    net3.load_state_dict(sd3)
+    net3.train()
+    sd2 = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd2.items()}
+    total, logs = generic_step(sd2, net3, _batch(z), W, lambda_xm_src=1.0, lambda_xm_trg=0.1, training=True)
+    ref = _logs(z)
+    for k in KEYS:
+        assert abs(float(logs[k].detach()) - ref[k]) < 1e-5 * max(1.0, abs(ref[k])), (k, float(logs[k].detach()), ref[k])
+    assert abs(float(total.detach()) - float(z["total"])) < 1e-5 * abs(float(z["total"]))
+    total.backward()
+    fm = _fillmod()
+    named = [(f"model.2d_net.model.{k}", v.grad) for k, v in sd2.items() if v.grad is not None]
+    named += [(f"model.3d_net.model.{k}", p.grad) for k, p in net3.named_parameters() if p.grad is not None]
+    assert sorted(k for k, _ in named) == sorted(z["grad_keys"])
+    rows = fm.digest_compare(z, "grad/", named)
+    gmax = max(r[4] for r in rows)
+    for k, rel, ratio, cos, rn in rows:
+        if rn < 1e-6 * gmax:  # a conv bias in front of a batch norm: zero up to rounding on both sides
+            continue
+        assert rel < 2e-3 and abs(ratio - 1) < 2e-3, (k, rel, ratio)
+    # cross_modal_loss alone (train.py:157-184): argument roles
+    a, b, c, d = (torch.from_numpy(t) for t in z["xm/args"])
+    l2d, l3d = cross_modal_loss(a, b, c, d)
+    assert abs(float(l2d) - z["xm/values"][0]) < 1e-6 and abs(float(l3d) - z["xm/values"][1]) < 1e-6
+
+
+def test_checkpoint_uses_the_reference_state_dict_keys():
+    """Lightning's checkpoint of the reference holds ``model.<net>.model.<param>`` (TrainModel.model = ModuleDict of ModelWrapper,
+    each holding ``.model``): the product's ``checkpoint()`` must write exactly those keys and read them back."""
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.train import TrainModel
+
+    z = np.load(G)
+    tm = TrainModel({"2d_net": Net2DSeg(6, pretrained=False), "3d_net": Net3DSeg(6, True, KW3D)}, None, None, {})
+    ck = tm.checkpoint()
+    assert sorted(ck["state_dict"].keys()) == sorted(z["state_dict_keys"])
+    saved = {k: v.clone() for k, v in ck["state_dict"].items()}  # what torch.save would have written
+    before = {k: v.clone() for k, v in tm.model.state_dict().items()}
+    with torch.no_grad():
+        for p in tm.model.parameters():
+            p.add_(1.0)
+    tm.load_checkpoint({"state_dict": saved})
+    assert all(torch.equal(v, before[k]) for k, v in tm.model.state_dict().items())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", [32, "fp16", "bf16"])
+def test_hip_training_step_reproduces_the_reference_step(precision):
+    """The product's TrainModel.training_step (joint [source | target] pass, HIP kernels) on the fixture's batch and weights.
+    precision 32: six terms and total within north_star's 1e-3 (measured in the assertion message on failure), every gradient
+    within 2e-2 relative L2 of the reference's (fp32 vs fp32: summation order through ~50 layers and the ReLU-mask flips it causes
+    on a tiny batch).  "fp16" (the default 16-bit format = the reference's precision: 16) / "bf16": 16-bit bounds."""
+    from mm2d3d_amd import nn2d
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.train import TrainModel
+
+    dev = torch.device("cuda:0")
+    z = np.load(G)
+    try:
+        n2, n3 = Net2DSeg(6, pretrained=False), Net3DSeg(6, True, KW3D)
+        sd2, sd3 = _weights(n2.state_dict(), n3.state_dict())
+        n2.load_state_dict(sd2)
+        n3.load_state_dict(sd3)
+        for m in n2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        tm = TrainModel({"2d_net": n2.to(dev), "3d_net": n3.to(dev)}, None,
+                        Loss([{"name": "cross_entropy", "weight": 1.0, "target": "segmentation", "args": {"weight": W}}]),
+                        dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, precision=precision))
+        tm.train()
+        total = tm.training_step(_batch(z, dev))
+        scale = 1024.0 if precision == "fp16" else 1.0  # the loss scale the trainer's GradScaler applies to fp16 gradient maps
+        (total * scale).backward()
+        ref = _logs(z)
+        tol = {32: 1e-3, "fp16": 4e-3, "bf16": 3e-2}[precision]
+        errs = {k: abs(tm.last_logs[f"train/{k}"].item() - ref[k]) / max(1.0, abs(ref[k])) for k in KEYS}
+        errs["total"] = abs(total.item() - float(z["total"])) / abs(float(z["total"]))
+        print(f"HIP step vs the reference's step, precision={precision}: " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+        for k, v in errs.items():
+            # the 3D-only term is fp32 on both sides in every mode
+            assert v < (1e-3 if k == "loss_segmentation_3d" else tol), (k, v)
+        fm = _fillmod()
+        named = [(f"model.2d_net.model.{k}", p.grad / scale) for k, p in n2.named_parameters() if p.grad is not None]
+        named += [(f"model.3d_net.model.{k}", p.grad / scale) for k, p in n3.named_parameters() if p.grad is not None]
+        assert sorted(k for k, _ in named) == sorted(z["grad_keys"])  # the same parameters stay without a gradient
+        rows = fm.digest_compare(z, "grad/", named)
+        gmax = max(r[4] for r in rows)
+        rel_tol, med_tol = {32: (5e-2, 5e-3), "fp16": (0.35, 3e-2), "bf16": (0.6, 0.12)}[precision]
+        rels = []
+        for k, rel, ratio, cos, rn in rows:
+            if rn < 1e-4 * gmax:
+                continue
+            rels.append((rel, k))
+            assert rel < rel_tol, (k, rel, ratio)
+        med = float(np.median([r for r, _ in rels]))
+        print(f"gradients vs the reference's: relative L2 (digest) median {med:.2e}, worst {max(rels)[0]:.2e} ({max(rels)[1]})")
+        assert med < med_tol, med
+        # running statistics after the step (both domains' updates, source first)
+        for k in z.files:
+            if not k.startswith("sd/"):
+                continue
+            name = k[len("sd/model."):]
+            net, rest = name.split(".model.", 1)
+            v = tm.model[net].state_dict()[rest].float().cpu().numpy()
+            atol = {32: 1e-4, "fp16": 2e-3, "bf16": 2e-2}[precision]
+            assert np.allclose(v, z[k], atol=atol, rtol={32: 1e-4, "fp16": 5e-3, "bf16": 5e-2}[precision]), k
+    finally:
+        nn2d.set_precision(nn2d.DEFAULT_PRECISION)
