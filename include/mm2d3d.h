@@ -9,8 +9,13 @@
  * Conventions
  *   - every pointer named *_dev or documented "device" is a HIP device pointer; *_host is host memory;
  *   - feature matrices are row-major fp32 with an explicit row stride `ld_*` in floats;
- *   - the library never allocates: outputs and workspaces are supplied by the caller
+ *   - the library never allocates device memory: outputs and workspaces are supplied by the caller
  *     (size queries: mm_*_ws_bytes); all work is enqueued on `stream` and returns immediately;
+ *   - no process-wide mutable state: what outlives a call (grid-barrier words, fault word, mode switches of the
+ *     single-launch batch norms) lives in a per-device HANDLE (mm_create) over memory the caller supplied; entry points
+ *     that use it take the handle first; modes of the stateless engines travel as explicit arguments; no entry point
+ *     reads an environment variable (the Python layer reads them once and passes them on).  One host thread per handle
+ *     at a time.  [The only process-wide memory are per-device "done" bits of idempotent hipFuncSetAttribute calls.]
  *   - return value 0 = ok, negative = error (MM_ERR_*), message via mm_last_error() (thread-local);
  *   - integer results (ids, rulebooks) are deterministic and follow the canonical orders of SURVEY.md A.8;
  *     floating-point reductions run in a fixed order (no float atomics): results are bit-stable run to run.
@@ -35,6 +40,28 @@ typedef void* mm_stream_t; /* hipStream_t */
 
 const char* mm_last_error(void);
 
+/* ---------------------------------------------------------------- per-device handle (csrc/handle.hip)
+ * The reference keeps the equivalent state inside torch / cuDNN / SparseConvNet handles; this ABI exposes it. */
+typedef void* mm_handle_t;
+size_t mm_handle_sync_bytes(void);  /* device memory, zero-filled by the caller: 64 barrier slots of 512 B (one per stream) */
+size_t mm_handle_fault_bytes(void); /* pinned, device-mapped host memory (hipHostMalloc / torch pinned), zero-filled */
+int mm_create(int device_id, void* sync_dev, size_t sync_bytes, void* fault_host, size_t fault_bytes, mm_handle_t* out);
+int mm_destroy(mm_handle_t h);
+#define MM_OPT_BN2D_FUSED 0   /* single-launch BatchNorm2d kernels: bit 0 = forward, bit 1 = backward; default 3 */
+#define MM_OPT_BN3D_FUSED 1   /* the same for the sparse rows (mm_bn_*); default 3 */
+#define MM_OPT_OS_SORT 2      /* reserved (the tile-table sort is an argument of mm_os_table_build) */
+#define MM_OPT_SPCONV_TERMS 3 /* reserved (the sparse engines take their mode as an argument, MM_SPCONV_*) */
+#define MM_OPT_DW_WIDE 4      /* reserved */
+/* returns the previous value (>= 0) or MM_ERR_ARG.  The single-launch batch-norm kernels need every CU at once: use 0 when
+ * several PROCESSES share one GPU, and clear the bit of a direction whose launches overlap kernels of another stream that
+ * spin-wait across their own workgroups (collectives, look-back scans; csrc/fused_bn.h). */
+int mm_set_option(mm_handle_t h, int option, int value);
+int mm_get_option(mm_handle_t h, int option);
+/* 1 if a single-launch batch-norm kernel launched through h gave up at its grid barrier since the last call (its grid was not
+ * co-resident).  That launch's outputs are invalid; the handle's single-launch kernels are switched off (three-kernel path) and
+ * its barrier words re-armed.  A host-memory read when nothing happened. */
+int mm_fault_poll(mm_handle_t h);
+
 /* ---------------------------------------------------------------- active sets and rulebooks (csrc/meta.hip)
  * Replaces the host hash-map work of scn.InputLayer(3, full_scale, mode=4) (EXP/3d_net/scn_unet.py:113,121)
  * and the rulebook construction of scn.SubmanifoldConvolution / Convolution / Deconvolution
@@ -55,8 +82,10 @@ size_t mm_dedupe_ws_bytes(int64_t n_bound);
  *   n_active_dev  device int32 [1];  err_dev device int32 [1] set non-zero on out-of-range coordinates */
 int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, const int32_t* n_dev, int shift,
                     uint64_t* tkeys, int32_t* tvals, int64_t cap, int32_t* item2vox, int32_t* vox_coords,
-                    int32_t* csr_off, int32_t* csr_items, int32_t* n_active_dev, int32_t* err_dev, void* ws,
+                    int32_t* csr_off, int32_t* csr_items, int32_t* n_active_dev, int32_t* err_dev, int no_spin, void* ws,
                     size_t ws_bytes, mm_stream_t stream);
+/* no_spin != 0 (here and below): only kernels whose workgroups never wait for each other (plain three-launch prefix sums
+ * instead of the decoupled look-back scan) - what a build on a side stream beside grid-barrier kernels needs. */
 
 /* nbr[k*n + o] = id of the active site at coord(o) + offset(k), k = ((dx+1)*3 + (dy+1))*3 + (dz+1), or -1 */
 /* out[0] = number of active rows with batch index < split.  Rows are in first-occurrence order of a batch-sorted point
@@ -76,9 +105,9 @@ size_t mm_rulebook_ws_bytes(int64_t n_out, int K);
  * csr_off = csr_pos = NULL skips the CSR (levels served by the output-stationary engine never read it);
  * mm_rulebook_csr builds it later from the same table (same workspace size). */
 int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, int32_t* rout, int32_t* offsets,
-                        int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes, mm_stream_t stream);
-int mm_rulebook_csr(const int32_t* nbr, int K, int64_t n_out, int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes,
-                    mm_stream_t stream);
+                        int32_t* csr_off, int32_t* csr_pos, int no_spin, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_rulebook_csr(const int32_t* nbr, int K, int64_t n_out, int32_t* csr_off, int32_t* csr_pos, int no_spin, void* ws,
+                    size_t ws_bytes, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- GPU-side sample preparation (csrc/dataprep.hip)
  * The loader-side numpy code of the reference for a whole batch of scenes, bit-exact with it:
@@ -109,23 +138,30 @@ size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K);
 /* out[dst[r]] (+)= in[src[r]] . W[k(r)] over a k-major rulebook (offsets_host = host copy of offsets[K+1]).
  *   unique_dst != 0: every destination row has exactly one rule (direct writes);
  *   else destinations are reduced through csr_off/csr_pos in ascending k and rows without rules become 0.
- *   weight element (k,ci,co) = W[kk*w_kstride + ci*s_ci + co*s_co], kk = kflip ? K-1-k : k. */
+ *   weight element (k,ci,co) = W[kk*w_kstride + ci*s_ci + co*s_co], kk = kflip ? K-1-k : k.
+ *   mode (fp32 rows): MM_SPCONV_DEFAULT = fp32-faithful three-term split-bf16 products on the matrix-rate-bound widths;
+ *   MM_SPCONV_FP32 = plain fp32 engines everywhere; MM_SPCONV_TWO_TERMS = two terms (faster; fails the gradient parity bar:
+ *   diagnostics only); | MM_SPCONV_DW_NARROW: the weight gradient keeps its <= 4 x 4 channel tiles. */
+#define MM_SPCONV_DEFAULT 0
+#define MM_SPCONV_FP32 1
+#define MM_SPCONV_TWO_TERMS 2
+#define MM_SPCONV_DW_NARROW 4
 int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
                     const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
                     int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
-                    int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, mm_stream_t stream);
+                    int64_t w_kstride, int s_ci, int s_co, int kflip, int mode, void* ws, size_t ws_bytes, mm_stream_t stream);
 /* The same with the weights' three-term bf16 fragments supplied by the caller (Wpk: written by mm_spconv_os_pack /
  * mm_spconv_os_pack_batch for the same K, Cin, Cout, strides and kflip; NULL = pack inside the call): a net packs every
  * layer once per optimiser step in one launch instead of once per layer call. */
 int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
                            const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
                            int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
-                           int64_t w_kstride, int s_ci, int s_co, int kflip, const void* Wpk, void* ws, size_t ws_bytes,
+                           int64_t w_kstride, int s_ci, int s_co, int kflip, const void* Wpk, int mode, void* ws, size_t ws_bytes,
                            mm_stream_t stream);
 size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Cout);
 /* dW[k][ci][co] (+)= sum over rules r of bucket k: in[src[r]][ci] * dout[dst[r]][co] */
 int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_do, int Cout, const int32_t* src,
-                 const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                 const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, int mode, void* ws,
                  size_t ws_bytes, mm_stream_t stream);
 
 /* ---------------------------------------------------------------- output-stationary engine (csrc/ostable.hip, csrc/osconv.hip)
@@ -136,14 +172,12 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
 int mm_up_neighbors(const int32_t* vox_coords_fine, int64_t n_fine, const int32_t* fine2coarse, int32_t* nbr,
                     mm_stream_t stream);
 size_t mm_os_table_ws_bytes(int64_t n, int K);
-/* The sort behind mm_os_table_build: 0 = Onesweep radix sort (default), 1 = merge sort (identical result; its workgroups do not
- * wait for each other, which makes the build safe on a stream that runs beside grid-barrier kernels, see mm_bn2d_set_fused).
- * Returns the previous setting. */
-int mm_os_table_set_sort(int merge);
 /* nbr[K][n] -> dst[npad] (rows sorted by neighbour bitmask, -1 = padding), nbrp[K][npad], tmask[nt];
  * nt = ceil(n / tile_rows), npad = nt * tile_rows, tile_rows a multiple of 64 (the engine takes 64) */
-int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32_t* dst, int32_t* nbrp, uint32_t* tmask,
-                      void* ws, size_t ws_bytes, mm_stream_t stream);
+/* sort_merge: 0 = rocPRIM Onesweep radix sort (default), 1 = merge sort (identical result; its workgroups do not wait for each
+ * other, which makes the build safe on a stream that runs beside grid-barrier kernels, see MM_OPT_BN2D_FUSED) */
+int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int sort_merge, int32_t* dst, int32_t* nbrp,
+                      uint32_t* tmask, void* ws, size_t ws_bytes, mm_stream_t stream);
 /* three-term bf16 MFMA fragments of a weight tensor: element (k,ci,co) = W[kk*w_kstride + ci*s_ci + co*s_co],
  * kk = kflip ? K-1-k : k */
 size_t mm_spconv_os_pack_bytes(int K, int Cin, int Cout);
@@ -171,7 +205,7 @@ int mm_spconv_os_apply_bf16(const void* in, int ld_in, int Cin, void* out, int l
 /* dW[k][ci][co] (+)= sum over the rules of bucket k of in[src][ci] * dout[dst][co]; in / dout bf16 rows, dW fp32;
  * workspace of mm_spconv_dw_ws_bytes */
 int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
-                      const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                      const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, int mode, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
 /* The fp16 kind of the 16-bit activation mode (BASELINE.json configs[4] "fp16 activations"; the reference trains with
  * ``precision: 16`` = fp16 autocast + GradScaler, train.yaml:11): the sparse rows are IEEE fp16, the weights one fp16 term per
@@ -184,7 +218,7 @@ int mm_spconv_os_apply_f16(const void* in, int ld_in, int Cin, void* out, int ld
                            const int32_t* dst, const int32_t* nbrp, const uint32_t* tmask, int64_t n_tiles, int tile_rows,
                            mm_stream_t stream);
 int mm_spconv_dw_f16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
-                     const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                     const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, int mode, void* ws,
                      size_t ws_bytes, mm_stream_t stream);
 /* The weight gradient in two calls: mm_spconv_dw_partial writes the partial slabs of ONE layer (fp32 rows; bf16 rows when
  * bf16 == 1, IEEE fp16 rows when bf16 == 2) into ``partial`` (mm_spconv_dw_ws_bytes; must stay untouched until the reduce) and the 33 slab offsets of the
@@ -194,7 +228,7 @@ int mm_spconv_dw_f16(const void* in, int ld_in, int Cin, const void* dout, int l
  * Bit-identical to mm_spconv_dw (same slabs, same order).  Replaces the per-layer tail of scn's ConvolutionFunction /
  * SubmanifoldConvolutionFunction backward (reference call sites scn_unet.py:43-52,68-77,114). */
 int mm_spconv_dw_partial(int bf16, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
-                         const int32_t* dst, const int32_t* offsets_host, int K, void* partial, size_t partial_bytes,
+                         const int32_t* dst, const int32_t* offsets_host, int K, int mode, void* partial, size_t partial_bytes,
                          int32_t* blk_start_host, mm_stream_t stream);
 int mm_spconv_dw_desc_bytes(void);
 int64_t mm_spconv_dw_reduce_blocks(int ne, int K);
@@ -202,45 +236,40 @@ int mm_spconv_dw_reduce_batch(const void* descs_dev, int n, int64_t total_blocks
 
 /* ---------------------------------------------------------------- batch norm + (leaky) ReLU (csrc/bn.hip)
  * scn.BatchNormReLU / BatchNormLeakyReLU (scn_unet.py:42,44,51,66,73,116); momentum = keep fraction (0.9). */
-/* Row sets that fit on chip take single-launch training kernels (fp32 rows; see mm_bn2d_set_fused for the rules):
- * mask bit 0 = mm_bn_fwd_train, bit 1 = mm_bn_bwd; default 3 or the environment's MM_BN_FUSED.  Returns the previous mask. */
-int mm_bn_set_fused(int mask);
-/* 1 if a single-launch kernel gave up at its grid barrier since the last call (its grid was not co-resident: another process or
- * a spin-waiting kernel of another stream held CUs).  That launch's outputs are invalid; the kernels are switched off for the
- * rest of the process (three-kernel path) and the barrier words re-armed.  A host-memory read when nothing happened. */
-int mm_bn_fused_fault(void);
+/* Row sets that fit on chip take single-launch training kernels (one workgroup per CU, rows kept on chip across two grid
+ * barriers) when the handle allows it: mm_set_option(h, MM_OPT_BN3D_FUSED, mask), bit 0 = forward, bit 1 = backward. */
 size_t mm_bn_ws_bytes(int C);
 /* Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step;
  * train.py:186-292 calls the net once per domain) are normalised with their OWN batch statistics and the running
  * buffers are updated group 0 first, then group 1.  Ns = N (or 0): single batch.  save_mean/save_invstd: [G][C]. */
-int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+int mm_bn_fwd_train(mm_handle_t h, const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
                    const float* running_mean, const float* running_var, float eps, float leak, float* y, int ld_y,
                    mm_stream_t stream);
-int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn_bwd(mm_handle_t h, const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 /* the same three entry points over bf16 rows (16-bit activation mode): x / y / dy / dx bf16 [N, C] (ld in elements),
  * statistics and parameters fp32 */
-int mm_bn_fwd_train_bf16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+int mm_bn_fwd_train_bf16(mm_handle_t h, const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                          float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
                          float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn_fwd_eval_bf16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
                         const float* running_mean, const float* running_var, float eps, float leak, void* y, int ld_y,
                         mm_stream_t stream);
-int mm_bn_bwd_bf16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn_bwd_bf16(mm_handle_t h, const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
                    const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
                    float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 /* ... and over IEEE fp16 rows (the fp16 kind of the 16-bit activation mode: train.yaml:11 ``precision: 16``) */
-int mm_bn_fwd_train_f16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+int mm_bn_fwd_train_f16(mm_handle_t h, const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                         float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
                         float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn_fwd_eval_f16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
                        const float* running_mean, const float* running_var, float eps, float leak, void* y, int ld_y,
                        mm_stream_t stream);
-int mm_bn_bwd_f16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn_bwd_f16(mm_handle_t h, const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
                   const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
                   float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 
@@ -336,16 +365,13 @@ int mm_pack_weights_bf16_batch(const int64_t* desc, int ndesc, int64_t total_blo
 /* ---------------------------------------------------------------- BatchNorm2d (+residual) (+ReLU), NHWC bf16 (csrc/bn2d.hip) */
 size_t mm_bn2d_ws_bytes(int C);
 /* Maps that fit on chip (every map of the headline step but the largest ones) take single-launch training kernels:
- * one workgroup per CU keeps its rows in registers / LDS across two grid barriers, so x (and dy) are read once.
- * mask bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd; default 3, or the environment's MM_BN2D_FUSED; 0 = always the
- * reduce / finalize / apply kernels.  Returns the previous mask.  Use 0 when several PROCESSES share one GPU, and keep
- * bit 1 clear while collectives of another stream overlap the backward pass (see csrc/bn2d.hip). */
-int mm_bn2d_set_fused(int mask);
-int mm_bn2d_fused_fault(void); /* as mm_bn_fused_fault, for the BatchNorm2d kernels */
+ * one workgroup per CU keeps its rows in registers / LDS across two grid barriers, so x (and dy) are read once - when the handle
+ * allows it: mm_set_option(h, MM_OPT_BN2D_FUSED, mask), bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd, 0 = always the
+ * reduce / finalize / apply kernels (see mm_set_option for when). */
 /* Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source / target halves of a jointly
  * batched step; train.py:186-292 calls each net once per domain) and the running buffers are updated group 0 first,
  * then group 1, as two consecutive calls would.  Ns = N (or 0): ordinary single batch.  save_mean/save_invstd: [G][C]. */
-int mm_bn2d_fwd_train(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn2d_fwd_train(mm_handle_t h, const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
@@ -354,7 +380,7 @@ int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t
                      int ld_y, mm_stream_t stream);
 /* yout == NULL with relu != 0 (forward without residual): the ReLU mask is recomputed from x and the saved statistics.
  * dy2 != NULL: the incoming gradient is dy + dy2 (a map with two consumers: residual / concat), summed in the kernel. */
-int mm_bn2d_bwd(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y,
+int mm_bn2d_bwd(mm_handle_t h, const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y,
                 int relu, int64_t N, int64_t Ns, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
                 int ld_dx, void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                 mm_stream_t stream);
@@ -395,8 +421,7 @@ int mm_colsum_f32(const float* x, int ld, int64_t N, int C, float* out, int accu
  * The reference's 2D branch runs under ``precision: 16`` = fp16 autocast + GradScaler (config/run/train.yaml:11).  The kernels of
  * csrc/conv2d.hip, bn2d.hip and misc2d.hip are built a second time with IEEE fp16 as the 16-bit storage format
  * (v_mfma_f32_32x32x16_f16 / v_mfma_f32_16x16x32_f16; csrc/h16.h) and exported under the suffix _f16: same arguments, same
- * semantics, "bf16" in the descriptions above reads "fp16".  The switches and the fault word are per build
- * (mm_bn2d_set_fused_f16, mm_bn2d_fused_fault_f16).  mm_copy_rows_bf16 / mm_concat_bf16 move 2-byte elements and serve both.
+ * semantics, "bf16" in the descriptions above reads "fp16".  One handle serves both builds (same option, same fault word).  mm_copy_rows_bf16 / mm_concat_bf16 move 2-byte elements and serve both.
  * Gradient maps in fp16 need the loss scale of mm2d3d_amd/amp.py (mm_grad_nonfinite ... mm_amp_update below). */
 int mm_conv2d_gemm_f16(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
@@ -411,17 +436,15 @@ int mm_stem_prep_f16(const float* in, int B, int C, int H, int W, int pad, int H
 int mm_pack_weights_f16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st,
                          int64_t sk, mm_stream_t stream);
 int mm_pack_weights_f16_batch(const int64_t* desc, int ndesc, int64_t total_blocks, mm_stream_t stream);
-int mm_bn2d_fused_fault_f16(void);
-int mm_bn2d_set_fused_f16(int mask);
 size_t mm_bn2d_ws_bytes_f16(int C);
-int mm_bn2d_fwd_train_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn2d_fwd_train_f16(mm_handle_t h, const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);
-int mm_bn2d_bwd_f16(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y,
+int mm_bn2d_bwd_f16(mm_handle_t h, const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y,
                 int relu, int64_t N, int64_t Ns, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
                 int ld_dx, void* dres, int ld_dr, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes,
                 mm_stream_t stream);

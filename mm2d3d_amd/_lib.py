@@ -23,28 +23,34 @@ vp, i32, i64, sz, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t, C.c_f
 # name -> (restype, argtypes); mirrors include/mm2d3d.h
 _PROTOS = {
     "mm_last_error": (C.c_char_p, []),
+    "mm_handle_sync_bytes": (sz, []),
+    "mm_handle_fault_bytes": (sz, []),
+    "mm_create": (i32, [i32, vp, sz, vp, sz, C.POINTER(vp)]),
+    "mm_destroy": (i32, [vp]),
+    "mm_set_option": (i32, [vp, i32, i32]),
+    "mm_get_option": (i32, [vp, i32]),
+    "mm_fault_poll": (i32, [vp]),
     "mm_hash_capacity": (i64, [i64]),
     "mm_dedupe_ws_bytes": (sz, [i64]),
-    "mm_voxel_dedupe": (i32, [vp, i32, i64, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_voxel_dedupe": (i32, [vp, i32, i64, vp, i32, vp, vp, i64, vp, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
     "mm_batch_lower_bound": (i32, [vp, vp, i32, vp, vp]),
     "mm_subm_neighbors": (i32, [vp, i64, i32, vp, vp, i64, vp, vp]),
     "mm_down_neighbors": (i32, [vp, i64, vp, i64, vp, vp]),
     "mm_rulebook_ws_bytes": (sz, [i64, i32]),
-    "mm_rulebook_compact": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "mm_rulebook_csr": (i32, [vp, i32, i64, vp, vp, vp, sz, vp]),
+    "mm_rulebook_compact": (i32, [vp, i32, i64, vp, vp, vp, vp, vp, i32, vp, sz, vp]),
+    "mm_rulebook_csr": (i32, [vp, i32, i64, vp, vp, i32, vp, sz, vp]),
     "mm_spconv_ws_bytes": (sz, [i64, i32, i32, i32]),
-    "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, sz, vp]),
-    "mm_spconv_apply_packed": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, vp, sz, vp]),
+    "mm_spconv_apply": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, i32, vp, sz, vp]),
+    "mm_spconv_apply_packed": (i32, [vp, i32, i32, vp, i32, i32, i64, vp, vp, vp, vp, i32, vp, vp, i32, vp, i64, i32, i32, i32, vp, i32, vp, sz, vp]),
     "mm_spconv_dw_ws_bytes": (sz, [vp, i32, i32, i32]),
-    "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_spconv_dw": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp, sz, vp]),
     "mm_voxelize_ws_bytes": (sz, [i64, i32]),
     "mm_voxelize_batch": (i32, [vp, vp, vp, i32, vp, vp, i32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "mm_project_batch": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "mm_collect_points": (i32, [vp, vp, i64, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
     "mm_up_neighbors": (i32, [vp, i64, vp, vp, vp]),
     "mm_os_table_ws_bytes": (sz, [i64, i32]),
-    "mm_os_table_set_sort": (i32, [i32]),
-    "mm_os_table_build": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, sz, vp]),
+    "mm_os_table_build": (i32, [vp, i32, i64, i32, i32, vp, vp, vp, vp, sz, vp]),
     "mm_spconv_os_pack_bytes": (sz, [i32, i32, i32]),
     "mm_spconv_os_pack_blocks": (i64, [i32, i32, i32]),
     "mm_spconv_os_pack_desc_fields": (i32, []),
@@ -55,25 +61,25 @@ _PROTOS = {
     "mm_spconv_os_pack_bf16": (i32, [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_spconv_os_pack_batch_bf16": (i32, [vp, i32, i64, vp]),
     "mm_spconv_os_apply_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp]),
-    "mm_spconv_dw_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
+    "mm_spconv_dw_bf16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp, sz, vp]),
     "mm_spconv_os_pack_f16": (i32, [vp, i64, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_spconv_os_pack_batch_f16": (i32, [vp, i32, i64, vp]),
     "mm_spconv_os_apply_f16": (i32, [vp, i32, i32, vp, i32, i32, vp, i32, vp, vp, vp, i64, i32, vp]),
-    "mm_spconv_dw_f16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, sz, vp]),
-    "mm_spconv_dw_partial": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, sz, vp, vp]),
+    "mm_spconv_dw_f16": (i32, [vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp, sz, vp]),
+    "mm_spconv_dw_partial": (i32, [i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, i32, vp, sz, vp, vp]),
     "mm_spconv_dw_desc_bytes": (i32, []),
     "mm_spconv_dw_reduce_blocks": (i64, [i32, i32]),
     "mm_spconv_dw_reduce_batch": (i32, [vp, i32, i64, vp]),
-    "mm_bn_fwd_train_bf16": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn_fwd_train_bf16": (i32, [vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval_bf16": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
-    "mm_bn_bwd_bf16": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
-    "mm_bn_fwd_train_f16": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn_bwd_bf16": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn_fwd_train_f16": (i32, [vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval_f16": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
-    "mm_bn_bwd_f16": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn_bwd_f16": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_bn_ws_bytes": (sz, [i32]),
-    "mm_bn_fwd_train": (i32, [vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn_fwd_train": (i32, [vp, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, f32, f32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn_fwd_eval": (i32, [vp, i32, i64, i32, vp, vp, vp, vp, f32, f32, vp, i32, vp]),
-    "mm_bn_bwd": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn_bwd": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, f32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_point_ws_bytes": (sz, [i32, i32]),
     "mm_gate_fwd": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "mm_gate_bwd": (i32, [vp, vp, vp, i64, i32, vp, vp, vp, vp, i32, vp, sz, vp]),
@@ -111,13 +117,9 @@ _PROTOS = {
     "mm_pack_weights_bf16_batch": (i32, [vp, i32, i64, vp]),
     "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_bn2d_ws_bytes": (sz, [i32]),
-    "mm_bn2d_set_fused": (i32, [i32]),
-    "mm_bn_set_fused": (i32, [i32]),
-    "mm_bn_fused_fault": (i32, []),
-    "mm_bn2d_fused_fault": (i32, []),
-    "mm_bn2d_fwd_train": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn2d_fwd_train": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
-    "mm_bn2d_bwd": (i32, [vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),
+    "mm_bn2d_bwd": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_colsum_bf16": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
     "mm_copy_rows_bf16": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "mm_concat_bf16": (i32, [vp, vp, i32, vp, i64, i32, vp]),
@@ -142,8 +144,6 @@ H16_2D = {
     "mm_stem_prep": "mm_stem_prep_f16",
     "mm_pack_weights_bf16": "mm_pack_weights_f16",
     "mm_pack_weights_bf16_batch": "mm_pack_weights_f16_batch",
-    "mm_bn2d_fused_fault": "mm_bn2d_fused_fault_f16",
-    "mm_bn2d_set_fused": "mm_bn2d_set_fused_f16",
     "mm_bn2d_ws_bytes": "mm_bn2d_ws_bytes_f16",
     "mm_bn2d_fwd_train": "mm_bn2d_fwd_train_f16",
     "mm_bn2d_fwd_eval": "mm_bn2d_fwd_eval_f16",
@@ -183,17 +183,123 @@ def lib():
     return _lib
 
 
-def bn2d_set_fused(mask: int) -> int:
-    """mm_bn2d_set_fused for BOTH builds of csrc/bn2d.hip (bf16 and IEEE fp16 storage keep separate switches); returns the previous
-    mask of the bf16 build (the two are always set together through this function)."""
-    l = lib()
-    l.mm_bn2d_set_fused_f16(mask)
-    return int(l.mm_bn2d_set_fused(mask))
+# ---------------------------------------------------------------------------------------------- per-device handles
+# include/mm2d3d.h: the library keeps no process-wide state; what outlives a call (the grid-barrier words and the fault word of
+# the single-launch batch norms, their switches) lives in a handle over memory supplied from here.  The environment variables
+# that used to be read inside the library are read HERE, once, and passed on explicitly.
+OPT_BN2D_FUSED, OPT_BN3D_FUSED = 0, 1
+SPCONV_DEFAULT, SPCONV_FP32, SPCONV_TWO_TERMS, SPCONV_DW_NARROW = 0, 1, 2, 4
 
 
-def bn2d_fused_fault() -> int:
-    l = lib()
-    return int(l.mm_bn2d_fused_fault()) | int(l.mm_bn2d_fused_fault_f16())
+def _env_int(name, default):
+    v = os.environ.get(name)
+    try:
+        return int(v) if v not in (None, "") else default
+    except ValueError:
+        return default
+
+
+def spconv_mode_from_env():
+    """mode argument of the fp32 sparse engines (MM_SPCONV_FP32 / MM_SPCONV_SPLIT=2 / MM_DW_WIDE=0: diagnostics)."""
+    mode = SPCONV_FP32 if os.environ.get("MM_SPCONV_FP32") else (SPCONV_TWO_TERMS if _env_int("MM_SPCONV_SPLIT", 3) == 2 else SPCONV_DEFAULT)
+    if _env_int("MM_DW_WIDE", 1) == 0:
+        mode |= SPCONV_DW_NARROW
+    return mode
+
+
+class Handle:
+    """mm_create over torch-allocated memory: zero-filled barrier words on the device, a pinned (device-mapped) fault word.
+    ``bn2d_fused`` / ``bn3d_fused``: bit 0 = forward, bit 1 = backward single-launch kernels (default: MM_BN2D_FUSED /
+    MM_BN_FUSED of the environment, else 3)."""
+
+    def __init__(self, device=None, bn2d_fused=None, bn3d_fused=None):
+        L = lib()
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("mm2d3d_amd: a handle belongs to a GPU (HIP path only, no CPU fallback)")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
+        self._sync = torch.zeros(int(L.mm_handle_sync_bytes()), dtype=torch.uint8, device=dev)
+        self._fault = torch.zeros(int(L.mm_handle_fault_bytes()), dtype=torch.uint8).pin_memory()
+        torch.cuda.synchronize(dev)  # the zero fill has run before any kernel of any stream meets at these words
+        out = vp()
+        check(L.mm_create(dev.index, self._sync.data_ptr(), self._sync.numel(), self._fault.data_ptr(), self._fault.numel(),
+                          C.byref(out)), "mm_create")
+        self.h = out.value
+        self.set(OPT_BN2D_FUSED, _env_int("MM_BN2D_FUSED", 3) if bn2d_fused is None else bn2d_fused)
+        self.set(OPT_BN3D_FUSED, _env_int("MM_BN_FUSED", 3) if bn3d_fused is None else bn3d_fused)
+
+    def set(self, option, value):
+        """Returns the previous value."""
+        prev = int(lib().mm_set_option(self.h, option, int(value)))
+        if prev < 0:
+            check(prev, "mm_set_option")
+        return prev
+
+    def get(self, option):
+        return int(lib().mm_get_option(self.h, option))
+
+    def fault_poll(self):
+        return int(lib().mm_fault_poll(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_HANDLES = {}
+_HANDLE_STACK = []
+
+
+def handle(device=None):
+    """The handle operators launch through: the innermost ``use()`` handle of the device, else the device's default handle."""
+    idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    for h in reversed(_HANDLE_STACK):
+        if h.device.index == idx:
+            return h
+    h = _DEFAULT_HANDLES.get(idx)
+    if h is None:
+        h = _DEFAULT_HANDLES[idx] = Handle(torch.device("cuda", idx))
+    return h
+
+
+@contextlib.contextmanager
+def use(h):
+    """Operators of ``h``'s device launch through ``h`` inside this context (a trainer with its own switches)."""
+    _HANDLE_STACK.append(h)
+    try:
+        yield h
+    finally:
+        _HANDLE_STACK.remove(h)
+
+
+def bn2d_set_fused(mask: int, device=None) -> int:
+    """Single-launch BatchNorm2d kernels of the CURRENT handle (bit 0 forward, bit 1 backward); returns the previous mask."""
+    return handle(device).set(OPT_BN2D_FUSED, mask)
+
+
+def bn3d_set_fused(mask: int, device=None) -> int:
+    return handle(device).set(OPT_BN3D_FUSED, mask)
+
+
+def fault_poll(device=None) -> int:
+    """1 if a single-launch batch-norm kernel of the current handle gave up at its grid barrier since the last call."""
+    idx = torch.cuda.current_device() if device is None or torch.device(device).index is None else torch.device(device).index
+    hs = [h for h in _HANDLE_STACK if h.device.index == idx]
+    if idx in _DEFAULT_HANDLES:
+        hs.append(_DEFAULT_HANDLES[idx])
+    bad = 0
+    for h in hs:
+        bad |= h.fault_poll()
+    return bad
 
 
 def exported_symbols():

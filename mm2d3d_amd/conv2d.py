@@ -207,8 +207,12 @@ class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w, b, stride, padding), square kernel, Cin and Cout multiples of 64."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding):
+    def forward(ctx, x, weight, bias, stride, padding, handoff=None):
+        """``handoff``: the input map has ANOTHER consumer whose backward delivers the main gradient to the map's producer (a
+        BasicBlock input read by conv1 and by the 1x1 downsample, backbones.py layer2-4.0): this layer's data gradient is then
+        left in the producer's slot (nn2d.GradHandoff) instead of being summed by an autograd add kernel."""
         _lib.require_cuda(x, "x")
+        ctx.handoff = handoff
         x, ldx = nhwc_pitch(x)
         Bn, Cin, H, W = x.shape
         Cout, _, KH, KW = weight.shape
@@ -265,7 +269,10 @@ class Conv2dFn(torch.autograd.Function):
                 _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T, ldx=ldx, ldy=ldy)
         if has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(as_nhwc_bf16(dy))
-        return dx, dw, db, None, None
+        if ctx.handoff is not None and dx is not None:  # the producer's backward kernels add it (fp32) to the other consumer's
+            ctx.handoff.extra.append(dx)
+            dx = None
+        return dx, dw, db, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):

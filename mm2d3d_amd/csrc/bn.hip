@@ -348,6 +348,7 @@ struct Fused3P {
   int accumulate;
   double* partial;
   unsigned* sync;
+  unsigned* fault;
 };
 
 __device__ inline FusedBuf fused_buf32(const void* base, int64_t N, int ld, int C, int slot, int cv) {
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(FT) void k_bn_fused_fwd(const Fused3P p) {
   fused_block_sums<4>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
   for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
-  fused_barrier(p.sync, (unsigned)G, flag0);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0);
   {
     const int ngrp = p.G1 > 0 ? 2 : 1;
     for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(FT) void k_bn_fused_fwd(const Fused3P p) {
       }
     }
   }
-  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0 + 1u);
   if (!g.active) return;
   const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
 #pragma unroll
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(FT) void k_bn_fused_bwd(const Fused3P p) {
   fused_block_sums<4>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
   for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
-  fused_barrier(p.sync, (unsigned)G, flag0);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0);
   {
     const int ngrp = p.G1 > 0 ? 2 : 1;
     for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
@@ -539,7 +540,7 @@ __global__ __launch_bounds__(FT) void k_bn_fused_bwd(const Fused3P p) {
       }
     }
   }
-  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0 + 1u);
   if (!g.active) return;
 #pragma unroll
   for (int k = 0; k < RMAX; k++) asm volatile("" : "+v"(xr[k]));
@@ -606,13 +607,13 @@ static const void* const k_fused3_fns[] = {(const void*)k_bn_fused_fwd<8>,  (con
                                            (const void*)k_bn_fused_bwd<8>,  (const void*)k_bn_fused_bwd<20>, (const void*)k_bn_fused_bwd<36>};
 
 // true: launched.  fp32 rows with 16-byte pieces only; maps too large for the chip fall through to the three-kernel path
-static int bn_fused_try(bool backward, Fused3P& p, int64_t ldmax, hipStream_t s, bool* done) {
+static int bn_fused_try(MMHandle* H, bool backward, Fused3P& p, int64_t ldmax, hipStream_t s, bool* done) {
   *done = false;
   if (p.C % 4 != 0 || (p.ld_x % 4) || p.N * ldmax * 4 >= (1ll << 31)) return MM_OK;
   FusedPlan pl;
-  int rc = fused_plan(p.N, p.Ns, p.C, 4, 36, backward, "MM_BN_FUSED", k_fused3_fns, 6, s, &pl);
+  int rc = fused_plan(H, MM_OPT_BN3D_FUSED, 0, p.N, p.Ns, p.C, 4, 36, backward, k_fused3_fns, 6, s, &pl);
   if (rc || !pl.ok) return rc;
-  p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R, p.sync = pl.sync;
+  p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R, p.sync = pl.sync, p.fault = pl.fault;
   const dim3 grid(pl.G0 + pl.G1), blk(FT);
   if (!backward) {
     if (pl.R <= 8) hipLaunchKernelGGL(k_bn_fused_fwd<8>, grid, blk, FUSED_LDS, s, p);
@@ -647,7 +648,7 @@ static void split_blocks(int64_t N, int64_t& Ns, int C, int VEC, bool stats, int
 // Ns: rows [0,Ns) and [Ns,N) (the active sites of the source and of the target scenes of a jointly batched step) are
 // normalised with their OWN statistics; Ns = N (or 0): ordinary single batch.  save_mean / save_invstd: [G][C].
 template <typename E>
-static int bn_fwd_train(const E* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+static int bn_fwd_train(MMHandle* H, const E* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float eps, float momentum, float leak, E* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C > 0 && C <= 4 * T && ld_x >= C && ld_y >= C, "bn_fwd: bad shape C=%d", C);
@@ -665,7 +666,7 @@ static int bn_fwd_train(const E* x, int ld_x, int64_t N, int64_t Ns, int C, cons
       p.weight = weight, p.bias = bias, p.running_mean = running_mean, p.running_var = running_var;
       p.eps = eps, p.momentum = momentum, p.leak = leak, p.save_mean = save_mean, p.save_invstd = save_invstd, p.partial = partial;
       bool done;
-      int rc = bn_fused_try(false, p, std::max(ld_x, ld_y), s, &done);
+      int rc = bn_fused_try(H, false, p, std::max(ld_x, ld_y), s, &done);
       if (rc || done) return rc;
     }
   }
@@ -712,7 +713,7 @@ static int bn_fwd_eval(const E* x, int ld_x, int64_t N, int C, const float* weig
 
 // training backward; dweight/dbias may be null; accumulate != 0 adds into them; Ns and [G][C] statistics as in the forward
 template <typename E>
-static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+static int bn_bwd(MMHandle* H, const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, E* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(C > 0 && C <= 4 * T && ld_x >= C && ld_dy >= C && ld_dx >= C, "bn_bwd: bad shape");
@@ -734,7 +735,7 @@ static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64
       p.save_mean = (float*)save_mean, p.save_invstd = (float*)save_invstd, p.sums = sums, p.dweight = dweight, p.dbias = dbias;
       p.accumulate = accumulate, p.partial = partial;
       bool done;
-      int rc = bn_fused_try(true, p, std::max(std::max(ld_x, ld_dy), ld_dx), s, &done);
+      int rc = bn_fused_try(H, true, p, std::max(std::max(ld_x, ld_dy), ld_dx), s, &done);
       if (rc || done) return rc;
     }
   }
@@ -762,23 +763,16 @@ static int bn_bwd(const E* x, int ld_x, const E* dy, int ld_dy, int64_t N, int64
 
 extern "C" {
 
-// Single-launch training kernels of the fp32 row path: bit 0 = mm_bn_fwd_train, bit 1 = mm_bn_bwd (default 3, or the
-// environment variable MM_BN_FUSED); returns the previous mask.  Same residency rules as mm_bn2d_set_fused.
-int mm_bn_fused_fault(void) { return fused_fault_poll(); }
-
-int mm_bn_set_fused(int mask) {
-  const int prev = fused_mask("MM_BN_FUSED");
-  g_fused_enabled = mask & 3;
-  return prev;
-}
-
+// Which path runs (single-launch grid-barrier kernels or reduce / finalize / apply) is the HANDLE's choice:
+// mm_set_option(h, MM_OPT_BN3D_FUSED, mask), bit 0 = forward, bit 1 = backward.  Same residency rules as the 2D kernels.
 size_t mm_bn_ws_bytes(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 
 
-int mm_bn_fwd_train(const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+int mm_bn_fwd_train(void* h, const float* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                     float* running_mean, float* running_var, float eps, float momentum, float leak, float* y, int ld_y,
                     float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
-  return bn_fwd_train<float>(x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak, y, ld_y, save_mean,
+  MM_CHECK_HANDLE(h);
+  return bn_fwd_train<float>(H, x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak, y, ld_y, save_mean,
                              save_invstd, ws, ws_bytes, s);
 }
 int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
@@ -786,18 +780,20 @@ int mm_bn_fwd_eval(const float* x, int ld_x, int64_t N, int C, const float* weig
                    hipStream_t s) {
   return bn_fwd_eval<float>(x, ld_x, N, C, weight, bias, running_mean, running_var, eps, leak, y, ld_y, s);
 }
-int mm_bn_bwd(const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn_bwd(void* h, const float* x, int ld_x, const float* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
               const float* bias, const float* save_mean, const float* save_invstd, float leak, float* dx, int ld_dx,
               float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
-  return bn_bwd<float>(x, ld_x, dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak, dx, ld_dx, dweight, dbias,
+  MM_CHECK_HANDLE(h);
+  return bn_bwd<float>(H, x, ld_x, dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak, dx, ld_dx, dweight, dbias,
                        accumulate, ws, ws_bytes, s);
 }
 // the same three entry points over bf16 rows (16-bit activation mode): x / y / dy / dx are bf16 [N, C], statistics and
 // parameters stay fp32
-int mm_bn_fwd_train_bf16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+int mm_bn_fwd_train_bf16(void* h, const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                          float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
                          float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
-  return bn_fwd_train<__bf16>((const __bf16*)x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak,
+  MM_CHECK_HANDLE(h);
+  return bn_fwd_train<__bf16>(H, (const __bf16*)x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak,
                               (__bf16*)y, ld_y, save_mean, save_invstd, ws, ws_bytes, s);
 }
 int mm_bn_fwd_eval_bf16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
@@ -805,18 +801,20 @@ int mm_bn_fwd_eval_bf16(const void* x, int ld_x, int64_t N, int C, const float* 
                         hipStream_t s) {
   return bn_fwd_eval<__bf16>((const __bf16*)x, ld_x, N, C, weight, bias, running_mean, running_var, eps, leak, (__bf16*)y, ld_y, s);
 }
-int mm_bn_bwd_bf16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn_bwd_bf16(void* h, const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
                    const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
                    float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
-  return bn_bwd<__bf16>((const __bf16*)x, ld_x, (const __bf16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
+  MM_CHECK_HANDLE(h);
+  return bn_bwd<__bf16>(H, (const __bf16*)x, ld_x, (const __bf16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
                         (__bf16*)dx, ld_dx, dweight, dbias, accumulate, ws, ws_bytes, s);
 }
 
 // ... and over IEEE fp16 rows
-int mm_bn_fwd_train_f16(const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
+int mm_bn_fwd_train_f16(void* h, const void* x, int ld_x, int64_t N, int64_t Ns, int C, const float* weight, const float* bias,
                         float* running_mean, float* running_var, float eps, float momentum, float leak, void* y, int ld_y,
                         float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, hipStream_t s) {
-  return bn_fwd_train<_Float16>((const _Float16*)x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak,
+  MM_CHECK_HANDLE(h);
+  return bn_fwd_train<_Float16>(H, (const _Float16*)x, ld_x, N, Ns, C, weight, bias, running_mean, running_var, eps, momentum, leak,
                                 (_Float16*)y, ld_y, save_mean, save_invstd, ws, ws_bytes, s);
 }
 int mm_bn_fwd_eval_f16(const void* x, int ld_x, int64_t N, int C, const float* weight, const float* bias,
@@ -824,10 +822,11 @@ int mm_bn_fwd_eval_f16(const void* x, int ld_x, int64_t N, int C, const float* w
                        hipStream_t s) {
   return bn_fwd_eval<_Float16>((const _Float16*)x, ld_x, N, C, weight, bias, running_mean, running_var, eps, leak, (_Float16*)y, ld_y, s);
 }
-int mm_bn_bwd_f16(const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
+int mm_bn_bwd_f16(void* h, const void* x, int ld_x, const void* dy, int ld_dy, int64_t N, int64_t Ns, int C, const float* weight,
                   const float* bias, const float* save_mean, const float* save_invstd, float leak, void* dx, int ld_dx,
                   float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
-  return bn_bwd<_Float16>((const _Float16*)x, ld_x, (const _Float16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
+  MM_CHECK_HANDLE(h);
+  return bn_bwd<_Float16>(H, (const _Float16*)x, ld_x, (const _Float16*)dy, ld_dy, N, Ns, C, weight, bias, save_mean, save_invstd, leak,
                           (_Float16*)dx, ld_dx, dweight, dbias, accumulate, ws, ws_bytes, s);
 }
 

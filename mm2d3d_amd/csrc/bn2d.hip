@@ -374,6 +374,7 @@ struct FusedP {
   int accumulate;
   double* partial;  // [G0+G1][2][C]
   unsigned* sync;   // arrival counter at [0], release word at [FUSED_FLAG]
+  unsigned* fault;  // the handle's fault word (device address of pinned host memory)
 };
 
 template <int RMAX, bool RES>
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
   fused_block_sums<8>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
   for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
-  fused_barrier(p.sync, (unsigned)G, flag0);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0);
   {
     // statistics: one wave per channel, channels dealt round-robin over the workgroups; both groups by the same wave, the
     // running buffers updated group 0 first, then group 1 (what two consecutive forward calls do)
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
       }
     }
   }
-  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0 + 1u);
   if (!g.active) return;
   const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
   // the kept rows stay PACKED across the barrier: without this the compiler keeps the phase-1 unpacked floats alive instead
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
   fused_block_sums<8>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
   for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
-  fused_barrier(p.sync, (unsigned)G, flag0);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0);
   {
     const int ngrp = p.G1 > 0 ? 2 : 1;
     for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
       }
     }
   }
-  fused_barrier(p.sync, (unsigned)G, flag0 + 1u);
+  fused_barrier(p.sync, p.fault, (unsigned)G, flag0 + 1u);
   if (!g.active) return;
 #pragma unroll
   for (int k = 0; k < RMAX; k++) asm volatile("" : "+v"(xr[k]));  // keep the rows packed across the barrier (see the forward kernel)
@@ -684,15 +685,13 @@ constexpr int k_fused_nfns = (int)(sizeof(k_fused_fns) / sizeof(k_fused_fns[0]))
 
 extern "C" {
 
-// Selects the single-launch training kernels per direction: bit 0 = mm_bn2d_fwd_train, bit 1 = mm_bn2d_bwd (default 3, or the
-// value of the environment variable MM_BN2D_FUSED); 0 = always the reduce / finalize / apply kernels.  Returns the previous mask.
-int MM_SYM(mm_bn2d_fused_fault)(void) { return fused_fault_poll(); }
-
-int MM_SYM(mm_bn2d_set_fused)(int mask) {
-  const int prev = fused_mask("MM_BN2D_FUSED");
-  g_fused_enabled = mask & 3;
-  return prev;
-}
+// Which path runs is the HANDLE's choice (mm_set_option(h, MM_OPT_BN2D_FUSED, mask): bit 0 = mm_bn2d_fwd_train, bit 1 =
+// mm_bn2d_bwd single-launch; 0 = always the reduce / finalize / apply kernels) - no process-wide switch.
+#ifdef MM_ACT_FP16
+constexpr int BN2D_UNIT = 2;
+#else
+constexpr int BN2D_UNIT = 1;
+#endif
 
 size_t MM_SYM(mm_bn2d_ws_bytes)(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
 
@@ -716,10 +715,11 @@ static void split_blocks(int64_t N, int64_t& Ns, int C, bool stats, int& b0, int
 // Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source and target halves of a jointly
 // batched step, train.py:186-292 calls the net once per domain); Ns = N (or 0) is the ordinary single-batch case.
 // save_mean / save_invstd: fp32 [G][C], G = 2 when split.
-int MM_SYM(mm_bn2d_fwd_train)(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+int MM_SYM(mm_bn2d_fwd_train)(void* h, const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                       hipStream_t s) {
+  MM_CHECK_HANDLE(h);
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_y % 8 == 0, "bn2d: C must be a multiple of 8, <= 2048");
   if (ws_bytes < (size_t)MAX_PART * 2 * C * sizeof(double)) {
     mm_set_error("bn2d: workspace too small");
@@ -729,7 +729,7 @@ int MM_SYM(mm_bn2d_fwd_train)(const void* x, int ld_x, const void* res, int ld_r
   int nb0, nb1, ab0, ab1;
   if (Ns <= 0 || Ns >= N) Ns = N;
   FusedPlan pl;
-  int rc = fused_plan(N, Ns, C, 8, 36, false, "MM_BN2D_FUSED", k_fused_fns, k_fused_nfns, s, &pl);
+  int rc = fused_plan(H, MM_OPT_BN2D_FUSED, BN2D_UNIT, N, Ns, C, 8, 36, false, k_fused_fns, k_fused_nfns, s, &pl);
   if (rc) return rc;
   const int64_t ldmax_f = std::max(std::max(ld_x, ld_y), res ? ld_r : 0);
   if (pl.ok && (!res || ld_r % 8 == 0) && N * ldmax_f * 2 < (1ll << 31)) {  // 32-bit buffer offsets
@@ -739,7 +739,7 @@ int MM_SYM(mm_bn2d_fwd_train)(const void* x, int ld_x, const void* res, int ld_r
     p.N = N, p.Ns = Ns, p.C = C, p.relu = relu, p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R;
     p.weight = weight, p.bias = bias, p.running_mean = running_mean, p.running_var = running_var, p.nbt = num_batches_tracked;
     p.eps = eps, p.momentum = momentum, p.save_mean = save_mean, p.save_invstd = save_invstd;
-    p.partial = partial, p.sync = pl.sync;
+    p.partial = partial, p.sync = pl.sync, p.fault = pl.fault;
     const dim3 grid(pl.G0 + pl.G1), blk(FT);
 #define MM_FWD(RM)                                                                                  \
   do {                                                                                              \
@@ -782,10 +782,11 @@ int MM_SYM(mm_bn2d_fwd_eval)(const void* x, int ld_x, const void* res, int ld_r,
 // dy2 != NULL: the incoming gradient is dy + dy2 (the map had two consumers; summed here in fp32 instead of by an add kernel).
 // yout == NULL with relu != 0 (only valid when the forward had no residual input): the ReLU mask is recomputed from x,
 // weight, bias and the saved statistics instead of reading the output map.
-int MM_SYM(mm_bn2d_bwd)(const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y, int relu,
+int MM_SYM(mm_bn2d_bwd)(void* h, const void* x, int ld_x, const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* yout, int ld_y, int relu,
                 int64_t N, int64_t Ns, int C,
                 const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx, int ld_dx, void* dres, int ld_dr,
                 float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_HANDLE(h);
   MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T, "bn2d: C must be a multiple of 8, <= 2048");
   size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
   if (ws_bytes < need + 4 * C * sizeof(float)) {
@@ -797,7 +798,7 @@ int MM_SYM(mm_bn2d_bwd)(const void* x, int ld_x, const void* dy, int ld_dy, cons
   int nb0, nb1, ab0, ab1;
   if (Ns <= 0 || Ns >= N) Ns = N;
   FusedPlan pl;
-  int rc = fused_plan(N, Ns, C, 8, 36, true, "MM_BN2D_FUSED", k_fused_fns, k_fused_nfns, s, &pl);
+  int rc = fused_plan(H, MM_OPT_BN2D_FUSED, BN2D_UNIT, N, Ns, C, 8, 36, true, k_fused_fns, k_fused_nfns, s, &pl);
   if (rc) return rc;
   const int64_t ldmax_b = std::max(std::max(std::max(ld_x, ld_dy), std::max(ld_dx, dy2 ? ld_dy2 : 0)), std::max(yout ? ld_y : 0, dres ? ld_dr : 0));
   if (pl.ok && ld_x % 8 == 0 && ld_dy % 8 == 0 && ld_dx % 8 == 0 && (!dy2 || ld_dy2 % 8 == 0) && (!yout || ld_y % 8 == 0) &&
@@ -808,7 +809,7 @@ int MM_SYM(mm_bn2d_bwd)(const void* x, int ld_x, const void* dy, int ld_dy, cons
     p.N = N, p.Ns = Ns, p.C = C, p.relu = relu, p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R;
     p.weight = weight, p.bias = bias, p.save_mean = (float*)save_mean, p.save_invstd = (float*)save_invstd;
     p.sums = sums, p.dweight = dweight, p.dbias = dbias, p.accumulate = accumulate;
-    p.partial = partial, p.sync = pl.sync;
+    p.partial = partial, p.sync = pl.sync, p.fault = pl.fault;
     const dim3 grid(pl.G0 + pl.G1), blk(FT);
     const int mask = !relu ? 0 : (yout ? 2 : 1);
 #define MM_BWD(RM, D2)                                                                                        \

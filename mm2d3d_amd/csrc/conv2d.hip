@@ -46,6 +46,33 @@ struct ConvP {
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
 
+// ---- output rows from MFMA accumulators (gfx950 lane swaps).  The convolution kernels run the MFMA as W x X^T, so a lane holds,
+// per 32-cout fragment, 16 values of ONE pixel (column fr_ = lane & 31): rows (r & 3) + 8 (r >> 2) + 4 fh, i.e. four 8-byte
+// pieces per lane, and the two lanes of a pixel (fh = 0, 1) interleave them.  Stored as they stand that is 4 instructions of
+// 32 x 16-byte segments (what the round-1..3 epilogues did: measured 0.15 us of every 0.8 us (segment, tap) step of k_conv3x3w,
+// tools/conv3x3_diag.hip).  Two swaps make the rows whole first:
+//   v_permlane32_swap(D[q], D[q+1])   lanes 0-31 then hold the 16 contiguous bytes "chunk q" of their pixel, lanes 32-63 chunk q+1;
+//   v_permlane16_swap(X01, X23)       rows of 16 lanes: X01 = [px 0-15 chunk 0 | chunk 2 | chunk 1 | chunk 3], X23 the same for px 16-31;
+// -> 2 instructions of 16 x 64-byte segments per fragment.  D[q][w] = the packed pairs (acc[4q + 2w], acc[4q + 2w + 1]).
+// Afterwards lane L stores xa at pixel (L & 15) and xb at pixel 16 + (L & 15) of the fragment, both at channel 8 * frag_chunk(L).
+__device__ inline int frag_chunk(int lane) { return ((lane >> 4) & 1) * 2 + (lane >> 5); }  // rows of 16 lanes -> chunks 0, 2, 1, 3
+__device__ inline void frag_rows(unsigned (&D)[4][2], uint4& xa, uint4& xb) {
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    const auto r01 = __builtin_amdgcn_permlane32_swap(D[0][w], D[1][w], false, false);
+    const auto r23 = __builtin_amdgcn_permlane32_swap(D[2][w], D[3][w], false, false);
+    D[0][w] = r01[0], D[1][w] = r01[1], D[2][w] = r23[0], D[3][w] = r23[1];
+  }
+  // X01 = (D[0][0], D[0][1], D[1][0], D[1][1]), X23 = (D[2][0], D[2][1], D[3][0], D[3][1])
+  const auto s0 = __builtin_amdgcn_permlane16_swap(D[0][0], D[2][0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(D[0][1], D[2][1], false, false);
+  const auto s2 = __builtin_amdgcn_permlane16_swap(D[1][0], D[3][0], false, false);
+  const auto s3 = __builtin_amdgcn_permlane16_swap(D[1][1], D[3][1], false, false);
+  xa = make_uint4(s0[0], s1[0], s2[0], s3[0]);
+  xb = make_uint4(s0[1], s1[1], s2[1], s3[1]);
+}
+
+
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
@@ -196,6 +223,52 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
   // pixel row wm*64 + i*32 + fr_: a lane holds runs of 4 consecutive channels of ONE pixel -> one pixel map per tile half
   // and 8-byte (bf16) / 16-byte (fp32) stores instead of 2-byte ones.
   const bool vec = !(p.Cn & 3) && !(p.ldo & 3) && !((uintptr_t)p.O & (p.out_f32 ? 15 : 7)) && !((uintptr_t)p.bias & 15);
+  if (!p.out_f32 && vec && !(p.Cn & 7) && !(p.ldo & 7) && !((uintptr_t)p.O & 15)) {
+    // 16-bit output: whole 64-byte rows (frag_rows above) - lane L stores, per 32-channel fragment, 16 bytes of GEMM row
+    // (L & 15) and of row 16 + (L & 15) of each 32-row block at channel chunk frag_chunk(L)
+    const int schunk = frag_chunk(lane);
+    auto out_row = [&](int64_t m) -> int64_t {
+      if (p.so != 1 || ooy || oox || p.Ho != p.Hg || p.Wo != p.Wg) {
+        const unsigned mu = (unsigned)m, t = mu / (unsigned)p.Wg;
+        const int gx = (int)(mu - t * (unsigned)p.Wg);
+        const int b = (int)(t / (unsigned)p.Hg), gy = (int)(t - (unsigned)b * (unsigned)p.Hg);
+        return ((int64_t)b * p.Ho + gy * p.so + ooy) * p.Wo + gx * p.so + oox;
+      }
+      return m;
+    };
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int64_t ma = m0 + wm * 64 + i * 32 + (lane & 15), mb = ma + 16;
+      u16* rowa = ma < M ? (u16*)p.O + out_row(ma) * p.ldo : nullptr;
+      u16* rowb = mb < M ? (u16*)p.O + out_row(mb) * p.ldo : nullptr;
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int nf = n0 + wn * (BN / 2) + j * 32;  // first channel of the fragment
+        unsigned D[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * q + e];
+          const int n = nf + 8 * q + 4 * fh;
+          if (p.bias && n < p.Cn) {
+            const float4 bb = *(const float4*)&p.bias[n];
+            v[0] += bb.x, v[1] += bb.y, v[2] += bb.z, v[3] += bb.w;
+          }
+          D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+          D[q][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+        }
+        uint4 xa, xb;
+        frag_rows(D, xa, xb);
+        const int n = nf + 8 * schunk;
+        if (n < p.Cn) {
+          if (rowa) *(uint4*)(rowa + n) = xa;
+          if (rowb) *(uint4*)(rowb + n) = xb;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int64_t m = m0 + wm * 64 + i * 32 + fr_;
@@ -261,6 +334,10 @@ struct C3P {
   int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
   int tiles_y, tiles_x;
 };
+// DIAG (tools/conv3x3_diag.hip only; the library instantiates DIAG = 0): parts of k_conv3x3w switched off at COMPILE time to see
+// what a step is made of - 1: no MFMA  2: no fragment reads (and no MFMA)  4: W DMA from the zero line  8: halo DMA from the zero
+// line  16: no output stores  32: no epilogue at all  64: epilogue arithmetic kept, ONE 4-byte store per item and lane
+#define MM_DIAG(p, bit) ((DIAG & (bit)) != 0)
 
 // Persistent kernel.  (The first-generation kernel - one 128-pixel patch per workgroup, deleted in round 3 - taught this:)
 // At these layer sizes a 128 px x 64 cout workgroup's MFMA work is ~1 us while
@@ -283,12 +360,13 @@ struct C3P {
 // TW = 16: 16 x 16 pixel tiles (large maps); TW = 32: 8 x 32 (low-resolution maps waste fewer out-of-image pixels).
 __device__ __attribute__((aligned(16))) unsigned int g_dump[256];  // sink for the stores of out-of-image pixels
 
+
 template <int N>
 __device__ inline void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int TW>
+template <int BN, int TW, int DIAG = 0>
 __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
   extern __shared__ __attribute__((aligned(16))) char smemc[];
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
@@ -380,12 +458,22 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
     const int row = wn * (BN / 2) + j * 32 + fr_;
     boff[j] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
   }
+  // epilogue (frag_rows): this lane stores rows of pixels 64 wm + 32 i + (lane & 15) and + 16, at 16-byte chunk schunk
+  int spy[2][2], spx[2][2];
+  const int schunk = frag_chunk(lane);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+      const int pix = 64 * wm + 32 * i + 16 * h2 + (lane & 15);
+      spy[i][h2] = pix / TW, spx[i][h2] = pix % TW;
+    }
 
   // producer cursors advance incrementally: no divisions between a barrier and the MFMAs
   int h_item = it_begin, h_c = 0, h_b, h_ty0, h_tx0, h_n0;
   decode(h_item, h_b, h_ty0, h_tx0, h_n0);
   auto issue_halo = [&](int buf) {  // 6 DMA instructions (5 for waves 3..7), always; then advance the cursor
-    const bool live = h_item < it_end;
+    const bool live = h_item < it_end && !MM_DIAG(p, 8);
     const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
     const u16* base = p.A + ((int64_t)(h_b * p.H + h_ty0) * p.W + h_tx0) * p.lda + h_c * 64;
     char* dst = lds + HS0 + buf * HSZB + wave * 1024;
@@ -414,7 +502,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
   };
   int w_item = it_begin, w_c = 0, w_tap = 0, w_n0 = (it_begin % ncb) * BN;
   auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
-    const bool live = w_item < it_end;
+    const bool live = w_item < it_end && !MM_DIAG(p, 4);
     const u16* base = live ? p.Wp + ((int64_t)w_n0 * 9 + w_tap) * p.Ca + w_c * 64 : (const u16*)g_zero16;
     char* dst = lds + buf * BSZB + wave * 1024;
 #pragma unroll
@@ -479,6 +567,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if (!MM_DIAG(p, 2)) {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         bf16x8 af[2], bf[TN];
@@ -486,11 +575,19 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
         for (int i = 0; i < 2; i++) af[i] = *(const bf16x8*)(lds + (((aoff[i][tap] + hb)) ^ (kk << 5)));
 #pragma unroll
         for (int j = 0; j < TN; j++) bf[j] = *(const bf16x8*)(lds + ((boff[j] ^ (kk << 5)) + slot));
+        if (MM_DIAG(p, 1)) {  // keep the reads alive without the matrix pipe
+#pragma unroll
+          for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) acc[i][j][0] += (float)af[i][0] + (float)bf[j][0];
+          continue;
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++)
             acc[i][j] = MM_MFMA_32x32x16(bf[j], af[i], acc[i][j]);  // D[cout][pixel]
+      }
       }
       slot = slot + BSZB == RW * BSZB ? 0 : slot + BSZB;
     }
@@ -499,13 +596,18 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       decode(c_item, b, ty0, tx0, n0);
       c_c = 0;
       c_item += G8;
+      if (MM_DIAG(p, 32)) continue;
+      unsigned diag_sum = 0;
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        const int y = ty0 + ppy[i], x = tx0 + ppx[i];
-        const bool inside = y < p.H && x < p.W;
-        u16* orow = p.O + ((int64_t)(b * p.H + y) * p.W + x) * p.ldo + n0 + wn * (BN / 2) + 4 * fh;
+        // after frag_rows this lane holds rows of the pixels sp[i][0] (xa) and sp[i][1] (xb), not of its own MFMA column
+        const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
+        const bool ina = ya < p.H && xa_ < p.W && !MM_DIAG(p, 16), inb = yb < p.H && xb_ < p.W && !MM_DIAG(p, 16);
+        u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + n0 + wn * (BN / 2) + 8 * schunk;
+        u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + n0 + wn * (BN / 2) + 8 * schunk;
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+        for (int j = 0; j < TN; j++) {
+          unsigned D[4][2];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
             float v[4];
@@ -515,12 +617,20 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
               if (p.bias) v[e] += biasl[n0 + wn * (BN / 2) + 32 * j + 8 * q + 4 * fh + e];
               acc[i][j][4 * q + e] = 0.f;
             }
-            uint2 o;
-            o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-            *(uint2*)(inside ? orow + 32 * j + 8 * q : (u16*)g_dump + lane * 4) = o;
+            D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            D[q][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
           }
+          uint4 xa, xb;
+          frag_rows(D, xa, xb);
+          if (MM_DIAG(p, 64)) {  // every value still used, one store per item: the price of the stores themselves
+            diag_sum ^= xa.x ^ xa.y ^ xa.z ^ xa.w ^ xb.x ^ xb.y ^ xb.z ^ xb.w;
+            continue;
+          }
+          *(uint4*)(ina ? rowa + 32 * j : (u16*)g_dump + lane * 8) = xa;
+          *(uint4*)(inb ? rowb + 32 * j : (u16*)g_dump + lane * 8) = xb;
+        }
       }
+      if (MM_DIAG(p, 64)) g_dump[lane] = diag_sum;
     }
   }
 }
@@ -536,7 +646,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   constexpr int HSZB = ((HROWS + 7) / 8) * 8 * 128;  // bytes per halo buffer, whole 1-KiB DMA pieces
   constexpr int NPIECE = (HROWS + 63) / 64;          // DMA rounds of 64 rows; the last one is partial (fewer waves issue it)
   constexpr int BSZB = 64 * 128;                     // bytes of one tap's W tile [64 cout][64 cin]
-  constexpr int NST = 8;                             // store instructions per wave and item
+  constexpr int NST = 4;                             // store instructions per wave and item (two 16-byte row stores per fragment)
   constexpr int HS0 = 9 * BSZB;
   char* const lds = smemc;
   float* biasl = (float*)(lds + HS0 + 2 * HSZB);
@@ -592,6 +702,15 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   }
   const int brow = wn * 32 + fr_;
   const int boff = brow * 128 + ((fh ^ ((brow >> 1) & 7)) << 4);
+  int spy[2][2], spx[2][2];  // epilogue (frag_rows): the pixels whose rows this lane stores
+  const int schunk = frag_chunk(lane);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+      const int pix = 64 * wm + 32 * i + 16 * h2 + (lane & 15);
+      spy[i][h2] = pix / TW, spx[i][h2] = pix % TW;
+    }
 
   int h_item = it_begin;
   auto issue_halo = [&](int buf) {
@@ -647,9 +766,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
     decode(item, b, ty0, tx0);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int y = ty0 + ppy[i], x = tx0 + ppx[i];
-      const bool inside = y < p.H && x < p.W;
-      u16* orow = p.O + ((int64_t)(b * p.H + y) * p.W + x) * p.ldo + wn * 32 + 4 * fh;
+      unsigned D[4][2];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         float v[4];
@@ -659,11 +776,16 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
           if (p.bias) v[e] += biasl[wn * 32 + 8 * q + 4 * fh + e];
           acc[i][4 * q + e] = 0.f;
         }
-        uint2 o;
-        o.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-        o.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-        *(uint2*)(inside ? orow + 8 * q : (u16*)g_dump + lane * 4) = o;
+        D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+        D[q][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
       }
+      uint4 xa, xb;
+      frag_rows(D, xa, xb);  // whole 64-byte rows: pixels (lane & 15) and 16 + (lane & 15) of the fragment, chunk schunk
+      const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
+      u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + wn * 32 + 8 * schunk;
+      u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + wn * 32 + 8 * schunk;
+      *(uint4*)(ya < p.H && xa_ < p.W ? rowa : (u16*)g_dump + lane * 8) = xa;
+      *(uint4*)(yb < p.H && xb_ < p.W ? rowb : (u16*)g_dump + lane * 8) = xb;
     }
     st = true;
   }
@@ -1235,7 +1357,7 @@ int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda
   // launches are bound by load latency, not by MFMA time; one stage buffer (24 KB) lets five workgroups share a CU instead of
   // three, which hides more of it than the one-step prefetch did (18240-tile stems 269 -> 231 us, 4560x4 transposed conv 441 -> 385).
   {
-    static const int single_max = getenv("MM_GEMM_SINGLE") ? atoi(getenv("MM_GEMM_SINGLE")) : 4;
+    constexpr int single_max = 4;
     p.nbuf = (ntaps * (Ca / 64) <= single_max && (Cn <= 64 || ntaps * (Ca / 64) == 1)) ? 1 : 2;
   }
   if (Cn <= 64) {
@@ -1243,10 +1365,9 @@ int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda
     hipLaunchKernelGGL(k_conv_gemm<64>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 64), nz), dim3(256), lds, s, p);
   } else {
     size_t lds = (size_t)p.nbuf * (128 * 64 + 128 * 64) * 2;
-    static bool once = false;
-    if (!once) {
+    static unsigned once = 0;  // per-device bit: see mm_attr_todo (common.h)
+    if (mm_attr_todo(&once)) {
       MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (128 * 64 + 128 * 64) * 2)));
-      once = true;
     }
     hipLaunchKernelGGL(k_conv_gemm<128>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 128), nz), dim3(256), lds, s, p);
   }
@@ -1280,23 +1401,21 @@ int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda,
     const size_t ldsw = (size_t)(2 * 344 * 64 + (bn == 128 ? 4 : 6) * bn * 64) * 2 + (bias ? (size_t)mm_cdiv(Cn, 512) * 512 * 4 : 0);
     int64_t grid = mm_cdiv(nitems, 8) * 8;  // a multiple of the 8 XCDs
     if (grid > 256) grid = 256;             // one resident 8-wave workgroup per CU
-    static bool once_w = false;
-    if (!once_w) {
+    static unsigned once_w = 0;  // per-device bit: see mm_attr_todo (common.h)
+    if (mm_attr_todo(&once_w)) {
       const int mx = (2 * 344 * 64 + 4 * 128 * 64) * 2 + 4096;
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-      once_w = true;
     }
     if (Ca == 64 && Cn == 64) {  // weights resident in LDS
       const int hrows = tw == 16 ? 18 * 18 : 10 * 34;
       const size_t ldsr = (size_t)9 * 64 * 128 + 2 * (size_t)((hrows + 7) / 8) * 8 * 128 + 256;
-      static bool once_r = false;
-      if (!once_r) {
+      static unsigned once_r = 0;  // per-device bit: see mm_attr_todo (common.h)
+      if (mm_attr_todo(&once_r)) {
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        once_r = true;
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
@@ -1374,10 +1493,9 @@ int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ld
     }
     q.partial = (float*)ws;
     constexpr int lds9 = 4 * (128 + 184) * 128;
-    static bool attr9 = false;
-    if (!attr9) {
+    static unsigned attr9 = 0;  // per-device bit: see mm_attr_todo (common.h)
+    if (mm_attr_todo(&attr9)) {
       MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3n, hipFuncAttributeMaxDynamicSharedMemorySize, lds9));
-      attr9 = true;
     }
     hipLaunchKernelGGL(k_wgrad3x3n, dim3((unsigned)(nsplit9 * q.ntile)), dim3(512), lds9, s, q);
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,

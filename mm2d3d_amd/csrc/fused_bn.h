@@ -1,11 +1,9 @@
 // Shared pieces of the single-launch batch-norm training kernels (csrc/bn2d.hip: NHWC bf16 maps; csrc/bn.hip: fp32 sparse rows).
-// Included inside each translation unit: the device helpers are inline and the host-side state (barrier words, switch) is
-// per translation unit.
+// Included inside each translation unit: the device helpers are inline; the host-side state (barrier words, fault word, switches)
+// lives in the caller's handle (common.h MMHandle, include/mm2d3d.h mm_create).
 #pragma once
 
 #include <algorithm>
-#include <cstdlib>
-#include <mutex>
 
 #include "common.h"
 
@@ -23,8 +21,8 @@ namespace {
 // workgroup needs more than half of a CU's registers/LDS (one per CU).  Another PROCESS running the same kernel on the
 // same GPU can starve both grids: the wait is bounded (FUSED_TIMEOUT_TICKS of the 100 MHz wall clock); a barrier that runs
 // out of time raises a fault word in pinned host memory, releases the grid and lets the launch finish with invalid outputs
-// (no trap: the HIP context survives); the host polls the word (mm_bn_fused_fault / mm_bn2d_fused_fault; the trainer does it
-// every step and raises), which also switches the process to the three-kernel path.  MM_BN2D_FUSED=0 selects that path up front.
+// (no trap: the HIP context survives); the host polls the word (mm_fault_poll; the trainer does it every step and raises), which
+// also switches the handle to the three-kernel path.  mm_set_option(h, MM_OPT_BN2D_FUSED, 0) selects that path up front.
 // A kernel of another stream that holds LDS on some CUs makes the grid wait for it, and one that spin-waits across its own
 // workgroups (decoupled look-back scan / Onesweep sort, an RCCL collective) can DEADLOCK with it - each holds CUs the other's
 // missing workgroups need (tools/barrier_stress.py reproduces this with torch.cumsum on a second stream): the data-parallel trainer therefore takes the three-kernel path (ddp.py), and so do the directions that share the GPU
@@ -38,10 +36,10 @@ constexpr unsigned long long FUSED_TIMEOUT_TICKS = 1000000000ull;  // 10 s
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Where a grid barrier that ran out of time reports it: a word of pinned host memory (set once per device by fused_plan).
-// The launch then runs out with invalid outputs instead of killing the HIP context with a trap; the host polls the word
-// (mm_bn_fused_fault / mm_bn2d_fused_fault), switches the single-launch kernels off and re-arms the barrier words.
-__device__ unsigned* g_fused_fault_dev;
+// Where a grid barrier that ran out of time reports it: a word of pinned host memory owned by the handle the launch came
+// through (MMHandle::fault_dev, passed with the kernel parameters).  The launch then runs out with invalid outputs instead of
+// killing the HIP context with a trap; the host polls the word (mm_fault_poll), which switches the handle's single-launch kernels
+// off and re-arms its barrier words.
 
 
 __device__ inline double fused_wave_sum(double v) {
@@ -133,7 +131,7 @@ __device__ inline void fused_wave_sums(const double* partial, int b0, int b1, in
 
 // Grid barrier (every workgroup of the launch is resident, see the header).  The last workgroup to arrive (its increment wraps
 // the counter to 0) advances the release word from flag_old to flag_old + 1; the others poll the release word.
-__device__ inline void fused_barrier(unsigned* sync, unsigned G, unsigned flag_old) {
+__device__ inline void fused_barrier(unsigned* sync, unsigned* fault, unsigned G, unsigned flag_old) {
   stores_acked();   // this thread's xcd_store()s have reached the coherence point
   __syncthreads();  // ... and so have the whole workgroup's
   if (threadIdx.x == 0) {
@@ -148,7 +146,7 @@ __device__ inline void fused_barrier(unsigned* sync, unsigned G, unsigned flag_o
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > FUSED_TIMEOUT_TICKS) {
           // the grid is not co-resident (see the header): report it, release everybody, let the launch run out
-          if (g_fused_fault_dev) __hip_atomic_store(g_fused_fault_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           xcd_store(&sync[FUSED_FLAG], flag_old + 1u);
           break;
         }
@@ -223,87 +221,47 @@ __device__ inline void fused_st(const FusedBuf& b, int64_t row, const u32x4 v) {
 
 }  // namespace
 
-// ---- host side of the single-launch kernels
+// ---- host side of the single-launch kernels: all state lives in the caller's handle (common.h MMHandle)
 struct FusedPlan {
   bool ok;
   int G0, G1, R;
   unsigned* sync;
+  unsigned* fault;
 };
 
-static std::mutex g_fused_mu;
-static unsigned* g_fused_sync[16];       // per device: 64 slots x 512 B (arrival counter | release word), zero-initialised
-static hipStream_t g_fused_stream[16][64];
-static int g_fused_nstream[16];
-static int g_fused_cus[16];
-static int g_fused_state[16];             // 0: not probed, 1: usable, -1: this device cannot run the single-launch kernels
-static unsigned* g_fused_fault_host;      // pinned, mapped: written by a kernel whose grid barrier timed out
-static int g_fused_enabled = -1;  // bit 0: forward, bit 1: backward; -1: take the environment variable (default 3) on first use
-
-static int fused_mask(const char* env) {
-  if (g_fused_enabled < 0) {
-    const char* e = getenv(env);
-    g_fused_enabled = e ? (atoi(e) & 3) : 3;
-  }
-  return g_fused_enabled;
-}
+constexpr int FUSED_ROWS_TARGET = 6;  // about six rows per thread (measured on the 79 BatchNorm2d shapes of the bench step)
 
 // Grid and rows per thread for a map of N rows (Ns in the first statistics group) and C channels; ok = false: use the
-// three-kernel path (map too large to keep on chip, channel count outside the layout, or the environment switch).
-// vec: channels per 16-byte access (8 bf16 / 4 fp32); fns: the translation unit's fused kernels (their dynamic LDS limit is raised once)
-static int fused_plan(int64_t N, int64_t Ns, int C, int vec, int rmax, bool backward, const char* env, const void* const* fns, int nfns,
-                      hipStream_t s, FusedPlan* pl) {
+// three-kernel path (map too large to keep on chip, channel count outside the layout, or the handle's switch).
+// vec: channels per 16-byte access (8 x 16 bit / 4 x fp32); fns: the translation unit's fused kernels (their dynamic LDS limit is
+// raised once per handle: bit ``unit`` of MMHandle::attr_done); opt: MM_OPT_BN2D_FUSED / MM_OPT_BN3D_FUSED
+static inline int fused_plan(MMHandle* H, int opt, int unit, int64_t N, int64_t Ns, int C, int vec, int rmax, bool backward,
+                             const void* const* fns, int nfns, hipStream_t s, FusedPlan* pl) {
   pl->ok = false;
-  fused_mask(env);
-  if (!(g_fused_enabled & (backward ? 2 : 1)) || N <= 0 || C % vec != 0 || C > FT || C < vec) return MM_OK;
-  int dev = 0;
-  MM_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 16) return MM_OK;
-  std::lock_guard<std::mutex> lock(g_fused_mu);
-  if (g_fused_state[dev] == 0) {
-    // one probe per device; any failure marks the device "three-kernel path only" instead of failing every BN call
-    g_fused_state[dev] = -1;
-    int cus = 0, lds_max = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || (size_t)lds_max < FUSED_LDS) {
-      (void)hipGetLastError();
-      return MM_OK;
-    }
-    void* q = nullptr;
-    bool good = hipMalloc(&q, 64 * 512) == hipSuccess && hipMemset(q, 0, 64 * 512) == hipSuccess;
+  if (!H->fused_ok || !(H->opt[opt] & (backward ? 2 : 1)) || N <= 0 || C % vec != 0 || C > FT || C < vec) return MM_OK;
+  if (!(H->attr_done & (1u << unit))) {
+    bool good = true;
     for (int i = 0; good && i < nfns; i++)
       good = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)FUSED_LDS) == hipSuccess;
-    if (good && !g_fused_fault_host) {
-      good = hipHostMalloc((void**)&g_fused_fault_host, 64, hipHostMallocMapped) == hipSuccess;
-      if (good) *g_fused_fault_host = 0;
-    }
-    unsigned* fault_dev = nullptr;
-    good = good && hipHostGetDevicePointer((void**)&fault_dev, g_fused_fault_host, 0) == hipSuccess &&
-           hipMemcpyToSymbol(HIP_SYMBOL(g_fused_fault_dev), &fault_dev, sizeof(fault_dev)) == hipSuccess;
     if (!good) {
       (void)hipGetLastError();
-      if (q) (void)hipFree(q);
+      H->fused_ok = 0;
       return MM_OK;
     }
-    // fused_wave_sums combines at most 4 x 64 workgroups per statistics group: never plan a wider grid than that
-    g_fused_cus[dev] = cus < 256 ? cus : 256;
-    g_fused_sync[dev] = (unsigned*)q;
-    g_fused_state[dev] = 1;
+    H->attr_done |= 1u << unit;
   }
-  if (g_fused_state[dev] < 0) return MM_OK;
   int slot = -1;
-  for (int i = 0; i < g_fused_nstream[dev]; i++)
-    if (g_fused_stream[dev][i] == s) slot = i;
+  for (int i = 0; i < H->nstream; i++)
+    if (H->streams[i] == s) slot = i;
   if (slot < 0) {
-    if (g_fused_nstream[dev] >= 64) return MM_OK;  // more streams than barrier slots: three-kernel path
-    slot = g_fused_nstream[dev]++;
-    g_fused_stream[dev][slot] = s;
+    if (H->nstream >= MM_SYNC_SLOTS) return MM_OK;  // more streams than barrier slots: three-kernel path
+    slot = H->nstream++;
+    H->streams[slot] = s;
   }
   const int rs = FT / (C / vec);
-  const int cus = g_fused_cus[dev];
-  if (cus < 2) return MM_OK;
+  const int cus = H->cus;
   const bool two = Ns > 0 && Ns < N;
-  static const int rows_target = getenv("MM_BN_ROWS") ? atoi(getenv("MM_BN_ROWS")) : 6;
-  int64_t G = mm_cdiv(N, (int64_t)rs * rows_target);  // about six rows per thread
+  int64_t G = mm_cdiv(N, (int64_t)rs * FUSED_ROWS_TARGET);
   if (G > cus) G = cus;
   if (G < (two ? 2 : 1)) G = two ? 2 : 1;
   int G0 = (int)G, G1 = 0;
@@ -318,27 +276,7 @@ static int fused_plan(int64_t N, int64_t Ns, int C, int vec, int rmax, bool back
   if (R > rmax) return MM_OK;
   pl->ok = true;
   pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;
-  pl->sync = g_fused_sync[dev] + slot * 128;
+  pl->sync = H->sync + slot * 128;
+  pl->fault = H->fault_dev;
   return MM_OK;
 }
-
-// 1 if a single-launch kernel of this translation unit gave up at its grid barrier since the last call (that launch's
-// outputs, and everything computed from them, are invalid).  The single-launch kernels are then switched off for the rest
-// of the process (three-kernel path) and the barrier words re-armed.  Costs one read of host memory when nothing happened.
-static int fused_fault_poll() {
-  if (!g_fused_fault_host || !__atomic_load_n(g_fused_fault_host, __ATOMIC_RELAXED)) return 0;
-  std::lock_guard<std::mutex> lock(g_fused_mu);
-  g_fused_enabled = 0;
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  for (int d = 0; d < 16; d++) {
-    if (!g_fused_sync[d]) continue;
-    (void)hipSetDevice(d);
-    (void)hipDeviceSynchronize();
-    (void)hipMemset(g_fused_sync[d], 0, 64 * 512);
-  }
-  (void)hipSetDevice(cur);
-  __atomic_store_n(g_fused_fault_host, 0u, __ATOMIC_RELAXED);
-  return 1;
-}
-

@@ -271,7 +271,7 @@ size_t mm_dedupe_ws_bytes(int64_t n) { return 4 * mm_align((size_t)(n + 1) * 4) 
 
 int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, const int32_t* n_dev, int shift,
                     uint64_t* tkeys, int32_t* tvals, int64_t cap, int32_t* item2vox, int32_t* vox_coords,
-                    int32_t* csr_off, int32_t* csr_items, int32_t* n_active_dev, int32_t* err_dev, void* ws,
+                    int32_t* csr_off, int32_t* csr_items, int32_t* n_active_dev, int32_t* err_dev, int no_spin, void* ws,
                     size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(n_bound >= 0 && cap >= 2 * n_bound && (cap & (cap - 1)) == 0, "dedupe: cap must be pow2 >= 2n (n=%lld cap=%lld)",
                (long long)n_bound, (long long)cap);
@@ -305,7 +305,7 @@ int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, cons
     hipLaunchKernelGGL(k_insert<int32_t>, dim3(g), dim3(T), 0, s, (const int32_t*)coords, n_bound, n_dev, shift,
                        (unsigned long long*)tkeys, tvals, mask, slot_of, err_dev);
   hipLaunchKernelGGL(k_flag_first, dim3(g), dim3(T), 0, s, slot_of, tvals, n_bound, n_dev, flag);
-  int rc = mm_exclusive_scan_i32(flag, rank, n_bound, n_active_dev, scan_ws, sws, s);
+  int rc = mm_exclusive_scan_i32(flag, rank, n_bound, n_active_dev, scan_ws, sws, s, no_spin);
   if (rc) return rc;
   if (coords_is_i64)
     hipLaunchKernelGGL(k_assign<int64_t>, dim3(g), dim3(T), 0, s, (const int64_t*)coords, n_bound, n_dev, shift, slot_of,
@@ -315,7 +315,7 @@ int mm_voxel_dedupe(const void* coords, int coords_is_i64, int64_t n_bound, cons
                        tvals, rank, item2vox, vox_coords, cnt);
   hipLaunchKernelGGL(k_store_ids, dim3(nblk(n_bound + 1)), dim3(T), 0, s, n_bound, n_dev, slot_of, flag, rank, tvals);
   // csr over voxels (bound n_bound); csr_off[n_bound] = number of items
-  rc = mm_exclusive_scan_i32(cnt, csr_off, n_bound, csr_off + n_bound, scan_ws, sws, s);
+  rc = mm_exclusive_scan_i32(cnt, csr_off, n_bound, csr_off + n_bound, scan_ws, sws, s, no_spin);
   if (rc) return rc;
   hipLaunchKernelGGL(k_fill_lists, dim3(g), dim3(T), 0, s, n_bound, n_dev, item2vox, csr_off, flag, csr_items);
   hipLaunchKernelGGL(k_sort_lists, dim3(g), dim3(T), 0, s, n_bound, n_active_dev, csr_off, csr_items);
@@ -352,7 +352,7 @@ size_t mm_rulebook_ws_bytes(int64_t n_out, int K) {
 // csr_off == csr_pos == NULL: only the rule lists (levels served by the output-stationary engine never read the CSR; a
 // caller that turns out to need it builds it later with mm_rulebook_csr from the same nbr table).
 int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, int32_t* rout, int32_t* offsets,
-                        int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes, hipStream_t s) {
+                        int32_t* csr_off, int32_t* csr_pos, int no_spin, void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= 64 && n_out >= 0 && (csr_off == nullptr) == (csr_pos == nullptr), "rulebook_compact: bad args");
   if (n_out == 0) {
     MM_HIP(hipMemsetAsync(offsets, 0, (size_t)(K + 1) * 4, s));
@@ -370,12 +370,12 @@ int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, 
     return MM_ERR_WORKSPACE;
   }
   hipLaunchKernelGGL(k_flags_from_nbr, dim3(nblk(total)), dim3(T), 0, s, nbr, total, pos);
-  int rc = mm_exclusive_scan_i32(pos, pos, total, pos + total, scan_ws, sws, s);
+  int rc = mm_exclusive_scan_i32(pos, pos, total, pos + total, scan_ws, sws, s, no_spin);
   if (rc) return rc;
   if (rin) hipLaunchKernelGGL(k_emit_rules, dim3(nblk(n_out), K), dim3(T), 0, s, nbr, pos, n_out, K, rin, rout, offsets, pos + total);
   if (csr_off) {
     hipLaunchKernelGGL(k_row_counts, dim3(nblk(n_out)), dim3(T), 0, s, nbr, n_out, K, cnt);
-    rc = mm_exclusive_scan_i32(cnt, csr_off, n_out, csr_off + n_out, scan_ws, sws, s);
+    rc = mm_exclusive_scan_i32(cnt, csr_off, n_out, csr_off + n_out, scan_ws, sws, s, no_spin);
     if (rc) return rc;
     hipLaunchKernelGGL(k_row_fill, dim3(nblk(n_out)), dim3(T), 0, s, nbr, pos, n_out, K, csr_off, csr_pos);
   }
@@ -384,10 +384,10 @@ int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, 
 }
 
 // The CSR half of mm_rulebook_compact alone (same nbr table, same workspace size): csr_off [n_out+1], csr_pos [n_rules].
-int mm_rulebook_csr(const int32_t* nbr, int K, int64_t n_out, int32_t* csr_off, int32_t* csr_pos, void* ws, size_t ws_bytes,
+int mm_rulebook_csr(const int32_t* nbr, int K, int64_t n_out, int32_t* csr_off, int32_t* csr_pos, int no_spin, void* ws, size_t ws_bytes,
                     hipStream_t s) {
   MM_CHECK_ARG(csr_off && csr_pos, "rulebook_csr: null output");
-  return mm_rulebook_compact(nbr, K, n_out, nullptr, nullptr, nullptr, csr_off, csr_pos, ws, ws_bytes, s);
+  return mm_rulebook_compact(nbr, K, n_out, nullptr, nullptr, nullptr, csr_off, csr_pos, no_spin, ws, ws_bytes, s);
 }
 
 // out[0] = number of active rows whose batch index < split (their row ids are 0 .. out[0]-1); n_dev: device row count

@@ -346,7 +346,7 @@ static int os_apply(int bf, const void* in_, int ld_in, int Cin, void* out_, int
   // at most 4 output-channel blocks per workgroup (64 KB of LDS partials), and at most THREE per launch: the four-block
   // instance needs 64 accumulator + 48 fragment registers and loses the occupancy that hides the gathers (64 output channels
   // from 32: 184 us as one launch of four, 124 us as two of two)
-  static const int maxw = getenv("MM_OS_MAXW") ? atoi(getenv("MM_OS_MAXW")) : 3;
+  constexpr int maxw = 3;
   int parts = (ncb + maxw - 1) / maxw;
   // small levels: more, narrower launches (each re-gathers its rows) until the grid covers the chip
   while (n_tiles * parts < 1024 && parts < ncb && (ncb + parts) / (parts + 1) >= 2) parts++;

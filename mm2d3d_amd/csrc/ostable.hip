@@ -20,7 +20,6 @@
 
 #include "common.h"
 
-int g_os_sort_merge = 0;  // also read by csrc/scan.hip
 
 namespace {
 
@@ -86,14 +85,6 @@ size_t sort_tmp_bytes(int64_t n, int K) {
 
 extern "C" {
 
-// 0 (default): Onesweep radix sort; 1: merge sort (no workgroup of the sort waits for another: safe beside grid-barrier kernels
-// of other streams).  Same result (both stable).  Returns the previous setting; applies to the calls of this process.
-int mm_os_table_set_sort(int merge) {
-  const int prev = g_os_sort_merge;
-  g_os_sort_merge = merge ? 1 : 0;
-  return prev;
-}
-
 size_t mm_os_table_ws_bytes(int64_t n, int K) {
   return 3 * mm_align((size_t)(n + 1) * 4) + mm_align(sort_tmp_bytes(n, K)) + 1024;
 }
@@ -107,8 +98,10 @@ int mm_up_neighbors(const int32_t* vox_coords_fine, int64_t n_fine, const int32_
 }
 
 // nbr [K][n] -> dst [npad], nbrp [K][npad], tmask [nt];  nt = ceil(n / tile_rows), npad = nt * tile_rows
-int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32_t* dst, int32_t* nbrp, uint32_t* tmask, void* ws,
-                      size_t ws_bytes, hipStream_t s) {
+// sort_merge: 0 = rocPRIM Onesweep radix sort (default); 1 = merge sort - no workgroup of the sort waits for another, safe beside
+// grid-barrier kernels of other streams.  Same result (both stable).
+int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int sort_merge, int32_t* dst, int32_t* nbrp, uint32_t* tmask,
+                      void* ws, size_t ws_bytes, hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= 32 && n >= 0 && tile_rows > 0 && tile_rows % 64 == 0, "os_table_build: bad arguments");
   if (n == 0) return MM_OK;
   const int64_t nt = mm_cdiv(n, tile_rows), npad = nt * tile_rows;
@@ -123,7 +116,7 @@ int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int32
     return MM_ERR_WORKSPACE;
   }
   hipLaunchKernelGGL(k_row_mask, dim3((unsigned)mm_cdiv(n, T)), dim3(T), 0, s, nbr, K, n, mask);
-  if (g_os_sort_merge) MM_HIP(sort_masks<SortCfgMerge>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
+  if (sort_merge) MM_HIP(sort_masks<SortCfgMerge>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
   else MM_HIP(sort_masks<SortCfg>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
   MM_HIP(hipMemsetAsync(tmask, 0, (size_t)nt * 4, s));
   hipLaunchKernelGGL(k_os_fill, dim3((unsigned)mm_cdiv(npad, T)), dim3(T), 0, s, nbr, K, n, npad, tile_rows, mask_sorted, perm, dst,

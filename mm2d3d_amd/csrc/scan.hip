@@ -99,7 +99,6 @@ __global__ __launch_bounds__(SCAN_T) void k_rescan(const int32_t* __restrict__ i
 }
 }  // namespace
 
-extern int g_os_sort_merge;  // csrc/ostable.hip: 1 = no kernel whose workgroups wait for each other
 
 static size_t lookback_bytes(int64_t n) {
   size_t b = 0;
@@ -113,7 +112,7 @@ size_t mm_scan_ws_bytes(int64_t n) {
 }
 
 int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_out, void* ws, size_t ws_bytes,
-                          hipStream_t s) {
+                          hipStream_t s, int no_spin) {
   if (n <= 0) {
     if (total_out) MM_HIP(hipMemsetAsync(total_out, 0, sizeof(int32_t), s));
     return MM_OK;
@@ -124,7 +123,7 @@ int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* t
   }
   int32_t* sums = (int32_t*)ws;
   int64_t nb = mm_cdiv(n, SCAN_BLK);
-  if (!g_os_sort_merge && total_out) {
+  if (!no_spin && total_out) {  // rocPRIM's single-pass scan: its workgroups spin on their predecessors (decoupled look-back)
     // in and out hold n + 1 elements (common.h): scan n + 1 of them, out[n] = the total (in[n] is read, its value does not
     // enter out[0..n])
     size_t tb = lookback_bytes(n + 1);

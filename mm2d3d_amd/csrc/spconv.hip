@@ -829,29 +829,24 @@ int launch_g(int nb, int nchunk, const float* in, int ld_in, const int32_t* src,
 
 }  // namespace
 
-// bf16 terms per fp32 operand in the split-product engines: 3 (fp32-faithful, default), 2 (MM_SPCONV_SPLIT=2), 0 = plain fp32
-static int split_terms() {
-  static const int nt = [] {
-    if (getenv("MM_SPCONV_FP32")) return 0;
-    const char* e = getenv("MM_SPCONV_SPLIT");
-    return (e && atoi(e) == 2) ? 2 : 3;
-  }();
-  return nt;
+// ``mode`` of the fp32-row entry points (include/mm2d3d.h MM_SPCONV_*): bits 0-1 = bf16 terms per fp32 operand in the
+// split-product engines - 0: three (fp32-faithful, default), 1: none (plain fp32 engines), 2: two (faster, fails the gradient
+// parity bar: diagnostics only); bit 2: dW keeps the <= 4 x 4 channel tiles.  The caller passes it with every call - the library
+// reads no environment variable and keeps no switch.
+static int split_terms(int mode) {
+  const int m = mode & 3;
+  return m == 0 ? 3 : (m == 1 ? 0 : 2);
 }
 
 // smallest input width that takes the split-product engines: 32 for fwd / dX (below that the fp32 engine streams as fast),
 // 16 for dW (its fp32 variant is bound by 4-byte gathers + 32-cycle MFMAs already at 16 channels).  Measured on the
 // bench step: dW 2.42 -> 2.17 ms, fwd + dX 5.04 -> 4.95 ms against a 64-channel threshold for both.
-static int split_min_cin(bool dw) {
-  static const int a = getenv("MM_SPCONV_SPLIT_MIN") ? atoi(getenv("MM_SPCONV_SPLIT_MIN")) : 32;
-  static const int d = getenv("MM_SPCONV_SPLIT_MIN_DW") ? atoi(getenv("MM_SPCONV_SPLIT_MIN_DW")) : 16;
-  return dw ? d : a;
-}
+static constexpr int split_min_cin(bool dw) { return dw ? 16 : 32; }
 
 template <int N, int NT>
 static int launch_s3(bool small, int nb, int nch, size_t lds, const float* in, int ld_in, const int32_t* src, const int32_t* d, float* tgt,
                      int ld_t, const __bf16* Wf3, int ncb, int K, int Cin, int tr, const KSeg& sg, hipStream_t s) {
-  static const int preload = getenv("MM_SPCONV_G_PRELOAD") ? atoi(getenv("MM_SPCONV_G_PRELOAD")) : 1;
+  constexpr int preload = 1;
   if (small) {
     hipLaunchKernelGGL((k_gather_gemm_s3<N, false, NT>), dim3(nb, nch), dim3(256), 0, s, in, ld_in, src, d, tgt, ld_t, Wf3, ncb, K, Cin, tr,
                        sg, preload);
@@ -887,7 +882,7 @@ size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K) {
 int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
                            const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
                            int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
-                           int64_t w_kstride, int s_ci, int s_co, int kflip, const void* Wpk, void* ws, size_t ws_bytes,
+                           int64_t w_kstride, int s_ci, int s_co, int kflip, const void* Wpk, int mode, void* ws, size_t ws_bytes,
                            hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0 && ld_in >= Cin && ld_out >= Cout, "spconv_apply: bad shape");
   MM_CHECK_ARG(unique_dst || (csr_off && csr_pos), "spconv_apply: the row CSR is required unless every destination is unique");
@@ -933,7 +928,7 @@ int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int 
   }
   MM_CHECK_ARG(((uintptr_t)ws % 16) == 0, "spconv_apply: workspace must be 16-B aligned");
   float* Wf = (float*)((char*)ws + tmp_bytes);
-  const int nt = split_terms();
+  const int nt = split_terms(mode);
   if (nt && !edge && Cin >= split_min_cin(false) && (unique_dst || Cout % 4 == 0) && R > 0) {  // matrix-rate-bound widths: split-bf16 products
     const int nq3 = (Cin + 31) / 32;
     MM_CHECK_ARG(ws_bytes >= tmp_bytes + (size_t)K * nq3 * ncb * 64 * 16 * nt, "spconv_apply: workspace too small for the split fragments");
@@ -957,7 +952,7 @@ int mm_spconv_apply_packed(const float* in, int ld_in, int Cin, float* out, int 
       return MM_ERR_UNSUPPORTED;
     }
     const int ncbw = ncb / nch;
-    static const int64_t small_r = getenv("MM_SPCONV_SMALL_R") ? atoll(getenv("MM_SPCONV_SMALL_R")) : 0;  // round 3: the LDS-staged form everywhere - with the W slice arriving by LDS-DMA it wins at every size (112->112 on 88k rules: 96 -> 57 us); the unstaged form re-reads the whole slice from L2 per wave
+    constexpr int64_t small_r = 0;  // round 3: the LDS-staged form everywhere - with the W slice arriving by LDS-DMA it wins at every size (112->112 on 88k rules: 96 -> 57 us); the unstaged form re-reads the whole slice from L2 per wave
     const bool small = R < small_r;
     int tr = small ? 64 : TR;
     while (!small && tr > 64 && mm_cdiv(R, tr) * nch < 1024) tr >>= 1;
@@ -1058,8 +1053,7 @@ static inline int dw_tile(int n) { return (n + ((n + 3) / 4) - 1) / ((n + 3) / 4
 constexpr int DW_WIDE_MIN_RULES = 200000;
 static void dw_tiles(int nci, int nco, bool wide_ok, int* ti, int* tj) {
   *ti = dw_tile(nci), *tj = dw_tile(nco);
-  static const bool wide = !(getenv("MM_DW_WIDE") && atoi(getenv("MM_DW_WIDE")) == 0);
-  if (!wide || !wide_ok || (nci <= 4 && nco <= 4)) return;
+  if (!wide_ok || (nci <= 4 && nco <= 4)) return;
   int best = (int)(mm_cdiv(nci, *ti) * mm_cdiv(nco, *tj)) * (*ti + *tj), area = *ti * *tj;
   for (int a = 1; a <= nci; a++) {
     const int i = (int)mm_cdiv(nci, a);
@@ -1089,9 +1083,9 @@ static int dw_chunk(int64_t R, int Cin, int Cout, bool wide_ok) {
 int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
                     const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
                     int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,
-                    int64_t w_kstride, int s_ci, int s_co, int kflip, void* ws, size_t ws_bytes, hipStream_t s) {
+                    int64_t w_kstride, int s_ci, int s_co, int kflip, int mode, void* ws, size_t ws_bytes, hipStream_t s) {
   return mm_spconv_apply_packed(in, ld_in, Cin, out, ld_out, Cout, n_out, src, dst, offsets_dev, offsets_host, K, csr_off, csr_pos,
-                                unique_dst, W, w_kstride, s_ci, s_co, kflip, nullptr, ws, ws_bytes, s);
+                                unique_dst, W, w_kstride, s_ci, s_co, kflip, nullptr, mode, ws, ws_bytes, s);
 }
 
 }  // extern "C"
@@ -1099,15 +1093,15 @@ int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out,
 namespace {
 
 // the partial slabs of one layer: partial[slab b][ci][co], slab b = rules [chunk b) of kernel offset find_k(b)
-int dw_partial(int bf, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
+int dw_partial(int bf, int mode, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
                const int32_t* dst, const int32_t* offsets_host, int K, void* ws, size_t ws_bytes, KSeg* seg_out, hipStream_t s) {
   MM_CHECK_ARG(K > 0 && K <= MAXK && Cin > 0 && Cout > 0, "spconv_dw: bad shape");
   MM_CHECK_ARG(bf >= 0 && bf <= 2, "spconv_dw: row kind must be 0 (fp32), 1 (bf16) or 2 (fp16)");
   MM_CHECK_ARG(!bf || (Cin % 16 == 0 && Cout % 16 == 0), "spconv_dw (16-bit rows): channels must be multiples of 16");
   KSeg& seg = *seg_out;
   const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
-  const int nt = bf ? -bf : (mfma_ok && Cin >= split_min_cin(true) ? split_terms() : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
-  const bool wide_ok = nt != 0 && offsets_host[K] >= DW_WIDE_MIN_RULES;  // the wide tiles exist for the split / 16-bit kernels
+  const int nt = bf ? -bf : (mfma_ok && Cin >= split_min_cin(true) ? split_terms(mode) : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
+  const bool wide_ok = nt != 0 && !(mode & 4) && offsets_host[K] >= DW_WIDE_MIN_RULES;  // the wide tiles exist for the split / 16-bit kernels
   const int chunk = dw_chunk(offsets_host[K], Cin, Cout, wide_ok);
   int nb = make_seg(offsets_host, K, chunk, &seg);
   const int ne = Cin * Cout;
@@ -1193,10 +1187,10 @@ size_t mm_spconv_dw_ws_bytes(const int32_t* offsets_host, int K, int Cin, int Co
 
 // dW[k][ci][co] (+)= sum over rules r of bucket k of in[src[r]][ci] * dout[dst[r]][co]
 int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_do, int Cout, const int32_t* src,
-                 const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                 const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, int mode, void* ws,
                  size_t ws_bytes, hipStream_t s) {
   KSeg seg;
-  int rc = dw_partial(0, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
+  int rc = dw_partial(0, mode, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
   if (rc != MM_OK) return rc;
   const int ne = Cin * Cout;
   hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, (const float*)ws, ne, K, seg, dW, accumulate);
@@ -1206,10 +1200,10 @@ int mm_spconv_dw(const float* in, int ld_in, int Cin, const float* dout, int ld_
 
 // 16-bit activation mode: in / dout are bf16 rows (ld in elements), dW stays fp32.  Cin, Cout multiples of 16.
 int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
-                      const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                      const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, int mode, void* ws,
                       size_t ws_bytes, hipStream_t s) {
   KSeg seg;
-  int rc = dw_partial(1, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
+  int rc = dw_partial(1, mode, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
   if (rc != MM_OK) return rc;
   const int ne = Cin * Cout;
   hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, (const float*)ws, ne, K, seg, dW, accumulate);
@@ -1219,10 +1213,10 @@ int mm_spconv_dw_bf16(const void* in, int ld_in, int Cin, const void* dout, int 
 
 // the same over IEEE fp16 rows
 int mm_spconv_dw_f16(const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
-                     const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, void* ws,
+                     const int32_t* dst, const int32_t* offsets_host, int K, float* dW, int accumulate, int mode, void* ws,
                      size_t ws_bytes, hipStream_t s) {
   KSeg seg;
-  int rc = dw_partial(2, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
+  int rc = dw_partial(2, mode, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, ws, ws_bytes, &seg, s);
   if (rc != MM_OK) return rc;
   const int ne = Cin * Cout;
   hipLaunchKernelGGL(k_dw_reduce, dim3((unsigned)mm_cdiv(ne, 32), K), dim3(256), 0, s, (const float*)ws, ne, K, seg, dW, accumulate);
@@ -1236,11 +1230,11 @@ int mm_spconv_dw_f16(const void* in, int ld_in, int Cin, const void* dout, int l
 // receives the MAXK + 1 = 33 slab offsets per kernel offset that the reduce needs (a row of its descriptor table).
 // bf16 = 1 / 2: in / dout are bf16 / IEEE fp16 rows.  Same kernels, same slabs, same summation order as mm_spconv_dw: bit-identical.
 int mm_spconv_dw_partial(int bf16, const void* in, int ld_in, int Cin, const void* dout, int ld_do, int Cout, const int32_t* src,
-                         const int32_t* dst, const int32_t* offsets_host, int K, void* partial, size_t partial_bytes,
+                         const int32_t* dst, const int32_t* offsets_host, int K, int mode, void* partial, size_t partial_bytes,
                          int32_t* blk_start_host, hipStream_t s) {
   MM_CHECK_ARG(blk_start_host != nullptr, "spconv_dw_partial: no descriptor row");
   KSeg seg;
-  int rc = dw_partial(bf16, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, partial, partial_bytes, &seg, s);
+  int rc = dw_partial(bf16, mode, in, ld_in, Cin, dout, ld_do, Cout, src, dst, offsets_host, K, partial, partial_bytes, &seg, s);
   if (rc != MM_OK) return rc;
   for (int k = 0; k <= MAXK; k++) blk_start_host[k] = seg.blk_start[k];
   return MM_OK;

@@ -78,9 +78,9 @@ class GradAllReducer:
 
             keep = 1 if os.environ.get("MM_DDP_BN_FUSED", "0") != "0" else 0
             was2d = _lib.bn2d_set_fused(0)
-            was3d = _lib.lib().mm_bn_set_fused(0)
+            was3d = _lib.bn3d_set_fused(0)
             _lib.bn2d_set_fused(was2d & keep)
-            _lib.lib().mm_bn_set_fused(was3d & keep)
+            _lib.bn3d_set_fused(was3d & keep)
             self.bn_path = ("forward single-launch, backward three-kernel (MM_DDP_BN_FUSED=1)" if keep and (was2d | was3d) & 1
                             else "three-kernel in both directions")
             if (was2d | was3d) & ~keep and (not dist.is_initialized() or dist.get_rank(process_group) == 0):

@@ -61,7 +61,17 @@ class BasicBlock(nn.Module):
 
     def forward(self, x, out=None):
         """``out``: optional NHWC channel slice the block's result is written into (see nn2d.CatBuffer)."""
-        identity = x if self.downsample is None else self.downsample(x)
+        if self.downsample is None:
+            identity = x
+        elif (self._fused and not nn2d.fp32_mode() and torch.is_grad_enabled() and getattr(x, "_mm_handoff", None) is not None
+              and isinstance(self.downsample[0], nn2d.Conv2d)):
+            # x is read by conv1 AND by the 1x1 downsample: the downsample's data gradient goes to x's producer through its
+            # hand-off slot (nn2d.GradHandoff) instead of an autograd add of two full maps
+            identity = self.downsample[0](x, handoff=x._mm_handoff)
+            for m in list(self.downsample)[1:]:
+                identity = m(identity)
+        else:
+            identity = self.downsample(x)
         if self._fused:
             y = self.bn1(self.conv1(x))
             return self.bn2(self.conv2(y), identity, out=out, residual_shared=self.downsample is None)

@@ -72,7 +72,7 @@ def _need_gpu(x, what):
 
 
 class Conv2d(nn.Conv2d):
-    def forward(self, x):
+    def forward(self, x, handoff=None):
         _need_gpu(x, "Conv2d")
         k = self.kernel_size
         if fp32_mode():
@@ -83,7 +83,7 @@ class Conv2d(nn.Conv2d):
         if _c2d.hip_eligible(self.in_channels, self.out_channels, k[0], k[1], self.stride[0], self.padding[0], self.dilation[0],
                              self.groups) and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] \
                 and self.padding_mode == "zeros":
-            return _c2d.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
+            return _c2d.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], handoff)
         if k == (7, 7) and self.stride == (1, 1) and self.padding == (3, 3) and self.in_channels <= 8 and self.bias is None \
                 and self.out_channels % 64 == 0 and self.groups == 1:
             return _c2d.StemConvFn.apply(x, self.weight)  # the two stems (backbones.py:23-25)
@@ -143,7 +143,8 @@ class _BN2dFn(torch.autograd.Function):
             stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
             ctx.Ns = Ns
-            check(L.mm_bn2d_fwd_train(ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+            ctx.hd = hd = _lib.handle(x.device)  # barrier words / fault word / switches (include/mm2d3d.h mm_create); also the backward's
+            check(L.mm_bn2d_fwd_train(hd.h, ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
                                       ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), ldy, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats, bias)
             ctx.sinks = None
@@ -186,7 +187,7 @@ class _BN2dFn(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device)
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
-        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), lddy, ptr(dy2), lddy2, ptr(ymask), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight),
+        check(L.mm_bn2d_bwd(ctx.hd.h, ptr(x), ldx, ptr(dy), lddy, ptr(dy2), lddy2, ptr(ymask), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight),
                             ptr(bias),
                             ptr(stats[0]), ptr(stats[1]),
                             ptr(dx), C, ptr(dres), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),

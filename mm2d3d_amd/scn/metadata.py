@@ -18,6 +18,10 @@ from .. import _lib, domains
 from .._lib import check, ptr, stream
 
 I32 = torch.int32
+# 1 while a build runs on a side stream beside grid-barrier kernels: the ``no_spin`` / ``sort_merge`` argument of the metadata entry
+# points (include/mm2d3d.h) - only kernels whose workgroups never wait for each other.  An explicit argument of every call: the
+# library keeps no switch.
+NO_SPIN = [0]
 
 
 class _Readback:
@@ -81,7 +85,7 @@ class Rulebook:
         self.csr_pos = torch.empty(max(self.n_rules, 1), dtype=I32, device=dev)
         self.csr_off = torch.empty(self.n_out + 1, dtype=I32, device=dev)
         ws = _lib.workspace.get(int(L.mm_rulebook_ws_bytes(self.n_out, self.K)), dev)
-        check(L.mm_rulebook_csr(ptr(self.nbr), self.K, self.n_out, ptr(self.csr_off), ptr(self.csr_pos), ptr(ws), ws.numel(), stream()),
+        check(L.mm_rulebook_csr(ptr(self.nbr), self.K, self.n_out, ptr(self.csr_off), ptr(self.csr_pos), NO_SPIN[0], ptr(ws), ws.numel(), stream()),
               "rulebook_csr")
         self.nbr = None
 
@@ -168,14 +172,14 @@ class Metadata:
         # Nothing on the side stream may spin-wait across workgroups (the caller's stream may run single-launch batch norms,
         # csrc/fused_bn.h): the tile-table sort switches from Onesweep to the merge sort, everything else here is already free of
         # inter-workgroup waits (three-kernel scans, bounded CAS loops).
-        prev = _lib.lib().mm_os_table_set_sort(1)
+        prev, NO_SPIN[0] = NO_SPIN[0], 1
         try:
             with torch.cuda.stream(side_stream), _lib.workspace_slot("meta"):
                 md.build_levels(coords_i64)
                 md.build_rulebooks()
                 md.ready = side_stream.record_event()
         finally:
-            _lib.lib().mm_os_table_set_sort(prev)
+            NO_SPIN[0] = prev
         # the tensors were allocated on the side stream and are consumed on ``cur``: tell the caching allocator
         for t in md.tensors():
             t.record_stream(cur)
@@ -242,7 +246,7 @@ class Metadata:
             check(
                 L.mm_voxel_dedupe(ptr(src), is64, n_pts, ndev, shift, ptr(lv.tkeys), ptr(lv.tvals), cap,
                                   ptr(lv.item2vox), ptr(lv.coords), ptr(lv.csr_off), ptr(lv.csr_items),
-                                  ptr(counts[l : l + 1]), ptr(err), ptr(ws), ws.numel(), stream()),
+                                  ptr(counts[l : l + 1]), ptr(err), NO_SPIN[0], ptr(ws), ws.numel(), stream()),
                 "voxel_dedupe",
             )
             if split is not None:
@@ -291,7 +295,7 @@ class Metadata:
         ws = _lib.workspace.get(int(L.mm_dedupe_ws_bytes(n)), dev)
         check(
             L.mm_voxel_dedupe(ptr(fine.coords), 0, n, None, 1, ptr(lv.tkeys), ptr(lv.tvals), lv.cap, ptr(lv.item2vox),
-                              ptr(lv.coords), ptr(lv.csr_off), ptr(lv.csr_items), ptr(cnt[0:1]), ptr(cnt[1:2]), ptr(ws),
+                              ptr(lv.coords), ptr(lv.csr_off), ptr(lv.csr_items), ptr(cnt[0:1]), ptr(cnt[1:2]), NO_SPIN[0], ptr(ws),
                               ws.numel(), stream()),
             "voxel_dedupe",
         )
@@ -326,7 +330,7 @@ class Metadata:
         ws = _lib.workspace.get(int(L.mm_rulebook_ws_bytes(n_out, K)), dev)
         check(
             L.mm_rulebook_compact(ptr(nbr), K, n_out, ptr(rb.rin), ptr(rb.rout), ptr(offsets_dev), ptr(rb.csr_off),
-                                  ptr(rb.csr_pos), ptr(ws), ws.numel(), stream()),
+                                  ptr(rb.csr_pos), NO_SPIN[0], ptr(ws), ws.numel(), stream()),
             "rulebook_compact",
         )
         return rb
@@ -344,7 +348,7 @@ class Metadata:
         t.nbrp = torch.empty(K * npad, dtype=I32, device=dev)
         t.tmask = torch.empty(t.n_tiles, dtype=I32, device=dev)
         ws = _lib.workspace.get(int(L.mm_os_table_ws_bytes(n, K)), dev)
-        check(L.mm_os_table_build(ptr(nbr), K, n, t.tile_rows, ptr(t.dst), ptr(t.nbrp), ptr(t.tmask), ptr(ws), ws.numel(),
+        check(L.mm_os_table_build(ptr(nbr), K, n, t.tile_rows, NO_SPIN[0], ptr(t.dst), ptr(t.nbrp), ptr(t.tmask), ptr(ws), ws.numel(),
                                   stream()), "os_table_build")
         return t
 

@@ -65,7 +65,7 @@ def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_
     check(
         L.mm_spconv_apply_packed(ptr(x), x.stride(0), cin, ptr(out), cout, cout, n_out, ptr(src), ptr(dst), ptr(rb.offsets_dev),
                                  rb.offsets_ptr, K, ptr(rb.csr_off), ptr(rb.csr_pos), 1 if unique else 0, ptr(w_kcc),
-                                 cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, ptr(wpk), ptr(ws), ws.numel(), stream()),
+                                 cw_in * cw_out, s_ci, s_co, 1 if kflip else 0, ptr(wpk), ENGINE_MODE[0], ptr(ws), ws.numel(), stream()),
         "spconv_apply",
     )
     return out
@@ -185,6 +185,9 @@ def _apply_os(x, weight, w_kcc, table, cout, transpose, kflip):
 
 
 BF16 = torch.bfloat16
+# ``mode`` argument of the fp32 sparse engines (include/mm2d3d.h MM_SPCONV_*): the environment is read HERE, once - the library
+# itself reads no environment variable (MM_SPCONV_FP32 / MM_SPCONV_SPLIT=2 / MM_DW_WIDE=0 are diagnostics)
+ENGINE_MODE = [_lib.spconv_mode_from_env()]
 F16 = torch.float16
 H16 = (BF16, F16)  # the two kinds of 16-bit rows
 
@@ -212,7 +215,7 @@ def _dw_bf16(x, dout, rb, src, dst, cin, cout, sink=None):
     ws = _lib.workspace.get(int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), x.device)
     check((L.mm_spconv_dw_f16 if x.dtype == F16 else L.mm_spconv_dw_bf16)(
         ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
-        ptr(dW), 0 if sink is None else 1, ptr(ws), ws.numel(), stream()), "spconv_dw_16")
+        ptr(dW), 0 if sink is None else 1, ENGINE_MODE[0], ptr(ws), ws.numel(), stream()), "spconv_dw_16")
     return dW
 
 
@@ -223,7 +226,7 @@ def _dw(x, dout, rb, src, dst, cin, cout, sink=None):
     ws = _lib.workspace.get(int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout)), x.device)
     check(
         L.mm_spconv_dw(ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst), rb.offsets_ptr, rb.K,
-                       ptr(dW), 0 if sink is None else 1, ptr(ws), ws.numel(), stream()),
+                       ptr(dW), 0 if sink is None else 1, ENGINE_MODE[0], ptr(ws), ws.numel(), stream()),
         "spconv_dw",
     )
     return dW
@@ -308,7 +311,7 @@ def _dw_partial(x, dout, rb, src, dst, cin, cout, sink, param, bf16, partial=Non
         partial = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     row = np.empty(_DWB.rows(), dtype=np.int32)
     check(L.mm_spconv_dw_partial((2 if x.dtype == F16 else 1) if bf16 else 0, ptr(x), x.stride(0), cin, ptr(dout), dout.stride(0), cout, ptr(src), ptr(dst),
-                                 rb.offsets_ptr, rb.K, ptr(partial), nbytes, row.ctypes.data, stream()), "spconv_dw_partial")
+                                 rb.offsets_ptr, rb.K, ENGINE_MODE[0], ptr(partial), nbytes, row.ctypes.data, stream()), "spconv_dw_partial")
     return partial, row
 
 
@@ -479,7 +482,7 @@ class SparseConvFunction(torch.autograd.Function):
                 dw = dw.reshape(ctx.wshape)
         return dx, dw, None, None, None, None, None
 
-def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, y, ldy, st):
+def _bn16_fwd(L, h, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, y, ldy, st):
     """bf16 rows.  With a plain ReLU (leak 0) the rows ARE an NHWC bf16 map of N pixels: the BatchNorm2d entry points apply
     (same statistics groups, pitches, fp32 parameters) and bring the single-launch kernels of csrc/bn2d.hip; torch's momentum
     convention is 1 - scn's keep fraction.  Other leak values take the row kernels of csrc/bn.hip."""
@@ -488,7 +491,7 @@ def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, 
         if training:
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
             check((L.mm_bn2d_fwd_train_f16 if f16 else L.mm_bn2d_fwd_train)(
-                x_ptr(x), ldx, None, c, N, Ns, c, w, b, rm, rv, None, eps, 1.0 - momentum, 1, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws),
+                h, x_ptr(x), ldx, None, c, N, Ns, c, w, b, rm, rv, None, eps, 1.0 - momentum, 1, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws),
                 ws.numel(), stream()), "bn2d_fwd_train")
         else:
             check((L.mm_bn2d_fwd_eval_f16 if f16 else L.mm_bn2d_fwd_eval)(x_ptr(x), ldx, None, c, N, c, w, b, rm, rv, eps, 1, y, ldy,
@@ -497,22 +500,22 @@ def _bn16_fwd(L, x, ldx, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, 
     if training:
         ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
         check((L.mm_bn_fwd_train_f16 if f16 else L.mm_bn_fwd_train_bf16)(
-            x_ptr(x), ldx, N, Ns, c, w, b, rm, rv, eps, momentum, leak, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws), ws.numel(), stream()),
+            h, x_ptr(x), ldx, N, Ns, c, w, b, rm, rv, eps, momentum, leak, y, ldy, ptr(st[0]), ptr(st[1]), ptr(ws), ws.numel(), stream()),
             "bn_fwd_train")
     else:
         check((L.mm_bn_fwd_eval_f16 if f16 else L.mm_bn_fwd_eval_bf16)(x_ptr(x), ldx, N, c, w, b, rm, rv, eps, leak, y, ldy, stream()),
               "bn_fwd_eval")
 
 
-def _bn16_bwd(L, x, ldx, dy, lddy, N, Ns, c, w, b, st, leak, dx, dwt, dbt, acc):
+def _bn16_bwd(L, h, x, ldx, dy, lddy, N, Ns, c, w, b, st, leak, dx, dwt, dbt, acc):
     f16 = x.dtype == F16
     if leak == 0.0 and c % 8 == 0 and ldx % 8 == 0 and lddy % 8 == 0:
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(c)), x.device)
-        check((L.mm_bn2d_bwd_f16 if f16 else L.mm_bn2d_bwd)(x_ptr(x), ldx, dy, lddy, None, 0, None, c, 1, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]),
+        check((L.mm_bn2d_bwd_f16 if f16 else L.mm_bn2d_bwd)(h, x_ptr(x), ldx, dy, lddy, None, 0, None, c, 1, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]),
                                                             ptr(dx), c, None, c, dwt, dbt, acc, ptr(ws), ws.numel(), stream()), "bn2d_bwd")
         return
     ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
-    check((L.mm_bn_bwd_f16 if f16 else L.mm_bn_bwd_bf16)(x_ptr(x), ldx, dy, lddy, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), leak, ptr(dx), c,
+    check((L.mm_bn_bwd_f16 if f16 else L.mm_bn_bwd_bf16)(h, x_ptr(x), ldx, dy, lddy, N, Ns, c, w, b, ptr(st[0]), ptr(st[1]), leak, ptr(dx), c,
                                                          dwt, dbt, acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
 
 
@@ -520,13 +523,18 @@ def x_ptr(x):
     return x if isinstance(x, int) else ptr(x)
 
 
-def _bn_entry(L, dtype):
-    """(forward training, forward eval, backward) row kernels of csrc/bn.hip for fp32 / bf16 / IEEE fp16 rows."""
+def _bn_entry(L, dtype, h):
+    """(forward training, forward eval, backward) row kernels of csrc/bn.hip for fp32 / bf16 / IEEE fp16 rows; the training
+    entry points launch through handle ``h`` (include/mm2d3d.h mm_create: barrier words, fault word, switches)."""
+    import functools
+
     if dtype == BF16:
-        return L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16, L.mm_bn_bwd_bf16
-    if dtype == F16:
-        return L.mm_bn_fwd_train_f16, L.mm_bn_fwd_eval_f16, L.mm_bn_bwd_f16
-    return L.mm_bn_fwd_train, L.mm_bn_fwd_eval, L.mm_bn_bwd
+        t, e, b = L.mm_bn_fwd_train_bf16, L.mm_bn_fwd_eval_bf16, L.mm_bn_bwd_bf16
+    elif dtype == F16:
+        t, e, b = L.mm_bn_fwd_train_f16, L.mm_bn_fwd_eval_f16, L.mm_bn_bwd_f16
+    else:
+        t, e, b = L.mm_bn_fwd_train, L.mm_bn_fwd_eval, L.mm_bn_bwd
+    return functools.partial(t, h), e, functools.partial(b, h)
 
 
 class BatchNormActFunction(torch.autograd.Function):
@@ -537,7 +545,8 @@ class BatchNormActFunction(torch.autograd.Function):
         act16 = x.dtype in H16
         x = _c(x) if act16 else _c(x.to(F32))
         ctx.act16 = act16
-        fwd_train, fwd_eval = _bn_entry(L, x.dtype)[:2]
+        ctx.hd = hd = _lib.handle(x.device)  # the backward launches through the handle of the forward
+        fwd_train, fwd_eval = _bn_entry(L, x.dtype, hd.h)[:2]
         N, C = x.shape
         y = torch.empty_like(x)
         if training:
@@ -545,7 +554,7 @@ class BatchNormActFunction(torch.autograd.Function):
             ctx.Ns = Ns
             stats = torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=x.device)
             if act16 and weight is not None:
-                _bn16_fwd(L, x, C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), True, eps, momentum, leak,
+                _bn16_fwd(L, hd.h, x, C, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), True, eps, momentum, leak,
                           ptr(y), C, stats)
             else:
                 ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, x.device)
@@ -561,7 +570,7 @@ class BatchNormActFunction(torch.autograd.Function):
                 gradsink.claim(ctx, bias, True)
                 ctx.sinks = (weight, bias)
         elif act16 and weight is not None:
-            _bn16_fwd(L, x, C, N, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), False, eps, momentum, leak, ptr(y), C,
+            _bn16_fwd(L, hd.h, x, C, N, N, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), False, eps, momentum, leak, ptr(y), C,
                       None)
             ctx.save_for_backward()
         else:
@@ -593,9 +602,9 @@ class BatchNormActFunction(torch.autograd.Function):
             db = dbt = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
             acc = 0
         if ctx.act16 and weight is not None:
-            _bn16_bwd(L, x, C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), stats, ctx.leak, dx, ptr(dwt), ptr(dbt), acc)
+            _bn16_bwd(L, ctx.hd.h, x, C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), stats, ctx.leak, dx, ptr(dwt), ptr(dbt), acc)
         else:
-            check(_bn_entry(L, x.dtype)[2](ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak,
+            check(_bn_entry(L, x.dtype, ctx.hd.h)[2](ptr(x), C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), ptr(stats[0]), ptr(stats[1]), ctx.leak,
                                            ptr(dx), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()), "bn_bwd")
         if ctx.sinks is not None:
             gradsink.done(wp)
@@ -617,7 +626,8 @@ class BatchNormActJoinFunction(torch.autograd.Function):
         for x in xs:
             _lib.require_cuda(x, "features")
         es = 2 if act16 else 4
-        fwd_train, fwd_eval = _bn_entry(L, xs[0].dtype)[:2]
+        ctx.hd = hd = _lib.handle(xs[0].device)
+        fwd_train, fwd_eval = _bn_entry(L, xs[0].dtype, hd.h)[:2]
         N = xs[0].shape[0]
         widths = [x.shape[1] for x in xs]
         C = sum(widths)
@@ -629,7 +639,7 @@ class BatchNormActJoinFunction(torch.autograd.Function):
             rm, rv = ptr(running_mean) + 4 * off, ptr(running_var) + 4 * off
             st = torch.empty((2, 2 if Ns < N else 1, c), dtype=F32, device=x.device) if training else None
             if act16:
-                _bn16_fwd(L, x, c, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, ptr(y) + es * off, C, st)
+                _bn16_fwd(L, hd.h, x, c, N, Ns, c, w, b, rm, rv, training, eps, momentum, leak, ptr(y) + es * off, C, st)
             elif training:
                 ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)
                 check(fwd_train(ptr(x), c, N, Ns, c, w, b, rm, rv, eps, momentum, leak, ptr(y) + es * off, C, ptr(st[0]), ptr(st[1]),
@@ -667,12 +677,12 @@ class BatchNormActJoinFunction(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=dy.device)
             db = dbt = torch.empty(C, dtype=F32, device=dy.device)
             acc = 0
-        bwd = _bn_entry(L, xs[0].dtype)[2]
+        bwd = _bn_entry(L, xs[0].dtype, ctx.hd.h)[2]
         dxs, off = [], 0
         for x, st, c in zip(xs, stats, ctx.widths):
             dx = torch.empty_like(x)
             if ctx.act16:
-                _bn16_bwd(L, x, c, ptr(dy) + es * off, C, N, ctx.Ns, c, ptr(weight) + 4 * off, ptr(bias) + 4 * off, st, ctx.leak, dx,
+                _bn16_bwd(L, ctx.hd.h, x, c, ptr(dy) + es * off, C, N, ctx.Ns, c, ptr(weight) + 4 * off, ptr(bias) + 4 * off, st, ctx.leak, dx,
                           ptr(dwt) + 4 * off, ptr(dbt) + 4 * off, acc)
             else:
                 ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(c)) + 8 * c, x.device)

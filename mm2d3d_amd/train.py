@@ -60,6 +60,11 @@ class TrainModel(nn.Module):
         # arguments (init_scale, growth_interval, ...).
         self._scaler_cfg = train_kwargs.get("loss_scale", nn2d.half_kind() == "fp16" or scn.ACTIVATION_DTYPE[0] == torch.float16)
         self.scaler = None
+        # The trainer's own C-ABI handle (include/mm2d3d.h mm_create: grid-barrier words, fault word and switches of the
+        # single-launch batch norms) - two trainers in one process do not share switches.  ``bn2d_fused`` / ``bn3d_fused``: bit 0 =
+        # forward, bit 1 = backward single-launch kernels (default: the environment's MM_BN2D_FUSED / MM_BN_FUSED, else 3).
+        self._handle_cfg = (train_kwargs.get("bn2d_fused"), train_kwargs.get("bn3d_fused"))
+        self.handle = None
         self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
@@ -77,8 +82,23 @@ class TrainModel(nn.Module):
         self.best = {k: 0.0 for k in ("best_source_iou", "best_target_iou", "best_source_iou_3d", "best_target_iou_3d",
                                       "best_source_iou_avg", "best_target_iou_avg")}
 
+    def _use(self):
+        """Context in which this trainer's operators launch through its own handle (created on first use, on the parameters' GPU)."""
+        import contextlib
+
+        if self.handle is None:
+            p = next(self.model.parameters(), None)
+            if p is None or not p.is_cuda:
+                return contextlib.nullcontext()
+            self.handle = _lib.Handle(p.device, *self._handle_cfg)
+        return _lib.use(self.handle)
+
     # ------------------------------------------------------------------ Lightning-shaped hooks
     def configure_optimizers(self):
+        with self._use():
+            return self._configure_optimizers()
+
+    def _configure_optimizers(self):
         for name in self.modules_name:
             opt, sched = self._opt_factories[name].build(self.model[name].parameters())
             self.optimizers.append(opt)
@@ -155,7 +175,7 @@ class TrainModel(nn.Module):
                         from . import _lib
 
                         _lib.bn2d_set_fused(0)
-                        _lib.lib().mm_bn_set_fused(0)
+                        _lib.bn3d_set_fused(0)
                     main = torch.cuda.current_stream(dev)
                     self._s3d.wait_event(step_start)
                     with torch.cuda.stream(self._s3d):
@@ -193,7 +213,8 @@ class TrainModel(nn.Module):
         return loss_2d + loss_3d
 
     def training_step(self, batch, batch_idx=0):
-        return self._generic_step(batch, "train")
+        with self._use():
+            return self._generic_step(batch, "train")
 
     # ------------------------------------------------------------------ sparse metadata one step ahead
     # The voxel hash / rulebook build of the 3D branch needs two small device -> host read-backs (row counts size the
@@ -242,6 +263,10 @@ class TrainModel(nn.Module):
 
     @torch.no_grad()
     def _generic_step_val(self, batch, stage):
+        with self._use():
+            return self._generic_step_val_impl(batch, stage)
+
+    def _generic_step_val_impl(self, batch, stage):
         self.model.eval()
         p2d, _, _, _ = self(batch, model_name=self.modules_name[0])
         p3d, _, _ = self(batch, model_name=self.modules_name[1])
@@ -326,13 +351,12 @@ class TrainModel(nn.Module):
             self.best[k] = ckpt.get(k, self.best[k])
 
     # ------------------------------------------------------------------ what Lightning's loop does around it
-    @staticmethod
-    def _check_bn_fault(when):
+    def _check_bn_fault(self, when):
         """A read of pinned host memory, written by a single-launch batch-norm kernel whose grid barrier ran out of time.  Polled at
         the start of every step and again before the optimiser step: a barrier waits 10 s before it gives up, by which
         time the host has long filled the queue and sits in the step's read-back wait, so the second poll normally sees a fault of
         the step it belongs to before that step's gradients are applied; the first poll catches what is left."""
-        if _lib.bn2d_fused_fault() | _lib.lib().mm_bn_fused_fault():
+        if (self.handle.fault_poll() if self.handle is not None else _lib.fault_poll()):
             raise RuntimeError(f"a single-launch batch-norm kernel of {when} gave up at its grid barrier (its grid shared the GPU "
                                "with another process or a spin-waiting kernel): that step's results are invalid - skip its optimiser "
                                "step / restore the last checkpoint; the process now uses the three-kernel batch norms")
@@ -340,6 +364,10 @@ class TrainModel(nn.Module):
     def fit_step(self, batch, next_batch=None):
         """One optimiser step on ``batch``.  ``next_batch``: the batch of the following call (the very dict that will be passed
         to it) - its sparse metadata is then built during this step (see ``prefetch``)."""
+        with self._use():
+            return self._fit_step(batch, next_batch)
+
+    def _fit_step(self, batch, next_batch=None):
         if not self.optimizers:
             self.configure_optimizers()
         self._check_bn_fault("an earlier step")

@@ -74,3 +74,58 @@ def test_loss_registry_api_matches_reference_semantics():
     assert "cross_entropy" in repr(loss)
     pred, gt = torch.tensor([[1.0, 2.0], [0.5, 0.0]]), torch.tensor([[1.5, 0.0], [0.0, 1.0]])
     assert abs(float(loss("depth", pred=pred, gt=gt)) - np.mean([0.5, 1.0])) < 1e-6  # l1 over gt > 0
+
+
+def test_library_keeps_no_switches_and_reads_no_environment():
+    """SURVEY.md section 8b row 5 / include/mm2d3d.h conventions: no process-wide mutable state, no environment variable read
+    inside the library (the Python layer reads them once and passes them on), per-device handle entry points exported."""
+    from mm2d3d_amd import _lib
+
+    declared = _declared()
+    for name in ("mm_create", "mm_destroy", "mm_set_option", "mm_get_option", "mm_fault_poll", "mm_handle_sync_bytes",
+                 "mm_handle_fault_bytes"):
+        assert name in declared, name
+    for gone in ("mm_bn2d_set_fused", "mm_bn_set_fused", "mm_os_table_set_sort", "mm_bn2d_fused_fault", "mm_bn_fused_fault"):
+        assert gone not in declared, f"{gone}: a process-wide switch"
+    L = _lib.lib()
+    assert int(L.mm_handle_sync_bytes()) == 64 * 512 and int(L.mm_handle_fault_bytes()) >= 4
+    # handle entry points refuse what is not a handle
+    assert L.mm_destroy(None) != 0 and L.mm_set_option(None, 0, 0) < 0 and b"handle" in L.mm_last_error()
+    src = "".join(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "mm2d3d_amd", "csrc"))
+                  if f.endswith((".hip", ".h")))
+    # (the shared object still imports getenv: rocPRIM's headers, used for one radix sort and the prefix scans, query it themselves)
+    assert "getenv(" not in src and "hipMalloc(" not in src and "hipHostMalloc(" not in src  # the library allocates nothing
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_two_handles_with_different_modes_in_one_process():
+    """Two handles on one GPU, one with the single-launch batch norms, one without: both behave, and the switch of one does not
+    reach the other."""
+    from mm2d3d_amd import _lib, nn2d
+
+    dev = torch.device("cuda:0")
+    fused, plain = _lib.Handle(dev, bn2d_fused=3, bn3d_fused=3), _lib.Handle(dev, bn2d_fused=0, bn3d_fused=0)
+    assert fused.get(_lib.OPT_BN2D_FUSED) == 3 and plain.get(_lib.OPT_BN2D_FUSED) == 0
+    torch.manual_seed(0)
+    x = torch.randn(4, 64, 24, 40, device=dev).to(nn2d._c2d.HALF[0]).contiguous(memory_format=torch.channels_last)
+    outs = []
+    for h in (fused, plain, fused):
+        bn = nn2d.BatchNorm2d(64, relu=True).to(dev)
+        xi = x.clone().requires_grad_(True)
+        with _lib.use(h):
+            assert _lib.handle(dev) is h
+            y = bn(xi)
+        y.float().square().sum().backward()  # outside the context: the backward launches through the forward's handle
+        outs.append((y.detach().float(), xi.grad.float(), bn.running_mean.clone()))
+    assert _lib.handle(dev) is not fused and _lib.handle(dev) is not plain
+    for a, b in ((outs[0], outs[1]), (outs[0], outs[2])):
+        assert torch.allclose(a[0], b[0], atol=2e-2, rtol=2e-2) and torch.allclose(a[2], b[2], atol=1e-5)
+        assert torch.allclose(a[1], b[1], atol=5e-2, rtol=5e-2)
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])  # the same handle twice: bit-identical
+    assert fused.get(_lib.OPT_BN2D_FUSED) == 3 and plain.get(_lib.OPT_BN2D_FUSED) == 0 and fused.fault_poll() == 0
+    prev = plain.set(_lib.OPT_BN2D_FUSED, 1)
+    assert prev == 0 and plain.get(_lib.OPT_BN2D_FUSED) == 1 and fused.get(_lib.OPT_BN2D_FUSED) == 3
+    fused.close(), plain.close()

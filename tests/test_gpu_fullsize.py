@@ -289,7 +289,7 @@ def test_full_joint_step_at_bench_size_c5_16bit_rows(kind):
             return {"source": f(src), "target": f(trg)}
 
         loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
-        tk = dict(lambda_xm_src=0.1, lambda_xm_trg=0.01)  # the vKITTI experiment's weights (config.yaml:107-108)
+        tk = dict(lambda_xm_src=0.1, lambda_xm_trg=0.01, precision=kind)  # the vKITTI experiment's weights (config.yaml:107-108); 2D maps in the same 16-bit kind as the rows
         opts = {}
         for k in ("2d_net", "3d_net"):
             o = Optimizer("adamw", lr=0.001)

@@ -347,7 +347,8 @@ def _bn2d_call(L, fused, x, ldx, res, dy, dy2, N, Ns, C, relu, w, b, use_yout):
     from mm2d3d_amd._lib import check, ptr, stream
 
     dev = x.device
-    prev = L.mm_bn2d_set_fused(3 if fused else 0)
+    prev = _lib.bn2d_set_fused(3 if fused else 0)  # the current handle's switch (include/mm2d3d.h MM_OPT_BN2D_FUSED)
+    h = _lib.handle(dev).h
     try:
         rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
         nbt = torch.zeros(1, dtype=torch.int64, device=dev)
@@ -358,14 +359,14 @@ def _bn2d_call(L, fused, x, ldx, res, dy, dy2, N, Ns, C, relu, w, b, use_yout):
         dw, db = torch.full((C,), 0.25, device=dev), torch.full((C,), -0.5, device=dev)  # accumulate = 1 adds to these
         stats = torch.zeros((2, 2 if 0 < Ns < N else 1, C), device=dev)
         ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), dev)
-        check(L.mm_bn2d_fwd_train(ptr(x), ldx, ptr(res), C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), ptr(nbt), 1e-5, 0.1, int(relu), ptr(y), C,
+        check(L.mm_bn2d_fwd_train(h, ptr(x), ldx, ptr(res), C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), ptr(nbt), 1e-5, 0.1, int(relu), ptr(y), C,
                                   ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "fwd")
         yout = y if use_yout else None
-        check(L.mm_bn2d_bwd(ptr(x), ldx, ptr(dy), C, ptr(dy2), C if dy2 is not None else 0, ptr(yout), C, int(relu), N, Ns, C, ptr(w), ptr(b),
+        check(L.mm_bn2d_bwd(h, ptr(x), ldx, ptr(dy), C, ptr(dy2), C if dy2 is not None else 0, ptr(yout), C, int(relu), N, Ns, C, ptr(w), ptr(b),
                             ptr(stats[0]), ptr(stats[1]), ptr(dx), C, ptr(dres), C, ptr(dw), ptr(db), 1, ptr(ws), ws.numel(), stream()), "bwd")
         torch.cuda.synchronize()
     finally:
-        L.mm_bn2d_set_fused(prev)
+        _lib.bn2d_set_fused(prev)
     return dict(y=y, dx=dx, dres=dres, dw=dw, db=db, stats=stats, rm=rm, rv=rv, nbt=nbt)
 
 

@@ -206,20 +206,21 @@ def test_batchnorm_single_launch_kernels_equal_the_three_kernel_path(N, Ns, C, l
     b = torch.randn(C, generator=g).to(dev)
 
     def run(mask):
-        prev = L.mm_bn_set_fused(mask)
+        prev = _lib.bn3d_set_fused(mask)
+        h = _lib.handle(dev).h
         try:
             rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
             y, dx = torch.zeros(N, C, device=dev), torch.zeros(N, C, device=dev)
             dw, db = torch.full((C,), 0.5, device=dev), torch.full((C,), -1.0, device=dev)
             stats = torch.zeros((2, 2 if 0 < Ns < N else 1, C), device=dev)
             ws = _lib.workspace.get(int(L.mm_bn_ws_bytes(C)) + 8 * C, dev)
-            check(L.mm_bn_fwd_train(ptr(x), pitch, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), 1e-4, 0.9, leak, ptr(y), C, ptr(stats[0]),
+            check(L.mm_bn_fwd_train(h, ptr(x), pitch, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), 1e-4, 0.9, leak, ptr(y), C, ptr(stats[0]),
                                     ptr(stats[1]), ptr(ws), ws.numel(), stream()), "fwd")
-            check(L.mm_bn_bwd(ptr(x), pitch, ptr(dy), C, N, Ns, C, ptr(w), ptr(b), ptr(stats[0]), ptr(stats[1]), leak, ptr(dx), C, ptr(dw),
+            check(L.mm_bn_bwd(h, ptr(x), pitch, ptr(dy), C, N, Ns, C, ptr(w), ptr(b), ptr(stats[0]), ptr(stats[1]), leak, ptr(dx), C, ptr(dw),
                               ptr(db), 1, ptr(ws), ws.numel(), stream()), "bwd")
             torch.cuda.synchronize()
         finally:
-            L.mm_bn_set_fused(prev)
+            _lib.bn3d_set_fused(prev)
         return dict(y=y, dx=dx, dw=dw, db=db, stats=stats, rm=rm, rv=rv)
 
     a, c = run(3), run(0)
@@ -414,7 +415,7 @@ def test_act16_batchnorm(act16_mode):
     C, N = 48, 3000
     x = (torch.randn(N, C) * 2 + 0.5).to(act16_mode)
     bn = scn.BatchNormReLU(C).to(dev)
-    ref = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=0.1).double()
+    ref = torch.nn.BatchNorm1d(C, eps=1e-4, momentum=1.0 - bn.momentum).double()  # scn momentum = keep fraction (default 0.99)
     with torch.no_grad():
         bn.weight.copy_(torch.rand(C) + 0.5)
         bn.bias.copy_(torch.randn(C) * 0.1)

@@ -294,8 +294,6 @@ def test_branches_on_two_streams_equal_the_single_stream_step():
     from mm2d3d_amd.train import TrainModel
 
     dev = _dev()
-    L = _lib.lib()
-    prev2, prev3 = L.mm_bn2d_set_fused(0), L.mm_bn_set_fused(0)
     try:
         torch.manual_seed(1)
         kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
@@ -307,7 +305,7 @@ def test_branches_on_two_streams_equal_the_single_stream_step():
         n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
         mk = lambda: {"source": make_batch(5, 2, "nuscenes", (96, 128), device=dev), "target": make_batch(6, 2, "nuscenes", (96, 128), device=dev)}
         loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
-        kwargs = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False)
+        kwargs = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False, bn2d_fused=0, bn3d_fused=0)  # three-kernel batch norms on both handles
         one = TrainModel({"2d_net": n2, "3d_net": n3}, None, loss, dict(kwargs))
         two = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(kwargs, overlap_branches=1))
         for _ in range(3):  # several steps: the stream handoffs repeat with recycled allocator blocks
@@ -327,8 +325,7 @@ def test_branches_on_two_streams_equal_the_single_stream_step():
                 if p.grad is not None:
                     assert torch.equal(p.grad, q.grad), name
     finally:
-        L.mm_bn2d_set_fused(prev2)
-        L.mm_bn_set_fused(prev3)
+        pass
 
 
 def test_gradient_sinks_equal_autograd_accumulation():

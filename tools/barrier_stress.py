@@ -41,7 +41,8 @@ if kind.startswith("metadata"):
 
     coords = make_batch(2, 16, "nuscenes", (32, 48), 6, device=dev)["x"][0]
     if kind == "metadata_onesweep":
-        L.mm_os_table_set_sort = lambda merge: 0  # leave Onesweep on
+        from mm2d3d_amd.scn import metadata as _md
+        _md.NO_SPIN = type('K', (list,), {'__setitem__': lambda self, i, v: None})([0])  # leave Onesweep / look-back scans on
 
 
 def side_work():
@@ -70,9 +71,9 @@ while time.perf_counter() - t0 < secs:
         elif kind != "none":
             for _ in range(4):
                 side_work()
-        check(L.mm_bn2d_fwd_train(ptr(x), C, None, C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), None, 1e-5, 0.1, 1, ptr(y), C, ptr(stats[0]),
+        check(L.mm_bn2d_fwd_train(_lib.handle(x.device).h, ptr(x), C, None, C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), None, 1e-5, 0.1, 1, ptr(y), C, ptr(stats[0]),
                                   ptr(stats[1]), ptr(ws), ws.numel(), stream()), "fwd")
-        check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, None, 0, None, C, 1, N, Ns, C, ptr(w), ptr(b), ptr(stats[0]), ptr(stats[1]), ptr(dx), C, None,
+        check(L.mm_bn2d_bwd(_lib.handle(x.device).h, ptr(x), C, ptr(dy), C, None, 0, None, C, 1, N, Ns, C, ptr(w), ptr(b), ptr(stats[0]), ptr(stats[1]), ptr(dx), C, None,
                             C, ptr(dw), ptr(db), 1, ptr(ws), ws.numel(), stream()), "bwd")
         n += 2
         if os.environ.get("CHECK"):  # same inputs every call: statistics, outputs and gradients must be bit-identical every time

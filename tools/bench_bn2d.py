@@ -69,11 +69,11 @@ def time_shape(dev, N, Ns, C, res, relu, two, iters=30):
     ymask = y if (res or not relu) else None
 
     def f():
-        check(L.mm_bn2d_fwd_train(ptr(x), C, ptr(r), C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), None, 1e-5, 0.1, int(relu), ptr(y), C,
+        check(L.mm_bn2d_fwd_train(_lib.handle(x.device).h, ptr(x), C, ptr(r), C, N, Ns, C, ptr(w), ptr(b), ptr(rm), ptr(rv), None, 1e-5, 0.1, int(relu), ptr(y), C,
                                   ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "fwd")
 
     def g():
-        check(L.mm_bn2d_bwd(ptr(x), C, ptr(dy), C, ptr(dy2), C if two else 0, ptr(ymask), C, int(relu), N, Ns, C, ptr(w), ptr(b),
+        check(L.mm_bn2d_bwd(_lib.handle(x.device).h, ptr(x), C, ptr(dy), C, ptr(dy2), C if two else 0, ptr(ymask), C, int(relu), N, Ns, C, ptr(w), ptr(b),
                             ptr(stats[0]), ptr(stats[1]), ptr(dx), C, ptr(dres), C, ptr(dw), ptr(db), 1, ptr(ws), ws.numel(), stream()), "bwd")
 
     out = []
@@ -110,11 +110,11 @@ def main():
     print("three-kernel path (3k) against the single-launch kernels (1k); GB/s = single-pass traffic / time of the 1k column")
     print(f"{'rows':>9s} {'rows g0':>9s} {'C':>4s} res relu dy2 calls {'MB':>7s} {'fwd 3k':>8s} {'fwd 1k':>8s} {'bwd 3k':>8s} {'bwd 1k':>8s} {'fwd GB/s':>9s} {'bwd GB/s':>9s}")
     for (N, Ns, C, res, relu, two), n in sorted(shapes.items(), key=lambda kv: -kv[0][0] * kv[0][2]):
-        prev = L.mm_bn2d_set_fused(0)
+        prev = _lib.bn2d_set_fused(0)
         tf0, tb0 = time_shape(dev, N, Ns, C, res, relu, two)
-        L.mm_bn2d_set_fused(3)
+        _lib.bn2d_set_fused(3)
         tf, tb = time_shape(dev, N, Ns, C, res, relu, two)
-        L.mm_bn2d_set_fused(prev)
+        _lib.bn2d_set_fused(prev)
         mb = N * C * 2 / 1e6
         bf = mb * (2 + (1 if res else 0))  # x read once + y written (+ residual): the single-pass floor
         bb = mb * (3 + (1 if two else 0) + (2 if res else 0))  # x, dy (, dy2, yout) read + dx (, dres) written
