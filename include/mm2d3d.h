@@ -316,6 +316,20 @@ int mm_lift_scatter(const float* dout, int C, const int64_t* upix_off, const int
 /* backward of the lifting without compaction: order = stable argsort of the pixel keys, first[e] marks run starts */
 int mm_lift_scatter_runs(const float* dout, int C, const int64_t* order, const unsigned char* first,
                          const int64_t* sorted_off, int64_t N, int64_t chan_stride, float* dseg, mm_stream_t stream);
+/* The lifting index built on the device in three launches (csrc/lift.hip; round 4).  rc: device int64 [n, 2] (row, col) of every
+ * point, scenes concatenated (img_indices of lib/dataset/__init__.py:74,111); counts: device int64 [nb] points per scene.
+ * key [n] = pixel id (b*H + row)*W + col (rows / cols clamped into the map; err[0] = 1 if one was outside - the reference asserts
+ * these bounds in its loader, nuscenes_dataloader.py:280-283); skey / order [n] = the keys ascending and the point at each sorted
+ * position (stable radix sort).  no_spin: see mm_voxel_dedupe. */
+size_t mm_lift_index_ws_bytes(int64_t n);
+int mm_lift_index(const int64_t* rc, const int64_t* counts, int nb, int64_t n, int H, int W, int no_spin, int32_t* key, int32_t* skey,
+                  int32_t* order, int32_t* err, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* out[p][c] = seg[b*sb + row*sy + col*sx + c*sc] at the pixel of point p (2d_net/model.py:131-137) */
+int mm_lift_gather_key(const float* seg, int64_t sb, int64_t sy, int64_t sx, int64_t sc, const int32_t* key, int64_t N, int C, int H,
+                       int W, float* out, mm_stream_t stream);
+/* its backward: dseg (zero-filled by the caller) at every pixel with points = the sum of dout over them, ascending point order */
+int mm_lift_scatter_key(const float* dout, int C, const int32_t* order, const int32_t* skey, int64_t N, int H, int W, int64_t sb,
+                        int64_t sy, int64_t sx, int64_t sc, float* dseg, mm_stream_t stream);
 /* evaluation (EXP/train.py:297-339): confusion matrices [3][C][C] int64 of argmax(2D), argmax(3D), argmax(softmax mean) */
 int mm_eval_confusion(const float* logits2d, int ld2, const float* logits3d, int ld3, const int64_t* labels, int64_t N,
                       int C, int64_t ignore_index, int64_t* cm, mm_stream_t stream);
@@ -344,7 +358,8 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, mm_stream_t stream);
 /* 3x3 stride-1 pad-1 convolution (flip 0) or its data gradient (flip 1, Wp = [ci][tap][co]) from a halo tile staged once
- * for all 9 taps (EXP/2d_net/backbones.py ResNet34 BasicBlocks; EXP/2d_net/model.py:68-71 decoder convolutions) */
+ * for all 9 taps (EXP/2d_net/backbones.py ResNet34 BasicBlocks; EXP/2d_net/model.py:68-71 decoder convolutions).
+ * flip | 2: a ragged last round of work items is NOT cut into half items (A/B measurements; results are the same sums). */
 int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
                     const float* bias, int flip, mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps);

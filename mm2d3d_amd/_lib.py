@@ -95,6 +95,10 @@ _PROTOS = {
     "mm_lift_gather": (i32, [vp, i64, vp, i64, i32, vp, vp]),
     "mm_lift_scatter": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp]),
     "mm_lift_scatter_runs": (i32, [vp, i32, vp, vp, vp, i64, i64, vp, vp]),
+    "mm_lift_index_ws_bytes": (sz, [i64]),
+    "mm_lift_index": (i32, [vp, vp, i32, i64, i32, i32, i32, vp, vp, vp, vp, vp, sz, vp]),
+    "mm_lift_gather_key": (i32, [vp, i64, i64, i64, i64, vp, i64, i32, i32, i32, vp, vp]),
+    "mm_lift_scatter_key": (i32, [vp, i32, vp, vp, i64, i32, i32, i64, i64, i64, i64, vp, vp]),
     "mm_eval_confusion": (i32, [vp, i32, vp, i32, vp, i64, i32, i64, vp, vp]),
     "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp]),
     "mm_grad_nonfinite": (i32, [vp, i64, vp, vp]),

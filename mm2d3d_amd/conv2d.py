@@ -73,6 +73,10 @@ def as_nhwc_bf16(x):
     return x
 
 
+import os as _os
+
+# mm_conv2d_3x3s1's flip argument, bit 1: whole work items only (A/B of the half-item last round; MM_CONV_WHOLE_ITEMS=1)
+WHOLE_ITEMS = [2 if _os.environ.get("MM_CONV_WHOLE_ITEMS", "0") != "0" else 0]
 PARAM_EPOCH = [0]  # bumped by FlatAdamW.step(): packed bf16 copies of the fp32 master weights are valid for one epoch
 
 
@@ -225,7 +229,7 @@ class Conv2dFn(torch.autograd.Function):
         tx = [kw - padding for _ in range(KH) for kw in range(KW)]
         b = bias.detach().float().contiguous() if bias is not None else None
         if (KH, KW, stride, padding) == (3, 3, 1, 1):  # halo-tile kernel: input patch staged once for all 9 taps
-            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0, stream()),
+            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0 | WHOLE_ITEMS[0], stream()),
                   "conv2d_3x3s1")
         else:
             _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b, lda=ldx)
@@ -251,7 +255,7 @@ class Conv2dFn(torch.autograd.Function):
             Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T, ctx.wowner, "dgrad")  # [ci][t][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x.device, memory_format=CL)
             if (KH, KW, stride, padding) == (3, 3, 1, 1):
-                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1, stream()),
+                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1 | WHOLE_ITEMS[0], stream()),
                       "conv2d_3x3s1")
             else:
                 ty = [padding - kh for kh in range(KH) for _ in range(KW)]

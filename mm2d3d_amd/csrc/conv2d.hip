@@ -332,6 +332,7 @@ struct C3P {
   const u16* Wp;  // [n][9][Ca]
   const float* bias;
   int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
+  int whole; // != 0: never cut a ragged last round into half items (A/B measurements)
   int tiles_y, tiles_x;
 };
 // DIAG (tools/conv3x3_diag.hip only; the library instantiates DIAG = 0): parts of k_conv3x3w switched off at COMPILE time to see
@@ -403,11 +404,28 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
   // a tile's halo (its cout blocks are consecutive items) run on one XCD at the same time and share its L2
   const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
   const int per = (nitems + 7) >> 3;
-  const int it_begin = xcd * per + local;
+  const int x_begin = xcd * per;
   const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
-  if (it_begin >= it_end) return;
-  const int my_items = (it_end - it_begin + G8 - 1) / G8;
+  // The workgroups of an XCD take its items round-robin.  A ragged last round (rem of the G8 workgroups busy, the others done)
+  // was up to half of a layer's time at the bench's sizes (256-channel maps: 40 items per XCD on 32 workgroups = two rounds, the
+  // second a quarter full).  Round 4: when at most half of the workgroups would be busy in that round, its items are cut into
+  // their two 64-cout halves - twice as many workgroups, each with half the MFMAs and three quarters of the fragment reads per
+  // step (same halo, half a weight tile; the other half of the tile's DMA reads the zero line so that the DMA counts stay exact).
+  const int n_x = it_end > x_begin ? it_end - x_begin : 0;
+  const int r_full = n_x / G8, rem = n_x - r_full * G8;
+  const bool halfmode = BN == 128 && rem > 0 && 2 * rem <= G8 && !p.whole;
+  const int my_items = r_full + ((halfmode ? local < 2 * rem : local < rem) ? 1 : 0);
+  if (my_items == 0) return;
   const int nseg = my_items * nchunk;
+  // k-th item of this workgroup; half = -1: the whole BN-cout block, 0 / 1: its lower / upper 64 couts
+  auto item_of = [&](int k, int& half) {
+    if (halfmode && k == r_full) {
+      half = local & 1;
+      return x_begin + r_full * G8 + (local >> 1);
+    }
+    half = -1;
+    return x_begin + local + k * G8;
+  };
 
   auto decode = [&](int item, int& b, int& ty0, int& tx0, int& n0) {
     n0 = (item % ncb) * BN;
@@ -458,6 +476,8 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
     const int row = wn * (BN / 2) + j * 32 + fr_;
     boff[j] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
   }
+  const int browh = wn * 32 + fr_;  // half item: this wave's ONE 32-cout fragment of the 64 valid rows of the W tile
+  const int boffh = browh * 128 + ((fh ^ ((browh >> 1) & 7)) << 4);
   // epilogue (frag_rows): this lane stores rows of pixels 64 wm + 32 i + (lane & 15) and + 16, at 16-byte chunk schunk
   int spy[2][2], spx[2][2];
   const int schunk = frag_chunk(lane);
@@ -470,10 +490,10 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
     }
 
   // producer cursors advance incrementally: no divisions between a barrier and the MFMAs
-  int h_item = it_begin, h_c = 0, h_b, h_ty0, h_tx0, h_n0;
-  decode(h_item, h_b, h_ty0, h_tx0, h_n0);
+  int h_k = 0, h_c = 0, h_b, h_ty0, h_tx0, h_n0, h_half;
+  decode(item_of(0, h_half), h_b, h_ty0, h_tx0, h_n0);
   auto issue_halo = [&](int buf) {  // 6 DMA instructions (5 for waves 3..7), always; then advance the cursor
-    const bool live = h_item < it_end && !MM_DIAG(p, 8);
+    const bool live = h_k < my_items && !MM_DIAG(p, 8);
     const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
     const u16* base = p.A + ((int64_t)(h_b * p.H + h_ty0) * p.W + h_tx0) * p.lda + h_c * 64;
     char* dst = lds + HS0 + buf * HSZB + wave * 1024;
@@ -496,25 +516,26 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
     }
     if (++h_c == nchunk) {
       h_c = 0;
-      h_item += G8;
-      if (h_item < it_end) decode(h_item, h_b, h_ty0, h_tx0, h_n0);
+      if (++h_k < my_items) decode(item_of(h_k, h_half), h_b, h_ty0, h_tx0, h_n0);
     }
   };
-  int w_item = it_begin, w_c = 0, w_tap = 0, w_n0 = (it_begin % ncb) * BN;
+  int w_k = 0, w_c = 0, w_tap = 0, w_half, w_n0;
+  w_n0 = (item_of(0, w_half) % ncb) * BN + (w_half > 0 ? 64 : 0);
   auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
-    const bool live = w_item < it_end && !MM_DIAG(p, 4);
+    const bool live = w_k < my_items && !MM_DIAG(p, 4);
     const u16* base = live ? p.Wp + ((int64_t)w_n0 * 9 + w_tap) * p.Ca + w_c * 64 : (const u16*)g_zero16;
     char* dst = lds + buf * BSZB + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < NB; i++)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + (live ? wl[i] : 0)),
+    for (int i = 0; i < NB; i++) {
+      const bool real = live && !(i > 0 && w_half >= 0);  // a half item: rows 64.. of the tile are not read, their DMA reads the zero line
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(real ? base + wl[i] : (const u16*)g_zero16),
                                        (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+    }
     if (++w_tap == 9) {
       w_tap = 0;
       if (++w_c == nchunk) {
         w_c = 0;
-        w_item += G8;
-        w_n0 = (w_item % ncb) * BN;
+        if (++w_k < my_items) w_n0 = (item_of(w_k, w_half) % ncb) * BN + (w_half > 0 ? 64 : 0);
       }
     }
   };
@@ -558,7 +579,8 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  int c_item = it_begin, c_c = 0;  // consumer cursor
+  int c_k = 0, c_c = 0, c_half;    // consumer cursor
+  int c_item = item_of(0, c_half);
   int slot = 0;                    // byte offset of the W ring slot of the current step
   for (int seg = 0; seg < nseg; seg++) {
     const int hb = (seg & 1) * HSZB;
@@ -568,25 +590,30 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if (!MM_DIAG(p, 2)) {
+      // a half item (workgroup-uniform, BN = 128 only): ONE 32-cout fragment per wave, rows wn * 32 .. of the tile's 64 valid rows
+      const bool halfit = BN == 128 && c_half >= 0;
+      const int b0sel = halfit ? boffh : boff[0];
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
-        bf16x8 af[2], bf[TN];
+        bf16x8 af[2];
 #pragma unroll
         for (int i = 0; i < 2; i++) af[i] = *(const bf16x8*)(lds + (((aoff[i][tap] + hb)) ^ (kk << 5)));
-#pragma unroll
-        for (int j = 0; j < TN; j++) bf[j] = *(const bf16x8*)(lds + ((boff[j] ^ (kk << 5)) + slot));
+        const bf16x8 bf0 = *(const bf16x8*)(lds + ((b0sel ^ (kk << 5)) + slot));
         if (MM_DIAG(p, 1)) {  // keep the reads alive without the matrix pipe
 #pragma unroll
-          for (int i = 0; i < 2; i++)
-#pragma unroll
-            for (int j = 0; j < TN; j++) acc[i][j][0] += (float)af[i][0] + (float)bf[j][0];
+          for (int i = 0; i < 2; i++) acc[i][0][0] += (float)af[i][0] + (float)bf0[0];
           continue;
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++) acc[i][0] = MM_MFMA_32x32x16(bf0, af[i], acc[i][0]);  // D[cout][pixel]
+        if (TN > 1 && !halfit) {
 #pragma unroll
-          for (int j = 0; j < TN; j++)
-            acc[i][j] = MM_MFMA_32x32x16(bf[j], af[i], acc[i][j]);  // D[cout][pixel]
+          for (int j = 1; j < TN; j++) {
+            const bf16x8 bfj = *(const bf16x8*)(lds + ((boff[j] ^ (kk << 5)) + slot));
+#pragma unroll
+            for (int i = 0; i < 2; i++) acc[i][j] = MM_MFMA_32x32x16(bfj, af[i], acc[i][j]);
+          }
+        }
       }
       }
       slot = slot + BSZB == RW * BSZB ? 0 : slot + BSZB;
@@ -594,8 +621,10 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
     if (++c_c == nchunk) {  // item finished: D row (reg&3) + 8*(reg>>2) + 4*fh = output channel, column fr_ = pixel
       int b, ty0, tx0, n0;
       decode(c_item, b, ty0, tx0, n0);
+      const int jn = (BN == 128 && c_half >= 0) ? 1 : TN;                                   // fragments of this item per wave
+      const int cbase = n0 + ((BN == 128 && c_half >= 0) ? c_half * 64 + wn * 32 : wn * (BN / 2));  // this wave's first channel
       c_c = 0;
-      c_item += G8;
+      if (++c_k < my_items) c_item = item_of(c_k, c_half);
       if (MM_DIAG(p, 32)) continue;
       unsigned diag_sum = 0;
 #pragma unroll
@@ -603,10 +632,11 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
         // after frag_rows this lane holds rows of the pixels sp[i][0] (xa) and sp[i][1] (xb), not of its own MFMA column
         const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
         const bool ina = ya < p.H && xa_ < p.W && !MM_DIAG(p, 16), inb = yb < p.H && xb_ < p.W && !MM_DIAG(p, 16);
-        u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + n0 + wn * (BN / 2) + 8 * schunk;
-        u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + n0 + wn * (BN / 2) + 8 * schunk;
+        u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + cbase + 8 * schunk;
+        u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + cbase + 8 * schunk;
 #pragma unroll
         for (int j = 0; j < TN; j++) {
+          if (j < jn) {
           unsigned D[4][2];
 #pragma unroll
           for (int q = 0; q < 4; q++) {
@@ -614,7 +644,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
               v[e] = acc[i][j][4 * q + e];
-              if (p.bias) v[e] += biasl[n0 + wn * (BN / 2) + 32 * j + 8 * q + 4 * fh + e];
+              if (p.bias) v[e] += biasl[cbase + 32 * j + 8 * q + 4 * fh + e];
               acc[i][j][4 * q + e] = 0.f;
             }
             D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
@@ -628,6 +658,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
           }
           *(uint4*)(ina ? rowa + 32 * j : (u16*)g_dump + lane * 8) = xa;
           *(uint4*)(inb ? rowb + 32 * j : (u16*)g_dump + lane * 8) = xb;
+          }
         }
       }
       if (MM_DIAG(p, 64)) g_dump[lane] = diag_sum;
@@ -1381,7 +1412,7 @@ int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda,
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0, "conv2d_3x3s1: bad shape");
   C3P p;
   p.A = (const u16*)A; p.B = B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O; p.Cn = Cn; p.ldo = ldo;
-  p.Wp = (const u16*)Wp; p.bias = bias; p.flip = flip;
+  p.Wp = (const u16*)Wp; p.bias = bias; p.flip = flip & 1; p.whole = (flip >> 1) & 1;  // flip bit 1: whole items only
   p.tiles_y = (int)mm_cdiv(H, 8); p.tiles_x = (int)mm_cdiv(W, 16);
   const int64_t nt = (int64_t)B * p.tiles_y * p.tiles_x;
   if (nt == 0) return MM_OK;

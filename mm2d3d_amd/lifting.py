@@ -44,16 +44,13 @@ class PixelIndex:
     def __init__(self, img_indices, H, W, device):
         dev = torch.device(device)
         self.H, self.W, self.device = H, W, device
-        self._bad = None
+        self._joint = {}  # joint gradient buffers of maps that are channel slices of one NHWC buffer (see _LiftFn.backward)
+        self._err = None  # device flag: an index was outside the map (device-side lists only; host lists are checked on the host)
         if len(img_indices) and all(isinstance(ix, torch.Tensor) and ix.is_cuda for ix in img_indices):
             counts = [int(ix.shape[0]) for ix in img_indices]
             self.n = int(sum(counts))
             rc_d = torch.cat([ix.reshape(-1, 2) for ix in img_indices], 0).to(dev, torch.int64)
             cnt_d = torch.tensor(counts, dtype=torch.int64).to(dev, non_blocking=True)
-            if self.n:
-                self._bad = ((rc_d < 0).any() | (rc_d[:, 0] >= H).any() | (rc_d[:, 1] >= W).any())
-                # whatever the caller passed, the gather / scatter kernels only ever see addresses inside the map
-                rc_d = torch.stack([rc_d[:, 0].clamp(0, H - 1), rc_d[:, 1].clamp(0, W - 1)], 1)
             rows = img_indices
         else:
             rows = [np.asarray(ix.cpu() if isinstance(ix, torch.Tensor) else ix, dtype=np.int64).reshape(-1, 2) for ix in img_indices]
@@ -77,29 +74,25 @@ class PixelIndex:
             both = stage["buf"][: nb + 2 * self.n].to(dev, non_blocking=True)
             stage["event"].record(cur)
             cnt_d, rc_d = both[:nb], both[nb:].view(-1, 2)
-        b = torch.repeat_interleave(torch.arange(len(rows), device=device), cnt_d, output_size=self.n)
-        self.b, self.r, self.c = b, rc_d[:, 0], rc_d[:, 1]
-        key = (b * H + self.r) * W + self.c                   # flat pixel id b*H*W + r*W + c
-        self.skey, self.order = torch.sort(key, stable=True)  # stable: ascending point order inside a pixel
-        first = torch.ones(self.n, dtype=torch.bool, device=device)
-        if self.n > 1:
-            first[1:] = self.skey[1:] != self.skey[:-1]
-        self.first = first.to(torch.uint8)
-        self._cache = {}
+        # one device-side build (csrc/lift.hip): pixel keys, stable (key, point) radix sort - three launches (rounds 1-3: ~25 torch
+        # launches: repeat_interleave, arange, key arithmetic, sort, run flags, offset tables)
+        L = _lib.lib()
+        self.rc, self.counts = rc_d.contiguous(), cnt_d.contiguous()
+        self.key = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        self.skey = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        self.order = torch.empty(max(self.n, 1), dtype=torch.int32, device=dev)
+        if self._err is None:
+            self._err = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = _lib.workspace.get(int(L.mm_lift_index_ws_bytes(self.n)), dev)
+        from .scn import metadata as _md
+
+        check(L.mm_lift_index(ptr(self.rc), ptr(self.counts), len(counts), self.n, H, W, _md.NO_SPIN[0], ptr(self.key), ptr(self.skey),
+                              ptr(self.order), ptr(self._err), ptr(ws), ws.numel(), stream()), "lift_index")
 
     def check(self):
         """Raises IndexError if a device-side index was out of the image (one small read-back; call it off the hot path)."""
-        if self._bad is not None and bool(self._bad.item()):
+        if self._err is not None and bool(self._err.item()):
             raise IndexError("img_indices out of the image bounds")
-
-    def offsets(self, sb, sy, sx, sorted_order=False):
-        """Element offset of channel 0 of every point's pixel in a [B,C,H,W] map with strides (sb, *, sy, sx); with
-        ``sorted_order`` the offsets follow the key-sorted order (for the backward)."""
-        k = (int(sb), int(sy), int(sx), sorted_order)
-        if k not in self._cache:
-            off = self.b * int(sb) + self.r * int(sy) + self.c * int(sx)
-            self._cache[k] = off.index_select(0, self.order).contiguous() if sorted_order else off.contiguous()
-        return self._cache[k]
 
 
 class _LiftFn(torch.autograd.Function):
@@ -110,10 +103,16 @@ class _LiftFn(torch.autograd.Function):
         seg = seg.to(F32)
         B, C, H, W = seg.shape
         assert (H, W) == (index.H, index.W)
-        pix = index.offsets(seg.stride(0), seg.stride(2), seg.stride(3))
         out = torch.empty((index.n, C), dtype=F32, device=seg.device)
-        check(L.mm_lift_gather(ptr(seg), seg.stride(1), ptr(pix), index.n, C, ptr(out), stream()), "lift_gather")
+        check(L.mm_lift_gather_key(ptr(seg), seg.stride(0), seg.stride(2), seg.stride(3), seg.stride(1), ptr(index.key), index.n, C, H, W,
+                                   ptr(out), stream()), "lift_gather")
         ctx.index, ctx.shape = index, seg.shape
+        # seg may be a channel slice of a wider NHWC map (the two heads of nn2d.fused_heads are the halves of ONE [B, h, w, 2 nc]
+        # buffer): remember the layout, the backward then writes its slice of ONE joint gradient buffer instead of a map of its own
+        ctx.slice = None
+        if seg.stride(1) == 1 and seg.stride(3) > C and seg.stride(2) == W * seg.stride(3) and seg.stride(0) == H * W * seg.stride(3):
+            off = seg.storage_offset() % seg.stride(3)
+            ctx.slice = (seg.data_ptr() - 4 * off, int(seg.stride(3)), int(off))
         return out
 
     @staticmethod
@@ -123,11 +122,34 @@ class _LiftFn(torch.autograd.Function):
         B, C, H, W = ctx.shape
         dout = dout.to(F32).contiguous()
         # gradient map in NHWC (what the fused heads' backward reads coalesced); logical shape stays [B,C,H,W]
-        dseg = torch.zeros((B, H, W, C), dtype=F32, device=dout.device).permute(0, 3, 1, 2)
-        soff = index.offsets(dseg.stride(0), dseg.stride(2), dseg.stride(3), sorted_order=True)
-        check(L.mm_lift_scatter_runs(ptr(dout), C, ptr(index.order), ptr(index.first), ptr(soff), index.n, dseg.stride(1), ptr(dseg),
-                                     stream()), "lift_scatter_runs")
+        if ctx.slice is not None:
+            base, pitch, off = ctx.slice
+            joint = index._joint.get(base)
+            if joint is None or joint.shape != (B, H, W, pitch):
+                joint = index._joint[base] = torch.zeros((B, H, W, pitch), dtype=F32, device=dout.device)
+            dseg = joint[..., off:off + C].permute(0, 3, 1, 2)
+        else:
+            dseg = torch.zeros((B, H, W, C), dtype=F32, device=dout.device).permute(0, 3, 1, 2)
+        check(L.mm_lift_scatter_key(ptr(dout), C, ptr(index.order), ptr(index.skey), index.n, H, W, dseg.stride(0), dseg.stride(2),
+                                    dseg.stride(3), dseg.stride(1), ptr(dseg), stream()), "lift_scatter")
+        # the per-channel sum of the dense gradient map = the sum over the points (what a bias behind the map needs): [N, C] instead
+        # of a reduction over the whole map
+        COLSUMS[dseg.data_ptr()] = (dout.sum(0), dseg.shape)
         return dseg, None
+
+
+# per-channel sums of the gradient maps produced by the last lifting backward passes, keyed by the map's address
+# (nn2d._HeadsFn.backward takes them for the 1x1 heads' bias gradients; popped on use, bounded)
+COLSUMS = {}
+
+
+def pop_colsum(dmap):
+    hit = COLSUMS.pop(dmap.data_ptr(), None)
+    if len(COLSUMS) > 16:
+        COLSUMS.clear()
+    if hit is None or tuple(hit[1]) != tuple(dmap.shape):
+        return None
+    return hit[0]
 
 
 def lift(seg, index: PixelIndex):

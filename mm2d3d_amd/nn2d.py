@@ -400,16 +400,28 @@ class _HeadsFn(torch.autograd.Function):
         x, Wj = ctx.saved_tensors
         h, w, nc, wshape = ctx.dims
         B, C, Hp, Wp = x.shape
-        dout = torch.empty((B, h, w, 2 * nc), dtype=F32, device=x.device)  # NHWC
-        dout[..., :nc] = d1.permute(0, 2, 3, 1)
-        dout[..., nc:] = d2.permute(0, 2, 3, 1)
+        # the two lifting backward passes wrote the halves of ONE [B, h, w, 2 nc] buffer (lifting._LiftFn): take it as it is
+        if (d1.dtype == F32 and d2.dtype == F32 and d2.data_ptr() == d1.data_ptr() + 4 * nc and d1.stride() == d2.stride()
+                and d1.stride() == (h * w * 2 * nc, 1, w * 2 * nc, 2 * nc)):
+            dout = torch.as_strided(d1, (B, h, w, 2 * nc), (h * w * 2 * nc, w * 2 * nc, 2 * nc, 1))
+        else:
+            dout = torch.empty((B, h, w, 2 * nc), dtype=F32, device=x.device)  # NHWC
+            dout[..., :nc] = d1.permute(0, 2, 3, 1)
+            dout[..., nc:] = d2.permute(0, 2, 3, 1)
         dx = torch.empty_like(x)
         dWj = torch.empty_like(Wj)
         ws = _lib.workspace.get(int(L.mm_head_ws_bytes(B, h, w, Hp, Wp, C, 2 * nc)), x.device)
         check(L.mm_head_bwd(ptr(x), B, Hp, Wp, C, h, w, C, ptr(Wj), 2 * nc, ptr(dout), ptr(dx), ptr(dWj), ptr(ws), ws.numel(), stream()),
               "head_bwd")
-        db = dout.sum((0, 1, 2))
-        return dx, None, None, dWj[:nc].reshape(wshape), db[:nc], dWj[nc:].reshape(wshape), db[nc:]
+        from . import lifting
+
+        s1, s2 = lifting.pop_colsum(d1), lifting.pop_colsum(d2)
+        if s1 is not None and s2 is not None:  # bias gradients = sums over the points (lifting backward), not over the maps
+            db1, db2 = s1, s2
+        else:
+            db = dout.sum((0, 1, 2))
+            db1, db2 = db[:nc], db[nc:]
+        return dx, None, None, dWj[:nc].reshape(wshape), db1, dWj[nc:].reshape(wshape), db2
 
 
 def fused_heads(x, h, w, conv_main: nn.Conv2d, conv_aux: nn.Conv2d):

@@ -151,3 +151,33 @@ def test_conv3x3_weight_grad_patch_ring(cin, cout, B, hw, half2d):
     again = w.clone().requires_grad_(True)
     Conv2dFn.apply(x, again, None, 1, 1).backward(g)
     assert torch.equal(again.grad, wh.grad)  # fixed summation order
+
+
+@pytest.mark.parametrize("cin,cout,B,hw", [
+    (128, 128, 20, (64, 64)),   # 320 items on 256 workgroups: 40 per XCD = one round of 32 + 8 items cut into 16 half items
+    (128, 256, 9, (48, 80)),    # two cout blocks per tile: 270 items, 34 per XCD (the last XCD 32): 2 items -> 4 half items
+    (256, 128, 17, (64, 64)),   # 272 items, four input chunks per item
+])
+def test_conv3x3_ragged_last_round_runs_as_half_items(cin, cout, B, hw, half2d):
+    """k_conv3x3w<128, .>: when the last round of an XCD's items would keep at most half of its workgroups busy, those items run as
+    two 64-cout halves on twice as many workgroups (csrc/conv2d.hip).  Forward (bias included) and data gradient (the same kernel
+    with flipped taps) against torch fp32 on the same 16-bit-rounded operands."""
+    from mm2d3d_amd.conv2d import Conv2dFn
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + B)
+    H, W = hw
+    x = torch.randn(B, cin, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (9 * cin)) ** 0.5).to(dev).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(dev).requires_grad_(True)
+    y = Conv2dFn.apply(x, w, b, 1, 1)
+    gy = torch.randn(B, cout, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+    (gx,) = torch.autograd.grad(y, [x], gy)
+    xr = x.detach().float().requires_grad_(True)
+    yr = F.conv2d(xr, w.detach().to(half2d).float(), b.detach(), 1, 1)
+    (gxr,) = torch.autograd.grad(yr, [xr], gy.float())
+    rel = lambda a, c: float((a.detach().float() - c.detach()).norm() / c.detach().norm())
+    assert rel(y, yr) < 4e-3 and rel(gx, gxr) < 4e-3, (rel(y, yr), rel(gx, gxr))
+    assert float((y.detach().float() - yr.detach()).abs().max()) <= 2e-2 * float(yr.detach().abs().max())
+    y2 = Conv2dFn.apply(x, w, b, 1, 1)
+    assert torch.equal(y2, y)  # same schedule, same sums
