@@ -549,6 +549,17 @@ def main(argv=None):
     sync()
     dt = time.perf_counter() - t0
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    # host time of one step issued into an EMPTY queue (synchronised before each): what the host needs to enqueue a step when the
+    # GPU never pushes back.  host_enqueue_ms_per_step above is taken inside the timed loop, where a full queue throttles the host.
+    idle_host = []
+    for _ in range(3):
+        cur, nxt = nxt, next_batch()
+        sync()
+        h0 = time.perf_counter()
+        tm.fit_step(cur, next_batch=nxt if pipeline else None)
+        idle_host.append((time.perf_counter() - h0) * 1e3)
+    sync()
+    idle_host.sort()
     rank_ms = [dt / a.steps * 1e3]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -572,7 +583,8 @@ def main(argv=None):
                                "2 CE + 4 KL, backward, AdamW x2 + OneCycle", "scenes_per_gpu_per_step": 2 * B,
                    "points_per_gpu_per_step": int(n_pts),
                    "distinct_batches_rotated": nb, "points_per_step_by_batch": [int(v) for v in n_pts_each],
-                   "host_enqueue_ms_per_step": round(host_s / a.steps * 1e3, 3), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
+                   "host_enqueue_ms_per_step": round(host_s / a.steps * 1e3, 3),
+                   "host_enqueue_ms_empty_queue": round(idle_host[1], 3), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
                    "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)],
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
     }

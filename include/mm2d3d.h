@@ -356,12 +356,22 @@ int mm_amp_update(float* scale_dev, int* tracker_dev, const int* found_dev, int 
  * gx*so+oox(+z&1)); covers Conv2d fwd / dgrad (stride 1, 2) and ConvTranspose2d(k2,s2) fwd / dgrad. */
 int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
-                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, mm_stream_t stream);
+                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats,
+                   int64_t split_m, mm_stream_t stream);
+/* BatchNorm statistics in the epilogue (``stats`` non-NULL; 16-bit output only): the convolution also files, per 64-pixel
+ * sub-block of its output and per statistics group, the per-channel sum and sum of squares of the ROUNDED outputs in
+ *     stats[2 * sub + g][q][Cn] fp32   (q = 0: sum, 1: sum of squares; rows = mm_conv2d_gemm_stat_rows / _3x3s1_stat_rows)
+ * every element of which is written by exactly one lane (no atomics, no zero fill needed).  Group 0 = GEMM rows [0, split_m)
+ * (mm_conv2d_gemm, rows within one z slice) / batch entries [0, split_b) (mm_conv2d_3x3s1), group 1 = the others: the
+ * [source | target] halves of the joint pass (xmuda.py:45-46 calls the network once per domain).  mm_bn2d_fwd_train_pre turns
+ * the slab into batch statistics - the training BatchNorm2d behind a convolution then never reads the map for its sums. */
+int64_t mm_conv2d_gemm_stat_rows(int64_t M, int nz);
+int64_t mm_conv2d_3x3s1_stat_rows(int B, int H, int W);
 /* 3x3 stride-1 pad-1 convolution (flip 0) or its data gradient (flip 1, Wp = [ci][tap][co]) from a halo tile staged once
  * for all 9 taps (EXP/2d_net/backbones.py ResNet34 BasicBlocks; EXP/2d_net/model.py:68-71 decoder convolutions).
  * flip | 2: a ragged last round of work items is NOT cut into half items (A/B measurements; results are the same sums). */
 int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
-                    const float* bias, int flip, mm_stream_t stream);
+                    const float* bias, int flip, float* stats, int split_b, mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps);
 /* dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k], base grid = dY pixels */
 int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
@@ -390,6 +400,17 @@ int mm_bn2d_fwd_train(mm_handle_t h, const void* x, int ld_x, const void* res, i
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
+/* The same with the batch statistics taken from the slab the producing convolution filled (mm_conv2d_gemm / mm_conv2d_3x3s1
+ * ``stats``, slab_rows = its *_stat_rows): a finalize launch (fp64 sums in a fixed order) + one streaming apply pass.  No pass
+ * over x for the sums, no grid barrier, hence no handle and no residency rule. */
+/* 1 when mm_bn2d_fwd_train (backward = 0) / mm_bn2d_bwd (1) would run as ONE launch for N rows of C channels under the handle's
+ * present options (shape rule only).  The Python layer asks before a convolution: maps too large for one launch get their
+ * statistics from the convolution's epilogue (mm_bn2d_fwd_train_pre), the others are read once by the single-launch kernel anyway. */
+int mm_bn2d_single_launch(mm_handle_t h, int64_t N, int64_t Ns, int C, int backward);
+int mm_bn2d_fwd_train_pre(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+                          const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                          float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, const float* slab,
+                          int64_t slab_rows, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);
@@ -440,9 +461,12 @@ int mm_colsum_f32(const float* x, int ld, int64_t N, int C, float* out, int accu
  * Gradient maps in fp16 need the loss scale of mm2d3d_amd/amp.py (mm_grad_nonfinite ... mm_amp_update below). */
 int mm_conv2d_gemm_f16(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
-                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, mm_stream_t stream);
+                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats,
+                   int64_t split_m, mm_stream_t stream);
+int64_t mm_conv2d_gemm_stat_rows_f16(int64_t M, int nz);
+int64_t mm_conv2d_3x3s1_stat_rows_f16(int B, int H, int W);
 int mm_conv2d_3x3s1_f16(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
-                    const float* bias, int flip, mm_stream_t stream);
+                    const float* bias, int flip, float* stats, int split_b, mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes_f16(int64_t M, int Cn, int Ck, int ntaps);
 int mm_conv2d_wgrad_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
@@ -456,6 +480,11 @@ int mm_bn2d_fwd_train_f16(mm_handle_t h, const void* x, int ld_x, const void* re
                       const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                       float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, void* ws,
                       size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_single_launch_f16(mm_handle_t h, int64_t N, int64_t Ns, int C, int backward);
+int mm_bn2d_fwd_train_pre_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+                          const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                          float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, const float* slab,
+                          int64_t slab_rows, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);

@@ -107,8 +107,10 @@ _PROTOS = {
     "mm_adamw_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "mm_amp_update": (i32, [vp, vp, vp, i32, f64, f64, i32, vp]),
     "mm_conv2d_gemm": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp,
-                             vp, i32, i64, i32, vp, vp]),
-    "mm_conv2d_3x3s1": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp]),
+                             vp, i32, i64, i32, vp, vp, i64, vp]),
+    "mm_conv2d_3x3s1": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp, i32, vp]),
+    "mm_conv2d_gemm_stat_rows": (i64, [i64, i32]),
+    "mm_conv2d_3x3s1_stat_rows": (i64, [i32, i32, i32]),
     "mm_conv2d_wgrad_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_conv2d_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, i64, i32, vp, sz,
                               vp]),
@@ -122,6 +124,8 @@ _PROTOS = {
     "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_bn2d_ws_bytes": (sz, [i32]),
     "mm_bn2d_fwd_train": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
+    "mm_bn2d_single_launch": (i32, [vp, i64, i64, i32, i32]),
+    "mm_bn2d_fwd_train_pre": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, i64, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
     "mm_bn2d_bwd": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_colsum_bf16": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
@@ -143,6 +147,10 @@ class HipLibraryMissing(RuntimeError):
 H16_2D = {
     "mm_conv2d_gemm": "mm_conv2d_gemm_f16",
     "mm_conv2d_3x3s1": "mm_conv2d_3x3s1_f16",
+    "mm_conv2d_gemm_stat_rows": "mm_conv2d_gemm_stat_rows_f16",
+    "mm_conv2d_3x3s1_stat_rows": "mm_conv2d_3x3s1_stat_rows_f16",
+    "mm_bn2d_fwd_train_pre": "mm_bn2d_fwd_train_pre_f16",
+    "mm_bn2d_single_launch": "mm_bn2d_single_launch_f16",
     "mm_conv2d_wgrad_ws_bytes": "mm_conv2d_wgrad_ws_bytes_f16",
     "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",
     "mm_stem_prep": "mm_stem_prep_f16",

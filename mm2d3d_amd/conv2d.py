@@ -12,7 +12,7 @@ import weakref
 
 import torch
 
-from . import _lib, gradsink
+from . import _lib, domains, gradsink
 from ._lib import check, ptr, stream
 
 CL = torch.channels_last
@@ -183,10 +183,48 @@ def _bias_grad(dy):
     return out
 
 
-def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None, lda=None):
+# BatchNorm statistics in the convolution epilogue (csrc/conv2d.hip stats_accum): a training-mode BatchNorm2d behind the layer then
+# takes its batch statistics from the slab instead of reading the map (nn2d._BN2dFn, mm_bn2d_fwd_train_pre).
+# MM_BN2D_PRE = auto (default): only for maps too large for the single-launch batch norm, which reads a map once anyway (same-box
+# A/B on the headline step, round 4: every layer 40.1-40.4 ms, none 39.3-39.9 - two extra launches per layer cost more than
+# the barriers they replace); 1: every layer; 0: never.
+BN_PRE = [{"0": False, "1": True}.get(_os.environ.get("MM_BN2D_PRE", "auto"), "auto")]
+
+
+def bn_pre_wanted(x_device, Bn, Ho, Wo, Cn):
+    """Should a convolution producing a [Bn, Cn, Ho, Wo] map for a training-mode BatchNorm2d file the statistics?"""
+    mode = BN_PRE[0]
+    if mode != "auto":
+        return bool(mode)
+    nf = domains.current()
+    N = Bn * Ho * Wo
+    Ns = nf * Ho * Wo if (nf is not None and 0 < nf < Bn) else N
+    return not lib2d().mm_bn2d_single_launch(_lib.handle(x_device).h, N, Ns, Cn, 0)
+
+
+def _stat_group_split(Bn):
+    """Number of leading batch entries in statistics group 0 (domains.split), Bn = a single group."""
+    nf = domains.current()
+    return nf if (nf is not None and 0 < nf < Bn) else Bn
+
+
+def _stat_slab(holder, rows, Cn, nf, Bn, device):
+    slab = torch.empty((rows, 2, Cn), dtype=torch.float32, device=device)
+    holder[0] = (slab, rows, nf, Bn)
+    return slab
+
+
+def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None, lda=None, stats=None):
+    """``stats``: a one-element list that receives (slab, rows, n_first, B) - the output's BatchNorm statistics slab."""
+    slab, split_m = None, 0
+    if stats is not None and bn_pre_wanted(out.device, Bn, Ho, Wo, Cn):
+        nf = _stat_group_split(Bn)
+        slab = _stat_slab(stats, int(lib2d().mm_conv2d_gemm_stat_rows(Bn * Hg * Wg, nz)), Cn, nf, Bn, out.device)
+        split_m = nf * Hg * Wg
     check(
         lib2d().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, lda or Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
-                                  Hg, Wg, so, 0, 0, sa, fr, len(ty), _arr(ty), _arr(tx), ptr(Wp), nz, wz, zpar, ptr(bias), stream()),
+                                  Hg, Wg, so, 0, 0, sa, fr, len(ty), _arr(ty), _arr(tx), ptr(Wp), nz, wz, zpar, ptr(bias), ptr(slab), split_m,
+                                  stream()),
         "conv2d_gemm",
     )
 
@@ -211,8 +249,8 @@ class Conv2dFn(torch.autograd.Function):
     """y = conv2d(x, w, b, stride, padding), square kernel, Cin and Cout multiples of 64."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, padding, handoff=None):
-        """``handoff``: the input map has ANOTHER consumer whose backward delivers the main gradient to the map's producer (a
+    def forward(ctx, x, weight, bias, stride, padding, handoff=None, stats=None):
+        """``stats``: see _gemm.  ``handoff``: the input map has ANOTHER consumer whose backward delivers the main gradient to the map's producer (a
         BasicBlock input read by conv1 and by the 1x1 downsample, backbones.py layer2-4.0): this layer's data gradient is then
         left in the producer's slot (nn2d.GradHandoff) instead of being summed by an autograd add kernel."""
         _lib.require_cuda(x, "x")
@@ -229,10 +267,14 @@ class Conv2dFn(torch.autograd.Function):
         tx = [kw - padding for _ in range(KH) for kw in range(KW)]
         b = bias.detach().float().contiguous() if bias is not None else None
         if (KH, KW, stride, padding) == (3, 3, 1, 1):  # halo-tile kernel: input patch staged once for all 9 taps
-            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0 | WHOLE_ITEMS[0], stream()),
-                  "conv2d_3x3s1")
+            slab, nf = None, Bn
+            if stats is not None and bn_pre_wanted(x.device, Bn, H, W, Cout):
+                nf = _stat_group_split(Bn)
+                slab = _stat_slab(stats, int(lib2d().mm_conv2d_3x3s1_stat_rows(Bn, H, W)), Cout, nf, Bn, x.device)
+            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0 | WHOLE_ITEMS[0], ptr(slab), nf,
+                                          stream()), "conv2d_3x3s1")
         else:
-            _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b, lda=ldx)
+            _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b, lda=ldx, stats=stats)
         ctx.save_for_backward(x, w)
         ctx.ldx = ldx
         ctx.cfg = (stride, padding, bias is not None)
@@ -255,8 +297,8 @@ class Conv2dFn(torch.autograd.Function):
             Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T, ctx.wowner, "dgrad")  # [ci][t][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x.device, memory_format=CL)
             if (KH, KW, stride, padding) == (3, 3, 1, 1):
-                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1 | WHOLE_ITEMS[0], stream()),
-                      "conv2d_3x3s1")
+                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1 | WHOLE_ITEMS[0], None, 0,
+                                              stream()), "conv2d_3x3s1")
             else:
                 ty = [padding - kh for kh in range(KH) for _ in range(KW)]
                 tx = [padding - kw for _ in range(KH) for kw in range(KW)]
@@ -276,14 +318,14 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.handoff is not None and dx is not None:  # the producer's backward kernels add it (fp32) to the other consumer's
             ctx.handoff.extra.append(dx)
             dx = None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
     """y = conv_transpose2d(x, w, b, stride=2), kernel 2x2: four 1x1 GEMMs with a pixel-shuffle store (blockIdx.z = parity)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, stats=None):
         _lib.require_cuda(x, "x")
         x = as_nhwc_bf16(x)
         Bn, Cin, H, W = x.shape
@@ -294,7 +336,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
         ctx.wowner = weight
         y = torch.empty((Bn, Cout, 2 * H, 2 * W), dtype=HALF[0], device=x.device, memory_format=CL)
         b = bias.detach().float().contiguous() if bias is not None else None
-        _gemm(x, Bn, H, W, Cin, y, 2 * H, 2 * W, Cout, H, W, 2, 1, 1, [0], [0], Wp, nz=4, wz=Cout * Cin, zpar=1, bias=b)
+        _gemm(x, Bn, H, W, Cin, y, 2 * H, 2 * W, Cout, H, W, 2, 1, 1, [0], [0], Wp, nz=4, wz=Cout * Cin, zpar=1, bias=b, stats=stats)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         return y
@@ -317,7 +359,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, dw, Cout * 4, 1, 4)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = _bias_grad(dy)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 _STEM_IDX = {}
@@ -356,7 +398,7 @@ class StemConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, img, weight):
+    def forward(ctx, img, weight, stats=None):
         _lib.require_cuda(img, "img")
         L = lib2d()
         img = img.float().contiguous()
@@ -372,8 +414,13 @@ class StemConvFn(torch.autograd.Function):
         y = torch.empty((Bn, Cout, H, W), dtype=HALF[0], device=img.device, memory_format=CL)
         ty = [t * R for t in range(T)]
         # virtual activation: pixel pitch (lda) 8, 64 channels, Wi = Wb - 7 valid window starts; output (y,x) reads row y + t*R at x
+        slab, split_m = None, 0
+        if stats is not None and bn_pre_wanted(img.device, Bn, H, W, Cout):
+            nf = _stat_group_split(Bn)
+            slab = _stat_slab(stats, int(L.mm_conv2d_gemm_stat_rows(Bn * H * W, 1)), Cout, nf, Bn, img.device)
+            split_m = nf * H * W
         check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, T, _arr(ty),
-                               _arr([0] * T), ptr(Wp), 1, 0, 0, None, stream()), "conv2d_gemm(stem)")
+                               _arr([0] * T), ptr(Wp), 1, 0, 0, None, ptr(slab), split_m, stream()), "conv2d_gemm(stem)")
         ctx.save_for_backward(xb)
         ctx.dims = (Bn, C, H, W, Cout, Hb, Wb, weight.shape)
         return y
@@ -392,6 +439,6 @@ class StemConvFn(torch.autograd.Function):
                                 ptr(dwp), T * 64, 64, 1, 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad(stem)")
         dw = torch.zeros((Cout, C * 49), dtype=torch.float32, device=dy.device)
         dw.index_copy_(1, src, dwp.index_select(1, valid))
-        return None, dw.view(wshape)
+        return None, dw.view(wshape), None
 
 

@@ -205,6 +205,49 @@ __global__ __launch_bounds__(256) void k_bn2d_finalize_fwd(const double* __restr
   }
 }
 
+// Batch statistics from the slab the producing convolution filled in its epilogue (csrc/conv2d.hip stats_accum; round 4):
+// slab[2 * sub + g][q][C] fp32 = the sums over one 64-pixel sub-block, q = 0: sum, 1: sum of squares.  This kernel adds the slab
+// rows of a range of sub-blocks in fp64 in a fixed order (sub-block lanes stride the range, then the lanes in order) and writes
+// one row of ``partial`` in k_bn2d_reduce's format, so k_bn2d_finalize_fwd finishes the job: blocks [0, nb0) take group 0's rows,
+// [nb0, nb0 + nb1) group 1's; nb1 == 0: one group, both rows of a sub-block are its.  No pass over the map, no atomics.
+__global__ __launch_bounds__(256) void k_bn2d_slab_reduce(const float* __restrict__ slab, int64_t nsub, int nb0, int nb1, int C,
+                                                          double* __restrict__ partial) {
+  __shared__ double red[256 * 4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int g = b >= nb0 ? 1 : 0, nb = g ? nb1 : nb0, r = g ? b - nb0 : b;
+  const int64_t per = (nsub + nb - 1) / nb, s0 = r * per, s1 = s0 + per < nsub ? s0 + per : nsub;
+  const int n4 = C / 2;                       // float4 columns of one [2][C] slab row
+  const int SL = n4 >= 256 ? 1 : 256 / n4;    // sub-block lanes
+  const float4* slab4 = (const float4*)slab;
+  for (int col0 = 0; col0 < n4; col0 += 256) {
+    const int col = col0 + (SL == 1 ? tid : tid % n4), sl = SL == 1 ? 0 : tid / n4;
+    const bool act = col < n4 && sl < SL;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (act)
+      for (int64_t sub = s0 + sl; sub < s1; sub += SL) {
+        const float4 v = slab4[(2 * sub + g) * n4 + col];
+        a[0] += (double)v.x, a[1] += (double)v.y, a[2] += (double)v.z, a[3] += (double)v.w;
+        if (nb1 == 0) {
+          const float4 w = slab4[(2 * sub + 1) * n4 + col];
+          a[0] += (double)w.x, a[1] += (double)w.y, a[2] += (double)w.z, a[3] += (double)w.w;
+        }
+      }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) red[tid * 4 + k] = a[k];
+    __syncthreads();
+    if (act && sl == 0) {
+      for (int l = 1; l < SL; l++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] += red[(l * n4 + col - col0) * 4 + k];
+      const int q = (col * 4) / C, c = col * 4 - q * C;
+      double* dst = partial + ((int64_t)b * 2 + q) * C + c;
+#pragma unroll
+      for (int k = 0; k < 4; k++) dst[k] = a[k];
+    }
+  }
+}
+
 // sums[g][0][C] = sum g, sums[g][1][C] = sum g*xhat per statistics group; dweight / dbias are the totals over the groups
 __global__ __launch_bounds__(256) void k_bn2d_finalize_bwd(const double* __restrict__ partial, int nb0, int nb1, int C,
                                                            float* __restrict__ sums /*[G][2][C]*/, float* __restrict__ dweight,
@@ -711,6 +754,19 @@ static void split_blocks(int64_t N, int64_t& Ns, int C, bool stats, int& b0, int
   }
 }
 
+// 1 when mm_bn2d_fwd_train / mm_bn2d_bwd (backward != 0) would take the single-launch kernels for N rows of C channels under the
+// handle's present options (shape rule only: pitches and the 2 GiB buffer limit are checked at the call).  A producer uses it to
+// decide whether to file statistics for mm_bn2d_fwd_train_pre (maps too large for one launch) or to leave the map to the
+// single-launch kernel, which reads it once anyway.
+int MM_SYM(mm_bn2d_single_launch)(void* h, int64_t N, int64_t Ns, int C, int backward) {
+  MMHandle* H = (MMHandle*)h;
+  if (!H || H->magic != MM_HANDLE_MAGIC) return 0;
+  if (!H->fused_ok || !(H->opt[MM_OPT_BN2D_FUSED] & (backward ? 2 : 1)) || N <= 0 || C % 8 != 0 || C > FT || C < 8) return 0;
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  int g0, g1;
+  return fused_shape(H->cus, N, Ns, C, 8, &g0, &g1) <= 36 ? 1 : 0;
+}
+
 // y = act(BN_train(x) + res); x,res,y NHWC bf16 [N rows, C]; momentum = torch's (0.1).
 // Ns: rows [0,Ns) and [Ns,N) are normalised with their OWN batch statistics (the source and target halves of a jointly
 // batched step, train.py:186-292 calls the net once per domain); Ns = N (or 0) is the ordinary single-batch case.
@@ -759,6 +815,37 @@ int MM_SYM(mm_bn2d_fwd_train)(void* h, const void* x, int ld_x, const void* res,
   hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
                      save_mean, save_invstd, num_batches_tracked);
   if (N > 0) {
+    split_blocks(N, Ns, C, false, ab0, ab1);
+    hipLaunchKernelGGL(k_bn2d_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N, C, save_mean,
+                       save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y, Ns, ab0);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// mm_bn2d_fwd_train with the batch statistics taken from the slab that the producing convolution filled in its epilogue
+// (mm_conv2d_3x3s1 / mm_conv2d_gemm ``stats``; slab_rows = mm_conv2d_*_stat_rows): slab reduce + finalize (both small) + ONE
+// streaming apply pass - no statistics pass over the map, no grid barrier (so no handle and no residency rule: safe beside any
+// other stream).  ws as for mm_bn2d_fwd_train.
+int MM_SYM(mm_bn2d_fwd_train_pre)(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int64_t Ns, int C, const float* weight,
+                          const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
+                          float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, const float* slab,
+                          int64_t slab_rows, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_y % 8 == 0, "bn2d: C must be a multiple of 8, <= 2048");
+  MM_CHECK_ARG(slab != nullptr && slab_rows > 0 && slab_rows % 2 == 0 && ((uintptr_t)slab % 16) == 0, "bn2d_fwd_train_pre: no statistics slab");
+  MM_CHECK_ARG(ws_bytes >= MM_SYM(mm_bn2d_ws_bytes)(C), "bn2d: workspace too small");
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  const int64_t nsub = slab_rows / 2;
+  int nb = (int)(nsub / 64 < 1 ? 1 : nsub / 64);  // >= 64 sub-blocks (4096 pixels) per block
+  if (nb > 256) nb = 256;
+  if (nb > MAX_PART / 2) nb = MAX_PART / 2;
+  const int nb0 = nb, nb1 = Ns < N ? nb : 0;
+  double* partial = (double*)ws;
+  hipLaunchKernelGGL(k_bn2d_slab_reduce, dim3(nb0 + nb1), dim3(256), 0, s, slab, nsub, nb0, nb1, C, partial);
+  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
+                     save_mean, save_invstd, num_batches_tracked);
+  if (N > 0) {
+    int ab0, ab1;
     split_blocks(N, Ns, C, false, ab0, ab1);
     hipLaunchKernelGGL(k_bn2d_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N, C, save_mean,
                        save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y, Ns, ab0);

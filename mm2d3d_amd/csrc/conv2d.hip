@@ -42,6 +42,8 @@ struct ConvP {
   const float* bias;
   int out_f32;
   int nbuf;  // LDS stage buffers: 2 (tile s+1 in flight while tile s is multiplied) or 1 when the whole K is one step
+  float* stats;     // BatchNorm statistics slab (see stats_accum), or NULL
+  int64_t split_m;  // GEMM rows [0, split_m) are statistics group 0, the others group 1
 };
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
@@ -73,6 +75,52 @@ __device__ inline void frag_rows(unsigned (&D)[4][2], uint4& xa, uint4& xb) {
 }
 
 
+
+// ---- BatchNorm statistics in the convolution epilogue (round 4; VERDICT r3 item 2: "statistics belong in the producing conv's
+// epilogue").  A training-mode BatchNorm2d behind a convolution needs sum(y) and sum(y^2) per channel; until now it read the whole
+// map again for them (k_bn2d_reduce / the load phase of the single-launch kernels, with two grid barriers).  After frag_rows a lane
+// holds 8 channels (chunk frag_chunk(lane)) of two pixels: the sums over the 64 pixels of a wave are 16 fused multiply-adds per
+// lane and fragment plus one reduce-scatter over the 16 lanes of a row (15 exchanges), and go to a slab
+//     slab[2 * sub + g][q][Cn],  sub = 64-pixel sub-block (pixel tile, wm), g = statistics group, q = 0: sum, 1: sum of squares
+// that a small finalize kernel adds up in fp64 in a fixed order (mm_bn2d_fwd_train_pre): deterministic, no atomics.  The sums are
+// taken over the ROUNDED 16-bit outputs - the values the normalisation will read.
+__device__ inline void stats_accum(const uint4& x, bool valid, float (&s)[16]) {
+  const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = valid ? h_lo(w[i]) : 0.f, b = valid ? h_hi(w[i]) : 0.f;
+    s[2 * i] += a, s[2 * i + 1] += b;
+    s[8 + 2 * i] = fmaf(a, a, s[8 + 2 * i]), s[8 + 2 * i + 1] = fmaf(b, b, s[8 + 2 * i + 1]);
+  }
+}
+// the total over the 16 lanes of a row (lanes 16 r .. 16 r + 15) of s[t] -> returned in lane t of the row (t = lane & 15)
+__device__ inline float row_reduce_scatter16(float (&s)[16], int t) {
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const float keep = (t & 8) ? s[8 + k] : s[k], send = (t & 8) ? s[k] : s[8 + k];
+    s[k] = keep + __shfl_xor(send, 8, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float keep = (t & 4) ? s[4 + k] : s[k], send = (t & 4) ? s[k] : s[4 + k];
+    s[k] = keep + __shfl_xor(send, 4, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const float keep = (t & 2) ? s[2 + k] : s[k], send = (t & 2) ? s[k] : s[2 + k];
+    s[k] = keep + __shfl_xor(send, 2, 64);
+  }
+  const float keep = (t & 1) ? s[1] : s[0], send = (t & 1) ? s[0] : s[1];
+  return keep + __shfl_xor(send, 1, 64);
+}
+// lane (row r, t) of the wave writes channel cfrag + 8 * frag_chunk + (t & 7), quantity t >> 3, of slab row ``row``; row ^ 1 (the
+// other statistics group of the same sub-block) gets a zero unless ``both`` says the caller writes it itself
+__device__ inline void stats_store(float* slab, int64_t row, int Cn, int cfrag, int lane, float v, bool zero_other) {
+  const int t = lane & 15, ch = cfrag + 8 * frag_chunk(lane) + (t & 7);
+  if (ch >= Cn) return;
+  slab[(row * 2 + (t >> 3)) * Cn + ch] = v;
+  if (zero_other) slab[((row ^ 1) * 2 + (t >> 3)) * Cn + ch] = 0.f;
+}
 
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
@@ -236,14 +284,25 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
       }
       return m;
     };
+    u16 *rowa[2], *rowb[2];
+    int64_t mra[2], mrb[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      const int64_t ma = m0 + wm * 64 + i * 32 + (lane & 15), mb = ma + 16;
-      u16* rowa = ma < M ? (u16*)p.O + out_row(ma) * p.ldo : nullptr;
-      u16* rowb = mb < M ? (u16*)p.O + out_row(mb) * p.ldo : nullptr;
+      mra[i] = m0 + wm * 64 + i * 32 + (lane & 15), mrb[i] = mra[i] + 16;
+      rowa[i] = mra[i] < M ? (u16*)p.O + out_row(mra[i]) * p.ldo : nullptr;
+      rowb[i] = mrb[i] < M ? (u16*)p.O + out_row(mrb[i]) * p.ldo : nullptr;
+    }
+    // BatchNorm statistics (stats_accum): sub-block = (z, 128-row block, wm); its 64 rows may straddle the boundary between the two
+    // statistics groups, so both groups' sums are formed and both slab rows written
+    const int64_t ssub = ((int64_t)z * gridDim.x + blockIdx.x) * 2 + wm;
 #pragma unroll
-      for (int j = 0; j < TN; j++) {
-        const int nf = n0 + wn * (BN / 2) + j * 32;  // first channel of the fragment
+    for (int j = 0; j < TN; j++) {
+      float st0[16], st1[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) st0[t] = st1[t] = 0.f;
+      const int nf = n0 + wn * (BN / 2) + j * 32;  // first channel of the fragment
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
         unsigned D[4][2];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -261,10 +320,20 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
         uint4 xa, xb;
         frag_rows(D, xa, xb);
         const int n = nf + 8 * schunk;
-        if (n < p.Cn) {
-          if (rowa) *(uint4*)(rowa + n) = xa;
-          if (rowb) *(uint4*)(rowb + n) = xb;
+        if (p.stats) {
+          stats_accum(xa, rowa[i] != nullptr && mra[i] < p.split_m, st0);
+          stats_accum(xb, rowb[i] != nullptr && mrb[i] < p.split_m, st0);
+          stats_accum(xa, rowa[i] != nullptr && mra[i] >= p.split_m, st1);
+          stats_accum(xb, rowb[i] != nullptr && mrb[i] >= p.split_m, st1);
         }
+        if (n < p.Cn) {
+          if (rowa[i]) *(uint4*)(rowa[i] + n) = xa;
+          if (rowb[i]) *(uint4*)(rowb[i] + n) = xb;
+        }
+      }
+      if (p.stats) {
+        stats_store(p.stats, 2 * ssub, p.Cn, nf, lane, row_reduce_scatter16(st0, lane & 15), false);
+        stats_store(p.stats, 2 * ssub + 1, p.Cn, nf, lane, row_reduce_scatter16(st1, lane & 15), false);
       }
     }
     return;
@@ -333,6 +402,8 @@ struct C3P {
   const float* bias;
   int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
   int whole; // != 0: never cut a ragged last round into half items (A/B measurements)
+  float* stats;  // BatchNorm statistics slab (see stats_accum), or NULL
+  int split_b;   // images [0, split_b) are statistics group 0, the others group 1
   int tiles_y, tiles_x;
 };
 // DIAG (tools/conv3x3_diag.hip only; the library instantiates DIAG = 0): parts of k_conv3x3w switched off at COMPILE time to see
@@ -623,42 +694,56 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       decode(c_item, b, ty0, tx0, n0);
       const int jn = (BN == 128 && c_half >= 0) ? 1 : TN;                                   // fragments of this item per wave
       const int cbase = n0 + ((BN == 128 && c_half >= 0) ? c_half * 64 + wn * 32 : wn * (BN / 2));  // this wave's first channel
+      const int64_t srow = 2 * ((int64_t)(c_item / ncb) * 4 + wm) + (b >= p.split_b ? 1 : 0);  // statistics slab row of this wave's 64 pixels
       c_c = 0;
       if (++c_k < my_items) c_item = item_of(c_k, c_half);
       if (MM_DIAG(p, 32)) continue;
       unsigned diag_sum = 0;
+      // after frag_rows this lane holds rows of the pixels sp[i][0] (xa) and sp[i][1] (xb), not of its own MFMA column
+      u16 *rowa[2], *rowb[2];
+      bool ina[2], inb[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        // after frag_rows this lane holds rows of the pixels sp[i][0] (xa) and sp[i][1] (xb), not of its own MFMA column
         const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
-        const bool ina = ya < p.H && xa_ < p.W && !MM_DIAG(p, 16), inb = yb < p.H && xb_ < p.W && !MM_DIAG(p, 16);
-        u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + cbase + 8 * schunk;
-        u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + cbase + 8 * schunk;
+        ina[i] = ya < p.H && xa_ < p.W, inb[i] = yb < p.H && xb_ < p.W;
+        rowa[i] = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + cbase + 8 * schunk;
+        rowb[i] = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + cbase + 8 * schunk;
+      }
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-          if (j < jn) {
-          unsigned D[4][2];
+      for (int j = 0; j < TN; j++) {
+        if (j < jn) {
+          float st[16];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            float v[4];
+          for (int t = 0; t < 16; t++) st[t] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              v[e] = acc[i][j][4 * q + e];
-              if (p.bias) v[e] += biasl[cbase + 32 * j + 8 * q + 4 * fh + e];
-              acc[i][j][4 * q + e] = 0.f;
+          for (int i = 0; i < 2; i++) {
+            unsigned D[4][2];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              float v[4];
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                v[e] = acc[i][j][4 * q + e];
+                if (p.bias) v[e] += biasl[cbase + 32 * j + 8 * q + 4 * fh + e];
+                acc[i][j][4 * q + e] = 0.f;
+              }
+              D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+              D[q][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
             }
-            D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            D[q][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            uint4 xa, xb;
+            frag_rows(D, xa, xb);
+            if (p.stats) {
+              stats_accum(xa, ina[i], st);
+              stats_accum(xb, inb[i], st);
+            }
+            if (MM_DIAG(p, 64)) {  // every value still used, one store per item: the price of the stores themselves
+              diag_sum ^= xa.x ^ xa.y ^ xa.z ^ xa.w ^ xb.x ^ xb.y ^ xb.z ^ xb.w;
+              continue;
+            }
+            *(uint4*)(ina[i] && !MM_DIAG(p, 16) ? rowa[i] + 32 * j : (u16*)g_dump + lane * 8) = xa;
+            *(uint4*)(inb[i] && !MM_DIAG(p, 16) ? rowb[i] + 32 * j : (u16*)g_dump + lane * 8) = xb;
           }
-          uint4 xa, xb;
-          frag_rows(D, xa, xb);
-          if (MM_DIAG(p, 64)) {  // every value still used, one store per item: the price of the stores themselves
-            diag_sum ^= xa.x ^ xa.y ^ xa.z ^ xa.w ^ xb.x ^ xb.y ^ xb.z ^ xb.w;
-            continue;
-          }
-          *(uint4*)(ina ? rowa + 32 * j : (u16*)g_dump + lane * 8) = xa;
-          *(uint4*)(inb ? rowb + 32 * j : (u16*)g_dump + lane * 8) = xb;
-          }
+          if (p.stats) stats_store(p.stats, srow, p.Cn, cbase + 32 * j, lane, row_reduce_scatter16(st, lane & 15), true);
         }
       }
       if (MM_DIAG(p, 64)) g_dump[lane] = diag_sum;
@@ -776,8 +861,12 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   int seg = 0;
   for (int item = it_begin; item < it_end; item += G8, seg++) {
     // this item's halo (and, the first time, the weights) must have landed; younger in the queue: the previous item's stores
-    if (st) wait_vm<NST>();
-    else wait_vm<0>();
+    if (st) {
+      if (p.stats) wait_vm<NST + 2>();  // + the two statistics stores of the previous item
+      else wait_vm<NST>();
+    } else {
+      wait_vm<0>();
+    }
     __builtin_amdgcn_s_barrier();  // ... for every wave, and everyone left the other halo buffer
     issue_halo((seg + 1) & 1);
     const int hb = (seg & 1) * HSZB;
@@ -795,6 +884,9 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
     }
     int b, ty0, tx0;
     decode(item, b, ty0, tx0);
+    float sst[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) sst[t] = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       unsigned D[4][2];
@@ -813,11 +905,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
       uint4 xa, xb;
       frag_rows(D, xa, xb);  // whole 64-byte rows: pixels (lane & 15) and 16 + (lane & 15) of the fragment, chunk schunk
       const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
+      const bool ina = ya < p.H && xa_ < p.W, inb = yb < p.H && xb_ < p.W;
       u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + wn * 32 + 8 * schunk;
       u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + wn * 32 + 8 * schunk;
-      *(uint4*)(ya < p.H && xa_ < p.W ? rowa : (u16*)g_dump + lane * 8) = xa;
-      *(uint4*)(yb < p.H && xb_ < p.W ? rowb : (u16*)g_dump + lane * 8) = xb;
+      if (p.stats) {
+        stats_accum(xa, ina, sst);
+        stats_accum(xb, inb, sst);
+      }
+      *(uint4*)(ina ? rowa : (u16*)g_dump + lane * 8) = xa;
+      *(uint4*)(inb ? rowb : (u16*)g_dump + lane * 8) = xb;
     }
+    if (p.stats)  // BatchNorm statistics of this wave's 64 pixels x 32 channels (see stats_accum); one more store per item
+      stats_store(p.stats, 2 * ((int64_t)item * 4 + wm) + (b >= p.split_b ? 1 : 0), p.Cn, wn * 32, lane, row_reduce_scatter16(sst, lane & 15),
+                  true);
     st = true;
   }
   wait_vm<0>();  // the dummy halo of the tail is still in flight: drain before the LDS is released
@@ -1368,15 +1468,18 @@ extern "C" {
 // Generic implicit GEMM (see ConvP).  ty/tx: host arrays of ntaps tap offsets.
 int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
-                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, hipStream_t s) {
+                   const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats, int64_t split_m,
+                   hipStream_t s) {
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
                "conv2d_gemm: Ca must be a multiple of 64 and pointers 16-B aligned (Ca=%d lda=%d)", Ca, lda);
+  MM_CHECK_ARG(!stats || (!out_f32 && Cn % 32 == 0 && ldo % 8 == 0 && ((uintptr_t)O % 16) == 0 && ((uintptr_t)bias % 16) == 0),
+               "conv2d_gemm: statistics need a 16-bit output, Cn a multiple of 32, ldo of 8");
   MM_CHECK_ARG(fr == 1 || fr == 2, "conv2d_gemm: fr must be 1 or 2");
   ConvP p;
   p.A = (const u16*)A; p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ca = Ca; p.lda = lda;
   p.O = O; p.Ho = Ho; p.Wo = Wo; p.Cn = Cn; p.ldo = ldo; p.out_f32 = out_f32;
   p.Hg = Hg; p.Wg = Wg; p.so = so; p.ooy = ooy; p.oox = oox; p.sa = sa; p.fr = fr;
-  p.W = (const u16*)Wp; p.wz = wz; p.zpar = zpar; p.bias = bias;
+  p.W = (const u16*)Wp; p.wz = wz; p.zpar = zpar; p.bias = bias; p.stats = stats; p.split_m = split_m;
   if (fill_taps(&p, ty, tx, ntaps)) {
     mm_set_error("conv2d_gemm: too many taps");
     return MM_ERR_ARG;
@@ -1407,12 +1510,27 @@ int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda
 }
 
 // 3x3, stride 1, pad 1 convolution (flip = 0) or its data gradient (flip = 1; Wp packed as [ci][tap][co]).  NHWC bf16.
+// Rows of the BatchNorm statistics slab a convolution call fills (each row: 2 x Cn floats; see stats_accum): two per 64-pixel
+// sub-block (one per statistics group).  The tile shape of mm_conv2d_3x3s1 is decided here exactly as in the launch below.
+static void c3_tiles(int H, int W, int* tw, int* tiles_y, int* tiles_x) {
+  const int64_t px16 = mm_cdiv(H, 16) * mm_cdiv(W, 16), px32 = mm_cdiv(H, 8) * mm_cdiv(W, 32);
+  *tw = px32 < px16 ? 32 : 16;
+  *tiles_y = (int)mm_cdiv(H, 256 / *tw), *tiles_x = (int)mm_cdiv(W, *tw);
+}
+int64_t MM_SYM(mm_conv2d_3x3s1_stat_rows)(int B, int H, int W) {
+  int tw, ty, tx;
+  c3_tiles(H, W, &tw, &ty, &tx);
+  return (int64_t)B * ty * tx * 4 * 2;
+}
+int64_t MM_SYM(mm_conv2d_gemm_stat_rows)(int64_t M, int nz) { return (int64_t)nz * mm_cdiv(M, 128) * 2 * 2; }
+
 int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp, const float* bias,
-                    int flip, hipStream_t s) {
+                    int flip, float* stats, int split_b, hipStream_t s) {
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0, "conv2d_3x3s1: bad shape");
   C3P p;
   p.A = (const u16*)A; p.B = B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O; p.Cn = Cn; p.ldo = ldo;
   p.Wp = (const u16*)Wp; p.bias = bias; p.flip = flip & 1; p.whole = (flip >> 1) & 1;  // flip bit 1: whole items only
+  p.stats = stats; p.split_b = split_b;
   p.tiles_y = (int)mm_cdiv(H, 8); p.tiles_x = (int)mm_cdiv(W, 16);
   const int64_t nt = (int64_t)B * p.tiles_y * p.tiles_x;
   if (nt == 0) return MM_OK;
@@ -1423,10 +1541,9 @@ int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda,
                "conv2d_3x3s1: output channels must be a multiple of 64 (<= 1024), ldo a multiple of 4, O 8-byte aligned (Cn=%d ldo=%d)", Cn, ldo);
   {
     // 16 x 16 tiles on large maps, 8 x 32 where that wastes fewer out-of-image pixels; 128-cout blocks when Cn allows
-    const int64_t px16 = mm_cdiv(H, 16) * mm_cdiv(W, 16), px32 = mm_cdiv(H, 8) * mm_cdiv(W, 32);
-    const int tw = px32 < px16 ? 32 : 16;
+    int tw;
+    c3_tiles(H, W, &tw, &p.tiles_y, &p.tiles_x);
     const int bn = Cn % 128 == 0 ? 128 : 64;
-    p.tiles_y = (int)mm_cdiv(H, 256 / tw); p.tiles_x = (int)mm_cdiv(W, tw);
     const int64_t nitems = (int64_t)B * p.tiles_y * p.tiles_x * (Cn / bn);
     MM_CHECK_ARG(nitems < (1ll << 30), "conv2d_3x3s1: too many tiles");
     const size_t ldsw = (size_t)(2 * 344 * 64 + (bn == 128 ? 4 : 6) * bn * 64) * 2 + (bias ? (size_t)mm_cdiv(Cn, 512) * 512 * 4 : 0);

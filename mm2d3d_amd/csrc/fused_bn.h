@@ -235,6 +235,25 @@ constexpr int FUSED_ROWS_TARGET = 6;  // about six rows per thread (measured on 
 // three-kernel path (map too large to keep on chip, channel count outside the layout, or the handle's switch).
 // vec: channels per 16-byte access (8 x 16 bit / 4 x fp32); fns: the translation unit's fused kernels (their dynamic LDS limit is
 // raised once per handle: bit ``unit`` of MMHandle::attr_done); opt: MM_OPT_BN2D_FUSED / MM_OPT_BN3D_FUSED
+// workgroups per statistics group and row slices per thread of a single-launch kernel on N rows of C channels (shape rule only)
+static inline int64_t fused_shape(int cus, int64_t N, int64_t Ns, int C, int vec, int* G0_, int* G1_) {
+  const int rs = FT / (C / vec);
+  const bool two = Ns > 0 && Ns < N;
+  int64_t G = mm_cdiv(N, (int64_t)rs * FUSED_ROWS_TARGET);
+  if (G > cus) G = cus;
+  if (G < (two ? 2 : 1)) G = two ? 2 : 1;
+  int G0 = (int)G, G1 = 0;
+  if (two) {
+    G0 = (int)((double)G * (double)Ns / (double)N + 0.5);
+    if (G0 < 1) G0 = 1;
+    if (G0 > (int)G - 1) G0 = (int)G - 1;
+    G1 = (int)G - G0;
+  }
+  const int64_t rpb0 = mm_cdiv(two ? Ns : N, G0), rpb1 = two ? mm_cdiv(N - Ns, G1) : 0;
+  *G0_ = G0, *G1_ = G1;
+  return mm_cdiv(rpb0 > rpb1 ? rpb0 : rpb1, rs);
+}
+
 static inline int fused_plan(MMHandle* H, int opt, int unit, int64_t N, int64_t Ns, int C, int vec, int rmax, bool backward,
                              const void* const* fns, int nfns, hipStream_t s, FusedPlan* pl) {
   pl->ok = false;
@@ -258,21 +277,8 @@ static inline int fused_plan(MMHandle* H, int opt, int unit, int64_t N, int64_t 
     slot = H->nstream++;
     H->streams[slot] = s;
   }
-  const int rs = FT / (C / vec);
-  const int cus = H->cus;
-  const bool two = Ns > 0 && Ns < N;
-  int64_t G = mm_cdiv(N, (int64_t)rs * FUSED_ROWS_TARGET);
-  if (G > cus) G = cus;
-  if (G < (two ? 2 : 1)) G = two ? 2 : 1;
-  int G0 = (int)G, G1 = 0;
-  if (two) {
-    G0 = (int)((double)G * (double)Ns / (double)N + 0.5);
-    if (G0 < 1) G0 = 1;
-    if (G0 > (int)G - 1) G0 = (int)G - 1;
-    G1 = (int)G - G0;
-  }
-  const int64_t rpb0 = mm_cdiv(two ? Ns : N, G0), rpb1 = two ? mm_cdiv(N - Ns, G1) : 0;
-  const int64_t R = mm_cdiv(rpb0 > rpb1 ? rpb0 : rpb1, rs);
+  int G0, G1;
+  const int64_t R = fused_shape(H->cus, N, Ns, C, vec, &G0, &G1);
   if (R > rmax) return MM_OK;
   pl->ok = true;
   pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;

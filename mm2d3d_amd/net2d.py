@@ -54,6 +54,8 @@ class BasicBlock(nn.Module):
         self.bn2 = norm_layer(planes)
         self.downsample = downsample
         self.stride = stride
+        nn2d.feeds_bn(self.conv1, self.bn1)  # batch statistics in the convolution's epilogue (nn2d._wants_stats)
+        nn2d.feeds_bn(self.conv2, self.bn2)
         self._fused = isinstance(self.bn1, nn2d.BatchNorm2d)
         if self._fused:  # ReLU after bn1, and (+identity, ReLU) after bn2, run inside the BN apply kernel
             self.bn1.relu = True
@@ -84,6 +86,7 @@ def _make_layer(inplanes, planes, blocks, stride, norm_layer):
     down = None
     if stride != 1 or inplanes != planes:
         down = nn.Sequential(nn2d.Conv2d(inplanes, planes, 1, stride, bias=False), (norm_layer or nn2d.BatchNorm2d)(planes))
+        nn2d.feeds_bn(down[0], down[1])
     layers = [BasicBlock(inplanes, planes, stride, down, norm_layer)]
     layers += [BasicBlock(planes, planes, norm_layer=norm_layer) for _ in range(1, blocks)]
     return nn.Sequential(*layers)
@@ -105,6 +108,7 @@ class Backbone(nn.Module):
         super().__init__()
         self.conv1 = nn2d.Conv2d(num_channel, 64, kernel_size=7, stride=1, padding=3, bias=False)
         self.bn1 = (norm_layer or nn2d.BatchNorm2d)(64)
+        nn2d.feeds_bn(self.conv1, self.bn1)
         self.relu = nn2d.ReLU(inplace=True)
         self.maxpool = nn2d.MaxPool2d(kernel_size=3, stride=2, padding=1)
         self.layer1 = _make_layer(64, 64, 3, 1, norm_layer)
@@ -195,6 +199,8 @@ class Net2DSeg(nn.Module):
                              nn2d.FusedAway())
         t_conv = nn.Sequential(nn2d.ConvTranspose2d(cout * num_concat_t, cin, kernel_size=2, stride=2),
                                nn2d.BatchNorm2d(cin, relu=True), nn2d.FusedAway())
+        nn2d.feeds_bn(conv[0], conv[1])
+        nn2d.feeds_bn(t_conv[0], t_conv[1])
         return conv, t_conv
 
     def _forward_fp32(self, data_batch, img, hints, img_indices, h, w):

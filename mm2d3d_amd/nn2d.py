@@ -71,7 +71,28 @@ def _need_gpu(x, what):
         raise RuntimeError(f"mm2d3d_amd.nn2d.{what}: input must be on the GPU (HIP path only, no CPU fallback)")
 
 
+def _wants_stats(m):
+    """A convolution directly in front of a training-mode BatchNorm2d files the batch statistics of its output in its epilogue
+    (``feeds_bn`` is set by the model's constructor; conv2d.BN_PRE / MM_BN2D_PRE=0 turns the scheme off)."""
+    return [None] if (m.feeds_bn and m.training and _c2d.BN_PRE[0] is not False) else None
+
+
+def _with_stats(y, holder):
+    if holder is not None and holder[0] is not None:
+        y._mm_stats = holder[0]
+    return y
+
+
+def feeds_bn(conv, bn):
+    """Marks ``conv`` as the producer of ``bn``'s input (see _wants_stats); returns conv."""
+    if isinstance(bn, BatchNorm2d) and isinstance(conv, (Conv2d, ConvTranspose2d)):
+        conv.feeds_bn = True
+    return conv
+
+
 class Conv2d(nn.Conv2d):
+    feeds_bn = False
+
     def forward(self, x, handoff=None):
         _need_gpu(x, "Conv2d")
         k = self.kernel_size
@@ -83,14 +104,18 @@ class Conv2d(nn.Conv2d):
         if _c2d.hip_eligible(self.in_channels, self.out_channels, k[0], k[1], self.stride[0], self.padding[0], self.dilation[0],
                              self.groups) and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] \
                 and self.padding_mode == "zeros":
-            return _c2d.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], handoff)
+            st = _wants_stats(self)
+            return _with_stats(_c2d.Conv2dFn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0], handoff, st), st)
         if k == (7, 7) and self.stride == (1, 1) and self.padding == (3, 3) and self.in_channels <= 8 and self.bias is None \
                 and self.out_channels % 64 == 0 and self.groups == 1:
-            return _c2d.StemConvFn.apply(x, self.weight)  # the two stems (backbones.py:23-25)
+            st = _wants_stats(self)
+            return _with_stats(_c2d.StemConvFn.apply(x, self.weight, st), st)  # the two stems (backbones.py:23-25)
         raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d: shape not on the hot path: {self}")
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
+    feeds_bn = False
+
     def forward(self, x, output_size=None):
         _need_gpu(x, "ConvTranspose2d")
         if fp32_mode():
@@ -101,7 +126,8 @@ class ConvTranspose2d(nn.ConvTranspose2d):
         if not (self.kernel_size == (2, 2) and self.stride == (2, 2) and self.padding == (0, 0) and self.output_padding == (0, 0)
                 and self.groups == 1 and self.in_channels % 64 == 0 and self.out_channels % 64 == 0 and output_size is None):
             raise NotImplementedError("hot path: ConvTranspose2d kernel 2, stride 2, channels multiple of 64")
-        return _c2d.ConvTranspose2dFn.apply(x, self.weight, self.bias)
+        st = _wants_stats(self)
+        return _with_stats(_c2d.ConvTranspose2dFn.apply(x, self.weight, self.bias, st), st)
 
 
 class GradHandoff:
@@ -119,7 +145,8 @@ class GradHandoff:
 class _BN2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, res, weight, bias, running_mean, running_var, training, eps, momentum, relu, nbt=None, out=None, handoff=None,
-                res_handoff=None):
+                res_handoff=None, pre=None):
+        """``pre``: (slab, rows, n_first, B) - the statistics slab the producing convolution filled in its epilogue."""
         L = _c2d.lib2d()
         ctx.handoff, ctx.res_handoff = handoff, res_handoff
         x, ldx = _c2d.nhwc_pitch(x)
@@ -144,8 +171,15 @@ class _BN2dFn(torch.autograd.Function):
             ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
             ctx.Ns = Ns
             ctx.hd = hd = _lib.handle(x.device)  # barrier words / fault word / switches (include/mm2d3d.h mm_create); also the backward's
-            check(L.mm_bn2d_fwd_train(hd.h, ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
-                                      ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), ldy, ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
+            if pre is not None and pre[2] == (nf if (nf is not None and 0 < nf < B) else B) and pre[3] == B and pre[0].shape[2] == C:
+                # batch statistics from the producer's epilogue: no statistics pass over x, no grid barrier
+                check(L.mm_bn2d_fwd_train_pre(ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var),
+                                              ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), ldy, ptr(stats[0]), ptr(stats[1]), ptr(pre[0]),
+                                              pre[1], ptr(ws), ws.numel(), stream()), "bn2d_fwd_train_pre")
+            else:
+                check(L.mm_bn2d_fwd_train(hd.h, ptr(x), ldx, ptr(res), ldr, N, Ns, C, ptr(weight), ptr(bias), ptr(running_mean),
+                                          ptr(running_var), ptr(nbt), eps, momentum, 1 if relu else 0, ptr(y), ldy, ptr(stats[0]), ptr(stats[1]),
+                                          ptr(ws), ws.numel(), stream()), "bn2d_fwd_train")
             ctx.save_for_backward(x, y, weight, stats, bias)
             ctx.sinks = None
             if weight is not None and bias is not None and gradsink.claim(ctx, weight, ctx.needs_input_grad[2]):
@@ -198,7 +232,7 @@ class _BN2dFn(torch.autograd.Function):
         if dres is not None and ctx.res_handoff is not None:  # the residual's producer sums it in its own backward kernels
             ctx.res_handoff.extra.append(dres)
             dres = None
-        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, None
+        return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -222,9 +256,11 @@ class BatchNorm2d(nn.BatchNorm2d):
         res_handoff = getattr(residual, "_mm_handoff", None) if (track and residual is not None and residual_shared) else None
         y = _BN2dFn.apply(x, residual, self.weight, self.bias, self.running_mean, self.running_var, use_batch, float(self.eps),
                           float(self.momentum if self.momentum is not None else 0.1), bool(self.relu), nbt,
-                          [out] if out is not None else None, handoff, res_handoff)
+                          [out] if out is not None else None, handoff, res_handoff, getattr(x, "_mm_stats", None) if use_batch else None)
         if handoff is not None:
             y._mm_handoff = handoff
+        if getattr(x, "_mm_stats", None) is not None:
+            x._mm_stats = None  # the slab has served
         return y
 
 

@@ -181,3 +181,86 @@ def test_conv3x3_ragged_last_round_runs_as_half_items(cin, cout, B, hw, half2d):
     assert float((y.detach().float() - yr.detach()).abs().max()) <= 2e-2 * float(yr.detach().abs().max())
     y2 = Conv2dFn.apply(x, w, b, 1, 1)
     assert torch.equal(y2, y)  # same schedule, same sums
+
+
+def _slab_totals(holder, C):
+    slab, rows, nf, B = holder[0]
+    assert slab.shape == (rows, 2, C) and rows % 2 == 0
+    return slab.view(rows // 2, 2, 2, C).double().sum(0)  # [group][q][C]
+
+
+def _expect_totals(y, nf):
+    yf = y.detach().double()
+    B = y.shape[0]
+    out = torch.zeros(2, 2, y.shape[1], dtype=torch.float64, device=y.device)
+    for g, (b0, b1) in enumerate(((0, nf), (nf, B))):
+        if b1 > b0:
+            out[g, 0] = yf[b0:b1].sum((0, 2, 3))
+            out[g, 1] = (yf[b0:b1] ** 2).sum((0, 2, 3))
+    return out
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,p,B,hw", [
+    ("conv", 64, 64, 3, 1, 1, 5, (19, 23)),      # k_conv3x3r (weights resident)
+    ("conv", 128, 64, 3, 1, 1, 3, (20, 28)),     # k_conv3x3w<64, .>
+    ("conv", 128, 128, 3, 1, 1, 20, (64, 64)),   # k_conv3x3w<128, 16>, ragged last round -> half items
+    ("conv", 128, 256, 3, 1, 1, 9, (48, 80)),    # two cout blocks per tile, half items
+    ("conv", 256, 256, 3, 1, 1, 4, (8, 30)),     # k_conv3x3w<128, 32>
+    ("conv", 64, 128, 3, 2, 1, 5, (20, 28)),     # implicit GEMM (stride 2)
+    ("conv", 64, 128, 1, 2, 0, 5, (21, 27)),     # 1x1 downsample
+    ("tconv", 128, 64, 2, 2, 0, 3, (9, 13)),     # transposed convolution: four parity GEMMs
+    ("stem", 3, 64, 7, 1, 3, 3, (30, 41)),
+    ("stem", 1, 64, 7, 1, 3, 4, (17, 50)),
+])
+@pytest.mark.parametrize("split", [False, True])
+def test_conv_epilogue_files_batchnorm_statistics(kind, cin, cout, k, s, p, B, hw, split, half2d):
+    """``stats=``: the convolutions file per-sub-block sums / sums of squares of their ROUNDED outputs (csrc/conv2d.hip stats_accum);
+    summed over the sub-blocks they are the per-channel, per-group totals of the map - every slab element written exactly once
+    (the slab starts as NaN), the map itself unchanged by the option."""
+    from mm2d3d_amd import domains
+    from mm2d3d_amd.conv2d import Conv2dFn, ConvTranspose2dFn, StemConvFn
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + cout + B)
+    H, W = hw
+    nf = (B // 2 or 1) if split else B
+    if kind == "stem":
+        x = torch.randn(B, cin, H, W, generator=g).to(dev)
+        w = (torch.randn(cout, cin, 7, 7, generator=g) * 0.1).to(dev)
+        run = lambda st: StemConvFn.apply(x, w, st)
+    elif kind == "tconv":
+        x = torch.randn(B, cin, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cin, cout, 2, 2, generator=g) * (1.0 / cin) ** 0.5).to(dev)
+        b = torch.randn(cout, generator=g).to(dev)
+        run = lambda st: ConvTranspose2dFn.apply(x, w, b, st)
+    else:
+        x = torch.randn(B, cin, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(dev)
+        b = torch.randn(cout, generator=g).to(dev) if k == 3 and s == 1 else None
+        run = lambda st: Conv2dFn.apply(x, w, b, s, p, None, st)
+    import mm2d3d_amd.conv2d as c2d
+
+    real_empty = torch.empty
+
+    def nan_empty(*a, **kw):  # the slab must not rely on its initial contents
+        t = real_empty(*a, **kw)
+        if t.dtype == torch.float32 and t.dim() == 3 and t.shape[1] == 2:
+            t.fill_(float("nan"))
+        return t
+
+    holder = [None]
+    mode, c2d.BN_PRE[0] = c2d.BN_PRE[0], True  # every layer, not only the maps too large for the single-launch batch norm
+    with domains.split(nf if split else None):
+        c2d.torch.empty = nan_empty
+        try:
+            y = run(holder)
+        finally:
+            c2d.torch.empty = real_empty
+            c2d.BN_PRE[0] = mode
+        y0 = run(None)
+    assert torch.equal(y, y0)
+    assert holder[0][2] == nf and holder[0][3] == B
+    got, want = _slab_totals(holder, cout), _expect_totals(y, nf)
+    assert torch.isfinite(got).all()
+    scale = want.abs().amax(-1, keepdim=True).clamp_min(1e-6)
+    assert float(((got - want).abs() / scale).max()) < 2e-6, float(((got - want).abs() / scale).max())
