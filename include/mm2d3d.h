@@ -357,7 +357,10 @@ int mm_amp_update(float* scale_dev, int* tracker_dev, const int* found_dev, int 
 int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats,
-                   int64_t split_m, mm_stream_t stream);
+                   int64_t split_m, const void* addend, int ld_add, mm_stream_t stream);
+/* ``addend`` (16-bit output only): a 16-bit map of the output's shape (pixel pitch ld_add) added to the result, element by element
+ * as an add of the two maps would - the second gradient contribution of a map with two consumers (a BasicBlock input read by conv1
+ * and by the 1x1 downsample; the decoder's concat slice) joins here instead of in an add kernel. */
 /* BatchNorm statistics in the epilogue (``stats`` non-NULL; 16-bit output only): the convolution also files, per 64-pixel
  * sub-block of its output and per statistics group, the per-channel sum and sum of squares of the ROUNDED outputs in
  *     stats[2 * sub + g][q][Cn] fp32   (q = 0: sum, 1: sum of squares; rows = mm_conv2d_gemm_stat_rows / _3x3s1_stat_rows)
@@ -432,7 +435,9 @@ int mm_copy_rows_bf16(const void* src, int64_t ld_s, void* dst, int64_t ld_d, in
  * split != 0 is its backward: parts[i] = channel slice i of wide.  Channel counts multiples of 8, 1..4 parts. */
 int mm_concat_bf16(void* const* parts, const int* channels, int nparts, void* wide, int64_t N, int split, mm_stream_t stream);
 int mm_maxpool3x3s2_fwd(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, mm_stream_t stream);
-int mm_maxpool3x3s2_bwd(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, mm_stream_t stream);
+/* dy2 (optional): a second gradient of the pooled map (it had two consumers), summed with dy in fp32; ld_dy / ld_dy2 = pixel pitches */
+int mm_maxpool3x3s2_bwd(const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* idx, int B, int H, int W, int C, void* dx,
+                        mm_stream_t stream);
 size_t mm_head_ws_bytes(int B, int h, int w, int Hp, int Wp, int C, int NJ);
 /* AvgPool2d(5,1,2) + Conv2d 1x1 of both heads (EXP/2d_net/model.py:59-60,129-130,158,163-164): out NHWC fp32 [B,h,w,NJ] */
 int mm_head_fwd(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias,
@@ -462,7 +467,7 @@ int mm_colsum_f32(const float* x, int ld, int64_t N, int C, float* out, int accu
 int mm_conv2d_gemm_f16(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats,
-                   int64_t split_m, mm_stream_t stream);
+                   int64_t split_m, const void* addend, int ld_add, mm_stream_t stream);
 int64_t mm_conv2d_gemm_stat_rows_f16(int64_t M, int nz);
 int64_t mm_conv2d_3x3s1_stat_rows_f16(int B, int H, int W);
 int mm_conv2d_3x3s1_f16(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
@@ -495,7 +500,8 @@ int mm_bn2d_bwd_f16(mm_handle_t h, const void* x, int ld_x, const void* dy, int 
 int mm_colsum_f16(const void* x, int ld_x, int64_t N, int C, float* out, int accumulate, void* ws, size_t ws_bytes,
                    mm_stream_t stream);
 int mm_maxpool3x3s2_fwd_f16(const void* x, int ldx, int B, int H, int W, int C, void* y, void* idx, mm_stream_t stream);
-int mm_maxpool3x3s2_bwd_f16(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, mm_stream_t stream);
+int mm_maxpool3x3s2_bwd_f16(const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* idx, int B, int H, int W, int C, void* dx,
+                        mm_stream_t stream);
 size_t mm_head_ws_bytes_f16(int B, int h, int w, int Hp, int Wp, int C, int NJ);
 int mm_head_fwd_f16(const void* x, int B, int Hp, int Wp, int ld, int h, int w, int C, const float* Wj, const float* bias,
                 int NJ, float* out, void* ws, size_t ws_bytes, mm_stream_t stream);

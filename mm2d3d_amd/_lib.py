@@ -107,7 +107,7 @@ _PROTOS = {
     "mm_adamw_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "mm_amp_update": (i32, [vp, vp, vp, i32, f64, f64, i32, vp]),
     "mm_conv2d_gemm": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp,
-                             vp, i32, i64, i32, vp, vp, i64, vp]),
+                             vp, i32, i64, i32, vp, vp, i64, vp, i32, vp]),
     "mm_conv2d_3x3s1": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp, i32, vp]),
     "mm_conv2d_gemm_stat_rows": (i64, [i64, i32]),
     "mm_conv2d_3x3s1_stat_rows": (i64, [i32, i32, i32]),
@@ -132,7 +132,7 @@ _PROTOS = {
     "mm_copy_rows_bf16": (i32, [vp, i64, vp, i64, i64, i32, vp]),
     "mm_concat_bf16": (i32, [vp, vp, i32, vp, i64, i32, vp]),
     "mm_maxpool3x3s2_fwd": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
-    "mm_maxpool3x3s2_bwd": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "mm_maxpool3x3s2_bwd": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, vp]),
     "mm_head_ws_bytes": (sz, [i32, i32, i32, i32, i32, i32, i32]),
     "mm_head_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
     "mm_head_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]),

@@ -172,13 +172,13 @@ def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
     return e.out
 
 
-def _bias_grad(dy):
-    """dy.sum((0, 2, 3)) of an NHWC bf16 gradient in one pass (fp64 combination), fp32 result."""
+def _bias_grad(dy, into=None):
+    """dy.sum((0, 2, 3)) of an NHWC bf16 gradient in one pass (fp64 combination), fp32 result; ``into``: accumulate there."""
     L = lib2d()
     Bn, C, H, W = dy.shape
-    out = torch.empty(C, dtype=torch.float32, device=dy.device)
+    out = torch.empty(C, dtype=torch.float32, device=dy.device) if into is None else into
     ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), dy.device)
-    check(L.mm_colsum_bf16(ptr(dy), C, Bn * H * W, C, ptr(out), 0, ptr(ws), ws.numel(), stream()),
+    check(L.mm_colsum_bf16(ptr(dy), C, Bn * H * W, C, ptr(out), 0 if into is None else 1, ptr(ws), ws.numel(), stream()),
           "colsum")
     return out
 
@@ -214,8 +214,10 @@ def _stat_slab(holder, rows, Cn, nf, Bn, device):
     return slab
 
 
-def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None, lda=None, stats=None):
-    """``stats``: a one-element list that receives (slab, rows, n_first, B) - the output's BatchNorm statistics slab."""
+def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz=1, wz=0, zpar=0, bias=None, lda=None, stats=None,
+          addend=None, ld_add=0):
+    """``stats``: a one-element list that receives (slab, rows, n_first, B) - the output's BatchNorm statistics slab.
+    ``addend``: a 16-bit map of the output's shape (pixel pitch ``ld_add``) added to the result in the epilogue."""
     slab, split_m = None, 0
     if stats is not None and bn_pre_wanted(out.device, Bn, Ho, Wo, Cn):
         nf = _stat_group_split(Bn)
@@ -224,7 +226,7 @@ def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz
     check(
         lib2d().mm_conv2d_gemm(ptr(A), Bn, Hi, Wi, Ca, lda or Ca, ptr(out), Ho, Wo, Cn, Cn, 1 if out.dtype == torch.float32 else 0,
                                   Hg, Wg, so, 0, 0, sa, fr, len(ty), _arr(ty), _arr(tx), ptr(Wp), nz, wz, zpar, ptr(bias), ptr(slab), split_m,
-                                  stream()),
+                                  ptr(addend), ld_add, stream()),
         "conv2d_gemm",
     )
 
@@ -280,6 +282,7 @@ class Conv2dFn(torch.autograd.Function):
         ctx.cfg = (stride, padding, bias is not None)
         ctx.wowner = weight
         ctx.wparam = weight if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]) else None
+        ctx.bparam = bias if (bias is not None and gradsink.claim(ctx, bias, ctx.needs_input_grad[2])) else None
         return y
 
     @staticmethod
@@ -302,7 +305,18 @@ class Conv2dFn(torch.autograd.Function):
             else:
                 ty = [padding - kh for kh in range(KH) for _ in range(KW)]
                 tx = [padding - kw for _ in range(KH) for kw in range(KW)]
-                _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd, lda=ldy)
+                add, ld_add = None, 0
+                if ctx.handoff is not None and ctx.handoff.extra:
+                    # the map has a third consumer whose contribution already waits in the slot (a backbone feature read by the
+                    # next stage's conv1, its 1x1 downsample and the decoder's concat): it joins in this kernel's epilogue, the
+                    # producer's backward then reads two maps and no add kernel runs
+                    e = ctx.handoff.extra[-1]
+                    if e.dtype == HALF[0] and tuple(e.shape) == (Bn, Cin, H, W):
+                        cand, cld = nhwc_pitch(e)
+                        if cand.data_ptr() == e.data_ptr():  # usable as it lies (no copy was needed)
+                            ctx.handoff.extra.pop()
+                            add, ld_add = cand, cld
+                _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd, lda=ldy, addend=add, ld_add=ld_add)
         if ctx.needs_input_grad[1]:
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]
             tx = [kw - padding for _ in range(KH) for kw in range(KW)]
@@ -314,7 +328,11 @@ class Conv2dFn(torch.autograd.Function):
                 dw = torch.empty_like(w)
                 _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, dw, Cin * T, 1, T, ldx=ldx, ldy=ldy)
         if has_bias and ctx.needs_input_grad[2]:
-            db = _bias_grad(as_nhwc_bf16(dy))
+            if ctx.bparam is not None:
+                _bias_grad(as_nhwc_bf16(dy), into=ctx.bparam._mm_sink)
+                gradsink.done(ctx.bparam)
+            else:
+                db = _bias_grad(as_nhwc_bf16(dy))
         if ctx.handoff is not None and dx is not None:  # the producer's backward kernels add it (fp32) to the other consumer's
             ctx.handoff.extra.append(dx)
             dx = None
@@ -339,6 +357,8 @@ class ConvTranspose2dFn(torch.autograd.Function):
         _gemm(x, Bn, H, W, Cin, y, 2 * H, 2 * W, Cout, H, W, 2, 1, 1, [0], [0], Wp, nz=4, wz=Cout * Cin, zpar=1, bias=b, stats=stats)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        ctx.wparam = weight if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]) else None
+        ctx.bparam = bias if (bias is not None and gradsink.claim(ctx, bias, ctx.needs_input_grad[2])) else None
         return y
 
     @staticmethod
@@ -354,11 +374,19 @@ class ConvTranspose2dFn(torch.autograd.Function):
             dx = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x.device, memory_format=CL)
             _gemm(dy, Bn, 2 * H, 2 * W, Cout, dx, H, W, Cin, H, W, 1, 2, 1, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
             # roles: "dY" := x (base grid H x W, n = ci), "X" := dy (source pixel (2y+a, 2x+b), k = co)
-            _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, dw, Cout * 4, 1, 4)
+            if ctx.wparam is not None:  # straight into the optimiser's gradient arena
+                _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, ctx.wparam._mm_sink, Cout * 4, 1, 4, accumulate=1)
+                gradsink.done(ctx.wparam)
+            else:
+                dw = torch.empty_like(w)
+                _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, dw, Cout * 4, 1, 4)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _bias_grad(dy)
+            if ctx.bparam is not None:
+                _bias_grad(dy, into=ctx.bparam._mm_sink)
+                gradsink.done(ctx.bparam)
+            else:
+                db = _bias_grad(dy)
         return dx, dw, db, None
 
 
@@ -420,7 +448,7 @@ class StemConvFn(torch.autograd.Function):
             slab = _stat_slab(stats, int(L.mm_conv2d_gemm_stat_rows(Bn * H * W, 1)), Cout, nf, Bn, img.device)
             split_m = nf * H * W
         check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, T, _arr(ty),
-                               _arr([0] * T), ptr(Wp), 1, 0, 0, None, ptr(slab), split_m, stream()), "conv2d_gemm(stem)")
+                               _arr([0] * T), ptr(Wp), 1, 0, 0, None, ptr(slab), split_m, None, 0, stream()), "conv2d_gemm(stem)")
         ctx.save_for_backward(xb)
         ctx.dims = (Bn, C, H, W, Cout, Hb, Wb, weight.shape)
         return y

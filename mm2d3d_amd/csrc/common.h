@@ -66,6 +66,7 @@ struct MMArena {
 // scan): what a build on a side stream beside grid-barrier kernels needs (fused_bn.h)
 int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* total_out, void* ws, size_t ws_bytes,
                           hipStream_t s, int no_spin = 0);
+int mm_exclusive_scan_nonneg_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes, hipStream_t s, int no_spin = 0);
 size_t mm_scan_ws_bytes(int64_t n);
 
 // ---------------------------------------------------------------------------------------------------------- per-device handle

@@ -44,6 +44,8 @@ struct ConvP {
   int nbuf;  // LDS stage buffers: 2 (tile s+1 in flight while tile s is multiplied) or 1 when the whole K is one step
   float* stats;     // BatchNorm statistics slab (see stats_accum), or NULL
   int64_t split_m;  // GEMM rows [0, split_m) are statistics group 0, the others group 1
+  const u16* addend;  // 16-bit map of the output's shape added (in fp32) before the rounding, or NULL: a second gradient
+  int ld_add;         // contribution of the same map summed here instead of by an add kernel (pixel pitch ld_add)
 };
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
@@ -84,6 +86,14 @@ __device__ inline void frag_rows(unsigned (&D)[4][2], uint4& xa, uint4& xb) {
 //     slab[2 * sub + g][q][Cn],  sub = 64-pixel sub-block (pixel tile, wm), g = statistics group, q = 0: sum, 1: sum of squares
 // that a small finalize kernel adds up in fp64 in a fixed order (mm_bn2d_fwd_train_pre): deterministic, no atomics.  The sums are
 // taken over the ROUNDED 16-bit outputs - the values the normalisation will read.
+// eight 16-bit values + eight 16-bit values (each sum formed in fp32 and rounded: what an elementwise add of the two maps gives)
+__device__ inline uint4 add_h8(const uint4& a, const uint4& b) {
+  const unsigned x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+  unsigned r[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) r[i] = (unsigned)f2bf(h_lo(x[i]) + h_lo(y[i])) | ((unsigned)f2bf(h_hi(x[i]) + h_hi(y[i])) << 16);
+  return make_uint4(r[0], r[1], r[2], r[3]);
+}
 __device__ inline void stats_accum(const uint4& x, bool valid, float (&s)[16]) {
   const unsigned w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -285,12 +295,16 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
       return m;
     };
     u16 *rowa[2], *rowb[2];
+    const u16 *adda[2], *addb[2];
     int64_t mra[2], mrb[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       mra[i] = m0 + wm * 64 + i * 32 + (lane & 15), mrb[i] = mra[i] + 16;
-      rowa[i] = mra[i] < M ? (u16*)p.O + out_row(mra[i]) * p.ldo : nullptr;
-      rowb[i] = mrb[i] < M ? (u16*)p.O + out_row(mrb[i]) * p.ldo : nullptr;
+      const int64_t ora = mra[i] < M ? out_row(mra[i]) : -1, orb = mrb[i] < M ? out_row(mrb[i]) : -1;
+      rowa[i] = ora >= 0 ? (u16*)p.O + ora * p.ldo : nullptr;
+      rowb[i] = orb >= 0 ? (u16*)p.O + orb * p.ldo : nullptr;
+      adda[i] = p.addend && ora >= 0 ? p.addend + ora * p.ld_add : nullptr;
+      addb[i] = p.addend && orb >= 0 ? p.addend + orb * p.ld_add : nullptr;
     }
     // BatchNorm statistics (stats_accum): sub-block = (z, 128-row block, wm); its 64 rows may straddle the boundary between the two
     // statistics groups, so both groups' sums are formed and both slab rows written
@@ -320,6 +334,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
         uint4 xa, xb;
         frag_rows(D, xa, xb);
         const int n = nf + 8 * schunk;
+        if (p.addend && n < p.Cn) {  // rows are whole here: 16 bytes of the addend per lane and row
+          if (adda[i]) xa = add_h8(xa, *(const uint4*)(adda[i] + n));
+          if (addb[i]) xb = add_h8(xb, *(const uint4*)(addb[i] + n));
+        }
         if (p.stats) {
           stats_accum(xa, rowa[i] != nullptr && mra[i] < p.split_m, st0);
           stats_accum(xb, rowb[i] != nullptr && mrb[i] < p.split_m, st0);
@@ -409,6 +427,7 @@ struct C3P {
 // DIAG (tools/conv3x3_diag.hip only; the library instantiates DIAG = 0): parts of k_conv3x3w switched off at COMPILE time to see
 // what a step is made of - 1: no MFMA  2: no fragment reads (and no MFMA)  4: W DMA from the zero line  8: halo DMA from the zero
 // line  16: no output stores  32: no epilogue at all  64: epilogue arithmetic kept, ONE 4-byte store per item and lane
+// 128: accumulators consumed by an empty asm, no epilogue (the MFMAs survive dead-code elimination)
 #define MM_DIAG(p, bit) ((DIAG & (bit)) != 0)
 
 // Persistent kernel.  (The first-generation kernel - one 128-pixel patch per workgroup, deleted in round 3 - taught this:)
@@ -698,6 +717,18 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       c_c = 0;
       if (++c_k < my_items) c_item = item_of(c_k, c_half);
       if (MM_DIAG(p, 32)) continue;
+      if (MM_DIAG(p, 128)) {  // the accumulators are consumed (the MFMAs stay) but nothing of the epilogue runs
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+              asm volatile("" ::"v"(acc[i][j][r]));
+              acc[i][j][r] = 0.f;
+            }
+        continue;
+      }
       unsigned diag_sum = 0;
       // after frag_rows this lane holds rows of the pixels sp[i][0] (xa) and sp[i][1] (xb), not of its own MFMA column
       u16 *rowa[2], *rowb[2];
@@ -1469,17 +1500,21 @@ extern "C" {
 int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats, int64_t split_m,
-                   hipStream_t s) {
+                   const void* addend, int ld_add, hipStream_t s) {
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)Wp % 16) == 0,
                "conv2d_gemm: Ca must be a multiple of 64 and pointers 16-B aligned (Ca=%d lda=%d)", Ca, lda);
   MM_CHECK_ARG(!stats || (!out_f32 && Cn % 32 == 0 && ldo % 8 == 0 && ((uintptr_t)O % 16) == 0 && ((uintptr_t)bias % 16) == 0),
                "conv2d_gemm: statistics need a 16-bit output, Cn a multiple of 32, ldo of 8");
+  MM_CHECK_ARG(!addend || (!out_f32 && Cn % 8 == 0 && ldo % 8 == 0 && ld_add % 8 == 0 && ((uintptr_t)O % 16) == 0 && ((uintptr_t)addend % 16) == 0 &&
+                           ((uintptr_t)bias % 16) == 0),
+               "conv2d_gemm: an addend needs a 16-bit output, channels and pitches multiples of 8, 16-byte aligned maps");
   MM_CHECK_ARG(fr == 1 || fr == 2, "conv2d_gemm: fr must be 1 or 2");
   ConvP p;
   p.A = (const u16*)A; p.B = B; p.Hi = Hi; p.Wi = Wi; p.Ca = Ca; p.lda = lda;
   p.O = O; p.Ho = Ho; p.Wo = Wo; p.Cn = Cn; p.ldo = ldo; p.out_f32 = out_f32;
   p.Hg = Hg; p.Wg = Wg; p.so = so; p.ooy = ooy; p.oox = oox; p.sa = sa; p.fr = fr;
   p.W = (const u16*)Wp; p.wz = wz; p.zpar = zpar; p.bias = bias; p.stats = stats; p.split_m = split_m;
+  p.addend = (const u16*)addend; p.ld_add = ld_add;
   if (fill_taps(&p, ty, tx, ntaps)) {
     mm_set_error("conv2d_gemm: too many taps");
     return MM_ERR_ARG;

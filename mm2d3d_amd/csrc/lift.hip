@@ -74,7 +74,9 @@ __global__ __launch_bounds__(T) void k_lift_scatter_key(const float* __restrict_
   dseg[key_offset(k, HW, W, sb, sy, sx) + (int64_t)c * sc] = s;
 }
 
-using SortCfg = rocprim::default_config;
+// (rocPRIM's default switches to a merge sort below 2^20 keys: 20 launch-bound passes for the 140k points of a batch; Onesweep needs a
+// histogram + one scatter pass per 8 key bits - see csrc/ostable.hip)
+using SortCfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 16384>;
 using SortCfgMerge = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, ((size_t)1 << 40)>;
 template <typename Cfg>
 hipError_t sort_keys(void* tmp, size_t& bytes, const int32_t* key, int32_t* skey, int32_t* order, int64_t n, unsigned bits, hipStream_t s) {

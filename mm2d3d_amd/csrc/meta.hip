@@ -194,12 +194,6 @@ __global__ __launch_bounds__(T) void k_down_nbr(const int32_t* __restrict__ vc_f
   nbr[(int64_t)k * n_coarse + fine2coarse[i]] = (int32_t)i;
 }
 
-__global__ __launch_bounds__(T) void k_flags_from_nbr(const int32_t* __restrict__ nbr, int64_t total,
-                                                       int32_t* __restrict__ flag) {
-  int64_t f = (int64_t)blockIdx.x * T + threadIdx.x;
-  if (f < total) flag[f] = nbr[f] >= 0;
-}
-
 __global__ __launch_bounds__(T) void k_emit_rules(const int32_t* __restrict__ nbr, const int32_t* __restrict__ pos,
                                                    int64_t n_out, int K, int32_t* __restrict__ rin,
                                                    int32_t* __restrict__ rout, int32_t* __restrict__ offsets,
@@ -369,8 +363,7 @@ int mm_rulebook_compact(const int32_t* nbr, int K, int64_t n_out, int32_t* rin, 
     mm_set_error("rulebook_compact: workspace too small (%zu < %zu)", ws_bytes, mm_rulebook_ws_bytes(n_out, K));
     return MM_ERR_WORKSPACE;
   }
-  hipLaunchKernelGGL(k_flags_from_nbr, dim3(nblk(total)), dim3(T), 0, s, nbr, total, pos);
-  int rc = mm_exclusive_scan_i32(pos, pos, total, pos + total, scan_ws, sws, s, no_spin);
+  int rc = mm_exclusive_scan_nonneg_i32(nbr, pos, total, scan_ws, sws, s, no_spin);  // pos[f] = rules before table entry f
   if (rc) return rc;
   if (rin) hipLaunchKernelGGL(k_emit_rules, dim3(nblk(n_out), K), dim3(T), 0, s, nbr, pos, n_out, K, rin, rout, offsets, pos + total);
   if (csr_off) {

@@ -104,8 +104,11 @@ __global__ __launch_bounds__(T) void k_maxpool_fwd(const u16* __restrict__ x, in
   *(unsigned long long*)(idx + pix * C + c8 * 8) = iw;
 }
 
-__global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, const unsigned char* __restrict__ idx, int B, int H,
-                                                    int W, int C, int Ho, int Wo, u16* __restrict__ dx) {
+// dy2 != NULL: the pooled map had two consumers (layer1.0's conv1 and its residual add, backbones.py:31-33); their gradients are
+// summed here in fp32 (pixel pitches ld_dy / ld_dy2) instead of by an add kernel
+__global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, int ld_dy, const u16* __restrict__ dy2, int ld_dy2,
+                                                    const unsigned char* __restrict__ idx, int B, int H, int W, int C, int Ho, int Wo,
+                                                    u16* __restrict__ dx) {
   const int C8 = C >> 3;
   const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: total < 2^32)
   const int64_t total = (int64_t)B * H * W * C8;
@@ -127,14 +130,21 @@ __global__ __launch_bounds__(T) void k_maxpool_bwd(const u16* __restrict__ dy, c
       if (ox >= Wo) continue;
       int kw = ix - (ox * 2 - 1);
       if (kw < 0 || kw > 2) continue;
-      int64_t o = ((int64_t)(b * Ho + oy) * Wo + ox) * C + c8 * 8;
-      unsigned long long iw = *(const unsigned long long*)(idx + o);
-      uint4 v = *(const uint4*)(dy + o);
+      const int64_t opix = (int64_t)(b * Ho + oy) * Wo + ox;
+      unsigned long long iw = *(const unsigned long long*)(idx + opix * C + c8 * 8);
+      uint4 v = *(const uint4*)(dy + opix * ld_dy + c8 * 8);
       unsigned wv[4] = {v.x, v.y, v.z, v.w};
       const unsigned tap = (unsigned)(kh * 3 + kw);
 #pragma unroll
       for (int i = 0; i < 8; i++)
         if (((iw >> (8 * i)) & 0xFFull) == tap) s[i] += (i & 1) ? h_hi(wv[i >> 1]) : h_lo(wv[i >> 1]);
+      if (dy2) {
+        const uint4 v2 = *(const uint4*)(dy2 + opix * ld_dy2 + c8 * 8);
+        const unsigned w2[4] = {v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          if (((iw >> (8 * i)) & 0xFFull) == tap) s[i] += (i & 1) ? h_hi(w2[i >> 1]) : h_lo(w2[i >> 1]);
+      }
     }
   }
   unsigned ow[4];
@@ -430,14 +440,15 @@ int MM_SYM(mm_maxpool3x3s2_fwd)(const void* x, int ldx, int B, int H, int W, int
   return MM_OK;
 }
 
-int MM_SYM(mm_maxpool3x3s2_bwd)(const void* dy, const void* idx, int B, int H, int W, int C, void* dx, hipStream_t s) {
+int MM_SYM(mm_maxpool3x3s2_bwd)(const void* dy, int ld_dy, const void* dy2, int ld_dy2, const void* idx, int B, int H, int W, int C, void* dx,
+                        hipStream_t s) {
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  MM_CHECK_ARG(C % 8 == 0, "maxpool: C must be a multiple of 8");
+  MM_CHECK_ARG(C % 8 == 0 && ld_dy % 8 == 0 && (!dy2 || ld_dy2 % 8 == 0), "maxpool: C and the pitches must be multiples of 8");
   int64_t total = (int64_t)B * H * W * (C / 8);
   if (total == 0) return MM_OK;
   MM_CHECK_ARG(total < (1ll << 32) - 4096, "maxpool: too many elements for 32-bit thread indices");
-  hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)dy, (const unsigned char*)idx, B, H, W,
-                     C, Ho, Wo, (u16*)dx);
+  hipLaunchKernelGGL(k_maxpool_bwd, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)dy, ld_dy, (const u16*)dy2, ld_dy2,
+                     (const unsigned char*)idx, B, H, W, C, Ho, Wo, (u16*)dx);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -25,8 +25,11 @@ namespace {
 
 constexpr int T = 256;
 
-__global__ __launch_bounds__(T) void k_row_mask(const int32_t* __restrict__ nbr, int K, int64_t n, uint32_t* __restrict__ mask) {
+// (also clears the tile masks k_os_fill ORs into: nt <= n, one launch less than a memset)
+__global__ __launch_bounds__(T) void k_row_mask(const int32_t* __restrict__ nbr, int K, int64_t n, uint32_t* __restrict__ mask,
+                                                 uint32_t* __restrict__ tmask, int64_t nt) {
   const int64_t o = (int64_t)blockIdx.x * T + threadIdx.x;
+  if (o < nt) tmask[o] = 0u;
   if (o >= n) return;
   uint32_t m = 0;
   for (int k = 0; k < K; k++) m |= (nbr[(int64_t)k * n + o] >= 0 ? 1u : 0u) << k;
@@ -115,10 +118,9 @@ int mm_os_table_build(const int32_t* nbr, int K, int64_t n, int tile_rows, int s
     mm_set_error("os_table_build: workspace too small (%zu < %zu)", ws_bytes, mm_os_table_ws_bytes(n, K));
     return MM_ERR_WORKSPACE;
   }
-  hipLaunchKernelGGL(k_row_mask, dim3((unsigned)mm_cdiv(n, T)), dim3(T), 0, s, nbr, K, n, mask);
+  hipLaunchKernelGGL(k_row_mask, dim3((unsigned)mm_cdiv(n, T)), dim3(T), 0, s, nbr, K, n, mask, tmask, nt);
   if (sort_merge) MM_HIP(sort_masks<SortCfgMerge>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
   else MM_HIP(sort_masks<SortCfg>(tmp, tmp_bytes, mask, mask_sorted, perm, n, K, s));
-  MM_HIP(hipMemsetAsync(tmask, 0, (size_t)nt * 4, s));
   hipLaunchKernelGGL(k_os_fill, dim3((unsigned)mm_cdiv(npad, T)), dim3(T), 0, s, nbr, K, n, npad, tile_rows, mask_sorted, perm, dst,
                      nbrp, tmask);
   MM_LAUNCH_CHECK();

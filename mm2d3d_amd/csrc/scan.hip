@@ -7,6 +7,8 @@
 #include <stdarg.h>
 
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "common.h"
 
@@ -53,13 +55,15 @@ __device__ inline int block_excl_scan(int v, int* tot) {
   return base + inc - v;
 }
 
+// FLAG: the scanned value is (in[i] >= 0) instead of in[i] (mm_exclusive_scan_nonneg_i32)
+template <bool FLAG>
 __global__ __launch_bounds__(SCAN_T) void k_block_sums(const int32_t* __restrict__ in, int32_t* __restrict__ sums,
                                                         int64_t n) {
   int64_t base = (int64_t)blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_PER;
   int v = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_PER; i++)
-    if (base + i < n) v += in[base + i];
+    if (base + i < n) v += FLAG ? (in[base + i] >= 0 ? 1 : 0) : in[base + i];
   int tot;
   block_excl_scan(v, &tot);
   if (threadIdx.x == 0) sums[blockIdx.x] = tot;
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_sums(int32_t* __restrict__ sums
   if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 
+template <bool FLAG>
 __global__ __launch_bounds__(SCAN_T) void k_rescan(const int32_t* __restrict__ in, int32_t* __restrict__ out,
                                                     const int32_t* __restrict__ sums, int64_t n) {
   int64_t base = (int64_t)blockIdx.x * SCAN_BLK + threadIdx.x * SCAN_PER;
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(SCAN_T) void k_rescan(const int32_t* __restrict__ i
   int v = 0;
 #pragma unroll
   for (int i = 0; i < SCAN_PER; i++) {
-    x[i] = (base + i < n) ? in[base + i] : 0;
+    x[i] = (base + i < n) ? (FLAG ? (in[base + i] >= 0 ? 1 : 0) : in[base + i]) : 0;
     v += x[i];
   }
   int tot;
@@ -97,6 +102,11 @@ __global__ __launch_bounds__(SCAN_T) void k_rescan(const int32_t* __restrict__ i
     ex += x[i];
   }
 }
+struct NonNeg {  // i -> (in[i] >= 0), 0 past the end: the look-back scan runs over n + 1 elements to produce the total
+  const int32_t* in;
+  int64_t n;
+  __host__ __device__ int32_t operator()(int64_t i) const { return i < n ? (in[i] >= 0 ? 1 : 0) : 0; }
+};
 }  // namespace
 
 
@@ -134,9 +144,38 @@ int mm_exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, int32_t* t
       return MM_OK;
     }
   }
-  hipLaunchKernelGGL(k_block_sums, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, sums, n);
+  hipLaunchKernelGGL(k_block_sums<false>, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, sums, n);
   hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, sums, nb, total_out);
-  hipLaunchKernelGGL(k_rescan, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, sums, n);
+  hipLaunchKernelGGL(k_rescan<false>, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, sums, n);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// out[i] = number of j < i with in[j] >= 0, out[n] = the count (out holds n + 1 elements; in exactly n, may alias nothing).
+// The rulebook compaction scans the neighbour table itself: no flag array is written and read back (round 4).
+int mm_exclusive_scan_nonneg_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes, hipStream_t s, int no_spin) {
+  if (n <= 0) {
+    MM_HIP(hipMemsetAsync(out, 0, sizeof(int32_t), s));
+    return MM_OK;
+  }
+  if (ws_bytes < mm_scan_ws_bytes(n)) {
+    mm_set_error("scan workspace too small: %zu < %zu", ws_bytes, mm_scan_ws_bytes(n));
+    return MM_ERR_WORKSPACE;
+  }
+  int32_t* sums = (int32_t*)ws;
+  int64_t nb = mm_cdiv(n, SCAN_BLK);
+  if (!no_spin) {
+    size_t tb = lookback_bytes(n + 1);
+    char* tmp = (char*)ws + mm_align((size_t)(nb + 1) * sizeof(int32_t));
+    if ((size_t)(tmp - (char*)ws) + tb <= ws_bytes) {
+      auto it = rocprim::make_transform_iterator(rocprim::counting_iterator<int64_t>(0), NonNeg{in, n});
+      MM_HIP(rocprim::exclusive_scan((void*)tmp, tb, it, out, (int32_t)0, (size_t)(n + 1), rocprim::plus<int32_t>(), s));
+      return MM_OK;
+    }
+  }
+  hipLaunchKernelGGL(k_block_sums<true>, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, sums, n);
+  hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, s, sums, nb, out + n);
+  hipLaunchKernelGGL(k_rescan<true>, dim3((unsigned)nb), dim3(SCAN_T), 0, s, in, out, sums, n);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -277,8 +277,9 @@ class ReLU(nn.ReLU):
 
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, handoff=None):
         L = _c2d.lib2d()
+        ctx.handoff = handoff
         x, ldx = _c2d.nhwc_pitch(x)
         B, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -294,10 +295,17 @@ class _MaxPoolFn(torch.autograd.Function):
         L = _c2d.lib2d()
         (idx,) = ctx.saved_tensors
         B, C, H, W = ctx.shape
-        dy = _c2d.as_nhwc_bf16(dy)
+        dy, ldy = _c2d.nhwc_pitch(dy)
+        dy2, ldy2 = None, 0
+        if ctx.handoff is not None and ctx.handoff.extra:  # the second consumer's contribution (see GradHandoff)
+            extra, ctx.handoff.extra = ctx.handoff.extra, []
+            for e in extra[1:]:
+                dy = dy + e
+                dy, ldy = _c2d.nhwc_pitch(dy)
+            dy2, ldy2 = _c2d.nhwc_pitch(extra[0])
         dx = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=dy.device, memory_format=CL)
-        check(L.mm_maxpool3x3s2_bwd(ptr(dy), ptr(idx), B, H, W, C, ptr(dx), stream()), "maxpool_bwd")
-        return dx
+        check(L.mm_maxpool3x3s2_bwd(ptr(dy), ldy, ptr(dy2), ldy2, ptr(idx), B, H, W, C, ptr(dx), stream()), "maxpool_bwd")
+        return dx, None
 
 
 class MaxPool2d(nn.MaxPool2d):
@@ -307,7 +315,11 @@ class MaxPool2d(nn.MaxPool2d):
             return torch.nn.functional.max_pool2d(x.contiguous(), self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode)
         if (self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode) != (3, 2, 1, 1, False):
             raise NotImplementedError("hot path: MaxPool2d(3, 2, 1)")
-        return _MaxPoolFn.apply(x)
+        handoff = GradHandoff() if (torch.is_grad_enabled() and x.requires_grad) else None
+        y = _MaxPoolFn.apply(x, handoff)
+        if handoff is not None:
+            y._mm_handoff = handoff  # layer1.0 reads the pooled map twice (conv1 and the residual add)
+        return y
 
 
 class AvgPool2d(nn.AvgPool2d):
