@@ -426,17 +426,21 @@ class StemConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, img, weight, stats=None):
+    def forward(ctx, img, weight, stats=None, pad_to=None):
+        """``pad_to`` = (Hp, Wp): the result of the convolution on the image zero-padded at the bottom / right to Hp x Wp
+        (2d_net/model.py:91-96 pads the inputs to multiples of 16) - the zeros are written by the staging kernel, no F.pad."""
         _lib.require_cuda(img, "img")
         L = lib2d()
         img = img.float().contiguous()
-        Bn, C, H, W = img.shape
+        Bn, C, Hs, Ws = img.shape
+        H, W = (Hs, Ws) if pad_to is None else (int(pad_to[0]), int(pad_to[1]))
+        assert H >= Hs and W >= Ws
         Cout, _, KH, KW = weight.shape
         assert (KH, KW) == (7, 7) and C <= 8 and Cout % 64 == 0
         R, T, flat, valid, src = _stem_index(C, img.device)
         Hb, Wb = H + 6 + 8, W + 6 + 2  # rows: taps reach R*T - 1 <= 7 rows further; cols: the 8-pixel window of the last column
         xb = torch.empty((Bn, Hb, Wb, 8), dtype=HALF[0], device=img.device)
-        check(L.mm_stem_prep(ptr(img), Bn, C, H, W, 3, Hb, Wb, R, ptr(xb), stream()), "stem_prep")
+        check(L.mm_stem_prep(ptr(img), Bn, C, Hs, Ws, 3, Hb, Wb, R, ptr(xb), stream()), "stem_prep")  # zeros outside Hs x Ws
         w = weight.detach().float().reshape(Cout, C * 49)
         Wp = torch.cat([w, w.new_zeros((Cout, 1))], 1).index_select(1, flat).to(HALF[0]).contiguous()  # [co][t][kw8][slot]
         y = torch.empty((Bn, Cout, H, W), dtype=HALF[0], device=img.device, memory_format=CL)
@@ -467,6 +471,6 @@ class StemConvFn(torch.autograd.Function):
                                 ptr(dwp), T * 64, 64, 1, 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad(stem)")
         dw = torch.zeros((Cout, C * 49), dtype=torch.float32, device=dy.device)
         dw.index_copy_(1, src, dwp.index_select(1, valid))
-        return None, dw.view(wshape), None
+        return None, dw.view(wshape), None, None
 
 

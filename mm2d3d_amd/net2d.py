@@ -132,12 +132,13 @@ class Backbone(nn.Module):
         last = layer[-1]
         return last(x, out=out) if (out is not None and getattr(last, "_fused", False)) else last(x)
 
-    def forward(self, x, outs=None):
-        """``outs``: optional destinations (channel slices of the decoder's concat buffers) for feats 0..2."""
+    def forward(self, x, outs=None, pad_to=None):
+        """``outs``: optional destinations (channel slices of the decoder's concat buffers) for feats 0..2.
+        ``pad_to``: (Hp, Wp) - the network runs on the image zero-padded to that size; the stem's staging kernel writes the zeros."""
         feats = []
         o = (list(outs) + [None] * 3)[:3] if outs is not None else [None] * 3
         if self._fused:
-            x = self.bn1(self.conv1(x), out=o[0])
+            x = self.bn1(self.conv1(x, pad_to=pad_to) if pad_to is not None else self.conv1(x), out=o[0])
         else:
             x = self.relu(self.bn1(self.conv1(x)))
         feats.append(x)
@@ -230,7 +231,8 @@ class Net2DSeg(nn.Module):
         # before any of this forward is queued, so the host never waits for the convolutions to drain
         _pixel_index(data_batch, h, w, img.device)
         pad_h, pad_w = (-h) % 16, (-w) % 16
-        if pad_h or pad_w:
+        fused_stems = not nn2d.fp32_mode() and self.rgb_backbone._fused and self.depth_backbone._fused
+        if (pad_h or pad_w) and not fused_stems:
             img = F.pad(img, [0, pad_w, 0, pad_h])
             hints = F.pad(hints, [0, pad_w, 0, pad_h])
         # The three full-resolution decoder concats [depth | up | rgb] are never copied: their buffers exist up front and
@@ -238,10 +240,11 @@ class Net2DSeg(nn.Module):
         # straight into their channel slices; the backbones keep reading those slices as pitched NHWC maps.
         if nn2d.fp32_mode():
             return self._forward_fp32(data_batch, img, hints, img_indices, h, w)
-        Bn, Hp, Wp = img.shape[0], img.shape[2], img.shape[3]
+        Bn, Hp, Wp = img.shape[0], h + pad_h, w + pad_w
+        pad_to = (Hp, Wp) if (fused_stems and (pad_h or pad_w)) else None  # the stems' staging kernels write the padding zeros
         cb = [nn2d.CatBuffer(Bn, (c, c, c), Hp >> l, Wp >> l, img.device) for l, c in enumerate(self.rgb_backbone.channels[:3])]
-        r = self.rgb_backbone(img, outs=[b.slot(2) for b in cb])
-        d = self.depth_backbone(hints, outs=[b.slot(0) for b in cb])
+        r = self.rgb_backbone(img, outs=[b.slot(2) for b in cb], pad_to=pad_to)
+        d = self.depth_backbone(hints, outs=[b.slot(0) for b in cb], pad_to=pad_to)
         for l in range(3):
             cb[l].put(0, d[l], shared=True)  # the backbones keep consuming these maps
             cb[l].put(2, r[l], shared=True)

@@ -93,7 +93,8 @@ def feeds_bn(conv, bn):
 class Conv2d(nn.Conv2d):
     feeds_bn = False
 
-    def forward(self, x, handoff=None):
+    def forward(self, x, handoff=None, pad_to=None):
+        """``pad_to`` (stems only): see conv2d.StemConvFn."""
         _need_gpu(x, "Conv2d")
         k = self.kernel_size
         if fp32_mode():
@@ -101,6 +102,8 @@ class Conv2d(nn.Conv2d):
                     and self.groups == 1 and self.padding_mode == "zeros"):
                 raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d (fp32): {self}")
             return _c2f.Conv2dF32Fn.apply(x, self.weight, self.bias, self.stride[0], self.padding[0])
+        if pad_to is not None and not (k == (7, 7) and self.in_channels <= 8 and not fp32_mode()):
+            raise NotImplementedError("nn2d.Conv2d(pad_to=): only the 7x7 stems stage their input (conv2d.StemConvFn)")
         if _c2d.hip_eligible(self.in_channels, self.out_channels, k[0], k[1], self.stride[0], self.padding[0], self.dilation[0],
                              self.groups) and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] \
                 and self.padding_mode == "zeros":
@@ -109,8 +112,8 @@ class Conv2d(nn.Conv2d):
         if k == (7, 7) and self.stride == (1, 1) and self.padding == (3, 3) and self.in_channels <= 8 and self.bias is None \
                 and self.out_channels % 64 == 0 and self.groups == 1:
             st = _wants_stats(self)
-            return _with_stats(_c2d.StemConvFn.apply(x, self.weight, st), st)  # the two stems (backbones.py:23-25)
-        raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d: shape not on the hot path: {self}")
+            return _with_stats(_c2d.StemConvFn.apply(x, self.weight, st, pad_to), st)  # the two stems (backbones.py:23-25)
+        raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d: shape not on the hot path: {self}")  # (pad_to is the stems' alone)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -275,6 +278,9 @@ class ReLU(nn.ReLU):
     pass
 
 
+MAXPOOL_HANDOFF = [False]  # see MaxPool2d.forward
+
+
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, handoff=None):
@@ -315,10 +321,13 @@ class MaxPool2d(nn.MaxPool2d):
             return torch.nn.functional.max_pool2d(x.contiguous(), self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode)
         if (self.kernel_size, self.stride, self.padding, self.dilation, self.ceil_mode) != (3, 2, 1, 1, False):
             raise NotImplementedError("hot path: MaxPool2d(3, 2, 1)")
-        handoff = GradHandoff() if (torch.is_grad_enabled() and x.requires_grad) else None
+        # layer1.0 reads the pooled map twice (conv1 and the residual add).  Summing the two gradients inside k_maxpool_bwd
+        # (dy2) was measured SLOWER than the add kernel it replaces (round 4, rocprofv3: 141 -> 205 us per call against a 40 us add:
+        # every pooled pixel is read by ~2.25 input pixels, so the second map is fetched 2.25 times): off unless asked for.
+        handoff = GradHandoff() if (MAXPOOL_HANDOFF[0] and torch.is_grad_enabled() and x.requires_grad) else None
         y = _MaxPoolFn.apply(x, handoff)
         if handoff is not None:
-            y._mm_handoff = handoff  # layer1.0 reads the pooled map twice (conv1 and the residual add)
+            y._mm_handoff = handoff
         return y
 
 

@@ -318,34 +318,42 @@ def test_full_joint_step_at_bench_size_c5_16bit_rows(kind):
         scn.set_activation_dtype(torch.float32)
 
 
-def test_mid_level_sparse_conv_at_kitti_size_vs_oracle():
-    """SubmanifoldConvolution 48 -> 48 on level 2 of one KITTI-shaped scan (121,600 points): the HIP engines against the
-    CPU oracle's rule-book convolution (forward, data gradient, weight gradient) on the scan's own level-2 active set."""
+@pytest.mark.parametrize("level,cin,cout", [
+    (2, 48, 48),    # mid level, the k-major gather engines
+    (4, 160, 80),   # a decoder layer after the concat: wide rows, three-term split-bf16 products on every engine
+    (0, 16, 16),    # level 0: the output-stationary engine on the largest active set of the scan
+])
+def test_sparse_conv_at_kitti_size_vs_oracle(level, cin, cout):
+    """SubmanifoldConvolution cin -> cout on one level of one KITTI-shaped scan (121,600 points): the HIP engines against the
+    CPU oracle's rule-book convolution (forward, data gradient, weight gradient) on the scan's own active set of that level -
+    "the engines equal each other" (the other tests of this file) tied to "the engines equal the oracle" at full size."""
     from mm2d3d_amd.scn import ops
 
     dev = _dev()
     from oracle import scn_ref
 
     md, coords_t = _metadata("kitti", 1)
-    lv = md.levels[2]
+    lv = md.levels[level]
     coords = coords_t.cpu().numpy()
     _, first = scn_ref.first_occurrence_ids(scn_ref.pack_keys(coords))
     rlv = scn_ref.Level(coords[first], 4096)
-    for _ in range(2):
+    for _ in range(level):
         rlv = scn_ref.down_rulebook(rlv)[1]
     assert rlv.n == lv.n
     rrb = scn_ref.subm_rulebook(rlv)
     assert rrb.n_rules == lv.subm.n_rules
-    g = torch.Generator().manual_seed(4)
-    x = torch.randn(lv.n, 48, generator=g)
-    w = torch.randn(27, 1, 48, 48, generator=g) * (2.0 / 48 / 27) ** 0.5
-    gout = torch.randn(lv.n, 48, generator=g)
-    xr, wr = x.clone().requires_grad_(True), w.reshape(27, 48, 48).clone().requires_grad_(True)
+    g = torch.Generator().manual_seed(4 + level)
+    x = torch.randn(lv.n, cin, generator=g)
+    w = torch.randn(27, 1, cin, cout, generator=g) * (2.0 / cin / 27) ** 0.5
+    gout = torch.randn(lv.n, cout, generator=g)
+    xr, wr = x.clone().requires_grad_(True), w.reshape(27, cin, cout).clone().requires_grad_(True)
     yr = scn_ref.rule_conv(xr, wr, rrb, lv.n)
     yr.backward(gout)
     xh, wh = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
     yh = ops.SparseConvFunction.apply(xh, wh, lv.subm, "subm", lv.n, lv.n)
     yh.backward(gout.to(dev))
-    for a, b, what in ((yh, yr, "fwd"), (xh.grad, xr.grad, "dX"), (wh.grad.reshape(27, 48, 48), wr.grad, "dW")):
+    for a, b, what in ((yh, yr, "fwd"), (xh.grad, xr.grad, "dX"), (wh.grad.reshape(27, cin, cout), wr.grad, "dW")):
         err = float((a.detach().cpu() - b.detach()).abs().max())
         assert err <= 1e-3 * max(1.0, float(b.abs().max())), (what, err)
+        rel = float((a.detach().cpu().double() - b.detach().double()).norm() / b.detach().double().norm())
+        assert rel <= 2e-5, (what, rel)  # fp32-faithful products: the relative L2 distance is rounding noise

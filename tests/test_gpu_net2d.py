@@ -82,6 +82,19 @@ def test_maxpool_cat_heads(half2d):
     yh.backward(g)
     yr.backward(g.float())
     assert _rel(xh.grad, xr.grad) < 1e-2
+    # second gradient of the pooled map joined inside the backward kernel (nn2d.MAXPOOL_HANDOFF; off by default: measured slower)
+    nn2d.MAXPOOL_HANDOFF[0] = True
+    try:
+        x2 = x.clone().requires_grad_(True)
+        y2 = nn2d.MaxPool2d(3, 2, 1)(x2)
+        g2 = torch.randn_like(yr).to(half2d)
+        y2._mm_handoff.extra.append(g2)
+        y2.backward(g)
+    finally:
+        nn2d.MAXPOOL_HANDOFF[0] = False
+    xr2 = x.float().requires_grad_(True)
+    F.max_pool2d(xr2, 3, 2, 1).backward(g.float() + g2.float())
+    assert _rel(x2.grad, xr2.grad) < 1e-2
     # concat
     a = torch.randn(2, 64, 5, 7, device=dev).to(half2d).contiguous(memory_format=CL).requires_grad_(True)
     b = torch.randn(2, 128, 5, 7, device=dev).to(half2d).contiguous(memory_format=CL).requires_grad_(True)

@@ -74,3 +74,82 @@ def test_forced_one_rank_rccl_step_equals_the_plain_step_bit_for_bit(monkeypatch
     finally:
         dist.destroy_process_group()
         pass
+
+
+def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_batch_norms_single_launch(monkeypatch):
+    """under data parallelism (i) no host synchronisation inside ``fit_step`` - ``Tensor.item`` / ``.cpu`` /
+    ``.tolist`` / ``bool(tensor)`` / ``torch.cuda.synchronize`` are booby-trapped from the third step on (the collective "graph
+    changed" flag is read one step late from pinned memory, ddp._read_flag); (ii) the forward batch norms stay on the single-launch
+    kernels (no collective runs beside the forward pass: stream order), the backward ones take the three-kernel path; (iii) the
+    losses follow the plain trainer's (whose backward uses the single-launch kernels: other summation order, same mathematics)."""
+    import copy
+
+    from mm2d3d_amd import _lib
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = torch.device("cuda:0")
+    _lib.lib()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(1)
+        kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+        n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+        for m in n2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+
+        def opts():
+            out = {}
+            for k in ("2d_net", "3d_net"):
+                o = Optimizer("adamw", lr=0.001)
+                o.set_scheduler("one_cycle", max_lr=0.005, total_steps=100)
+                out[k] = o
+            return out
+
+        mk = lambda: {"source": make_batch(5, 2, "nuscenes", (96, 128), device=dev), "target": make_batch(6, 2, "nuscenes", (96, 128), device=dev)}
+        loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
+        tk = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False)
+        monkeypatch.setenv("MM_DDP_FORCE", "1")
+        monkeypatch.delenv("MM_DDP_BN_FUSED", raising=False)
+        ddp = TrainModel({"2d_net": n2, "3d_net": n3}, opts(), loss, dict(tk))
+        ddp.configure_optimizers()
+        monkeypatch.setenv("MM_DDP_FORCE", "0")
+        plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, opts(), loss, dict(tk))
+        plain.configure_optimizers()
+        assert ddp.reducer.active and ddp.reducer.bn_path == "forward single-launch, backward three-kernel"
+        assert ddp.handle.get(_lib.OPT_BN2D_FUSED) == 1 and ddp.handle.get(_lib.OPT_BN3D_FUSED) == 1
+        assert plain.handle.get(_lib.OPT_BN2D_FUSED) == 3
+
+        def trap(name, orig=None):
+            def boom(*a, **k):
+                if orig is not None and not (a and isinstance(a[0], torch.Tensor) and a[0].is_cuda):
+                    return orig(*a, **k)  # a host tensor: no device involved
+                raise AssertionError(f"host synchronisation inside fit_step: {name}")
+            return boom
+
+        losses = []
+        for step in range(6):
+            batch_a, batch_b = mk(), mk()
+            if step >= 2:
+                with monkeypatch.context() as mp:
+                    for name in ("item", "cpu", "tolist", "__bool__", "numpy"):
+                        mp.setattr(torch.Tensor, name, trap("Tensor." + name, getattr(torch.Tensor, name)))
+                    mp.setattr(torch.cuda, "synchronize", trap("torch.cuda.synchronize"))
+                    mp.setattr(torch.cuda.Stream, "synchronize", trap("Stream.synchronize"))
+                    la = ddp.fit_step(batch_a)
+            else:
+                la = ddp.fit_step(batch_a)
+            lb = plain.fit_step(batch_b)
+            torch.cuda.synchronize()
+            losses.append((float(la), float(lb)))
+        for step, (a, b) in enumerate(losses):
+            assert abs(a - b) <= 2e-3 * abs(b), (step, a, b)
+        assert ddp.reducer.drain_flag() is False
+    finally:
+        dist.destroy_process_group()

@@ -339,6 +339,23 @@ def test_net3d_forward_backward_vs_oracle(residual, engine):
     for name, (e_hip, e_ref, e_pert) in errs.items():
         assert e_hip <= max(4.0 * e_ref, 8.0 * noise, 4.0 * e_pert, flip), \
             f"grad {name}: hip-vs-fp64 {e_hip:.3e}, fp32-oracle-vs-fp64 {e_ref:.3e}, oracle 1-ulp sensitivity {e_pert:.3e}"
+    # A max-norm envelope alone would let a systematically wrong gradient through as long as it stays small:
+    # per tensor also the direction (cosine) and the relative L2 distance to the fp64 oracle, each against what the fp32 oracle
+    # itself achieves.  A mask flip moves single elements, not the direction of a whole tensor.
+    for name, p in hip.named_parameters():
+        if p.grad is None:
+            continue
+        t = g64[name].grad.double().flatten()
+        h = p.grad.detach().cpu().double().flatten()
+        r = g32[name].grad.double().flatten()
+        if float(t.norm()) < 1e-9:
+            assert float(h.norm()) < 1e-6, name
+            continue
+        cos_h = float((h @ t) / (h.norm() * t.norm()).clamp_min(1e-300))
+        cos_r = float((r @ t) / (r.norm() * t.norm()).clamp_min(1e-300))
+        l2_h, l2_r = float((h - t).norm() / t.norm()), float((r - t).norm() / t.norm())
+        assert cos_h >= min(1.0 - 1e-4, 1.0 - 16.0 * (1.0 - cos_r)) - (2e-3 if residual else 0.0), (name, cos_h, cos_r)
+        assert l2_h <= max(8.0 * l2_r, 2e-3) + (5e-2 if residual else 0.0), (name, l2_h, l2_r)
     for (n1, b1), (n2, b2) in zip(sorted(hip.named_buffers()), sorted(ref.named_buffers())):
         assert n1 == n2
         _close(b1, b2, what=f"buffer {n1}")

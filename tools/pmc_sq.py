@@ -2,17 +2,39 @@
 
     rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \
               SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d <dir> -- python3 bench.py --steps 3 --warmup 2 --no-extras
-    python tools/pmc_sq.py <dir> > profiles/rNN/pmc_sq_step.json
+    python tools/pmc_sq.py <dir> [fp16|bf16] > profiles/rNN/pmc_sq_step.json
+
+The record is stamped with the sha256 of the 2D kernel sources (csrc/conv2d.hip + csrc/h16.h), the git commit and the 16-bit
+storage format of the run: bench.py quotes MFMA-busy figures only from a record whose fingerprint matches the tree it runs in.
 
 SQ_* counters tick in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES in cycles (divided by 4 here), so every figure is a fraction of the
 wave cycles of the kernel's waves.  MFMA pipe utilisation = mfma_busy_cycles_per_wave_cycle x resident waves per SIMD.
 """
 import glob
+import hashlib
 import json
 import os
 import re
 import sqlite3
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SQ_SOURCES = ("conv2d.hip", "h16.h")  # bench.py SQ_SOURCES
+
+
+def conv2d_sources_sha256():
+    h = hashlib.sha256()
+    for f in SQ_SOURCES:
+        h.update(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
+    except OSError:
+        return "unknown"
 
 
 def short(name):
@@ -45,7 +67,9 @@ def main():
             "wait_inst_lds": round(c.get("SQ_WAIT_INST_LDS", 0) / wc, 3),
             "lds_bank_conflict_per_lds_active": round(c.get("SQ_LDS_BANK_CONFLICT", 0) / lds, 3) if lds > 0 else 0.0,
         }
-    print(json.dumps({"what": __doc__.strip().split("\n\n")[1].replace("\n", " "), "kernels": out}, indent=1))
+    git = os.environ.get("MM_GIT_HEAD") or git_head()  # the GPU box has no .git: the collecting script passes the commit in
+    print(json.dumps({"what": __doc__.strip().split("\n\n")[1].replace("\n", " "), "conv2d_sources_sha256": conv2d_sources_sha256(),
+                      "git": git, "storage": sys.argv[2] if len(sys.argv) > 2 else "fp16", "kernels": out}, indent=1))
 
 
 if __name__ == "__main__":
