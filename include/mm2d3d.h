@@ -375,6 +375,11 @@ int64_t mm_conv2d_3x3s1_stat_rows(int B, int H, int W);
  * flip | 2: a ragged last round of work items is NOT cut into half items (A/B measurements; results are the same sums). */
 int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
                     const float* bias, int flip, float* stats, int split_b, mm_stream_t stream);
+/* Two such convolutions (or data gradients) of ONE shape - the same layer of the RGB and of the depth encoder, EXP/2d_net/model.py:43-46 -
+ * in one launch: one work-item list over both problems, so the persistent kernel's partly filled last round is shared (at the
+ * bench's sizes a 256-channel layer alone leaves half the chip idle for a third of its time).  Same results as two calls. */
+int mm_conv2d_3x3s1_pair(const void* A0, const void* A1, int B, int H, int W, int Ca, int lda, void* O0, void* O1, int Cn, int ldo,
+                         const void* Wp0, const void* Wp1, int flip, float* stats0, float* stats1, int split_b, mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps);
 /* dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k], base grid = dY pixels */
 int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
@@ -472,6 +477,8 @@ int64_t mm_conv2d_gemm_stat_rows_f16(int64_t M, int nz);
 int64_t mm_conv2d_3x3s1_stat_rows_f16(int B, int H, int W);
 int mm_conv2d_3x3s1_f16(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
                     const float* bias, int flip, float* stats, int split_b, mm_stream_t stream);
+int mm_conv2d_3x3s1_pair_f16(const void* A0, const void* A1, int B, int H, int W, int Ca, int lda, void* O0, void* O1, int Cn, int ldo,
+                         const void* Wp0, const void* Wp1, int flip, float* stats0, float* stats1, int split_b, mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes_f16(int64_t M, int Cn, int Ck, int ntaps);
 int mm_conv2d_wgrad_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,

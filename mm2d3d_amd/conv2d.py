@@ -339,6 +339,84 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+# Two 3x3 convolutions of one shape in ONE launch (mm_conv2d_3x3s1_pair): the same layer of the RGB and of the depth backbone.
+# MM_CONV_PAIR=0: two launches (A/B).
+PAIR = [_os.environ.get("MM_CONV_PAIR", "1") != "0"]
+
+
+def pairable(x1, x2, w1, w2):
+    """Can Conv2dPairFn take these (dense NHWC maps of one shape, 3x3 weights of one shape, not the 64 -> 64 resident-weights case)?"""
+    if not PAIR[0] or x1.shape != x2.shape or w1.shape != w2.shape or tuple(w1.shape[2:]) != (3, 3):
+        return False
+    cout, cin = w1.shape[0], w1.shape[1]
+    if cin % 64 or cout % 64 or (cin == 64 and cout == 64):
+        return False
+    for x in (x1, x2):
+        B, C, H, W = x.shape
+        if x.dtype != HALF[0] or x.stride() != (H * W * C, 1, W * C, C) or x.data_ptr() % 16:
+            return False
+    return True
+
+
+class Conv2dPairFn(torch.autograd.Function):
+    """(conv2d(x1, w1), conv2d(x2, w2)), 3x3 stride 1 pad 1, no bias, one launch forward and one for the two data gradients."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w1, w2, stats1=None, stats2=None):
+        _lib.require_cuda(x1, "x1")
+        Bn, Cin, H, W = x1.shape
+        Cout = w1.shape[0]
+        wf = [w.detach().float().contiguous() for w in (w1, w2)]
+        Wp = [_pack(w, 1, Cout, 9, Cin, 0, Cin * 9, 1, 9, owner, "fwd") for w, owner in zip(wf, (w1, w2))]
+        y = [torch.empty((Bn, Cout, H, W), dtype=HALF[0], device=x1.device, memory_format=CL) for _ in range(2)]
+        slabs, nf = [None, None], Bn
+        if stats1 is not None and stats2 is not None and bn_pre_wanted(x1.device, Bn, H, W, Cout):
+            nf = _stat_group_split(Bn)
+            rows = int(lib2d().mm_conv2d_3x3s1_stat_rows(Bn, H, W))
+            slabs = [_stat_slab(h, rows, Cout, nf, Bn, x1.device) for h in (stats1, stats2)]
+        check(lib2d().mm_conv2d_3x3s1_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(y[0]), ptr(y[1]), Cout, Cout, ptr(Wp[0]), ptr(Wp[1]),
+                                           0 | WHOLE_ITEMS[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
+        ctx.save_for_backward(x1, x2, wf[0], wf[1])
+        ctx.owners = (w1, w2)
+        ctx.wparams = tuple(w if gradsink.claim(ctx, w, ctx.needs_input_grad[2 + i]) else None for i, w in enumerate((w1, w2)))
+        return y[0], y[1]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        x1, x2, wf1, wf2 = ctx.saved_tensors
+        xs, wfs = (x1, x2), (wf1, wf2)
+        Bn, Cin, H, W = x1.shape
+        Cout = wf1.shape[0]
+        dys = [as_nhwc_bf16(d) for d in (dy1, dy2)]
+        dx = [None, None]
+        need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1]]
+        if need[0] or need[1]:
+            Wd = [_pack(w, 1, Cin, 9, Cout, 0, 9, 1, Cin * 9, owner, "dgrad") for w, owner in zip(wfs, ctx.owners)]  # [ci][t][co]
+            if need[0] and need[1] and not (Cin == 64 and Cout == 64):
+                dx = [torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x1.device, memory_format=CL) for _ in range(2)]
+                check(lib2d().mm_conv2d_3x3s1_pair(ptr(dys[0]), ptr(dys[1]), Bn, H, W, Cout, Cout, ptr(dx[0]), ptr(dx[1]), Cin, Cin,
+                                                   ptr(Wd[0]), ptr(Wd[1]), 1 | WHOLE_ITEMS[0], None, None, 0, stream()), "conv2d_3x3s1_pair")
+            else:
+                for i in range(2):
+                    if need[i]:
+                        dx[i] = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x1.device, memory_format=CL)
+                        check(lib2d().mm_conv2d_3x3s1(ptr(dys[i]), Bn, H, W, Cout, Cout, ptr(dx[i]), Cin, Cin, ptr(Wd[i]), None,
+                                                      1 | WHOLE_ITEMS[0], None, 0, stream()), "conv2d_3x3s1")
+        dw = [None, None]
+        ty = [kh - 1 for kh in range(3) for _ in range(3)]
+        tx = [kw - 1 for _ in range(3) for kw in range(3)]
+        for i in range(2):
+            if not ctx.needs_input_grad[2 + i]:
+                continue
+            if ctx.wparams[i] is not None:  # straight into the optimiser's gradient arena
+                _wgrad(xs[i], Bn, H, W, Cin, dys[i], H, W, Cout, 1, ty, tx, ctx.wparams[i]._mm_sink, Cin * 9, 1, 9, accumulate=1)
+                gradsink.done(ctx.wparams[i])
+            else:
+                dw[i] = torch.empty_like(wfs[i])
+                _wgrad(xs[i], Bn, H, W, Cin, dys[i], H, W, Cout, 1, ty, tx, dw[i], Cin * 9, 1, 9)
+        return dx[0], dx[1], dw[0], dw[1], None, None
+
+
 class ConvTranspose2dFn(torch.autograd.Function):
     """y = conv_transpose2d(x, w, b, stride=2), kernel 2x2: four 1x1 GEMMs with a pixel-shuffle store (blockIdx.z = parity)."""
 

@@ -61,19 +61,35 @@ class BasicBlock(nn.Module):
             self.bn1.relu = True
             self.bn2.relu = True
 
-    def forward(self, x, out=None):
-        """``out``: optional NHWC channel slice the block's result is written into (see nn2d.CatBuffer)."""
+    def _identity(self, x):
         if self.downsample is None:
-            identity = x
-        elif (self._fused and not nn2d.fp32_mode() and torch.is_grad_enabled() and getattr(x, "_mm_handoff", None) is not None
-              and isinstance(self.downsample[0], nn2d.Conv2d)):
+            return x
+        if (self._fused and not nn2d.fp32_mode() and torch.is_grad_enabled() and getattr(x, "_mm_handoff", None) is not None
+                and isinstance(self.downsample[0], nn2d.Conv2d)):
             # x is read by conv1 AND by the 1x1 downsample: the downsample's data gradient goes to x's producer through its
             # hand-off slot (nn2d.GradHandoff) instead of an autograd add of two full maps
             identity = self.downsample[0](x, handoff=x._mm_handoff)
             for m in list(self.downsample)[1:]:
                 identity = m(identity)
-        else:
-            identity = self.downsample(x)
+            return identity
+        return self.downsample(x)
+
+    @staticmethod
+    def forward_pair(b1, b2, x1, x2, out1=None, out2=None):
+        """(b1(x1, out1), b2(x2, out2)) for the same block of the two backbones, their 3x3 stride-1 convolutions as pairs in one
+        launch each (nn2d.conv_pair): same arithmetic, the persistent kernel's last round shared between the two."""
+        if not (b1._fused and b2._fused) or nn2d.fp32_mode():
+            return b1(x1, out=out1), b2(x2, out=out2)
+        id1, id2 = b1._identity(x1), b2._identity(x2)
+        c1, c2 = nn2d.conv_pair(b1.conv1, b2.conv1, x1, x2)
+        y1, y2 = b1.bn1(c1), b2.bn1(c2)
+        c1, c2 = nn2d.conv_pair(b1.conv2, b2.conv2, y1, y2)
+        return (b1.bn2(c1, id1, out=out1, residual_shared=b1.downsample is None),
+                b2.bn2(c2, id2, out=out2, residual_shared=b2.downsample is None))
+
+    def forward(self, x, out=None):
+        """``out``: optional NHWC channel slice the block's result is written into (see nn2d.CatBuffer)."""
+        identity = self._identity(x)
         if self._fused:
             y = self.bn1(self.conv1(x))
             return self.bn2(self.conv2(y), identity, out=out, residual_shared=self.downsample is None)
@@ -151,6 +167,42 @@ class Backbone(nn.Module):
         x = self.dropout(self.layer4(x))
         feats.append(x)
         return feats
+
+
+def backbone_pair(r, d, img, hints, outs_r=None, outs_d=None, pad_to=None):
+    """(r(img, outs_r, pad_to), d(hints, outs_d, pad_to)) with layers 2-4 of the two encoders walked in lockstep, each pair of
+    3x3 stride-1 convolutions in one launch (BasicBlock.forward_pair).  The stems and layer1 (64 -> 64: weights-resident kernel,
+    thousands of work items per layer) run one after the other as before.  Dropout draws in the order r.l3, d.l3, r.l4, d.l4."""
+    if not (r._fused and d._fused) or nn2d.fp32_mode() or not nn2d._c2d.PAIR[0]:
+        return r(img, outs=outs_r, pad_to=pad_to), d(hints, outs=outs_d, pad_to=pad_to)
+    o_r = (list(outs_r) + [None] * 3)[:3] if outs_r is not None else [None] * 3
+    o_d = (list(outs_d) + [None] * 3)[:3] if outs_d is not None else [None] * 3
+    fr, fd = [], []
+    xs = []
+    for net, x, o, feats in ((r, img, o_r, fr), (d, hints, o_d, fd)):
+        x = net.bn1(net.conv1(x, pad_to=pad_to) if pad_to is not None else net.conv1(x), out=o[0])
+        feats.append(x)
+        x = Backbone._run(net.layer1, net.maxpool(x), o[1])
+        feats.append(x)
+        xs.append(x)
+    xr, xd = xs
+
+    def run_pair(lr, ld, xr, xd, out_r, out_d):
+        br, bd = list(lr), list(ld)
+        for i, (b1, b2) in enumerate(zip(br, bd)):
+            last = i == len(br) - 1
+            xr, xd = BasicBlock.forward_pair(b1, b2, xr, xd, out_r if last else None, out_d if last else None)
+        return xr, xd
+
+    xr, xd = run_pair(r.layer2, d.layer2, xr, xd, o_r[2], o_d[2])
+    fr.append(xr), fd.append(xd)
+    xr, xd = run_pair(r.layer3, d.layer3, xr, xd, None, None)
+    xr, xd = r.dropout(xr), d.dropout(xd)
+    fr.append(xr), fd.append(xd)
+    xr, xd = run_pair(r.layer4, d.layer4, xr, xd, None, None)
+    xr, xd = r.dropout(xr), d.dropout(xd)
+    fr.append(xr), fd.append(xd)
+    return fr, fd
 
 
 def _pixel_index(data_batch, h, w, device):
@@ -243,8 +295,7 @@ class Net2DSeg(nn.Module):
         Bn, Hp, Wp = img.shape[0], h + pad_h, w + pad_w
         pad_to = (Hp, Wp) if (fused_stems and (pad_h or pad_w)) else None  # the stems' staging kernels write the padding zeros
         cb = [nn2d.CatBuffer(Bn, (c, c, c), Hp >> l, Wp >> l, img.device) for l, c in enumerate(self.rgb_backbone.channels[:3])]
-        r = self.rgb_backbone(img, outs=[b.slot(2) for b in cb], pad_to=pad_to)
-        d = self.depth_backbone(hints, outs=[b.slot(0) for b in cb], pad_to=pad_to)
+        r, d = backbone_pair(self.rgb_backbone, self.depth_backbone, img, hints, [b.slot(2) for b in cb], [b.slot(0) for b in cb], pad_to)
         for l in range(3):
             cb[l].put(0, d[l], shared=True)  # the backbones keep consuming these maps
             cb[l].put(2, r[l], shared=True)

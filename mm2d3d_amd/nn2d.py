@@ -116,6 +116,22 @@ class Conv2d(nn.Conv2d):
         raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d: shape not on the hot path: {self}")  # (pad_to is the stems' alone)
 
 
+def conv_pair(m1, m2, x1, x2):
+    """(m1(x1), m2(x2)) for two Conv2d modules of one shape - the same layer of the two backbones - as ONE launch where the kernel
+    allows it (conv2d.Conv2dPairFn: 3x3 stride 1 pad 1, no bias, dense 16-bit maps), else as two calls."""
+    ok = (not fp32_mode() and isinstance(m1, Conv2d) and isinstance(m2, Conv2d) and m1.bias is None and m2.bias is None
+          and m1.kernel_size == m2.kernel_size == (3, 3) and m1.stride == m2.stride == (1, 1) and m1.padding == m2.padding == (1, 1)
+          and m1.dilation == m2.dilation == (1, 1) and m1.groups == m2.groups == 1 and m1.padding_mode == m2.padding_mode == "zeros"
+          and x1.is_cuda and x2.is_cuda and m1.training == m2.training and _c2d.pairable(x1, x2, m1.weight, m2.weight))
+    if not ok:
+        return m1(x1), m2(x2)
+    st1, st2 = _wants_stats(m1), _wants_stats(m2)
+    if (st1 is None) != (st2 is None):
+        st1 = st2 = None
+    y1, y2 = _c2d.Conv2dPairFn.apply(x1, x2, m1.weight, m2.weight, st1, st2)
+    return _with_stats(y1, st1), _with_stats(y2, st2)
+
+
 class ConvTranspose2d(nn.ConvTranspose2d):
     feeds_bn = False
 

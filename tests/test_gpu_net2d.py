@@ -488,3 +488,48 @@ def test_batchnorm_from_epilogue_statistics_matches_the_statistics_pass(split, h
         d = float((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-12))
         cos = float((a.grad * b.grad).sum() / (a.grad.norm() * b.grad.norm()).clamp_min(1e-20))
         assert d < (2e-1 if half2d == torch.bfloat16 else 5e-2) and cos > (0.98 if half2d == torch.bfloat16 else 0.998), (n, d, cos)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, half2d):
+    """net2d.backbone_pair: layers 2-4 of the RGB and of the depth encoder in lockstep, each pair of 3x3 stride-1 convolutions (and of
+    their data gradients) as ONE launch over both problems (mm_conv2d_3x3s1_pair).  A work item computes what it computed before -
+    only which workgroup runs it changes - so features, running statistics and every gradient are bit-identical with the
+    one-after-the-other walk (MM_CONV_PAIR=0), with and without per-domain statistics groups."""
+    import copy
+
+    import mm2d3d_amd.conv2d as c2d
+    from mm2d3d_amd import domains
+    from mm2d3d_amd.net2d import Backbone, backbone_pair
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    r, d = Backbone(3, pretrained=False).to(dev).train(), Backbone(1, pretrained=False).to(dev).train()
+    for net in (r, d):
+        net.dropout.p = 0.0
+    r0, d0 = copy.deepcopy(r), copy.deepcopy(d)
+    img, hints = torch.randn(4, 3, 64, 96, device=dev), torch.randn(4, 1, 64, 96, device=dev)
+    projs = None
+
+    def run(a, b, pair):
+        nonlocal projs
+        was, c2d.PAIR[0] = c2d.PAIR[0], pair
+        try:
+            with domains.split(2 if split else None):
+                fa, fb = backbone_pair(a, b, img, hints)
+            if projs is None:
+                projs = [torch.randn_like(t.float()) for t in fa + fb]
+            sum((t.float() * p).sum() for t, p in zip(fa + fb, projs)).backward()
+        finally:
+            c2d.PAIR[0] = was
+        return fa + fb
+
+    f1, f0 = run(r, d, True), run(r0, d0, False)
+    assert len(f1) == 10
+    for a, b in zip(f1, f0):
+        assert torch.equal(a, b)
+    for m1, m0 in ((r, r0), (d, d0)):
+        for (n, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
+            assert torch.equal(a, b), n
+        for (n, a), (_, b) in zip(m1.named_parameters(), m0.named_parameters()):
+            assert a.grad is not None and torch.equal(a.grad, b.grad), n
