@@ -385,6 +385,11 @@ size_t mm_conv2d_wgrad_ws_bytes(int64_t M, int Cn, int Ck, int ntaps);
 int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
                     int64_t sk, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* The weight gradients of TWO 3x3 stride-1 pad-1 convolutions of one shape (the same layer of the two encoders) in the two launches
+ * one of them takes: twice the pixels per workgroup, half the partial slabs per problem.  ws: mm_conv2d_wgrad_ws_bytes(B*H*W, Cn, Ck, 9). */
+int mm_conv2d_wgrad3x3_pair(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1, int Cn,
+                            int ldy, float* dW0, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
+                            mm_stream_t stream);
 /* stem input (EXP/2d_net/backbones.py:23-25, 7x7 stride-1 conv on 3 / 1 channels): NCHW fp32 -> zero-bordered NHWC8 bf16 */
 int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, mm_stream_t stream);
 /* out[((z*N+n)*T+t)*K+k] = bf16(in[z*sz + n*sn + t*st + k*sk]) : fp32 master weights -> kernel layouts */
@@ -479,6 +484,9 @@ int mm_conv2d_3x3s1_f16(const void* A, int B, int H, int W, int Ca, int lda, voi
                     const float* bias, int flip, float* stats, int split_b, mm_stream_t stream);
 int mm_conv2d_3x3s1_pair_f16(const void* A0, const void* A1, int B, int H, int W, int Ca, int lda, void* O0, void* O1, int Cn, int ldo,
                          const void* Wp0, const void* Wp1, int flip, float* stats0, float* stats1, int split_b, mm_stream_t stream);
+int mm_conv2d_wgrad3x3_pair_f16(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1, int Cn,
+                            int ldy, float* dW0, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
+                            mm_stream_t stream);
 size_t mm_conv2d_wgrad_ws_bytes_f16(int64_t M, int Cn, int Ck, int ntaps);
 int mm_conv2d_wgrad_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,

@@ -115,6 +115,7 @@ _PROTOS = {
     "mm_conv2d_wgrad_ws_bytes": (sz, [i64, i32, i32, i32]),
     "mm_conv2d_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, i64, i32, vp, sz,
                               vp]),
+    "mm_conv2d_wgrad3x3_pair": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, i64, i64, i64, i32, vp, sz, vp]),
     "mm_conv2d_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp]),
     "mm_conv2d_f32_wgrad_ws_bytes": (sz, [i64, i32, i32, i32, i32]),
     "mm_conv2d_f32_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64,
@@ -155,6 +156,7 @@ H16_2D = {
     "mm_bn2d_single_launch": "mm_bn2d_single_launch_f16",
     "mm_conv2d_wgrad_ws_bytes": "mm_conv2d_wgrad_ws_bytes_f16",
     "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",
+    "mm_conv2d_wgrad3x3_pair": "mm_conv2d_wgrad3x3_pair_f16",
     "mm_stem_prep": "mm_stem_prep_f16",
     "mm_pack_weights_bf16": "mm_pack_weights_f16",
     "mm_pack_weights_bf16_batch": "mm_pack_weights_f16_batch",

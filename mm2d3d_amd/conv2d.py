@@ -342,6 +342,7 @@ class Conv2dFn(torch.autograd.Function):
 # Two 3x3 convolutions of one shape in ONE launch (mm_conv2d_3x3s1_pair): the same layer of the RGB and of the depth backbone.
 # MM_CONV_PAIR=0: two launches (A/B).
 PAIR = [_os.environ.get("MM_CONV_PAIR", "1") != "0"]
+PAIR_WGRAD = [_os.environ.get("MM_CONV_PAIR_WGRAD", "1") != "0"]  # the pairs' weight gradients in one launch too
 
 
 def pairable(x1, x2, w1, w2):
@@ -405,6 +406,20 @@ class Conv2dPairFn(torch.autograd.Function):
         dw = [None, None]
         ty = [kh - 1 for kh in range(3) for _ in range(3)]
         tx = [kw - 1 for _ in range(3) for kw in range(3)]
+        if PAIR_WGRAD[0] and ctx.needs_input_grad[2] and ctx.needs_input_grad[3] and (ctx.wparams[0] is None) == (ctx.wparams[1] is None):
+            # both weight gradients in the two launches one of them takes (mm_conv2d_wgrad3x3_pair)
+            L = lib2d()
+            sink = ctx.wparams[0] is not None
+            tgt = [wp._mm_sink for wp in ctx.wparams] if sink else [torch.empty_like(w) for w in wfs]
+            ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, Cin, 9)), x1.device)
+            check(L.mm_conv2d_wgrad3x3_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(dys[0]), ptr(dys[1]), Cout, Cout, ptr(tgt[0]), ptr(tgt[1]),
+                                            Cin * 9, 1, 9, 1 if sink else 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad3x3_pair")
+            if sink:
+                gradsink.done(ctx.wparams[0])
+                gradsink.done(ctx.wparams[1])
+            else:
+                dw = tgt
+            return dx[0], dx[1], dw[0], dw[1], None, None
         for i in range(2):
             if not ctx.needs_input_grad[2 + i]:
                 continue

@@ -1139,6 +1139,11 @@ struct Wg9P {
   int tiles_y, tiles_x;
   int patches_per_wg, ntile;
   float* partial;  // [nsplit][Cn][9][Ck]
+  // pair mode (mm_conv2d_wgrad3x3_pair): a second problem of the same shape; tiles [ntile, 2 ntile) of a split belong to it and its
+  // slabs follow problem 0's ([2][nsplit][Cn][9][Ck]).  Twice the patches per workgroup at the same number of slabs.
+  const u16* X1;
+  const u16* DY1;
+  int nsplit;
 };
 
 __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
@@ -1152,7 +1157,13 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
   const int wn = wave >> 1, wk = wave & 1;
   int v = blockIdx.x;
   if (!(gridDim.x & 7)) v = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // an XCD owns a contiguous range
-  const int split = v / p.ntile, tile = v - split * p.ntile;
+  const int ntile2 = p.X1 ? 2 * p.ntile : p.ntile;
+  const int split = v / ntile2;
+  int tile = v - split * ntile2;
+  const bool second = tile >= p.ntile;  // pair mode: this workgroup's tile belongs to problem 1
+  if (second) tile -= p.ntile;
+  const u16* const Xp = second ? p.X1 : p.X;
+  const u16* const DYp = second ? p.DY1 : p.DY;
   const int nkt = p.Ck >> 6;
   const int n0 = (tile / nkt) * 64, k0 = (tile % nkt) * 64;
   const int npatch = p.B * p.tiles_y * p.tiles_x;
@@ -1185,8 +1196,8 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
     const int ty0 = (t % p.tiles_y) * 8;
     const int b = t / p.tiles_y;
     const int64_t origin = (int64_t)(b * p.H + ty0) * p.W + tx0;
-    const u16* yb = p.DY + origin * p.ldy;
-    const u16* xb = p.X + origin * p.ldx;
+    const u16* yb = DYp + origin * p.ldy;
+    const u16* xb = Xp + origin * p.ldx;
     char* dst = smw + stage * STG + wave * 1024;
     const bool interior = ty0 >= 1 && ty0 + 9 <= p.H && tx0 >= 1 && tx0 + 17 <= p.W;
     if (interior) {
@@ -1341,7 +1352,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
     stage = (stage + 1) & (NSTG - 1);
   }
 #undef MM_TR
-  float* P = p.partial + (int64_t)split * p.Cn * 9 * p.Ck;
+  float* P = p.partial + (int64_t)((second ? p.nsplit : 0) + split) * p.Cn * 9 * p.Ck;
 #pragma unroll
   for (int t = 0; t < 9; t++)
 #pragma unroll
@@ -1380,7 +1391,13 @@ __device__ inline void wgrad_reduce_slices(const float* __restrict__ src, int64_
 // dW_torch[idx(n,tap,k)] (+)= sum_splits partial[s][n][tap][k];  out strides (sn, st, sk) express the torch layout
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
                                                        float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
-                                                       int accumulate) {
+                                                       int accumulate, float* __restrict__ dW1 = nullptr) {
+  // dW1 (pair mode): blocks [Cn * Ck / 32, 2 Cn * Ck / 32) sum the slabs of the second problem (they follow the first's) into dW1
+  if (dW1 && (int)blockIdx.x >= Cn * (Ck >> 5)) {
+    partial += (int64_t)nsplit * Cn * ntaps * Ck;
+    dW = dW1;
+  }
+  const int blk = dW1 ? (int)blockIdx.x % (Cn * (Ck >> 5)) : (int)blockIdx.x;
   // A workgroup owns (n, 32 consecutive k) for ALL taps.  Phase 1: thread (k, slice) adds the slabs i = slice, slice + 8, ...
   // of every tap (4-byte loads, 128-byte segments per 32 lanes, all independent).  Phase 2: the 8 slices are combined in a
   // fixed order (bit-stable) and the 32 x ntaps results are written in the ORDER OF THE DESTINATION: for a Conv2d weight
@@ -1390,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
   __shared__ float red[8][16][33];
   const int kl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int nkb = Ck >> 5;
-  const int n = blockIdx.x / nkb, k0 = (blockIdx.x - n * nkb) << 5;
+  const int n = blk / nkb, k0 = (blk - n * nkb) << 5;
   const int64_t ne = (int64_t)Cn * ntaps * Ck;
   const float* src = partial + ((int64_t)n * ntaps) * Ck + k0 + kl;
   if (ntaps == 9) wgrad_reduce_slices<9>(src, ne, Ck, nsplit, sl, kl, red);
@@ -1689,6 +1706,50 @@ size_t MM_SYM(mm_conv2d_wgrad_ws_bytes)(int64_t M, int Cn, int Ck, int ntaps) {
 }
 
 // dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k];   base grid = dY pixels (B,Hg,Wg), src = (gy*sa+ty, gx*sa+tx)
+// 3x3 stride-1 pad-1 weight gradient from halo tiles (k_wgrad3x3n + k_wgrad_reduce); X1 / dY1 / dW1 != NULL: a second problem of the
+// same shape in the same two launches (the same layer of the two encoders: twice the patches per workgroup, half the slabs each)
+static int wgrad3x3_launch(const void* X, const void* X1, const void* dY, const void* dY1, int B, int Hg, int Wg, int Ck, int ldx, int Cn,
+                           int ldy, float* dW, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
+                           hipStream_t s) {
+  const int np = X1 ? 2 : 1;
+  Wg9P q;
+  q.X = (const u16*)X; q.DY = (const u16*)dY; q.X1 = (const u16*)X1; q.DY1 = (const u16*)dY1;
+  q.B = B; q.H = Hg; q.W = Wg; q.Ck = Ck; q.ldx = ldx; q.Cn = Cn; q.ldy = ldy;
+  q.tiles_y = (int)mm_cdiv(Hg, 8); q.tiles_x = (int)mm_cdiv(Wg, 16);
+  const int64_t npatch = (int64_t)B * q.tiles_y * q.tiles_x;
+  q.ntile = (Cn / 64) * (Ck / 64);
+  // pixel splits: one workgroup per CU (the kernel is MFMA-bound per patch, so the makespan is the longest patch list),
+  // bounded by 40 MB of fp32 partial slabs, which are written and re-read
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n > 1024 ? 1024 : n;
+  }();
+  int64_t nsp = ncu / (np * q.ntile);
+  const int64_t cap = (int64_t)(40u << 20) / ((int64_t)np * Cn * 9 * Ck * 4);
+  if (nsp > cap) nsp = cap;
+  if (nsp > npatch) nsp = npatch;
+  if (nsp < 1) nsp = 1;
+  q.patches_per_wg = (int)mm_cdiv(npatch, nsp);
+  const int nsplit9 = (int)mm_cdiv(npatch, q.patches_per_wg);
+  q.nsplit = nsplit9;
+  if ((size_t)np * nsplit9 * Cn * 9 * Ck * sizeof(float) > ws_bytes) {
+    mm_set_error("conv2d_wgrad(3x3): workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  q.partial = (float*)ws;
+  constexpr int lds9 = 4 * (128 + 184) * 128;
+  static unsigned attr9 = 0;  // per-device bit: see mm_attr_todo (common.h)
+  if (mm_attr_todo(&attr9)) {
+    MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3n, hipFuncAttributeMaxDynamicSharedMemorySize, lds9));
+  }
+  hipLaunchKernelGGL(k_wgrad3x3n, dim3((unsigned)(nsplit9 * np * q.ntile)), dim3(512), lds9, s, q);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(np * Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,
+                     dW, sn, st, sk, accumulate, dW1);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
 int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
                     int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st, int64_t sk,
                     int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -1704,42 +1765,8 @@ int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ld
   const int64_t M = (int64_t)B * Hg * Wg;
   bool is3x3 = (ntaps == 9 && sa == 1 && Hi == Hg && Wi == Wg);
   for (int i = 0; i < 9 && is3x3; i++) is3x3 = (ty[i] == i / 3 - 1) && (tx[i] == i % 3 - 1);
-  if (is3x3 && M > 0) {
-    Wg9P q;
-    q.X = (const u16*)X; q.DY = (const u16*)dY; q.B = B; q.H = Hg; q.W = Wg; q.Ck = Ck; q.ldx = ldx; q.Cn = Cn; q.ldy = ldy;
-    q.tiles_y = (int)mm_cdiv(Hg, 8); q.tiles_x = (int)mm_cdiv(Wg, 16);
-    const int64_t npatch = (int64_t)B * q.tiles_y * q.tiles_x;
-    q.ntile = (Cn / 64) * (Ck / 64);
-    // pixel splits: one workgroup per CU (the kernel is MFMA-bound per patch, so the makespan is the longest patch list),
-    // bounded by 40 MB of fp32 partial slabs, which are written and re-read
-    static const int ncu = [] {
-      int dev = 0, n = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-      return n > 1024 ? 1024 : n;
-    }();
-    int64_t nsp = ncu / q.ntile;
-    const int64_t cap = (int64_t)(40u << 20) / ((int64_t)Cn * 9 * Ck * 4);
-    if (nsp > cap) nsp = cap;
-    if (nsp > npatch) nsp = npatch;
-    if (nsp < 1) nsp = 1;
-    q.patches_per_wg = (int)mm_cdiv(npatch, nsp);
-    const int nsplit9 = (int)mm_cdiv(npatch, q.patches_per_wg);
-    if ((size_t)nsplit9 * Cn * 9 * Ck * sizeof(float) > ws_bytes) {
-      mm_set_error("conv2d_wgrad(3x3): workspace too small");
-      return MM_ERR_WORKSPACE;
-    }
-    q.partial = (float*)ws;
-    constexpr int lds9 = 4 * (128 + 184) * 128;
-    static unsigned attr9 = 0;  // per-device bit: see mm_attr_todo (common.h)
-    if (mm_attr_todo(&attr9)) {
-      MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3n, hipFuncAttributeMaxDynamicSharedMemorySize, lds9));
-    }
-    hipLaunchKernelGGL(k_wgrad3x3n, dim3((unsigned)(nsplit9 * q.ntile)), dim3(512), lds9, s, q);
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,
-                       dW, sn, st, sk, accumulate);
-    MM_LAUNCH_CHECK();
-    return MM_OK;
-  }
+  if (is3x3 && M > 0)
+    return wgrad3x3_launch(X, nullptr, dY, nullptr, B, Hg, Wg, Ck, ldx, Cn, ldy, dW, nullptr, sn, st, sk, accumulate, ws, ws_bytes, s);
   p.mchunk = wgrad_chunk(M, Cn, Ck, ntaps);
   const int nsplit = (int)mm_cdiv(M, p.mchunk);
   if ((size_t)nsplit * Cn * ntaps * Ck * sizeof(float) > ws_bytes) {
@@ -1761,6 +1788,17 @@ int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ld
                      M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
   MM_LAUNCH_CHECK();
   return MM_OK;
+}
+
+// The weight gradients of two 3x3 stride-1 pad-1 convolutions of one shape (dW0 from X0 / dY0, dW1 from X1 / dY1; torch layout
+// [Cn][Ck][3][3] unless the strides say otherwise) in the two launches one of them takes.  ws as for one (mm_conv2d_wgrad_ws_bytes).
+int MM_SYM(mm_conv2d_wgrad3x3_pair)(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1, int Cn,
+                            int ldy, float* dW0, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
+                            hipStream_t s) {
+  MM_CHECK_ARG(Ck % 64 == 0 && Cn % 64 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "conv2d_wgrad3x3_pair: bad shape");
+  MM_CHECK_ARG(X0 && X1 && dY0 && dY1 && dW0 && dW1, "conv2d_wgrad3x3_pair: null pointer");
+  if ((int64_t)B * H * W == 0) return MM_OK;
+  return wgrad3x3_launch(X0, X1, dY0, dY1, B, H, W, Ck, ldx, Cn, ldy, dW0, dW1, sn, st, sk, accumulate, ws, ws_bytes, s);
 }
 
 int MM_SYM(mm_stem_prep)(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, hipStream_t s) {

@@ -494,8 +494,9 @@ def test_batchnorm_from_epilogue_statistics_matches_the_statistics_pass(split, h
 def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, half2d):
     """net2d.backbone_pair: layers 2-4 of the RGB and of the depth encoder in lockstep, each pair of 3x3 stride-1 convolutions (and of
     their data gradients) as ONE launch over both problems (mm_conv2d_3x3s1_pair).  A work item computes what it computed before -
-    only which workgroup runs it changes - so features, running statistics and every gradient are bit-identical with the
-    one-after-the-other walk (MM_CONV_PAIR=0), with and without per-domain statistics groups."""
+    only which workgroup runs it changes - so features, running statistics and every data gradient are bit-identical with the
+    one-after-the-other walk (MM_CONV_PAIR=0), with and without per-domain statistics groups; the paired weight gradients
+    (mm_conv2d_wgrad3x3_pair) add the same products over other pixel splits."""
     import copy
 
     import mm2d3d_amd.conv2d as c2d
@@ -532,4 +533,9 @@ def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, half2d):
         for (n, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
             assert torch.equal(a, b), n
         for (n, a), (_, b) in zip(m1.named_parameters(), m0.named_parameters()):
-            assert a.grad is not None and torch.equal(a.grad, b.grad), n
+            assert a.grad is not None, n
+            if a.dim() == 4 and a.shape[-1] == 3 and a.shape[0] > 64:
+                # paired weight gradients split the pixels over half as many partial slabs per problem: other fp32 summation order
+                assert float((a.grad - b.grad).norm() / b.grad.norm()) < 2e-6, n
+            else:
+                assert torch.equal(a.grad, b.grad), n

@@ -34,3 +34,28 @@ def run(B, C, H, W, reps=30):
 for C, H, W in ((256, 38, 60), (512, 19, 30), (128, 76, 120)):
     t16, t32 = run(16, C, H, W), run(32, C, H, W)
     print(f"{C} ch @ {H}x{W}: B=16 {t16:7.1f} us   B=32 {t32:7.1f} us   two launches of 16 = {2 * t16:7.1f} us   saving {100 * (1 - t32 / (2 * t16)):5.1f} %")
+
+
+def run_wgrad(B, C, H, W, reps=20):
+    x = torch.randn(B, C, H, W, device=dev).to(H16).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, C, H, W, device=dev).to(H16).contiguous(memory_format=torch.channels_last)
+    dw = torch.zeros(C, C, 3, 3, device=dev)
+    ty = [kh - 1 for kh in range(3) for _ in range(3)]
+    tx = [kw - 1 for _ in range(3) for kw in range(3)]
+    f = lambda: c2d._wgrad(x, B, H, W, C, dy, H, W, C, 1, ty, tx, dw, C * 9, 1, 9, accumulate=1)
+    for _ in range(3):
+        f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+print("weight gradient (k_wgrad3x3n + k_wgrad_reduce):")
+for C, H, W in ((256, 38, 60), (512, 19, 30), (128, 76, 120), (64, 152, 240)):
+    t16, t32 = run_wgrad(16, C, H, W), run_wgrad(32, C, H, W)
+    print(f"{C} ch @ {H}x{W}: B=16 {t16:7.1f} us   B=32 {t32:7.1f} us   two launches of 16 = {2 * t16:7.1f} us   saving {100 * (1 - t32 / (2 * t16)):5.1f} %")
