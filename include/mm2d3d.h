@@ -424,6 +424,23 @@ int mm_bn2d_fwd_train_pre(const void* x, int ld_x, const void* res, int ld_r, in
                           const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                           float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, const float* slab,
                           int64_t slab_rows, void* ws, size_t ws_bytes, mm_stream_t stream);
+/* Two BatchNorm2d problems of ONE shape (N, Ns, C and the scalars shared) - the same layer of the RGB and of the depth encoder,
+ * EXP/2d_net/model.py:43-46 - as ONE single-launch kernel where the maps allow it: half the CUs per problem, one pair of grid barriers
+ * and one statistics exchange for both (the small maps of the encoders' layers 2-4 are bound by those fixed costs, not by bytes);
+ * otherwise the two problems run one after the other exactly as mm_bn2d_fwd_train / mm_bn2d_bwd run them.  Same results either way. */
+typedef struct mm_bn2d_fwd_args {
+  const void* x; int ld_x; const void* res; int ld_r; const float* weight; const float* bias; float* running_mean; float* running_var;
+  int64_t* num_batches_tracked; void* y; int ld_y; float* save_mean; float* save_invstd;
+} mm_bn2d_fwd_args;
+typedef struct mm_bn2d_bwd_args {
+  const void* x; int ld_x; const void* dy; int ld_dy; const void* dy2; int ld_dy2; const void* yout; int ld_y;
+  const float* weight; const float* bias; const float* save_mean; const float* save_invstd; void* dx; int ld_dx; void* dres; int ld_dr;
+  float* dweight; float* dbias;
+} mm_bn2d_bwd_args;
+int mm_bn2d_fwd_train_pair(mm_handle_t h, const mm_bn2d_fwd_args* a, const mm_bn2d_fwd_args* b, int64_t N, int64_t Ns, int C, float eps,
+                           float momentum, int relu, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_bwd_pair(mm_handle_t h, const mm_bn2d_bwd_args* a, const mm_bn2d_bwd_args* b, int relu, int64_t N, int64_t Ns, int C, int accumulate,
+                     void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);
@@ -505,6 +522,10 @@ int mm_bn2d_fwd_train_pre_f16(const void* x, int ld_x, const void* res, int ld_r
                           const float* bias, float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps,
                           float momentum, int relu, void* y, int ld_y, float* save_mean, float* save_invstd, const float* slab,
                           int64_t slab_rows, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_fwd_train_pair_f16(mm_handle_t h, const mm_bn2d_fwd_args* a, const mm_bn2d_fwd_args* b, int64_t N, int64_t Ns, int C, float eps,
+                           float momentum, int relu, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_bwd_pair_f16(mm_handle_t h, const mm_bn2d_bwd_args* a, const mm_bn2d_bwd_args* b, int relu, int64_t N, int64_t Ns, int C, int accumulate,
+                     void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);

@@ -128,6 +128,8 @@ _PROTOS = {
     "mm_bn2d_fwd_train": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_single_launch": (i32, [vp, i64, i64, i32, i32]),
     "mm_bn2d_fwd_train_pre": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, i64, vp, sz, vp]),
+    "mm_bn2d_fwd_train_pair": (i32, [vp, vp, vp, i64, i64, i32, f32, f32, i32, vp, sz, vp]),
+    "mm_bn2d_bwd_pair": (i32, [vp, vp, vp, i32, i64, i64, i32, i32, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
     "mm_bn2d_bwd": (i32, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i64, i64, i32, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_colsum_bf16": (i32, [vp, i32, i64, i32, vp, i32, vp, sz, vp]),
@@ -139,6 +141,21 @@ _PROTOS = {
     "mm_head_fwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, sz, vp]),
     "mm_head_bwd": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, vp, vp, sz, vp]),
 }
+
+
+class Bn2dFwdArgs(C.Structure):
+    """include/mm2d3d.h mm_bn2d_fwd_args"""
+    _fields_ = [("x", C.c_void_p), ("ld_x", C.c_int), ("res", C.c_void_p), ("ld_r", C.c_int), ("weight", C.c_void_p), ("bias", C.c_void_p),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("num_batches_tracked", C.c_void_p), ("y", C.c_void_p),
+                ("ld_y", C.c_int), ("save_mean", C.c_void_p), ("save_invstd", C.c_void_p)]
+
+
+class Bn2dBwdArgs(C.Structure):
+    """include/mm2d3d.h mm_bn2d_bwd_args"""
+    _fields_ = [("x", C.c_void_p), ("ld_x", C.c_int), ("dy", C.c_void_p), ("ld_dy", C.c_int), ("dy2", C.c_void_p), ("ld_dy2", C.c_int),
+                ("yout", C.c_void_p), ("ld_y", C.c_int), ("weight", C.c_void_p), ("bias", C.c_void_p), ("save_mean", C.c_void_p),
+                ("save_invstd", C.c_void_p), ("dx", C.c_void_p), ("ld_dx", C.c_int), ("dres", C.c_void_p), ("ld_dr", C.c_int),
+                ("dweight", C.c_void_p), ("dbias", C.c_void_p)]
 
 
 class HipLibraryMissing(RuntimeError):
@@ -154,6 +171,8 @@ H16_2D = {
     "mm_conv2d_3x3s1_stat_rows": "mm_conv2d_3x3s1_stat_rows_f16",
     "mm_bn2d_fwd_train_pre": "mm_bn2d_fwd_train_pre_f16",
     "mm_bn2d_single_launch": "mm_bn2d_single_launch_f16",
+    "mm_bn2d_fwd_train_pair": "mm_bn2d_fwd_train_pair_f16",
+    "mm_bn2d_bwd_pair": "mm_bn2d_bwd_pair_f16",
     "mm_conv2d_wgrad_ws_bytes": "mm_conv2d_wgrad_ws_bytes_f16",
     "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",
     "mm_conv2d_wgrad3x3_pair": "mm_conv2d_wgrad3x3_pair_f16",

@@ -420,8 +420,16 @@ struct FusedP {
   unsigned* fault;  // the handle's fault word (device address of pinned host memory)
 };
 
+// Two problems in one launch (the same layer of the two encoders: one grid barrier pair, one statistics exchange and one launch for
+// both): workgroups [0, Ga) run problem a, the others problem b; the barrier counts all of them (a.sync == b.sync).
+struct FusedP2 {
+  FusedP a, b;
+  int Ga;
+};
+
+// bid = the workgroup's index within its problem, Gall = workgroups of the whole launch (what the grid barrier counts)
 template <int RMAX, bool RES>
-__global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
+__device__ __forceinline__ void bn2d_fused_fwd_body(const FusedP& p, const int bid, const unsigned Gall) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* red = (float*)smem;
   double* red2 = (double*)(smem + FUSED_RED);
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
   constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
   static_assert(RMAX % 4 == 0, "row groups of four");
   const int tid = threadIdx.x;
-  const FusedGeom g = fused_geom(p.N, p.Ns, p.C >> 3, p.G0, p.G1);
+  const FusedGeom g = fused_geom(p.N, p.Ns, p.C >> 3, p.G0, p.G1, bid);
   const int C = p.C;
   unsigned flag0 = 0;
   if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
@@ -460,15 +468,15 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
     }
   }
   fused_block_sums<8>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
-  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
+  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)bid * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
-  fused_barrier(p.sync, p.fault, (unsigned)G, flag0);
+  fused_barrier(p.sync, p.fault, Gall, flag0);
   {
     // statistics: one wave per channel, channels dealt round-robin over the workgroups; both groups by the same wave, the
     // running buffers updated group 0 first, then group 1 (what two consecutive forward calls do)
     const int ngrp = p.G1 > 0 ? 2 : 1;
-    if (blockIdx.x == 0 && tid == 0 && p.nbt) *p.nbt += ngrp;
-    for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
+    if (bid == 0 && tid == 0 && p.nbt) *p.nbt += ngrp;
+    for (int c = bid + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
       for (int gi = 0; gi < ngrp; gi++) {
         double sm, sq;
         fused_wave_sums(p.partial, gi ? p.G0 : 0, gi ? G : p.G0, C, c, sm, sq);
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
       }
     }
   }
-  fused_barrier(p.sync, p.fault, (unsigned)G, flag0 + 1u);
+  fused_barrier(p.sync, p.fault, Gall, flag0 + 1u);
   if (!g.active) return;
   const float *wp = p.weight ? p.weight : p.save_mean, *bp = p.bias ? p.bias : p.save_mean;
   // the kept rows stay PACKED across the barrier: without this the compiler keeps the phase-1 unpacked floats alive instead
@@ -538,11 +546,21 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
   }
 }
 
+template <int RMAX, bool RES>
+__global__ __launch_bounds__(FT) void k_bn2d_fused_fwd(const FusedP p) {
+  bn2d_fused_fwd_body<RMAX, RES>(p, (int)blockIdx.x, (unsigned)(p.G0 + p.G1));
+}
+template <int RMAX, bool RES>
+__global__ __launch_bounds__(FT) void k_bn2d_fused_fwd_pair(const FusedP2 pp) {
+  const bool second = (int)blockIdx.x >= pp.Ga;
+  bn2d_fused_fwd_body<RMAX, RES>(second ? pp.b : pp.a, second ? (int)blockIdx.x - pp.Ga : (int)blockIdx.x, gridDim.x);
+}
+
 // Backward: phase 1 keeps x (registers), the first FUSED_NL rows of dy (LDS) and the ReLU mask bits; sums are (sum g, sum g*x), turned
 // into sum g*xhat = invstd * (sum g*x - mean * sum g) in fp64 by the last workgroup.
 // MASK: 0 = no ReLU, 1 = mask recomputed from x, 2 = mask from the forward output
 template <int RMAX, bool DY2, int MASK>
-__global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
+__device__ __forceinline__ void bn2d_fused_bwd_body(const FusedP& p, const int bid, const unsigned Gall) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* red = (float*)smem;
   double* red2 = (double*)(smem + FUSED_RED);
@@ -551,7 +569,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
   constexpr int NREG = RMAX > FUSED_NL ? RMAX - FUSED_NL : 1;
   static_assert(RMAX % 4 == 0, "row groups of four");
   const int tid = threadIdx.x;
-  const FusedGeom g = fused_geom(p.N, p.Ns, p.C >> 3, p.G0, p.G1);
+  const FusedGeom g = fused_geom(p.N, p.Ns, p.C >> 3, p.G0, p.G1, bid);
   const int C = p.C;
   unsigned flag0 = 0;
   if (tid == 0) flag0 = xcd_load(&p.sync[FUSED_FLAG]);
@@ -615,12 +633,12 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
     }
   }
   fused_block_sums<8>(a, b, red, red2, outp, C, g.CV, g.rs, g.active);
-  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)blockIdx.x * 2 * C + pr, outp[pr]);
+  for (int pr = tid; pr < 2 * C; pr += FT) xcd_store(p.partial + (size_t)bid * 2 * C + pr, outp[pr]);
   const int G = p.G0 + p.G1;
-  fused_barrier(p.sync, p.fault, (unsigned)G, flag0);
+  fused_barrier(p.sync, p.fault, Gall, flag0);
   {
     const int ngrp = p.G1 > 0 ? 2 : 1;
-    for (int c = blockIdx.x + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
+    for (int c = bid + (tid >> 6) * G; c < C; c += (FT / 64) * G) {
       float ts = 0.f, tq = 0.f;
       for (int gi = 0; gi < ngrp; gi++) {
         double sg, sgx;
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
       }
     }
   }
-  fused_barrier(p.sync, p.fault, (unsigned)G, flag0 + 1u);
+  fused_barrier(p.sync, p.fault, Gall, flag0 + 1u);
   if (!g.active) return;
 #pragma unroll
   for (int k = 0; k < RMAX; k++) asm volatile("" : "+v"(xr[k]));  // keep the rows packed across the barrier (see the forward kernel)
@@ -701,6 +719,16 @@ __global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
   }
 }
 
+template <int RMAX, bool DY2, int MASK>
+__global__ __launch_bounds__(FT) void k_bn2d_fused_bwd(const FusedP p) {
+  bn2d_fused_bwd_body<RMAX, DY2, MASK>(p, (int)blockIdx.x, (unsigned)(p.G0 + p.G1));
+}
+template <int RMAX, bool DY2, int MASK>
+__global__ __launch_bounds__(FT) void k_bn2d_fused_bwd_pair(const FusedP2 pp) {
+  const bool second = (int)blockIdx.x >= pp.Ga;
+  bn2d_fused_bwd_body<RMAX, DY2, MASK>(second ? pp.b : pp.a, second ? (int)blockIdx.x - pp.Ga : (int)blockIdx.x, gridDim.x);
+}
+
 inline unsigned apply_blocks(int64_t N, int C) {
   int rs = T / (C / 8);
   return (unsigned)mm_cdiv(N, (int64_t)rs * APPLY_ROWS);
@@ -725,6 +753,17 @@ static const void* const k_fused_fns[] = {
     (const void*)k_bn2d_fused_bwd<36, false, 0>, (const void*)k_bn2d_fused_bwd<36, false, 1>, (const void*)k_bn2d_fused_bwd<36, false, 2>,
     (const void*)k_bn2d_fused_bwd<36, true, 0>,  (const void*)k_bn2d_fused_bwd<36, true, 1>,  (const void*)k_bn2d_fused_bwd<36, true, 2>};
 constexpr int k_fused_nfns = (int)(sizeof(k_fused_fns) / sizeof(k_fused_fns[0]));
+// the two-problem forms (maps of the encoders' layers 2-4: R <= 36 at half the CUs per problem)
+static const void* const k_fused_pair_fns[] = {
+    (const void*)k_bn2d_fused_fwd_pair<8, false>,     (const void*)k_bn2d_fused_fwd_pair<8, true>,      (const void*)k_bn2d_fused_fwd_pair<20, false>,
+    (const void*)k_bn2d_fused_fwd_pair<20, true>,     (const void*)k_bn2d_fused_fwd_pair<36, false>,    (const void*)k_bn2d_fused_fwd_pair<36, true>,
+    (const void*)k_bn2d_fused_bwd_pair<8, false, 0>,  (const void*)k_bn2d_fused_bwd_pair<8, false, 1>,  (const void*)k_bn2d_fused_bwd_pair<8, false, 2>,
+    (const void*)k_bn2d_fused_bwd_pair<8, true, 0>,   (const void*)k_bn2d_fused_bwd_pair<8, true, 1>,   (const void*)k_bn2d_fused_bwd_pair<8, true, 2>,
+    (const void*)k_bn2d_fused_bwd_pair<20, false, 0>, (const void*)k_bn2d_fused_bwd_pair<20, false, 1>, (const void*)k_bn2d_fused_bwd_pair<20, false, 2>,
+    (const void*)k_bn2d_fused_bwd_pair<20, true, 0>,  (const void*)k_bn2d_fused_bwd_pair<20, true, 1>,  (const void*)k_bn2d_fused_bwd_pair<20, true, 2>,
+    (const void*)k_bn2d_fused_bwd_pair<36, false, 0>, (const void*)k_bn2d_fused_bwd_pair<36, false, 1>, (const void*)k_bn2d_fused_bwd_pair<36, false, 2>,
+    (const void*)k_bn2d_fused_bwd_pair<36, true, 0>,  (const void*)k_bn2d_fused_bwd_pair<36, true, 1>,  (const void*)k_bn2d_fused_bwd_pair<36, true, 2>};
+constexpr int k_fused_pair_nfns = (int)(sizeof(k_fused_pair_fns) / sizeof(k_fused_pair_fns[0]));
 
 extern "C" {
 
@@ -732,8 +771,10 @@ extern "C" {
 // mm_bn2d_bwd single-launch; 0 = always the reduce / finalize / apply kernels) - no process-wide switch.
 #ifdef MM_ACT_FP16
 constexpr int BN2D_UNIT = 2;
+constexpr int BN2D_PAIR_UNIT = 4;
 #else
 constexpr int BN2D_UNIT = 1;
+constexpr int BN2D_PAIR_UNIT = 3;
 #endif
 
 size_t MM_SYM(mm_bn2d_ws_bytes)(int C) { return mm_align((size_t)MAX_PART * 2 * C * sizeof(double)) + mm_align(4 * C * sizeof(float)) + 256; }
@@ -854,6 +895,75 @@ int MM_SYM(mm_bn2d_fwd_train_pre)(const void* x, int ld_x, const void* res, int 
   return MM_OK;
 }
 
+// Two mm_bn2d_fwd_train problems of one shape (N, Ns, C, eps, momentum, relu shared; everything else per problem) - the same layer of
+// the two encoders, EXP/2d_net/model.py:43-46 - in ONE single-launch kernel where the maps allow it (half the CUs per problem, one
+// pair of grid barriers and one statistics exchange for both): the small maps of layers 2-4 are bound by exactly those fixed costs.
+// Otherwise the two problems run one after the other as mm_bn2d_fwd_train would run them.  ws as for mm_bn2d_fwd_train.
+typedef struct {
+  const void* x; int ld_x; const void* res; int ld_r; const float* weight; const float* bias; float* running_mean; float* running_var;
+  int64_t* num_batches_tracked; void* y; int ld_y; float* save_mean; float* save_invstd;
+} MMBn2dFwdArgs;
+
+int MM_SYM(mm_bn2d_fwd_train_pair)(void* h, const MMBn2dFwdArgs* a, const MMBn2dFwdArgs* b, int64_t N, int64_t Ns, int C, float eps, float momentum,
+                           int relu, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_HANDLE(h);
+  MM_CHECK_ARG(a && b && C % 8 == 0 && C / 8 <= T, "bn2d_fwd_train_pair: bad arguments");
+  if (ws_bytes < MM_SYM(mm_bn2d_ws_bytes)(C)) {
+    mm_set_error("bn2d: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  const MMBn2dFwdArgs* q[2] = {a, b};
+  bool same = (a->res == nullptr) == (b->res == nullptr);
+  int64_t ldmax = 0;
+  for (int i = 0; i < 2; i++) {
+    same = same && q[i]->ld_x % 8 == 0 && q[i]->ld_y % 8 == 0 && (!q[i]->res || q[i]->ld_r % 8 == 0);
+    ldmax = std::max(ldmax, (int64_t)std::max(std::max(q[i]->ld_x, q[i]->ld_y), q[i]->res ? q[i]->ld_r : 0));
+  }
+  FusedPlan pl;
+  pl.ok = false;
+  if (same && N * ldmax * 2 < (1ll << 31)) {
+    int rc = fused_plan(H, MM_OPT_BN2D_FUSED, BN2D_PAIR_UNIT, N, Ns, C, 8, 36, false, k_fused_pair_fns, k_fused_pair_nfns, s, &pl, 2);
+    if (rc) return rc;
+  }
+  if (!pl.ok) {
+    for (int i = 0; i < 2; i++) {
+      int rc = MM_SYM(mm_bn2d_fwd_train)(h, q[i]->x, q[i]->ld_x, q[i]->res, q[i]->ld_r, N, Ns, C, q[i]->weight, q[i]->bias, q[i]->running_mean,
+                                 q[i]->running_var, q[i]->num_batches_tracked, eps, momentum, relu, q[i]->y, q[i]->ld_y, q[i]->save_mean,
+                                 q[i]->save_invstd, ws, ws_bytes, s);
+      if (rc) return rc;
+    }
+    return MM_OK;
+  }
+  FusedP2 pp = {};
+  const int Gp = pl.G0 + pl.G1;
+  FusedP* fp[2] = {&pp.a, &pp.b};
+  for (int i = 0; i < 2; i++) {
+    FusedP& p = *fp[i];
+    p.x = (const u16*)q[i]->x, p.res = (const u16*)q[i]->res, p.y = (u16*)q[i]->y;
+    p.ld_x = q[i]->ld_x, p.ld_r = q[i]->ld_r, p.ld_y = q[i]->ld_y;
+    p.N = N, p.Ns = Ns, p.C = C, p.relu = relu, p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R;
+    p.weight = q[i]->weight, p.bias = q[i]->bias, p.running_mean = q[i]->running_mean, p.running_var = q[i]->running_var;
+    p.nbt = q[i]->num_batches_tracked;
+    p.eps = eps, p.momentum = momentum, p.save_mean = q[i]->save_mean, p.save_invstd = q[i]->save_invstd;
+    p.partial = (double*)ws + (size_t)i * Gp * 2 * C, p.sync = pl.sync, p.fault = pl.fault;
+  }
+  pp.Ga = Gp;
+  const dim3 grid(2 * Gp), blk(FT);
+  const bool res = a->res != nullptr;
+#define MM_FWD2(RM)                                                                                    \
+  do {                                                                                                 \
+    if (res) hipLaunchKernelGGL((k_bn2d_fused_fwd_pair<RM, true>), grid, blk, FUSED_LDS, s, pp);       \
+    else hipLaunchKernelGGL((k_bn2d_fused_fwd_pair<RM, false>), grid, blk, FUSED_LDS, s, pp);          \
+  } while (0)
+  if (pl.R <= 8) MM_FWD2(8);
+  else if (pl.R <= 20) MM_FWD2(20);
+  else MM_FWD2(36);
+#undef MM_FWD2
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
 int MM_SYM(mm_bn2d_fwd_eval)(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight, const float* bias,
                      const float* running_mean, const float* running_var, float eps, int relu, void* y, int ld_y, hipStream_t s) {
   MM_CHECK_ARG(C % 8 == 0, "bn2d: C must be a multiple of 8");
@@ -929,6 +1039,87 @@ int MM_SYM(mm_bn2d_bwd)(void* h, const void* x, int ld_x, const void* dy, int ld
                        ld_y, relu, N, C, save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)dres, ld_dr, Ns, ab0, bias, (const u16*)dy2,
                        ld_dy2);
   }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// Two mm_bn2d_bwd problems of one shape in one single-launch kernel (see mm_bn2d_fwd_train_pair); relu, N, Ns, C, accumulate shared.
+typedef struct {
+  const void* x; int ld_x; const void* dy; int ld_dy; const void* dy2; int ld_dy2; const void* yout; int ld_y;
+  const float* weight; const float* bias; const float* save_mean; const float* save_invstd; void* dx; int ld_dx; void* dres; int ld_dr;
+  float* dweight; float* dbias;
+} MMBn2dBwdArgs;
+
+int MM_SYM(mm_bn2d_bwd_pair)(void* h, const MMBn2dBwdArgs* a, const MMBn2dBwdArgs* b, int relu, int64_t N, int64_t Ns, int C, int accumulate, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_HANDLE(h);
+  MM_CHECK_ARG(a && b && C % 8 == 0 && C / 8 <= T, "bn2d_bwd_pair: bad arguments");
+  if (ws_bytes < MM_SYM(mm_bn2d_ws_bytes)(C)) {
+    mm_set_error("bn2d_bwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  if (Ns <= 0 || Ns >= N) Ns = N;
+  const MMBn2dBwdArgs* q[2] = {a, b};
+  bool same = (a->dy2 == nullptr) == (b->dy2 == nullptr) && (a->yout == nullptr) == (b->yout == nullptr);
+  int64_t ldmax = 0;
+  for (int i = 0; i < 2; i++) {
+    const MMBn2dBwdArgs& r = *q[i];
+    same = same && r.ld_x % 8 == 0 && r.ld_dy % 8 == 0 && r.ld_dx % 8 == 0 && (!r.dy2 || r.ld_dy2 % 8 == 0) && (!r.yout || r.ld_y % 8 == 0) &&
+           (!r.dres || r.ld_dr % 8 == 0);
+    ldmax = std::max(ldmax, (int64_t)std::max(std::max(std::max(r.ld_x, r.ld_dy), std::max(r.ld_dx, r.dy2 ? r.ld_dy2 : 0)),
+                                             std::max(r.yout ? r.ld_y : 0, r.dres ? r.ld_dr : 0)));
+  }
+  FusedPlan pl;
+  pl.ok = false;
+  if (same && N * ldmax * 2 < (1ll << 31)) {
+    int rc = fused_plan(H, MM_OPT_BN2D_FUSED, BN2D_PAIR_UNIT, N, Ns, C, 8, 36, true, k_fused_pair_fns, k_fused_pair_nfns, s, &pl, 2);
+    if (rc) return rc;
+  }
+  if (!pl.ok) {
+    for (int i = 0; i < 2; i++) {
+      const MMBn2dBwdArgs& r = *q[i];
+      int rc = MM_SYM(mm_bn2d_bwd)(h, r.x, r.ld_x, r.dy, r.ld_dy, r.dy2, r.ld_dy2, r.yout, r.ld_y, relu, N, Ns, C, r.weight, r.bias, r.save_mean,
+                           r.save_invstd, r.dx, r.ld_dx, r.dres, r.ld_dr, r.dweight, r.dbias, accumulate, ws, ws_bytes, s);
+      if (rc) return rc;
+    }
+    return MM_OK;
+  }
+  FusedP2 pp = {};
+  const int Gp = pl.G0 + pl.G1;
+  FusedP* fp[2] = {&pp.a, &pp.b};
+  for (int i = 0; i < 2; i++) {
+    FusedP& p = *fp[i];
+    const MMBn2dBwdArgs& r = *q[i];
+    p.x = (const u16*)r.x, p.dy = (const u16*)r.dy, p.dy2 = (const u16*)r.dy2, p.yout = (const u16*)r.yout, p.dx = (u16*)r.dx, p.dres = (u16*)r.dres;
+    p.ld_x = r.ld_x, p.ld_dy = r.ld_dy, p.ld_dy2 = r.ld_dy2, p.ld_y = r.ld_y, p.ld_dx = r.ld_dx, p.ld_dr = r.ld_dr;
+    p.N = N, p.Ns = Ns, p.C = C, p.relu = relu, p.G0 = pl.G0, p.G1 = pl.G1, p.R = pl.R;
+    p.weight = r.weight, p.bias = r.bias, p.save_mean = (float*)r.save_mean, p.save_invstd = (float*)r.save_invstd;
+    p.dweight = r.dweight, p.dbias = r.dbias, p.accumulate = accumulate;
+    p.partial = (double*)ws + (size_t)i * Gp * 2 * C;
+    p.sums = (float*)((double*)ws + (size_t)2 * Gp * 2 * C) + (size_t)i * 4 * C;  // behind both problems' partial rows (MAX_PART of them fit)
+    p.sync = pl.sync, p.fault = pl.fault;
+  }
+  pp.Ga = Gp;
+  const dim3 grid(2 * Gp), blk(FT);
+  const int mask = !relu ? 0 : (a->yout ? 2 : 1);
+  const bool d2 = a->dy2 != nullptr;
+#define MM_BWD2(RM, D2)                                                                                          \
+  do {                                                                                                           \
+    if (mask == 0) hipLaunchKernelGGL((k_bn2d_fused_bwd_pair<RM, D2, 0>), grid, blk, FUSED_LDS, s, pp);          \
+    else if (mask == 1) hipLaunchKernelGGL((k_bn2d_fused_bwd_pair<RM, D2, 1>), grid, blk, FUSED_LDS, s, pp);     \
+    else hipLaunchKernelGGL((k_bn2d_fused_bwd_pair<RM, D2, 2>), grid, blk, FUSED_LDS, s, pp);                    \
+  } while (0)
+  if (pl.R <= 8) {
+    if (d2) MM_BWD2(8, true);
+    else MM_BWD2(8, false);
+  } else if (pl.R <= 20) {
+    if (d2) MM_BWD2(20, true);
+    else MM_BWD2(20, false);
+  } else {
+    if (d2) MM_BWD2(36, true);
+    else MM_BWD2(36, false);
+  }
+#undef MM_BWD2
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

@@ -166,15 +166,17 @@ struct FusedGeom {
   int nrows;  // r1 - r0
 };
 
-__device__ inline FusedGeom fused_geom(int64_t N, int64_t Ns, int CV, int G0, int G1) {
+// bid: the workgroup's index within its problem (blockIdx.x unless the launch carries two problems, csrc/bn2d.hip pair kernels)
+__device__ inline FusedGeom fused_geom(int64_t N, int64_t Ns, int CV, int G0, int G1, int bid = -1) {
+  if (bid < 0) bid = (int)blockIdx.x;
   FusedGeom g;
   g.CV = CV;
   g.rs = FT / g.CV;
   g.slot = threadIdx.x / g.CV;
   g.cv = threadIdx.x - g.slot * g.CV;
   g.active = g.slot < g.rs;
-  g.grp = (int)blockIdx.x >= G0;
-  const int lb = g.grp ? blockIdx.x - G0 : blockIdx.x, nbg = g.grp ? G1 : G0;
+  g.grp = bid >= G0;
+  const int lb = g.grp ? bid - G0 : bid, nbg = g.grp ? G1 : G0;
   const int64_t gbase = g.grp ? Ns : 0;
   g.Ng = g.grp ? N - Ns : Ns;
   const int64_t rpb = (g.Ng + nbg - 1) / nbg;
@@ -254,8 +256,9 @@ static inline int64_t fused_shape(int cus, int64_t N, int64_t Ns, int C, int vec
   return mm_cdiv(rpb0 > rpb1 ? rpb0 : rpb1, rs);
 }
 
+// cus_div = 2: the plan of ONE of two problems that share a launch (half the CUs each; csrc/bn2d.hip pair entry points)
 static inline int fused_plan(MMHandle* H, int opt, int unit, int64_t N, int64_t Ns, int C, int vec, int rmax, bool backward,
-                             const void* const* fns, int nfns, hipStream_t s, FusedPlan* pl) {
+                             const void* const* fns, int nfns, hipStream_t s, FusedPlan* pl, int cus_div = 1) {
   pl->ok = false;
   if (!H->fused_ok || !(H->opt[opt] & (backward ? 2 : 1)) || N <= 0 || C % vec != 0 || C > FT || C < vec) return MM_OK;
   if (!(H->attr_done & (1u << unit))) {
@@ -278,7 +281,7 @@ static inline int fused_plan(MMHandle* H, int opt, int unit, int64_t N, int64_t 
     H->streams[slot] = s;
   }
   int G0, G1;
-  const int64_t R = fused_shape(H->cus, N, Ns, C, vec, &G0, &G1);
+  const int64_t R = fused_shape(H->cus / cus_div, N, Ns, C, vec, &G0, &G1);
   if (R > rmax) return MM_OK;
   pl->ok = true;
   pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;

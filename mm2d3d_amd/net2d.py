@@ -82,10 +82,9 @@ class BasicBlock(nn.Module):
             return b1(x1, out=out1), b2(x2, out=out2)
         id1, id2 = b1._identity(x1), b2._identity(x2)
         c1, c2 = nn2d.conv_pair(b1.conv1, b2.conv1, x1, x2)
-        y1, y2 = b1.bn1(c1), b2.bn1(c2)
+        y1, y2 = nn2d.bn_pair(b1.bn1, b2.bn1, c1, c2)
         c1, c2 = nn2d.conv_pair(b1.conv2, b2.conv2, y1, y2)
-        return (b1.bn2(c1, id1, out=out1, residual_shared=b1.downsample is None),
-                b2.bn2(c2, id2, out=out2, residual_shared=b2.downsample is None))
+        return nn2d.bn_pair(b1.bn2, b2.bn2, c1, c2, id1, id2, out1, out2, residual_shared=b1.downsample is None)
 
     def forward(self, x, out=None):
         """``out``: optional NHWC channel slice the block's result is written into (see nn2d.CatBuffer)."""

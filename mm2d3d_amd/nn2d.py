@@ -12,6 +12,8 @@ refused (no CPU fallback).  Still on torch ops (interim, listed in DESIGN.md): D
 from __future__ import annotations
 
 import ctypes
+import ctypes as C_
+import os
 
 import torch
 import torch.nn as nn
@@ -252,6 +254,138 @@ class _BN2dFn(torch.autograd.Function):
             ctx.res_handoff.extra.append(dres)
             dres = None
         return dx, dres, dw, db, None, None, None, None, None, None, None, None, None, None, None
+
+
+BN_PAIR = [os.environ.get("MM_BN2D_PAIR", "1") != "0"]  # the same BatchNorm2d layer of the two encoders as one launch (bn_pair)
+
+
+class _BN2dPairFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d(+residual)(+ReLU) of TWO maps of one shape with their own parameters - the same layer of the RGB and
+    of the depth encoder - through mm_bn2d_fwd_train_pair / mm_bn2d_bwd_pair: one single-launch kernel for both where the maps allow
+    it (the library decides; else it runs them one after the other).  Per problem the arithmetic of _BN2dFn."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, res1, res2, w1, w2, b1, b2, cfg1, cfg2):
+        """cfg = dict(running_mean, running_var, eps, momentum, relu, nbt, out, handoff, res_handoff)"""
+        L = _c2d.lib2d()
+        cfgs = (cfg1, cfg2)
+        xs, ress, ws_, bs = [x1, x2], [res1, res2], (w1, w2), (b1, b2)
+        ldx, ldr, ys, ldy = [0, 0], [0, 0], [None, None], [0, 0]
+        for i in range(2):
+            xs[i], ldx[i] = _c2d.nhwc_pitch(xs[i])
+            B, C, H, W = xs[i].shape
+            ldr[i] = C
+            if ress[i] is not None:
+                ress[i], ldr[i] = _c2d.nhwc_pitch(ress[i])
+            out = cfgs[i]["out"]
+            if out is not None:
+                dst = out[0].detach()
+                ys[i], ldy[i] = _c2d.nhwc_pitch(dst)
+                if ys[i].data_ptr() != dst.data_ptr() or tuple(ys[i].shape) != tuple(xs[i].shape) or ys[i].dtype != _c2d.HALF[0]:
+                    raise ValueError("BatchNorm2d(out=): destination must be an NHWC 16-bit channel slice of the output's shape")
+            else:
+                ys[i], ldy[i] = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=xs[i].device, memory_format=CL), C
+        B, C, H, W = xs[0].shape
+        N = B * H * W
+        nf = domains.current()
+        Ns = nf * H * W if (nf is not None and 0 < nf < B) else N
+        stats = [torch.empty((2, 2 if Ns < N else 1, C), dtype=F32, device=xs[0].device) for _ in range(2)]
+        ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), xs[0].device)
+        ctx.Ns = Ns
+        ctx.hd = hd = _lib.handle(xs[0].device)
+        args = []
+        for i in range(2):
+            c = cfgs[i]
+            args.append(_lib.Bn2dFwdArgs(ptr(xs[i]), ldx[i], ptr(ress[i]), ldr[i], ptr(ws_[i]), ptr(bs[i]), ptr(c["running_mean"]),
+                                         ptr(c["running_var"]), ptr(c["nbt"]), ptr(ys[i]), ldy[i], ptr(stats[i][0]), ptr(stats[i][1])))
+        check(L.mm_bn2d_fwd_train_pair(hd.h, C_.byref(args[0]), C_.byref(args[1]), N, Ns, C, cfg1["eps"], cfg1["momentum"], 1 if cfg1["relu"] else 0,
+                                       ptr(ws), ws.numel(), stream()), "bn2d_fwd_train_pair")
+        ctx.save_for_backward(xs[0], xs[1], ys[0], ys[1], w1, w2, stats[0], stats[1], b1, b2)
+        ctx.sinks = [None, None]
+        for i in range(2):
+            if gradsink.claim(ctx, ws_[i], ctx.needs_input_grad[4 + i]):
+                gradsink.claim(ctx, bs[i], True)
+                ctx.sinks[i] = (ws_[i], bs[i])
+        ctx.relu, ctx.has_res = cfg1["relu"], res1 is not None
+        ctx.lds = (ldx, ldy)
+        ctx.handoffs = (cfg1["handoff"], cfg2["handoff"])
+        ctx.res_handoffs = (cfg1["res_handoff"], cfg2["res_handoff"])
+        return ys[0], ys[1]
+
+    @staticmethod
+    def backward(ctx, dy1, dy2):
+        L = _c2d.lib2d()
+        x1, x2, y1, y2, w1, w2, st1, st2, b1, b2 = ctx.saved_tensors
+        xs, ys, ws_, bs, sts = (x1, x2), (y1, y2), (w1, w2), (b1, b2), (st1, st2)
+        ldx, ldy = ctx.lds
+        B, C, H, W = x1.shape
+        N = B * H * W
+        dys, lddy, dy2s, lddy2 = [dy1, dy2], [0, 0], [None, None], [0, 0]
+        for i in range(2):
+            dys[i], lddy[i] = _c2d.nhwc_pitch(dys[i])
+            h = ctx.handoffs[i]
+            if h is not None and h.extra:
+                extra, h.extra = h.extra, []
+                for e in extra[1:]:
+                    dys[i] = dys[i] + e
+                    dys[i], lddy[i] = _c2d.nhwc_pitch(dys[i])
+                dy2s[i], lddy2[i] = _c2d.nhwc_pitch(extra[0])
+        ymask = [ys[i] if (ctx.has_res or not ctx.relu) else None for i in range(2)]  # no residual: mask recomputed from x
+        dx = [torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x1.device, memory_format=CL) for _ in range(2)]
+        dres = [torch.empty_like(dx[i]) if ctx.has_res else None for i in range(2)]
+        wsb = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x1.device)
+        # the pair entry shares ``accumulate``: both problems into their sinks, or both into fresh tensors
+        both_sinks = ctx.sinks[0] is not None and ctx.sinks[1] is not None
+        tgt = []
+        for i in range(2):
+            if both_sinks:
+                tgt.append((ctx.sinks[i][0]._mm_sink, ctx.sinks[i][1]._mm_sink))
+            else:
+                tgt.append((torch.empty(C, dtype=F32, device=x1.device), torch.empty(C, dtype=F32, device=x1.device)))
+        args = [_lib.Bn2dBwdArgs(ptr(xs[i]), ldx[i], ptr(dys[i]), lddy[i], ptr(dy2s[i]), lddy2[i], ptr(ymask[i]), ldy[i], ptr(ws_[i]), ptr(bs[i]),
+                                 ptr(sts[i][0]), ptr(sts[i][1]), ptr(dx[i]), C, ptr(dres[i]), C, ptr(tgt[i][0]), ptr(tgt[i][1])) for i in range(2)]
+        check(L.mm_bn2d_bwd_pair(ctx.hd.h, C_.byref(args[0]), C_.byref(args[1]), 1 if ctx.relu else 0, N, ctx.Ns, C, 1 if both_sinks else 0,
+                                 ptr(wsb), wsb.numel(), stream()), "bn2d_bwd_pair")
+        dw, db = [None, None], [None, None]
+        for i in range(2):
+            if both_sinks:
+                gradsink.done(ctx.sinks[i][0])
+                gradsink.done(ctx.sinks[i][1])
+            elif ctx.sinks[i] is not None:  # only one of the two has a sink: add its fresh gradient there by hand
+                ctx.sinks[i][0]._mm_sink.add_(tgt[i][0])
+                ctx.sinks[i][1]._mm_sink.add_(tgt[i][1])
+                gradsink.done(ctx.sinks[i][0])
+                gradsink.done(ctx.sinks[i][1])
+            else:
+                dw[i], db[i] = tgt[i]
+            if dres[i] is not None and ctx.res_handoffs[i] is not None:
+                ctx.res_handoffs[i].extra.append(dres[i])
+                dres[i] = None
+        return dx[0], dx[1], dres[0], dres[1], dw[0], dw[1], db[0], db[1], None, None
+
+
+def bn_pair(m1, m2, x1, x2, res1=None, res2=None, out1=None, out2=None, residual_shared=False):
+    """(m1(x1, res1, out1), m2(x2, res2, out2)) for the same BatchNorm2d layer of the two encoders - one launch where the library can
+    (``_BN2dPairFn``), else two calls."""
+    ok = (BN_PAIR[0] and not fp32_mode() and isinstance(m1, BatchNorm2d) and isinstance(m2, BatchNorm2d) and m1.training and m2.training
+          and m1.track_running_stats and m2.track_running_stats and m1.affine and m2.affine and x1.is_cuda and x2.is_cuda
+          and x1.shape == x2.shape and (res1 is None) == (res2 is None) and bool(m1.relu) == bool(m2.relu)
+          and float(m1.eps) == float(m2.eps) and m1.momentum == m2.momentum
+          and getattr(x1, "_mm_stats", None) is None and getattr(x2, "_mm_stats", None) is None)
+    if not ok:
+        return (m1(x1, res1, out=out1, residual_shared=residual_shared), m2(x2, res2, out=out2, residual_shared=residual_shared))
+    cfgs = []
+    track = torch.is_grad_enabled() and x1.requires_grad and x2.requires_grad
+    for m, res, out in ((m1, res1, out1), (m2, res2, out2)):
+        cfgs.append(dict(running_mean=m.running_mean, running_var=m.running_var, eps=float(m.eps),
+                         momentum=float(m.momentum if m.momentum is not None else 0.1), relu=bool(m.relu), nbt=m.num_batches_tracked,
+                         out=[out] if out is not None else None, handoff=GradHandoff() if track else None,
+                         res_handoff=getattr(res, "_mm_handoff", None) if (track and res is not None and residual_shared) else None))
+    y1, y2 = _BN2dPairFn.apply(x1, x2, res1, res2, m1.weight, m2.weight, m1.bias, m2.bias, cfgs[0], cfgs[1])
+    for y, c in ((y1, cfgs[0]), (y2, cfgs[1])):
+        if c["handoff"] is not None:
+            y._mm_handoff = c["handoff"]
+    return y1, y2
 
 
 class BatchNorm2d(nn.BatchNorm2d):

@@ -490,13 +490,17 @@ def test_batchnorm_from_epilogue_statistics_matches_the_statistics_pass(split, h
         assert d < (2e-1 if half2d == torch.bfloat16 else 5e-2) and cos > (0.98 if half2d == torch.bfloat16 else 0.998), (n, d, cos)
 
 
+@pytest.mark.parametrize("bn_pairs", [False, True])
 @pytest.mark.parametrize("split", [False, True])
-def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, half2d):
+def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, bn_pairs, half2d):
     """net2d.backbone_pair: layers 2-4 of the RGB and of the depth encoder in lockstep, each pair of 3x3 stride-1 convolutions (and of
     their data gradients) as ONE launch over both problems (mm_conv2d_3x3s1_pair).  A work item computes what it computed before -
     only which workgroup runs it changes - so features, running statistics and every data gradient are bit-identical with the
     one-after-the-other walk (MM_CONV_PAIR=0), with and without per-domain statistics groups; the paired weight gradients
-    (mm_conv2d_wgrad3x3_pair) add the same products over other pixel splits."""
+    (mm_conv2d_wgrad3x3_pair) add the same products over other pixel splits.
+    ``bn_pairs``: the batch norms of the pairs as one single-launch kernel too (mm_bn2d_fwd_train_pair / mm_bn2d_bwd_pair): half the
+    workgroups per problem, so the batch statistics are summed in another order - the same mathematics to rounding, compared with
+    the bounds of two 16-bit pipelines whose statistics differ in the last bits."""
     import copy
 
     import mm2d3d_amd.conv2d as c2d
@@ -512,9 +516,12 @@ def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, half2d):
     img, hints = torch.randn(4, 3, 64, 96, device=dev), torch.randn(4, 1, 64, 96, device=dev)
     projs = None
 
+    from mm2d3d_amd import nn2d
+
     def run(a, b, pair):
         nonlocal projs
         was, c2d.PAIR[0] = c2d.PAIR[0], pair
+        was_bn, nn2d.BN_PAIR[0] = nn2d.BN_PAIR[0], bn_pairs and pair
         try:
             with domains.split(2 if split else None):
                 fa, fb = backbone_pair(a, b, img, hints)
@@ -523,10 +530,26 @@ def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, half2d):
             sum((t.float() * p).sum() for t, p in zip(fa + fb, projs)).backward()
         finally:
             c2d.PAIR[0] = was
+            nn2d.BN_PAIR[0] = was_bn
         return fa + fb
 
     f1, f0 = run(r, d, True), run(r0, d0, False)
     assert len(f1) == 10
+    if bn_pairs:
+        tol = 2e-2 if half2d == torch.bfloat16 else 3e-3
+        for a, b in zip(f1, f0):
+            assert float((a.detach().float() - b.detach().float()).abs().max()) <= tol * float(b.detach().float().abs().max())
+        for m1, m0 in ((r, r0), (d, d0)):
+            for (n, a), (_, b) in zip(m1.state_dict().items(), m0.state_dict().items()):
+                if "num_batches" in n:
+                    assert int(a) == int(b), n
+                else:
+                    assert float((a.float() - b.float()).abs().max()) <= 1e-5 * max(1.0, float(b.float().abs().max())), n
+            for (n, a), (_, b) in zip(m1.named_parameters(), m0.named_parameters()):
+                dd = float((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-12))
+                cos = float((a.grad * b.grad).sum() / (a.grad.norm() * b.grad.norm()).clamp_min(1e-20))
+                assert dd < (2e-1 if half2d == torch.bfloat16 else 5e-2) and cos > (0.98 if half2d == torch.bfloat16 else 0.998), (n, dd, cos)
+        return
     for a, b in zip(f1, f0):
         assert torch.equal(a, b)
     for m1, m0 in ((r, r0), (d, d0)):
