@@ -80,7 +80,15 @@ class BasicBlock(nn.Module):
         launch each (nn2d.conv_pair): same arithmetic, the persistent kernel's last round shared between the two."""
         if not (b1._fused and b2._fused) or nn2d.fp32_mode():
             return b1(x1, out=out1), b2(x2, out=out2)
-        id1, id2 = b1._identity(x1), b2._identity(x2)
+        if (b1.downsample is not None and b2.downsample is not None and len(b1.downsample) == 2 and len(b2.downsample) == 2
+                and isinstance(b1.downsample[0], nn2d.Conv2d) and isinstance(b2.downsample[0], nn2d.Conv2d) and torch.is_grad_enabled()
+                and getattr(x1, "_mm_handoff", None) is not None and getattr(x2, "_mm_handoff", None) is not None):
+            # the 1x1 downsample convolutions one after the other (implicit GEMM, handing their data gradients to the inputs'
+            # producers as in _identity), their batch norms as a pair
+            id1, id2 = nn2d.bn_pair(b1.downsample[1], b2.downsample[1], b1.downsample[0](x1, handoff=x1._mm_handoff),
+                                    b2.downsample[0](x2, handoff=x2._mm_handoff))
+        else:
+            id1, id2 = b1._identity(x1), b2._identity(x2)
         c1, c2 = nn2d.conv_pair(b1.conv1, b2.conv1, x1, x2)
         y1, y2 = nn2d.bn_pair(b1.bn1, b2.bn1, c1, c2)
         c1, c2 = nn2d.conv_pair(b1.conv2, b2.conv2, y1, y2)
