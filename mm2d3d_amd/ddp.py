@@ -36,11 +36,22 @@ class _Bucket:
 
 
 class GradAllReducer:
-    def __init__(self, optimizers, process_group=None, bucket_bytes=64 << 20, overlap=True, tail_bytes=8 << 20, force=None):
+    def __init__(self, optimizers, process_group=None, bucket_bytes=64 << 20, overlap=None, tail_bytes=8 << 20, force=None):
         """``force`` (default: MM_DDP_FORCE=1 in the environment): run the whole bucket / hook / collective machinery also in a
         world of ONE rank - the only way to execute the RCCL path on a one-GPU box (a one-rank all-reduce is still an RCCL
-        launch on RCCL's stream beside the backward pass)."""
+        launch on RCCL's stream beside the backward pass).
+
+        ``overlap`` (default: MM_DDP_OVERLAP, "0"): True = buckets go out from the backward hooks, beside the rest of backward - the
+        backward batch norms must then leave their single-launch (grid-barrier) kernels, +2.8 ms per 36.3 ms step on one MI355X
+        (profiles/r04/bench_n1_bn_as_under_ddp.json).  False = every bucket goes out in ``finish()``, after backward: the
+        collectives never share the GPU with a grid barrier, every batch norm keeps its single-launch kernel, and what is paid
+        instead is the exposed all-reduce of the 196 MB of fp32 gradients - 1.0-1.7 ms by the link arithmetic of DESIGN.md
+        section 6 (8 / 4 / 2 GPUs).  The cheaper of the two by that arithmetic is the default; no multi-GPU node was available to
+        measure either (MM_DDP_OVERLAP=1 selects the overlapped form)."""
         import os
+
+        if overlap is None:
+            overlap = os.environ.get("MM_DDP_OVERLAP", "0") != "0"
 
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -66,6 +77,8 @@ class GradAllReducer:
         self.bn_path = "as configured (no data-parallel group)"  # which batch-norm kernels run beside the collectives (bench line)
         if not self.active:
             return
+        if not overlap:
+            self.bn_path = "as configured: single-launch in both directions (collectives after backward, MM_DDP_OVERLAP=0)"
         if overlap and torch.cuda.is_available():
             # The single-launch batch-norm kernels (csrc/bn2d.hip, csrc/bn.hip) hold a grid barrier: every workgroup of the launch
             # must be resident at once.  BACKWARD runs beside the bucket all-reduces, whose kernels hold CUs for the length of a

@@ -52,12 +52,13 @@ def test_forced_one_rank_rccl_step_equals_the_plain_step_bit_for_bit(monkeypatch
         loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
         tk = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False, bn2d_fused=0, bn3d_fused=0)  # both trainers' handles on the three-kernel batch norms (what DDP selects)
         monkeypatch.setenv("MM_DDP_FORCE", "1")
+        monkeypatch.setenv("MM_DDP_OVERLAP", "1")  # buckets launched from the backward hooks, beside the rest of backward
         ddp = TrainModel({"2d_net": n2, "3d_net": n3}, opts(), loss, dict(tk))
         ddp.configure_optimizers()
         monkeypatch.setenv("MM_DDP_FORCE", "0")
         plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, opts(), loss, dict(tk))
         plain.configure_optimizers()
-        assert ddp.reducer.active and len(ddp.reducer.buckets) >= 2 and not plain.reducer.active
+        assert ddp.reducer.active and ddp.reducer.overlap and len(ddp.reducer.buckets) >= 2 and not plain.reducer.active
         for step in range(4):
             la, lb = ddp.fit_step(mk()), plain.fit_step(mk())
             torch.cuda.synchronize()
@@ -76,12 +77,15 @@ def test_forced_one_rank_rccl_step_equals_the_plain_step_bit_for_bit(monkeypatch
         pass
 
 
-def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_batch_norms_single_launch(monkeypatch):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_batch_norms_single_launch(monkeypatch, overlap):
     """under data parallelism (i) no host synchronisation inside ``fit_step`` - ``Tensor.item`` / ``.cpu`` /
     ``.tolist`` / ``bool(tensor)`` / ``torch.cuda.synchronize`` are booby-trapped from the third step on (the collective "graph
     changed" flag is read one step late from pinned memory, ddp._read_flag); (ii) the forward batch norms stay on the single-launch
     kernels (no collective runs beside the forward pass: stream order), the backward ones take the three-kernel path; (iii) the
-    losses follow the plain trainer's (whose backward uses the single-launch kernels: other summation order, same mathematics)."""
+    losses follow the plain trainer's (whose backward uses the single-launch kernels: other summation order, same mathematics).
+    ``overlap`` False (the default, MM_DDP_OVERLAP=0): every bucket goes out in finish(), after backward - no collective beside a
+    grid barrier, so every batch norm keeps its single-launch kernel and the step is the plain trainer's step bit for bit."""
     import copy
 
     from mm2d3d_amd import _lib
@@ -117,13 +121,22 @@ def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_bat
         tk = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False)
         monkeypatch.setenv("MM_DDP_FORCE", "1")
         monkeypatch.delenv("MM_DDP_BN_FUSED", raising=False)
+        if overlap:
+            monkeypatch.setenv("MM_DDP_OVERLAP", "1")
+        else:
+            monkeypatch.delenv("MM_DDP_OVERLAP", raising=False)
         ddp = TrainModel({"2d_net": n2, "3d_net": n3}, opts(), loss, dict(tk))
         ddp.configure_optimizers()
         monkeypatch.setenv("MM_DDP_FORCE", "0")
         plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, opts(), loss, dict(tk))
         plain.configure_optimizers()
-        assert ddp.reducer.active and ddp.reducer.bn_path == "forward single-launch, backward three-kernel"
-        assert ddp.handle.get(_lib.OPT_BN2D_FUSED) == 1 and ddp.handle.get(_lib.OPT_BN3D_FUSED) == 1
+        assert ddp.reducer.active and ddp.reducer.overlap == overlap
+        if overlap:
+            assert ddp.reducer.bn_path == "forward single-launch, backward three-kernel"
+            assert ddp.handle.get(_lib.OPT_BN2D_FUSED) == 1 and ddp.handle.get(_lib.OPT_BN3D_FUSED) == 1
+        else:
+            assert "single-launch in both directions" in ddp.reducer.bn_path
+            assert ddp.handle.get(_lib.OPT_BN2D_FUSED) == 3 and ddp.handle.get(_lib.OPT_BN3D_FUSED) == 3
         assert plain.handle.get(_lib.OPT_BN2D_FUSED) == 3
 
         def trap(name, orig=None):
@@ -149,7 +162,11 @@ def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_bat
             torch.cuda.synchronize()
             losses.append((float(la), float(lb)))
         for step, (a, b) in enumerate(losses):
-            assert abs(a - b) <= 2e-3 * abs(b), (step, a, b)
+            assert (abs(a - b) <= 2e-3 * abs(b)) if overlap else (a == b), (step, a, b)
+            if not overlap and step >= 1:
+                pass
+        if not overlap:
+            assert ddp.reducer.stats["early"] == 0 and ddp.reducer.stats["buckets"] == len(ddp.reducer.order)
         assert ddp.reducer.drain_flag() is False
     finally:
         dist.destroy_process_group()
