@@ -350,8 +350,8 @@ def pairable(x1, x2, w1, w2):
     if not PAIR[0] or x1.shape != x2.shape or w1.shape != w2.shape or tuple(w1.shape[2:]) != (3, 3):
         return False
     cout, cin = w1.shape[0], w1.shape[1]
-    if cin % 64 or cout % 64 or (cin == 64 and cout == 64):
-        return False
+    if cin % 64 or cout % 64:  # (64 -> 64: forward and data gradients stay single launches of the weights-resident kernel, the
+        return False           # weight gradients are paired)
     for x in (x1, x2):
         B, C, H, W = x.shape
         if x.dtype != HALF[0] or x.stride() != (H * W * C, 1, W * C, C) or x.data_ptr() % 16:
@@ -375,8 +375,13 @@ class Conv2dPairFn(torch.autograd.Function):
             nf = _stat_group_split(Bn)
             rows = int(lib2d().mm_conv2d_3x3s1_stat_rows(Bn, H, W))
             slabs = [_stat_slab(h, rows, Cout, nf, Bn, x1.device) for h in (stats1, stats2)]
-        check(lib2d().mm_conv2d_3x3s1_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(y[0]), ptr(y[1]), Cout, Cout, ptr(Wp[0]), ptr(Wp[1]),
-                                           0 | WHOLE_ITEMS[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
+        if Cin == 64 and Cout == 64:  # k_conv3x3r keeps ONE problem's weights resident in LDS: two launches
+            for i, x in enumerate((x1, x2)):
+                check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, Cin, ptr(y[i]), Cout, Cout, ptr(Wp[i]), None, 0 | WHOLE_ITEMS[0],
+                                              ptr(slabs[i]), nf, stream()), "conv2d_3x3s1")
+        else:
+            check(lib2d().mm_conv2d_3x3s1_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(y[0]), ptr(y[1]), Cout, Cout, ptr(Wp[0]), ptr(Wp[1]),
+                                               0 | WHOLE_ITEMS[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
         ctx.save_for_backward(x1, x2, wf[0], wf[1])
         ctx.owners = (w1, w2)
         ctx.wparams = tuple(w if gradsink.claim(ctx, w, ctx.needs_input_grad[2 + i]) else None for i, w in enumerate((w1, w2)))

@@ -10,6 +10,8 @@ BasicBlock stack [3,4,6,3] is built here.  Recorded parity decisions (SURVEY.md 
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -176,10 +178,13 @@ class Backbone(nn.Module):
         return feats
 
 
+PAIR_LAYER1 = [os.environ.get("MM_PAIR_LAYER1", "1") != "0"]  # layer1 in lockstep too (its weight gradients pair): A/B switch
+
+
 def backbone_pair(r, d, img, hints, outs_r=None, outs_d=None, pad_to=None):
     """(r(img, outs_r, pad_to), d(hints, outs_d, pad_to)) with layers 2-4 of the two encoders walked in lockstep, each pair of
-    3x3 stride-1 convolutions in one launch (BasicBlock.forward_pair).  The stems and layer1 (64 -> 64: weights-resident kernel,
-    thousands of work items per layer) run one after the other as before.  Dropout draws in the order r.l3, d.l3, r.l4, d.l4."""
+    3x3 stride-1 convolutions in one launch (BasicBlock.forward_pair).  The stems run one after the other; layer1 (64 -> 64:
+    weights-resident kernel, thousands of work items per layer) is walked in lockstep for its weight gradients' sake only.  Dropout draws in the order r.l3, d.l3, r.l4, d.l4."""
     if not (r._fused and d._fused) or nn2d.fp32_mode() or not nn2d._c2d.PAIR[0]:
         return r(img, outs=outs_r, pad_to=pad_to), d(hints, outs=outs_d, pad_to=pad_to)
     o_r = (list(outs_r) + [None] * 3)[:3] if outs_r is not None else [None] * 3
@@ -189,9 +194,7 @@ def backbone_pair(r, d, img, hints, outs_r=None, outs_d=None, pad_to=None):
     for net, x, o, feats in ((r, img, o_r, fr), (d, hints, o_d, fd)):
         x = net.bn1(net.conv1(x, pad_to=pad_to) if pad_to is not None else net.conv1(x), out=o[0])
         feats.append(x)
-        x = Backbone._run(net.layer1, net.maxpool(x), o[1])
-        feats.append(x)
-        xs.append(x)
+        xs.append(net.maxpool(x))
     xr, xd = xs
 
     def run_pair(lr, ld, xr, xd, out_r, out_d):
@@ -201,6 +204,13 @@ def backbone_pair(r, d, img, hints, outs_r=None, outs_d=None, pad_to=None):
             xr, xd = BasicBlock.forward_pair(b1, b2, xr, xd, out_r if last else None, out_d if last else None)
         return xr, xd
 
+    # layer1 (64 -> 64): the convolutions and data gradients stay single launches (weights-resident kernel), their weight gradients
+    # pair (half the partial slabs per problem); its 75 MB maps are too large for a batch-norm pair (the library runs them singly)
+    if PAIR_LAYER1[0]:
+        xr, xd = run_pair(r.layer1, d.layer1, xr, xd, o_r[1], o_d[1])
+    else:
+        xr, xd = Backbone._run(r.layer1, xr, o_r[1]), Backbone._run(d.layer1, xd, o_d[1])
+    fr.append(xr), fd.append(xd)
     xr, xd = run_pair(r.layer2, d.layer2, xr, xd, o_r[2], o_d[2])
     fr.append(xr), fd.append(xd)
     xr, xd = run_pair(r.layer3, d.layer3, xr, xd, None, None)
