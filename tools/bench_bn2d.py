@@ -20,6 +20,7 @@ def step_shapes(dev):
     from mm2d3d_amd import nn2d
     from mm2d3d_amd.synthetic import make_batch
 
+    nn2d.BN_PAIR[0] = False  # every layer through _BN2dFn, one problem per call: this tool times the layers singly
     tm = bench.build_trainer(dev)
     batch = {"source": make_batch(2, 8, "nuscenes", (302, 480), 6, device=dev, augment=True),
              "target": make_batch(3, 8, "nuscenes", (302, 480), 6, device=dev, augment=True)}
