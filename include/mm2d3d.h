@@ -361,6 +361,13 @@ int mm_conv2d_gemm(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* 
 /* ``addend`` (16-bit output only): a 16-bit map of the output's shape (pixel pitch ld_add) added to the result, element by element
  * as an add of the two maps would - the second gradient contribution of a map with two consumers (a BasicBlock input read by conv1
  * and by the 1x1 downsample; the decoder's concat slice) joins here instead of in an add kernel. */
+/* The data gradient of a STRIDE-2 convolution (k = 1 or 3; EXP/2d_net/backbones.py layer2-4.0: conv1 and the 1x1 downsample) by output
+ * parity: an input pixel of parity (py, px) receives only the taps with kh = py + pad, kw = px + pad (mod 2) - 1 + 2 + 2 + 4 of a 3x3
+ * filter's nine, 1 + 0 + 0 + 0 of a 1x1's - so the four parities run as four tap windows of one launch instead of every tap for
+ * every pixel with three quarters of them multiplying zeros (mm_conv2d_gemm with fr = 2).  dY [B,Ho,Wo,Cout] (pitch ldy), dX
+ * [B,H,W,Cin] (pitch ldx; H, W even), Wd [Cin][k*k][Cout]; addend as in mm_conv2d_gemm.  Bit-identical with the generic form. */
+int mm_conv2d_dgrad_s2(const void* dY, int B, int Ho, int Wo, int Cout, int ldy, void* dX, int H, int W, int Cin, int ldx, const void* Wd,
+                       int k, int pad, const void* addend, int ld_add, mm_stream_t stream);
 /* BatchNorm statistics in the epilogue (``stats`` non-NULL; 16-bit output only): the convolution also files, per 64-pixel
  * sub-block of its output and per statistics group, the per-channel sum and sum of squares of the ROUNDED outputs in
  *     stats[2 * sub + g][q][Cn] fp32   (q = 0: sum, 1: sum of squares; rows = mm_conv2d_gemm_stat_rows / _3x3s1_stat_rows)
@@ -495,6 +502,8 @@ int mm_conv2d_gemm_f16(const void* A, int B, int Hi, int Wi, int Ca, int lda, vo
                    int out_f32, int Hg, int Wg, int so, int ooy, int oox, int sa, int fr, int ntaps, const int* ty,
                    const int* tx, const void* Wp, int nz, int64_t wz, int zpar, const float* bias, float* stats,
                    int64_t split_m, const void* addend, int ld_add, mm_stream_t stream);
+int mm_conv2d_dgrad_s2_f16(const void* dY, int B, int Ho, int Wo, int Cout, int ldy, void* dX, int H, int W, int Cin, int ldx, const void* Wd,
+                       int k, int pad, const void* addend, int ld_add, mm_stream_t stream);
 int64_t mm_conv2d_gemm_stat_rows_f16(int64_t M, int nz);
 int64_t mm_conv2d_3x3s1_stat_rows_f16(int B, int H, int W);
 int mm_conv2d_3x3s1_f16(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,

@@ -110,6 +110,7 @@ _PROTOS = {
                              vp, i32, i64, i32, vp, vp, i64, vp, i32, vp]),
     "mm_conv2d_3x3s1": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, vp, i32, vp, i32, vp]),
     "mm_conv2d_3x3s1_pair": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, i32, vp, vp, i32, vp]),
+    "mm_conv2d_dgrad_s2": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, i32, vp]),
     "mm_conv2d_gemm_stat_rows": (i64, [i64, i32]),
     "mm_conv2d_3x3s1_stat_rows": (i64, [i32, i32, i32]),
     "mm_conv2d_wgrad_ws_bytes": (sz, [i64, i32, i32, i32]),
@@ -165,6 +166,7 @@ class HipLibraryMissing(RuntimeError):
 # the dense 2D kernels built for IEEE fp16 storage (csrc/h16.h): same prototypes under the suffix _f16
 H16_2D = {
     "mm_conv2d_gemm": "mm_conv2d_gemm_f16",
+    "mm_conv2d_dgrad_s2": "mm_conv2d_dgrad_s2_f16",
     "mm_conv2d_3x3s1": "mm_conv2d_3x3s1_f16",
     "mm_conv2d_3x3s1_pair": "mm_conv2d_3x3s1_pair_f16",
     "mm_conv2d_gemm_stat_rows": "mm_conv2d_gemm_stat_rows_f16",

@@ -316,7 +316,12 @@ class Conv2dFn(torch.autograd.Function):
                         if cand.data_ptr() == e.data_ptr():  # usable as it lies (no copy was needed)
                             ctx.handoff.extra.pop()
                             add, ld_add = cand, cld
-                _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd, lda=ldy, addend=add, ld_add=ld_add)
+                if DGRAD_S2[0] and stride == 2 and KH in (1, 3) and H % 2 == 0 and W % 2 == 0:
+                    # by output parity: only the taps that reach a pixel (csrc/conv2d.hip mm_conv2d_dgrad_s2), same sums
+                    check(lib2d().mm_conv2d_dgrad_s2(ptr(dy), Bn, Ho, Wo, Cout, ldy, ptr(dx), H, W, Cin, Cin, ptr(Wd), KH, padding, ptr(add),
+                                                     ld_add, stream()), "conv2d_dgrad_s2")
+                else:
+                    _gemm(dy, Bn, Ho, Wo, Cout, dx, H, W, Cin, H, W, 1, 1, stride, ty, tx, Wd, lda=ldy, addend=add, ld_add=ld_add)
         if ctx.needs_input_grad[1]:
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]
             tx = [kw - padding for _ in range(KH) for kw in range(KW)]
@@ -341,6 +346,7 @@ class Conv2dFn(torch.autograd.Function):
 
 # Two 3x3 convolutions of one shape in ONE launch (mm_conv2d_3x3s1_pair): the same layer of the RGB and of the depth backbone.
 # MM_CONV_PAIR=0: two launches (A/B).
+DGRAD_S2 = [_os.environ.get("MM_CONV_DGRAD_S2", "1") != "0"]  # stride-2 data gradients by output parity (A/B switch)
 PAIR = [_os.environ.get("MM_CONV_PAIR", "1") != "0"]
 PAIR_WGRAD = [_os.environ.get("MM_CONV_PAIR_WGRAD", "1") != "0"]  # the pairs' weight gradients in one launch too
 

@@ -46,6 +46,14 @@ struct ConvP {
   int64_t split_m;  // GEMM rows [0, split_m) are statistics group 0, the others group 1
   const u16* addend;  // 16-bit map of the output's shape added (in fp32) before the rounding, or NULL: a second gradient
   int ld_add;         // contribution of the same map summed here instead of by an add kernel (pixel pitch ld_add)
+  // Tap windows per blockIdx.z (mm_conv2d_dgrad_s2: the data gradient of a stride-2 convolution by OUTPUT PARITY - an input pixel
+  // of parity (py, px) receives only the taps with kh = py + pad, kw = px + pad (mod 2): 1 + 2 + 2 + 4 of the 9 taps of a 3x3
+  // filter, 1 + 0 + 0 + 0 of a 1x1; walking all taps for every pixel, as the generic form with fr = 2 does, multiplies zeros three
+  // quarters of the time).  zwin != 0: launch z walks taps [zt0[z], zt0[z] + znt[z]) of the list; wt[t] = that tap's index in the
+  // packed weight tensor (wtaps taps per row).
+  int zwin, wtaps;
+  short zt0[4], znt[4];
+  short wt[MAXT];
 };
 
 __device__ __attribute__((aligned(16))) const unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};  // source of padding chunks
@@ -167,7 +175,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
     }
   }
   const int kcn = p.Ca >> 6;
-  const int nsteps = p.ntaps * kcn;
+  const int tap0 = p.zwin ? p.zt0[z] : 0;
+  const int nsteps = (p.zwin ? p.znt[z] : p.ntaps) * kcn;
 
   // Lane-constant parts of the staging addresses, computed once (the per-step instruction stream between the barrier
   // and the MFMAs is what bounds these short-K kernels): for fr == 1 the source pixel of (row, tap) is
@@ -191,14 +200,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 #pragma unroll
   for (int i = 0; i < NBI; i++) {
     const int row = r0 + 32 * i;
-    wbase[i] = n0 + row < p.Cn ? Wz + (int64_t)(n0 + row) * p.ntaps * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3) : nullptr;
+    wbase[i] = n0 + row < p.Cn ? Wz + (int64_t)(n0 + row) * p.wtaps * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3) : nullptr;
   }
 
   // Stage tile s into LDS buffer `buf` with LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write.
   // One wave-instruction writes 1 KiB = 8 consecutive 128-B rows linearly, so the bank swizzle is applied to the
   // SOURCE chunk (lane (row, pc) fetches chunk pc ^ ((row>>1)&7)) and again on the fragment reads below.
   auto issue = [&](int s, int buf) {
-    const int tap = s / kcn, kc = s - tap * kcn;
+    const int tl = s / kcn, kc = s - tl * kcn, tap = tap0 + tl;
     const int ty = p.ty[tap], tx = p.tx[tap];
     if (p.fr == 1) {
       const int64_t toff = ((int64_t)ty * p.Wi + tx) * p.lda + kc * 64;
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
                                          0, 0);
       }
     }
-    const int woff = tap * p.Ca + kc * 64;
+    const int woff = p.wt[tap] * p.Ca + kc * 64;
 #pragma unroll
     for (int i = 0; i < NBI; i++) {
       const u16* g = wbase[i] ? wbase[i] + woff : (const u16*)g_zero16;
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_gemm(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  issue(0, 0);
+  if (nsteps > 0) issue(0, 0);  // (a parity without taps: the epilogue writes the addend / zeros)
   const int fr_ = lane & 31, fh = lane >> 5;
   for (int s = 0; s < nsteps; s++) {
     const int buf = s & (p.nbuf - 1);
@@ -1527,16 +1536,48 @@ __global__ __launch_bounds__(256) void k_stem_prep(const float* __restrict__ in,
 int fill_taps(ConvP* p, const int* ty, const int* tx, int nt) {
   if (nt > MAXT) return -1;
   p->ntaps = nt;
+  p->wtaps = nt;
+  p->zwin = 0;
   for (int i = 0; i < nt; i++) {
     p->ty[i] = (short)ty[i];
     p->tx[i] = (short)tx[i];
+    p->wt[i] = (short)i;
   }
+  for (int i = 0; i < 4; i++) p->zt0[i] = p->znt[i] = 0;
   return 0;
 }
 
 }  // namespace
 
 extern "C" {
+
+// launches k_conv_gemm for a filled ConvP; steps_max = the most (tap, 64-channel chunk) steps a workgroup walks
+static int gemm_launch(ConvP p, int nz, int steps_max, hipStream_t s) {
+  const int B = p.B, Hg = p.Hg, Wg = p.Wg, Cn = p.Cn;
+  const int64_t M = (int64_t)B * Hg * Wg;
+  if (M == 0) return MM_OK;
+  MM_CHECK_ARG(M < (1ll << 31), "conv2d_gemm: too many output pixels for 32-bit pixel indices");
+  // Short K (1x1 layers, the stems, the transposed convolutions: <= 4 steps of 64 channels) with 64 output channels: these
+  // launches are bound by load latency, not by MFMA time; one stage buffer (24 KB) lets five workgroups share a CU instead of
+  // three, which hides more of it than the one-step prefetch did (18240-tile stems 269 -> 231 us, 4560x4 transposed conv 441 -> 385).
+  {
+    constexpr int single_max = 4;
+    p.nbuf = (steps_max <= single_max && (Cn <= 64 || steps_max == 1)) ? 1 : 2;
+  }
+  if (Cn <= 64) {
+    size_t lds = (size_t)p.nbuf * (128 * 64 + 64 * 64) * 2;
+    hipLaunchKernelGGL(k_conv_gemm<64>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 64), nz), dim3(256), lds, s, p);
+  } else {
+    size_t lds = (size_t)p.nbuf * (128 * 64 + 128 * 64) * 2;
+    static unsigned once = 0;  // per-device bit: see mm_attr_todo (common.h)
+    if (mm_attr_todo(&once)) {
+      MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (128 * 64 + 128 * 64) * 2)));
+    }
+    hipLaunchKernelGGL(k_conv_gemm<128>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 128), nz), dim3(256), lds, s, p);
+  }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
 
 // Generic implicit GEMM (see ConvP).  ty/tx: host arrays of ntaps tap offsets.
 int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda, void* O, int Ho, int Wo, int Cn, int ldo,
@@ -1561,29 +1602,48 @@ int MM_SYM(mm_conv2d_gemm)(const void* A, int B, int Hi, int Wi, int Ca, int lda
     mm_set_error("conv2d_gemm: too many taps");
     return MM_ERR_ARG;
   }
-  const int64_t M = (int64_t)B * Hg * Wg;
-  if (M == 0) return MM_OK;
-  MM_CHECK_ARG(M < (1ll << 31), "conv2d_gemm: too many output pixels for 32-bit pixel indices");
-  // Short K (1x1 layers, the stems, the transposed convolutions: <= 4 steps of 64 channels) with 64 output channels: these
-  // launches are bound by load latency, not by MFMA time; one stage buffer (24 KB) lets five workgroups share a CU instead of
-  // three, which hides more of it than the one-step prefetch did (18240-tile stems 269 -> 231 us, 4560x4 transposed conv 441 -> 385).
-  {
-    constexpr int single_max = 4;
-    p.nbuf = (ntaps * (Ca / 64) <= single_max && (Cn <= 64 || ntaps * (Ca / 64) == 1)) ? 1 : 2;
-  }
-  if (Cn <= 64) {
-    size_t lds = (size_t)p.nbuf * (128 * 64 + 64 * 64) * 2;
-    hipLaunchKernelGGL(k_conv_gemm<64>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 64), nz), dim3(256), lds, s, p);
-  } else {
-    size_t lds = (size_t)p.nbuf * (128 * 64 + 128 * 64) * 2;
-    static unsigned once = 0;  // per-device bit: see mm_attr_todo (common.h)
-    if (mm_attr_todo(&once)) {
-      MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (128 * 64 + 128 * 64) * 2)));
+  return gemm_launch(p, nz, ntaps * (Ca / 64), s);
+}
+
+// The data gradient of a STRIDE-2 convolution (k x k, k = 1 or 3, padding pad; torch.nn.Conv2d of EXP/2d_net/backbones.py layer2-4.0:
+// conv1 3x3 / downsample 1x1) by output parity: dX[b][2 gy + py][2 gx + px][ci] = sum over the taps (kh, kw) with kh = py + pad,
+// kw = px + pad (mod 2) of dY[b][gy + (py + pad - kh) / 2][gx + (px + pad - kw) / 2][:] . Wd[ci][kh * k + kw][:].  Four launches-in-
+// one (blockIdx.z = parity) with 1 + 2 + 2 + 4 taps (3x3) or 1 + 0 + 0 + 0 (1x1) instead of all k x k taps for every pixel with three
+// quarters of them reading zeros (mm_conv2d_gemm with fr = 2).  H and W even.  Wd: [Cin][k*k][Cout] (the packed layout of every data
+// gradient here).  addend: see mm_conv2d_gemm.  Same sums in the same tap order per pixel: results identical to the generic form.
+int MM_SYM(mm_conv2d_dgrad_s2)(const void* dY, int B, int Ho, int Wo, int Cout, int ldy, void* dX, int H, int W, int Cin, int ldx, const void* Wd,
+                       int k, int pad, const void* addend, int ld_add, hipStream_t s) {
+  MM_CHECK_ARG(Cout % 64 == 0 && ldy % 8 == 0 && ((uintptr_t)dY % 16) == 0 && ((uintptr_t)Wd % 16) == 0, "conv2d_dgrad_s2: bad shape");
+  MM_CHECK_ARG((k == 1 || k == 3) && pad >= 0 && pad < k && H % 2 == 0 && W % 2 == 0 && Ho == (H + 2 * pad - k) / 2 + 1 &&
+                   Wo == (W + 2 * pad - k) / 2 + 1,
+               "conv2d_dgrad_s2: k must be 1 or 3, H and W even, (Ho, Wo) the stride-2 output size");
+  MM_CHECK_ARG(!addend || (Cin % 8 == 0 && ldx % 8 == 0 && ld_add % 8 == 0 && ((uintptr_t)dX % 16) == 0 && ((uintptr_t)addend % 16) == 0),
+               "conv2d_dgrad_s2: an addend needs channels and pitches multiples of 8, 16-byte aligned maps");
+  ConvP p;
+  p.A = (const u16*)dY; p.B = B; p.Hi = Ho; p.Wi = Wo; p.Ca = Cout; p.lda = ldy;
+  p.O = dX; p.Ho = H; p.Wo = W; p.Cn = Cin; p.ldo = ldx; p.out_f32 = 0;
+  p.Hg = H / 2; p.Wg = W / 2; p.so = 2; p.ooy = 0; p.oox = 0; p.sa = 1; p.fr = 1;
+  p.W = (const u16*)Wd; p.wz = 0; p.zpar = 1; p.bias = nullptr; p.stats = nullptr; p.split_m = 0;
+  p.addend = (const u16*)addend; p.ld_add = ld_add;
+  int nt = 0, most = 0;
+  for (int z = 0; z < 4; z++) {
+    const int py = z >> 1, px = z & 1;
+    p.zt0[z] = (short)nt;
+    for (int kh = 0; kh < k; kh++) {
+      if ((py + pad - kh) & 1) continue;
+      for (int kw = 0; kw < k; kw++) {
+        if ((px + pad - kw) & 1) continue;
+        p.ty[nt] = (short)((py + pad - kh) / 2);
+        p.tx[nt] = (short)((px + pad - kw) / 2);
+        p.wt[nt] = (short)(kh * k + kw);
+        nt++;
+      }
     }
-    hipLaunchKernelGGL(k_conv_gemm<128>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 128), nz), dim3(256), lds, s, p);
+    p.znt[z] = (short)(nt - p.zt0[z]);
+    if (p.znt[z] > most) most = p.znt[z];
   }
-  MM_LAUNCH_CHECK();
-  return MM_OK;
+  p.ntaps = nt; p.wtaps = k * k; p.zwin = 1;
+  return gemm_launch(p, 4, most * (Cout / 64), s);
 }
 
 // 3x3, stride 1, pad 1 convolution (flip = 0) or its data gradient (flip = 1; Wp packed as [ci][tap][co]).  NHWC bf16.

@@ -264,3 +264,34 @@ def test_conv_epilogue_files_batchnorm_statistics(kind, cin, cout, k, s, p, B, h
     assert torch.isfinite(got).all()
     scale = want.abs().amax(-1, keepdim=True).clamp_min(1e-6)
     assert float(((got - want).abs() / scale).max()) < 2e-6, float(((got - want).abs() / scale).max())
+
+
+@pytest.mark.parametrize("cin,cout,k,p,hw", [(64, 128, 3, 1, (20, 28)), (128, 256, 3, 1, (38, 60)), (64, 128, 1, 0, (20, 28)), (256, 512, 1, 0, (10, 14))])
+def test_stride2_data_gradient_by_output_parity_is_bit_identical_with_the_generic_form(cin, cout, k, p, hw, half2d):
+    """mm_conv2d_dgrad_s2: the data gradient of a stride-2 convolution as four tap windows (one per output parity) - the taps that
+    reach a pixel, in the same order, instead of all k x k with zeros in between: the same fp32 sums, bit for bit; also against
+    torch on the same 16-bit operands."""
+    import mm2d3d_amd.conv2d as c2d
+    from mm2d3d_amd.conv2d import Conv2dFn
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin + cout + k)
+    B, (H, W) = 3, hw
+    x = torch.randn(B, cin, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(cout, cin, k, k, generator=g) * (2.0 / (k * k * cin)) ** 0.5).to(dev)
+    gy = None
+    out = []
+    for mode in (True, False):
+        was, c2d.DGRAD_S2[0] = c2d.DGRAD_S2[0], mode
+        try:
+            y = Conv2dFn.apply(x, w, None, 2, p)
+            if gy is None:
+                gy = torch.randn(y.shape, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+            (gx,) = torch.autograd.grad(y, [x], gy)
+        finally:
+            c2d.DGRAD_S2[0] = was
+        out.append(gx)
+    assert torch.equal(out[0], out[1])
+    xr = x.detach().float().requires_grad_(True)
+    (gxr,) = torch.autograd.grad(F.conv2d(xr, w.to(half2d).float(), None, 2, p), [xr], gy.float())
+    assert float((out[0].float() - gxr).norm() / gxr.norm()) < 4e-3
