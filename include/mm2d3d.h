@@ -397,6 +397,14 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
 int mm_conv2d_wgrad3x3_pair(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1, int Cn,
                             int ldy, float* dW0, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
                             mm_stream_t stream);
+/* The 7x7 stride-1 stems (EXP/2d_net/backbones.py:23-25) on the staged image of mm_stem_prep: xb [B][Hb][Wb][8] with R = 8 / C image
+ * rows stacked per buffer pixel, T = ceil(7 / R) taps of 8 pixels x 8 slots, Wp [64][T][64]; output O [B][H][W][64] (pitch ldo).
+ * One persistent kernel with the weights resident in LDS and the RAW strip of a 16 x 16 tile staged once - the generic implicit GEMM
+ * fetched 128 bytes per output pixel and tap, 16 times the strip's bytes.  stats / split_b: BatchNorm statistics slab as for
+ * mm_conv2d_3x3s1, mm_conv2d_stem7_stat_rows(B, H, W) rows. */
+int64_t mm_conv2d_stem7_stat_rows(int B, int H, int W);
+int mm_conv2d_stem7(const void* xb, int B, int Hb, int Wb, int H, int W, int R, int T, void* O, int ldo, const void* Wp, float* stats,
+                    int split_b, mm_stream_t stream);
 /* stem input (EXP/2d_net/backbones.py:23-25, 7x7 stride-1 conv on 3 / 1 channels): NCHW fp32 -> zero-bordered NHWC8 bf16 */
 int mm_stem_prep(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, mm_stream_t stream);
 /* out[((z*N+n)*T+t)*K+k] = bf16(in[z*sz + n*sn + t*st + k*sk]) : fp32 master weights -> kernel layouts */
@@ -517,6 +525,9 @@ size_t mm_conv2d_wgrad_ws_bytes_f16(int64_t M, int Cn, int Ck, int ntaps);
 int mm_conv2d_wgrad_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
                     int64_t sk, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+int64_t mm_conv2d_stem7_stat_rows_f16(int B, int H, int W);
+int mm_conv2d_stem7_f16(const void* xb, int B, int Hb, int Wb, int H, int W, int R, int T, void* O, int ldo, const void* Wp, float* stats,
+                    int split_b, mm_stream_t stream);
 int mm_stem_prep_f16(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, mm_stream_t stream);
 int mm_pack_weights_f16(const float* in, void* out, int Z, int N, int T, int K, int64_t sz, int64_t sn, int64_t st,
                          int64_t sk, mm_stream_t stream);

@@ -124,6 +124,8 @@ _PROTOS = {
     "mm_colsum_f32": (i32, [vp, i32, i64, i32, vp, i32, vp]),
     "mm_pack_weights_bf16": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, vp]),
     "mm_pack_weights_bf16_batch": (i32, [vp, i32, i64, vp]),
+    "mm_conv2d_stem7_stat_rows": (i64, [i32, i32, i32]),
+    "mm_conv2d_stem7": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp, i32, vp]),
     "mm_stem_prep": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp]),
     "mm_bn2d_ws_bytes": (sz, [i32]),
     "mm_bn2d_fwd_train": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
@@ -179,6 +181,8 @@ H16_2D = {
     "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",
     "mm_conv2d_wgrad3x3_pair": "mm_conv2d_wgrad3x3_pair_f16",
     "mm_stem_prep": "mm_stem_prep_f16",
+    "mm_conv2d_stem7_stat_rows": "mm_conv2d_stem7_stat_rows_f16",
+    "mm_conv2d_stem7": "mm_conv2d_stem7_f16",
     "mm_pack_weights_bf16": "mm_pack_weights_f16",
     "mm_pack_weights_bf16_batch": "mm_pack_weights_f16_batch",
     "mm_bn2d_ws_bytes": "mm_bn2d_ws_bytes_f16",

@@ -346,6 +346,7 @@ class Conv2dFn(torch.autograd.Function):
 
 # Two 3x3 convolutions of one shape in ONE launch (mm_conv2d_3x3s1_pair): the same layer of the RGB and of the depth backbone.
 # MM_CONV_PAIR=0: two launches (A/B).
+STEM7 = [_os.environ.get("MM_CONV_STEM7", "1") != "0"]  # the 7x7 stems on their own kernel (A/B switch: 0 = generic implicit GEMM)
 DGRAD_S2 = [_os.environ.get("MM_CONV_DGRAD_S2", "1") != "0"]  # stride-2 data gradients by output parity (A/B switch)
 PAIR = [_os.environ.get("MM_CONV_PAIR", "1") != "0"]
 PAIR_WGRAD = [_os.environ.get("MM_CONV_PAIR_WGRAD", "1") != "0"]  # the pairs' weight gradients in one launch too
@@ -551,12 +552,20 @@ class StemConvFn(torch.autograd.Function):
         ty = [t * R for t in range(T)]
         # virtual activation: pixel pitch (lda) 8, 64 channels, Wi = Wb - 7 valid window starts; output (y,x) reads row y + t*R at x
         slab, split_m = None, 0
-        if stats is not None and bn_pre_wanted(img.device, Bn, H, W, Cout):
-            nf = _stat_group_split(Bn)
-            slab = _stat_slab(stats, int(L.mm_conv2d_gemm_stat_rows(Bn * H * W, 1)), Cout, nf, Bn, img.device)
-            split_m = nf * H * W
-        check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, T, _arr(ty),
-                               _arr([0] * T), ptr(Wp), 1, 0, 0, None, ptr(slab), split_m, None, 0, stream()), "conv2d_gemm(stem)")
+        if STEM7[0] and Cout == 64:
+            # the stems' own kernel (csrc/conv2d.hip k_stem7): weights resident, the raw strip of a tile staged once
+            nf = Bn
+            if stats is not None and bn_pre_wanted(img.device, Bn, H, W, Cout):
+                nf = _stat_group_split(Bn)
+                slab = _stat_slab(stats, int(L.mm_conv2d_stem7_stat_rows(Bn, H, W)), Cout, nf, Bn, img.device)
+            check(L.mm_conv2d_stem7(ptr(xb), Bn, Hb, Wb, H, W, R, T, ptr(y), Cout, ptr(Wp), ptr(slab), nf, stream()), "conv2d_stem7")
+        else:
+            if stats is not None and bn_pre_wanted(img.device, Bn, H, W, Cout):
+                nf = _stat_group_split(Bn)
+                slab = _stat_slab(stats, int(L.mm_conv2d_gemm_stat_rows(Bn * H * W, 1)), Cout, nf, Bn, img.device)
+                split_m = nf * H * W
+            check(L.mm_conv2d_gemm(ptr(xb), Bn, Hb, Wb, 64, 8, ptr(y), H, W, Cout, Cout, 0, H, W, 1, 0, 0, 1, 1, T, _arr(ty),
+                                   _arr([0] * T), ptr(Wp), 1, 0, 0, None, ptr(slab), split_m, None, 0, stream()), "conv2d_gemm(stem)")
         ctx.save_for_backward(xb)
         ctx.dims = (Bn, C, H, W, Cout, Hb, Wb, weight.shape)
         return y

@@ -988,6 +988,164 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   wait_vm<0>();  // the dummy halo of the tail is still in flight: drain before the LDS is released
 }
 
+// ------------------------------------------------------------------------------------------------ 7x7 stems
+// The two 7x7 stride-1 stems (EXP/2d_net/backbones.py:23-25) on the staged image of k_stem_prep: buffer pixel (y, x) holds 8 slots =
+// R = 8 / C vertically stacked rows of the C channels, and NT = ceil(7 / R) "taps" of 8 pixels x 8 slots = 64 virtual channels make
+// the filter (conv2d.py StemConvFn).  Through the generic implicit GEMM every output pixel fetched its own 128 bytes per tap -
+// neighbouring pixels' windows overlap in 7 of 8 pixels, so the RGB stem moved 1.2 GB of L2 -> LDS traffic for a 37 MB buffer and
+// ran at the LDS-DMA fill rate (209 us against 75 us for writing its 299 MB output).  Here (round 4): the raw STRIP of a 16 x 16
+// tile - 16 + (NT - 1) R rows of 23 buffer pixels, 16 bytes each - is staged once (<= 11 KB) and the MFMA pixel fragments are read
+// at shifted addresses (pixel x + j, row y + t R: one aligned 16-byte read per lane and 16-deep K slice); the <= 56 KB of weights
+// stay resident as in k_conv3x3r, whose item schedule, fragment layouts, epilogue and statistics option this kernel shares.
+// Strip rows are 32 pixels = 512 bytes apart: a multiple of 256, so the two image rows a ds_read_b128 lane group mixes (pixels
+// 0-3, 12-15 of one with 4-11 of the next) cover all 16 bank columns.  Two workgroups per CU.
+struct StemP {
+  const u16* xb;  // [B][Hb][Wb][8]
+  int B, Hb, Wb, H, W, R;
+  u16* O;  // [B][H][W][64] (pitch ldo)
+  int ldo;
+  const u16* Wp;  // [64][NT][64]
+  float* stats;
+  int split_b;
+  int tiles_y, tiles_x;
+};
+
+template <int NT>
+__global__ __launch_bounds__(512, 2) void k_stem7(StemP p) {
+  extern __shared__ __attribute__((aligned(16))) char smemc[];
+  constexpr int BSZB = 64 * 128;  // one tap's W tile [64 cout][64 k]
+  constexpr int HS0 = NT * BSZB;
+  constexpr int SRMAX = 16 + (NT - 1) * (NT == 1 ? 0 : (NT == 2 ? 4 : (NT == 4 ? 2 : 1)));  // strip rows: 16, 20, 22, 22
+  constexpr int SSZB = SRMAX * 512;
+  constexpr int NI = SRMAX / 2;   // DMA instructions per strip (two 32-pixel rows each)
+  constexpr int NST = 4;
+  char* const lds = smemc;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int cc = tid & 7, r0 = tid >> 3;
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(p.Wp + ((int64_t)r0 * NT + t) * 64 + ((cc ^ ((r0 >> 1) & 7)) << 3)),
+        (__attribute__((address_space(3))) void*)(lds + t * BSZB + wave * 1024), 16, 0, 0);
+  const int nitems = p.B * p.tiles_y * p.tiles_x;
+  const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int it_begin = xcd * per + local;
+  const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
+  if (it_begin >= it_end) {
+    wait_vm<0>();
+    return;
+  }
+  auto decode = [&](int item, int& b, int& ty0, int& tx0) {
+    int t = item;
+    tx0 = (t % p.tiles_x) * 16;
+    t /= p.tiles_x;
+    ty0 = (t % p.tiles_y) * 16;
+    b = t / p.tiles_y;
+  };
+  const int fr_ = lane & 31, fh = lane >> 5;
+  int aoff[2][NT];  // LDS byte offset of this lane's pixel fragment at tap t, K slice 0 (slice kk: + 32 bytes = two pixels on)
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int pix = 64 * wm + 32 * i + fr_, py = pix >> 4, px = pix & 15;
+#pragma unroll
+    for (int t = 0; t < NT; t++) aoff[i][t] = HS0 + ((py + t * p.R) * 32 + px + fh) * 16;
+  }
+  const int brow = wn * 32 + fr_;
+  const int boff = brow * 128 + ((fh ^ ((brow >> 1) & 7)) << 4);
+  int spy[2][2], spx[2][2];
+  const int schunk = frag_chunk(lane);
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+      const int pix = 64 * wm + 32 * i + 16 * h2 + (lane & 15);
+      spy[i][h2] = pix >> 4, spx[i][h2] = pix & 15;
+    }
+  const int srow = lane >> 5, spx_ = lane & 31;  // this lane's (row within the pair, pixel) of a strip DMA instruction
+  int h_item = it_begin;
+  auto issue_strip = [&](int buf) {  // instructions q = wave and wave + 8 (< NI), always; then advance the cursor
+    const bool live = h_item < it_end;
+    int b = 0, ty0 = 0, tx0 = 0;
+    if (live) decode(h_item, b, ty0, tx0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int q = wave + 8 * i;
+      if (q >= NI) break;
+      const int y = ty0 + 2 * q + srow, x = tx0 + spx_;
+      const bool ok = live && spx_ < 24 && y < p.Hb && x < p.Wb;
+      const u16* g = ok ? p.xb + (((int64_t)b * p.Hb + y) * p.Wb + x) * 8 : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(lds + HS0 + buf * SSZB + q * 1024), 16, 0, 0);
+    }
+    h_item += G8;
+  };
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  issue_strip(0);
+  bool st = false;
+  int seg = 0;
+  for (int item = it_begin; item < it_end; item += G8, seg++) {
+    if (st) {
+      if (p.stats) wait_vm<NST + 2>();
+      else wait_vm<NST>();
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    issue_strip((seg + 1) & 1);
+    const int hb = (seg & 1) * SSZB;
+#pragma unroll
+    for (int tap = 0; tap < NT; tap++) {
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        bf16x8 af[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[i] = *(const bf16x8*)(lds + aoff[i][tap] + hb + kk * 32);
+        const bf16x8 bf = *(const bf16x8*)(lds + ((boff ^ (kk << 5)) + tap * BSZB));
+#pragma unroll
+        for (int i = 0; i < 2; i++) acc[i] = MM_MFMA_32x32x16(bf, af[i], acc[i]);  // D[cout][pixel]
+      }
+    }
+    int b, ty0, tx0;
+    decode(item, b, ty0, tx0);
+    float sst[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) sst[t] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      unsigned D[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        D[q][0] = (unsigned)f2bf(acc[i][4 * q]) | ((unsigned)f2bf(acc[i][4 * q + 1]) << 16);
+        D[q][1] = (unsigned)f2bf(acc[i][4 * q + 2]) | ((unsigned)f2bf(acc[i][4 * q + 3]) << 16);
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[i][4 * q + e] = 0.f;
+      }
+      uint4 xa, xb;
+      frag_rows(D, xa, xb);
+      const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
+      const bool ina = ya < p.H && xa_ < p.W, inb = yb < p.H && xb_ < p.W;
+      u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + wn * 32 + 8 * schunk;
+      u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + wn * 32 + 8 * schunk;
+      if (p.stats) {
+        stats_accum(xa, ina, sst);
+        stats_accum(xb, inb, sst);
+      }
+      *(uint4*)(ina ? rowa : (u16*)g_dump + lane * 8) = xa;
+      *(uint4*)(inb ? rowb : (u16*)g_dump + lane * 8) = xb;
+    }
+    if (p.stats)
+      stats_store(p.stats, 2 * ((int64_t)item * 4 + wm) + (b >= p.split_b ? 1 : 0), 64, wn * 32, lane, row_reduce_scatter16(sst, lane & 15), true);
+    st = true;
+  }
+  wait_vm<0>();
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 struct WgP {
   const u16* X;   // [B,Hi,Wi,Ck]
@@ -1859,6 +2017,42 @@ int MM_SYM(mm_conv2d_wgrad3x3_pair)(const void* X0, const void* X1, int B, int H
   MM_CHECK_ARG(X0 && X1 && dY0 && dY1 && dW0 && dW1, "conv2d_wgrad3x3_pair: null pointer");
   if ((int64_t)B * H * W == 0) return MM_OK;
   return wgrad3x3_launch(X0, X1, dY0, dY1, B, H, W, Ck, ldx, Cn, ldy, dW0, dW1, sn, st, sk, accumulate, ws, ws_bytes, s);
+}
+
+// The 7x7 stride-1 stems on the staged image of mm_stem_prep (see k_stem7): xb [B][Hb][Wb][8], R rows per buffer pixel, T = ceil(7 / R)
+// taps of 64 virtual channels, Wp [64][T][64] (conv2d.py StemConvFn packs it), output O [B][H][W][64] (pitch ldo), optional
+// BatchNorm statistics slab of mm_conv2d_stem7_stat_rows(B, H, W) rows (stats_accum; images [0, split_b) are group 0).
+int64_t MM_SYM(mm_conv2d_stem7_stat_rows)(int B, int H, int W) { return (int64_t)B * mm_cdiv(H, 16) * mm_cdiv(W, 16) * 4 * 2; }
+
+int MM_SYM(mm_conv2d_stem7)(const void* xb, int B, int Hb, int Wb, int H, int W, int R, int T, void* O, int ldo, const void* Wp, float* stats,
+                    int split_b, hipStream_t s) {
+  MM_CHECK_ARG((T == 1 && R == 8) || (T == 2 && R == 4) || (T == 4 && R == 2) || (T == 7 && R == 1), "conv2d_stem7: (R, T) must be (8,1), (4,2), (2,4) or (1,7)");
+  MM_CHECK_ARG(Hb >= H + (T - 1) * R && Wb >= W + 7 && ldo % 8 == 0 && ((uintptr_t)xb % 16) == 0 && ((uintptr_t)Wp % 16) == 0 && ((uintptr_t)O % 16) == 0,
+               "conv2d_stem7: bad shape");
+  StemP p;
+  p.xb = (const u16*)xb; p.B = B; p.Hb = Hb; p.Wb = Wb; p.H = H; p.W = W; p.R = R; p.O = (u16*)O; p.ldo = ldo; p.Wp = (const u16*)Wp;
+  p.stats = stats; p.split_b = split_b;
+  p.tiles_y = (int)mm_cdiv(H, 16); p.tiles_x = (int)mm_cdiv(W, 16);
+  const int64_t nitems = (int64_t)B * p.tiles_y * p.tiles_x;
+  if (nitems == 0) return MM_OK;
+  MM_CHECK_ARG(nitems < (1ll << 30), "conv2d_stem7: too many tiles");
+  int64_t grid = mm_cdiv(nitems, 8) * 8;
+  if (grid > 512) grid = 512;  // two resident 8-wave workgroups per CU
+  const int sr = 16 + (T - 1) * R;
+  const size_t lds = (size_t)T * 64 * 128 + 2 * (size_t)sr * 512;
+  static unsigned once = 0;  // per-device bit: see mm_attr_todo (common.h)
+  if (mm_attr_todo(&once)) {
+    MM_HIP(hipFuncSetAttribute((const void*)k_stem7<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    MM_HIP(hipFuncSetAttribute((const void*)k_stem7<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    MM_HIP(hipFuncSetAttribute((const void*)k_stem7<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    MM_HIP(hipFuncSetAttribute((const void*)k_stem7<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+  }
+  if (T == 1) hipLaunchKernelGGL(k_stem7<1>, dim3((unsigned)grid), dim3(512), lds, s, p);
+  else if (T == 2) hipLaunchKernelGGL(k_stem7<2>, dim3((unsigned)grid), dim3(512), lds, s, p);
+  else if (T == 4) hipLaunchKernelGGL(k_stem7<4>, dim3((unsigned)grid), dim3(512), lds, s, p);
+  else hipLaunchKernelGGL(k_stem7<7>, dim3((unsigned)grid), dim3(512), lds, s, p);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
 }
 
 int MM_SYM(mm_stem_prep)(const float* in, int B, int C, int H, int W, int pad, int Hb, int Wb, int R, void* out, hipStream_t s) {

@@ -295,3 +295,39 @@ def test_stride2_data_gradient_by_output_parity_is_bit_identical_with_the_generi
     xr = x.detach().float().requires_grad_(True)
     (gxr,) = torch.autograd.grad(F.conv2d(xr, w.to(half2d).float(), None, 2, p), [xr], gy.float())
     assert float((out[0].float() - gxr).norm() / gxr.norm()) < 4e-3
+
+
+@pytest.mark.parametrize("cin,B,hw", [(3, 3, (30, 41)), (1, 4, (17, 50)), (3, 2, (64, 96)), (2, 2, (33, 20)), (5, 2, (16, 16)), (1, 1, (1, 1))])
+def test_stem_kernel_is_bit_identical_with_the_generic_implicit_gemm(cin, B, hw, half2d):
+    """k_stem7 (weights resident, the raw strip of a 16 x 16 tile staged once, pixel fragments read at shifted addresses) against the
+    generic implicit GEMM on the same staged image (MM_CONV_STEM7=0): the same products in the same order, bit for bit - every
+    (R, T) pair of the staging (C = 1: (8, 1), 2: (4, 2), 3: (2, 4), 5: (1, 7)), ragged tiles, the statistics slab included."""
+    import mm2d3d_amd.conv2d as c2d
+    from mm2d3d_amd.conv2d import StemConvFn
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin * 13 + B)
+    H, W = hw
+    img = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(64, cin, 7, 7, generator=g) * 0.1).to(dev)
+    outs, tots = [], []
+    mode = c2d.BN_PRE[0]
+    try:
+        c2d.BN_PRE[0] = True
+        for stem7 in (True, False):
+            was, c2d.STEM7[0] = c2d.STEM7[0], stem7
+            try:
+                holder = [None]
+                outs.append(StemConvFn.apply(img, w, holder))
+                tots.append(_slab_totals(holder, 64))
+            finally:
+                c2d.STEM7[0] = was
+    finally:
+        c2d.BN_PRE[0] = mode
+    assert torch.equal(outs[0], outs[1])
+    want = _expect_totals(outs[0], B)
+    scale = want.abs().amax(-1, keepdim=True).clamp_min(1e-6)
+    for t in tots:
+        assert float(((t - want).abs() / scale).max()) < 2e-6
+    yr = F.conv2d(img.to(half2d).float(), w.to(half2d).float(), None, 1, 3)
+    assert _rel(outs[0], yr) < 1e-2
