@@ -307,7 +307,11 @@ __global__ __launch_bounds__(T) void k_box5_slide(const float* __restrict__ in, 
 // dx[pix][c] = sum_j dz[pix][j] * Wj[j][c]  (bf16, zero outside the h x w region), partial dW[j][c] = sum_pix dz*x.
 // C = 64: a thread owns 4 channels of one pixel (8-byte loads/stores), 16 threads per pixel, 4 pixels per wave; the
 // per-block dW partial is folded over the wave's 4 pixel slots with two shuffles and over the 4 waves through LDS.
-template <int MJ>
+// PART 0: both results in one pass (234 registers at 12 outputs: two waves per SIMD); PART 1: dx only (reads dz, writes dx), PART 2:
+// the dW partials only (reads x and dz) - half the registers each, twice the occupancy.  Measured at the heads' 12 outputs (round 4):
+// 200 + 165 us against 308 us for the one pass - the loop is bound by its per-thread chain of dependent trips, not by registers -
+// so the split only serves output counts whose single pass would spill (> 12).
+template <int MJ, int PART>
 __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int Hp, int Wp, int ld, int B, int h, int w, int C,
                                                  const float* __restrict__ Wj, int NJ, const float* __restrict__ dz,
                                                  u16* __restrict__ dx, float* __restrict__ partial, int64_t pix_per_block) {
@@ -319,14 +323,14 @@ __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int H
   for (int j = 0; j < MJ; j++)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      wc[j][i] = j < NJ ? Wj[j * C + c4 + i] : 0.f;
+      wc[j][i] = (PART != 2 && j < NJ) ? Wj[j * C + c4 + i] : 0.f;
       acc[j][i] = 0.f;
     }
   const int64_t total = (int64_t)B * Hp * Wp;
   const int64_t p0 = (int64_t)blockIdx.x * pix_per_block;
   const int64_t p1 = p0 + pix_per_block < total ? p0 + pix_per_block : total;
   // UN pixels per thread and iteration, all loads issued before the arithmetic (the loop is latency-bound otherwise)
-  constexpr int UN = 4;
+  constexpr int UN = PART == 0 ? 4 : 2;  // (the light passes: fewer pixels in flight per thread, twice the waves per SIMD)
   for (int64_t pb = p0 + slot; pb < p1; pb += NSLOT * UN) {
     uint2 xv2[UN];
     float gj[UN][MJ];
@@ -339,10 +343,18 @@ __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int H
       in[u] = pp < p1 && yy < h && xx < w;
       xv2[u] = make_uint2(0u, 0u);
       if (in[u]) {
-        xv2[u] = *(const uint2*)(x + pp * ld + c4);
+        if (PART != 1) xv2[u] = *(const uint2*)(x + pp * ld + c4);
         const float* g = dz + ((int64_t)(b * h + yy) * w + xx) * NJ;
+        if (MJ % 4 == 0 && NJ == MJ && !((uintptr_t)dz & 15)) {  // the pixel's NJ floats as 16-byte loads (a quarter of the load instructions)
 #pragma unroll
-        for (int j = 0; j < MJ; j++) gj[u][j] = j < NJ ? g[j] : 0.f;
+          for (int q = 0; q < MJ / 4; q++) {
+            const float4 v = ((const float4*)g)[q];
+            gj[u][4 * q] = v.x, gj[u][4 * q + 1] = v.y, gj[u][4 * q + 2] = v.z, gj[u][4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < MJ; j++) gj[u][j] = j < NJ ? g[j] : 0.f;
+        }
       }
     }
 #pragma unroll
@@ -357,17 +369,20 @@ __global__ __launch_bounds__(T) void k_head_bwd(const u16* __restrict__ x, int H
           if (j < NJ) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-              o[i] = fmaf(gj[u][j], wc[j][i], o[i]);
-              acc[j][i] = fmaf(gj[u][j], xv[i], acc[j][i]);
+              if (PART != 2) o[i] = fmaf(gj[u][j], wc[j][i], o[i]);
+              if (PART != 1) acc[j][i] = fmaf(gj[u][j], xv[i], acc[j][i]);
             }
           }
       }
-      uint2 r;
-      r.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
-      r.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
-      *(uint2*)(dx + pp * ld + c4) = r;
+      if (PART != 2) {
+        uint2 r;
+        r.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        r.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        *(uint2*)(dx + pp * ld + c4) = r;
+      }
     }
   }
+  if (PART == 1) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int j = 0; j < MJ; j++)
@@ -528,13 +543,20 @@ int MM_SYM(mm_head_bwd)(const void* x, int B, int Hp, int Wp, int ld, int h, int
   int64_t npix = (int64_t)B * h * w;
   MM_CHECK_ARG(npix * NJ < (1ll << 32) - 4096, "head: too many elements for 32-bit thread indices");
   if (npix) launch_box5(dout, B, h, w, NJ, nullptr, dz, s);
-#define MM_HEAD_BWD(MJ)                                                                                                          \
-  hipLaunchKernelGGL(k_head_bwd<MJ>, dim3(nblk), dim3(T), (size_t)(T / 64) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, Wj, \
-                     NJ, dz, (u16*)dx, partial, ppb)
-  if (NJ <= 8) MM_HEAD_BWD(8);
-  else if (NJ <= 12) MM_HEAD_BWD(12);
-  else if (NJ <= 20) MM_HEAD_BWD(20);
-  else MM_HEAD_BWD(32);
+#define MM_HEAD_BWD(MJ, PART)                                                                                                         \
+  hipLaunchKernelGGL((k_head_bwd<MJ, PART>), dim3(nblk), dim3(T), (size_t)(T / 64) * NJ * C * 4, s, (const u16*)x, Hp, Wp, ld, B, h, w, C, \
+                     Wj, NJ, dz, (u16*)dx, partial, ppb)
+  if (NJ <= 8) {
+    MM_HEAD_BWD(8, 0);
+  } else if (NJ <= 12) {  // (the two heads of the net.  Two light passes measured 200 + 165 us against 308 for the one pass: not used)
+    MM_HEAD_BWD(12, 0);
+  } else if (NJ <= 20) {
+    MM_HEAD_BWD(20, 1);
+    MM_HEAD_BWD(20, 2);
+  } else {
+    MM_HEAD_BWD(32, 1);
+    MM_HEAD_BWD(32, 2);
+  }
 #undef MM_HEAD_BWD
   hipLaunchKernelGGL(k_sum_partials_f, dim3(NJ * C), dim3(64), 0, s, partial, nblk, NJ * C, dWj);
   MM_LAUNCH_CHECK();
