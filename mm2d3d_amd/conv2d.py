@@ -357,8 +357,8 @@ def pairable(x1, x2, w1, w2):
     if not PAIR[0] or x1.shape != x2.shape or w1.shape != w2.shape or tuple(w1.shape[2:]) != (3, 3):
         return False
     cout, cin = w1.shape[0], w1.shape[1]
-    if cin % 64 or cout % 64:  # (64 -> 64: forward and data gradients stay single launches of the weights-resident kernel, the
-        return False           # weight gradients are paired)
+    if cin % 64 or cout % 64:
+        return False
     for x in (x1, x2):
         B, C, H, W = x.shape
         if x.dtype != HALF[0] or x.stride() != (H * W * C, 1, W * C, C) or x.data_ptr() % 16:
@@ -382,13 +382,10 @@ class Conv2dPairFn(torch.autograd.Function):
             nf = _stat_group_split(Bn)
             rows = int(lib2d().mm_conv2d_3x3s1_stat_rows(Bn, H, W))
             slabs = [_stat_slab(h, rows, Cout, nf, Bn, x1.device) for h in (stats1, stats2)]
-        if Cin == 64 and Cout == 64:  # k_conv3x3r keeps ONE problem's weights resident in LDS: two launches
-            for i, x in enumerate((x1, x2)):
-                check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, Cin, ptr(y[i]), Cout, Cout, ptr(Wp[i]), None, 0 | WHOLE_ITEMS[0],
-                                              ptr(slabs[i]), nf, stream()), "conv2d_3x3s1")
-        else:
-            check(lib2d().mm_conv2d_3x3s1_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(y[0]), ptr(y[1]), Cout, Cout, ptr(Wp[0]), ptr(Wp[1]),
-                                               0 | WHOLE_ITEMS[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
+        # (64 -> 64: the weights-resident kernel pairs when the item list splits at an XCD boundary, else the entry point runs the
+        # two problems one after the other)
+        check(lib2d().mm_conv2d_3x3s1_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(y[0]), ptr(y[1]), Cout, Cout, ptr(Wp[0]), ptr(Wp[1]),
+                                           0 | WHOLE_ITEMS[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
         ctx.save_for_backward(x1, x2, wf[0], wf[1])
         ctx.owners = (w1, w2)
         ctx.wparams = tuple(w if gradsink.claim(ctx, w, ctx.needs_input_grad[2 + i]) else None for i, w in enumerate((w1, w2)))
@@ -405,7 +402,7 @@ class Conv2dPairFn(torch.autograd.Function):
         need = [ctx.needs_input_grad[0], ctx.needs_input_grad[1]]
         if need[0] or need[1]:
             Wd = [_pack(w, 1, Cin, 9, Cout, 0, 9, 1, Cin * 9, owner, "dgrad") for w, owner in zip(wfs, ctx.owners)]  # [ci][t][co]
-            if need[0] and need[1] and not (Cin == 64 and Cout == 64):
+            if need[0] and need[1]:
                 dx = [torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x1.device, memory_format=CL) for _ in range(2)]
                 check(lib2d().mm_conv2d_3x3s1_pair(ptr(dys[0]), ptr(dys[1]), Bn, H, W, Cout, Cout, ptr(dx[0]), ptr(dx[1]), Cin, Cin,
                                                    ptr(Wd[0]), ptr(Wd[1]), 1 | WHOLE_ITEMS[0], None, None, 0, stream()), "conv2d_3x3s1_pair")

@@ -834,11 +834,19 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;  // 4 (pixels) x 2 (couts)
   const int cc = tid & 7, r0 = tid >> 3;
+  // Pair mode (C3P::B1 < B; the host guarantees that the item list splits at an XCD boundary: XCDs 0-3 run problem 0, XCDs 4-7
+  // problem 1): a workgroup belongs to ONE problem for its whole life, so it loads that problem's weights once, as before.
+  const bool second = p.B1 < p.B && (blockIdx.x & 7) >= 4;
+  const u16* const Ap = second ? p.A1 : p.A;
+  u16* const Op = second ? p.O1 : p.O;
+  float* const slab = second ? p.stats1 : p.stats;
+  const u16* const Wq = second ? p.Wp1 : p.Wp;
+  const int b_off = second ? p.B1 : 0;  // first (virtual) image of this workgroup's problem
   // resident weights: tap t, cout row r0, 16-B chunk cc (swizzled) -> LDS [t][row][chunk]
 #pragma unroll
   for (int t = 0; t < 9; t++)
     __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(p.Wp + ((int64_t)r0 * 9 + t) * 64 + ((cc ^ ((r0 >> 1) & 7)) << 3)),
+        (const __attribute__((address_space(1))) void*)(Wq + ((int64_t)r0 * 9 + t) * 64 + ((cc ^ ((r0 >> 1) & 7)) << 3)),
         (__attribute__((address_space(3))) void*)(lds + t * BSZB + wave * 1024), 16, 0, 0);
   if (p.bias && tid < 64)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + tid),
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
     int b = 0, ty0 = 0, tx0 = 0;
     if (live) decode(h_item, b, ty0, tx0);
     const bool interior = live && ty0 >= 1 && ty0 + TH < p.H && tx0 >= 1 && tx0 + TW < p.W;
-    const u16* base = p.A + ((int64_t)(b * p.H + ty0) * p.W + tx0) * p.lda;
+    const u16* base = Ap + ((int64_t)((b - b_off) * p.H + ty0) * p.W + tx0) * p.lda;
     char* dst = lds + HS0 + buf * HSZB + wave * 1024;
 #pragma unroll
     for (int i = 0; i < NPIECE; i++) {
@@ -927,7 +935,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   for (int item = it_begin; item < it_end; item += G8, seg++) {
     // this item's halo (and, the first time, the weights) must have landed; younger in the queue: the previous item's stores
     if (st) {
-      if (p.stats) wait_vm<NST + 2>();  // + the two statistics stores of the previous item
+      if (slab) wait_vm<NST + 2>();  // + the two statistics stores of the previous item
       else wait_vm<NST>();
     } else {
       wait_vm<0>();
@@ -971,17 +979,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
       frag_rows(D, xa, xb);  // whole 64-byte rows: pixels (lane & 15) and 16 + (lane & 15) of the fragment, chunk schunk
       const int ya = ty0 + spy[i][0], xa_ = tx0 + spx[i][0], yb = ty0 + spy[i][1], xb_ = tx0 + spx[i][1];
       const bool ina = ya < p.H && xa_ < p.W, inb = yb < p.H && xb_ < p.W;
-      u16* rowa = p.O + ((int64_t)(b * p.H + ya) * p.W + xa_) * p.ldo + wn * 32 + 8 * schunk;
-      u16* rowb = p.O + ((int64_t)(b * p.H + yb) * p.W + xb_) * p.ldo + wn * 32 + 8 * schunk;
-      if (p.stats) {
+      u16* rowa = Op + ((int64_t)((b - b_off) * p.H + ya) * p.W + xa_) * p.ldo + wn * 32 + 8 * schunk;
+      u16* rowb = Op + ((int64_t)((b - b_off) * p.H + yb) * p.W + xb_) * p.ldo + wn * 32 + 8 * schunk;
+      if (slab) {
         stats_accum(xa, ina, sst);
         stats_accum(xb, inb, sst);
       }
       *(uint4*)(ina ? rowa : (u16*)g_dump + lane * 8) = xa;
       *(uint4*)(inb ? rowb : (u16*)g_dump + lane * 8) = xb;
     }
-    if (p.stats)  // BatchNorm statistics of this wave's 64 pixels x 32 channels (see stats_accum); one more store per item
-      stats_store(p.stats, 2 * ((int64_t)item * 4 + wm) + (b >= p.split_b ? 1 : 0), p.Cn, wn * 32, lane, row_reduce_scatter16(sst, lane & 15),
+    if (slab)  // BatchNorm statistics of this wave's 64 pixels x 32 channels (see stats_accum); one more store per item
+      stats_store(slab, 2 * ((int64_t)(item - (second ? p.B1 * p.tiles_y * p.tiles_x : 0)) * 4 + wm) + (b - b_off >= p.split_b ? 1 : 0), p.Cn,
+                  wn * 32, lane, row_reduce_scatter16(sst, lane & 15),
                   true);
     st = true;
   }
@@ -1891,13 +1900,23 @@ int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda,
 // Two 3x3 stride-1 pad-1 convolutions (or data gradients, flip = 1) of ONE shape in one launch: problem 0 = (A0, O0, Wp0, stats0),
 // problem 1 = (A1, O1, Wp1, stats1), B images each - the same layer of the RGB and of the depth backbone (EXP/2d_net/model.py:43-46
 // builds the two encoders from one constructor).  One item list over both problems: the persistent kernel's last, partly filled
-// round is shared (C3P::B1).  No bias (the backbones' convolutions have none), not for 64 -> 64 layers (weights-resident kernel).
+// round is shared (C3P::B1).  No bias (the backbones' convolutions have none).
 int MM_SYM(mm_conv2d_3x3s1_pair)(const void* A0, const void* A1, int B, int H, int W, int Ca, int lda, void* O0, void* O1, int Cn, int ldo,
                          const void* Wp0, const void* Wp1, int flip, float* stats0, float* stats1, int split_b, hipStream_t s) {
   MM_CHECK_ARG(Ca % 64 == 0 && lda % 8 == 0 && ((uintptr_t)A0 % 16) == 0 && ((uintptr_t)A1 % 16) == 0 && ((uintptr_t)Wp0 % 16) == 0 &&
                    ((uintptr_t)Wp1 % 16) == 0 && ((uintptr_t)O1 % 8) == 0,
                "conv2d_3x3s1_pair: bad shape");
-  MM_CHECK_ARG(!(Ca == 64 && Cn == 64), "conv2d_3x3s1_pair: 64 -> 64 layers run on the weights-resident kernel, one problem per launch");
+  if (Ca == 64 && Cn == 64) {
+    // the weights-resident kernel keeps ONE problem's weights in LDS: it pairs when the item list splits at an XCD boundary (items
+    // of one problem a multiple of 4; k_conv3x3r), else the two problems run one after the other
+    int tw, ty, tx;
+    c3_tiles(H, W, &tw, &ty, &tx);
+    if (((int64_t)B * ty * tx) % 4 != 0) {
+      int rc = MM_SYM(mm_conv2d_3x3s1)(A0, B, H, W, Ca, lda, O0, Cn, ldo, Wp0, nullptr, flip, stats0, split_b, s);
+      if (rc) return rc;
+      return MM_SYM(mm_conv2d_3x3s1)(A1, B, H, W, Ca, lda, O1, Cn, ldo, Wp1, nullptr, flip, stats1, split_b, s);
+    }
+  }
   MM_CHECK_ARG((stats0 == nullptr) == (stats1 == nullptr), "conv2d_3x3s1_pair: statistics for both problems or for neither");
   C3P p;
   p.A = (const u16*)A0; p.B = 2 * B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O0; p.Cn = Cn; p.ldo = ldo;

@@ -204,8 +204,8 @@ def backbone_pair(r, d, img, hints, outs_r=None, outs_d=None, pad_to=None):
             xr, xd = BasicBlock.forward_pair(b1, b2, xr, xd, out_r if last else None, out_d if last else None)
         return xr, xd
 
-    # layer1 (64 -> 64): the convolutions and data gradients stay single launches (weights-resident kernel), their weight gradients
-    # pair (half the partial slabs per problem); its 75 MB maps are too large for a batch-norm pair (the library runs them singly)
+    # layer1 (64 -> 64, weights-resident kernel: XCDs 0-3 run one encoder's items, XCDs 4-7 the other's); its 75 MB maps are too large
+    # for a batch-norm pair (the library runs them singly)
     if PAIR_LAYER1[0]:
         xr, xd = run_pair(r.layer1, d.layer1, xr, xd, o_r[1], o_d[1])
     else:
