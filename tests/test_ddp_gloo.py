@@ -205,3 +205,17 @@ def test_paired_shards_max_size_cycle():
     a = {i for _, t in paired_shards(37, 90, B, 0, world) for i in t}
     b = {i for _, t in paired_shards(37, 90, B, 1, world) for i in t}
     assert not (a & b)
+
+
+def test_collectives_after_backward_is_the_default_form(monkeypatch):
+    """GradAllReducer(overlap=None): MM_DDP_OVERLAP decides, and its default is "every bucket in finish(), after backward" - the form
+    in which no collective shares the GPU with a grid-barrier batch norm (ddp.py)."""
+    import torch
+
+    from mm2d3d_amd.ddp import GradAllReducer
+
+    monkeypatch.delenv("MM_DDP_OVERLAP", raising=False)
+    assert GradAllReducer([]).overlap is False
+    monkeypatch.setenv("MM_DDP_OVERLAP", "1")
+    assert GradAllReducer([]).overlap is True
+    assert GradAllReducer([], overlap=False).overlap is False
