@@ -618,8 +618,9 @@ def main(argv=None):
         out["roofline"] = conv_roofline(tm, batch, dev)
         out["roofline_2d"] = conv2d_roofline(tm, batch, dev)
         out["config"]["branch_only_fwd_bwd"] = branch_rates(tm, batch, dev)
-        print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
-        out["cpu_baseline"] = cpu_baseline()
+        if not os.environ.get("MM_BENCH_NO_CPU"):  # (diagnostic A/B runs skip the 20-40 s CPU leg; the default run never does)
+            print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
+            out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

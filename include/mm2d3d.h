@@ -333,18 +333,23 @@ int mm_lift_scatter_key(const float* dout, int C, const int32_t* order, const in
 /* evaluation (EXP/train.py:297-339): confusion matrices [3][C][C] int64 of argmax(2D), argmax(3D), argmax(softmax mean) */
 int mm_eval_confusion(const float* logits2d, int ld2, const float* logits3d, int ld3, const int64_t* labels, int64_t N,
                       int C, int64_t ignore_index, int64_t* cm, mm_stream_t stream);
-/* torch.optim.AdamW update over flat fp32 arenas (EXP/train.py:627-636); step counts from 1; g is multiplied by grad_scale */
+/* torch.optim.AdamW update over flat fp32 arenas (EXP/train.py:627-636); step counts from 1; g is multiplied by grad_scale.
+ * skip_dev / nskip (0 .. 16, may be NULL / 0): device words - the update is a no-op when any of them is nonzero (the
+ * data-parallel reducer's collective "this step's gradients are invalid" flags: decided on the device, no read-back) */
 int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
-                  double eps, double weight_decay, int64_t step, double grad_scale, mm_stream_t stream);
+                  double eps, double weight_decay, int64_t step, double grad_scale, const int* skip_dev, int nskip,
+                  mm_stream_t stream);
 /* Loss-scaled steps (the fp16 kind of the 16-bit activation mode; torch.cuda.amp.GradScaler semantics as driven by the
  * reference's ``precision: 16`` trainer, train.yaml:11) WITHOUT a read-back: scale, non-finite flag, clean-step tracker and
  * step counter live on the device.  mm_grad_nonfinite: found_dev[0] = 1 if any gradient is inf / nan (the caller zeroes it);
- * mm_amp_prepare: the coefficients of one parameter group's update (mm_amp_coef_bytes bytes) incl. 1 / scale and "skip";
+ * mm_amp_prepare: the coefficients of one parameter group's update (mm_amp_coef_bytes bytes) incl. 1 / scale and "skip" =
+ * any of found_dev[0 .. nfound) set - the flags of EVERY optimiser of the step (the reference's HybridOptim is one optimiser to
+ * the GradScaler, EXP/train.py:627-636: an overflow in either network skips both updates) plus the caller's extra skip words;
  * mm_adamw_step_dev: mm_adamw_step with those coefficients, a no-op when skip is set; mm_amp_update: GradScaler.update(). */
 int mm_grad_nonfinite(const float* g, int64_t n, int* found_dev, mm_stream_t stream);
 int mm_amp_coef_bytes(void);
-int mm_amp_prepare(const float* scale_dev, const int* found_dev, int64_t* step_dev, int advance, double lr, double beta1, double beta2,
-                   double eps, double weight_decay, double grad_scale, void* coef_dev, mm_stream_t stream);
+int mm_amp_prepare(const float* scale_dev, const int* found_dev, int nfound, int64_t* step_dev, int advance, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, double grad_scale, void* coef_dev, mm_stream_t stream);
 int mm_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const void* coef_dev, mm_stream_t stream);
 int mm_amp_update(float* scale_dev, int* tracker_dev, const int* found_dev, int nfound, double growth, double backoff, int interval,
                   mm_stream_t stream);

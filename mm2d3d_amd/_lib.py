@@ -13,7 +13,9 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmm2d3d_hip.so")
+# MM_LIB_PATH: a DIAGNOSTIC build of the same sources (tools/diag_lib.sh: parts of a kernel switched off at compile time) - the
+# measurement tools' A/B lever, never a fallback: a missing file still raises
+LIB_PATH = os.environ.get("MM_LIB_PATH") or os.path.join(_HERE, "libmm2d3d_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 _lib = None
@@ -100,10 +102,10 @@ _PROTOS = {
     "mm_lift_gather_key": (i32, [vp, i64, i64, i64, i64, vp, i64, i32, i32, i32, vp, vp]),
     "mm_lift_scatter_key": (i32, [vp, i32, vp, vp, i64, i32, i32, i64, i64, i64, i64, vp, vp]),
     "mm_eval_confusion": (i32, [vp, i32, vp, i32, vp, i64, i32, i64, vp, vp]),
-    "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp]),
+    "mm_adamw_step": (i32, [vp, vp, vp, vp, i64, f64, f64, f64, f64, f64, i64, f64, vp, i32, vp]),
     "mm_grad_nonfinite": (i32, [vp, i64, vp, vp]),
     "mm_amp_coef_bytes": (i32, []),
-    "mm_amp_prepare": (i32, [vp, vp, vp, i32, f64, f64, f64, f64, f64, f64, vp, vp]),
+    "mm_amp_prepare": (i32, [vp, vp, i32, vp, i32, f64, f64, f64, f64, f64, f64, vp, vp]),
     "mm_adamw_step_dev": (i32, [vp, vp, vp, vp, i64, vp, vp]),
     "mm_amp_update": (i32, [vp, vp, vp, i32, f64, f64, i32, vp]),
     "mm_conv2d_gemm": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp,

@@ -10,7 +10,7 @@ k_amp_update): a skipped step costs no read-back, the host never waits for the G
 
     scaler = GradScaler(device)
     (loss * scaler.scale_tensor).backward()          # or scaler.scale(loss).backward()
-    for o in optimizers: scaler.step(o, grad_scale)  # checks o's gradient arenas, updates unless non-finite
+    scaler.step_all(optimizers, grad_scale)          # checks every gradient arena; ONE decision: all update, or none does
     scaler.update()
 """
 from __future__ import annotations
@@ -42,15 +42,16 @@ class GradScaler:
         k = id(opt)
         if k not in self._found:
             nb = int(_lib.lib().mm_amp_coef_bytes())
-            if len(self._found) >= self._flags.numel():
-                raise RuntimeError("GradScaler: more than 16 optimisers")
+            if len(self._found) >= self._flags.numel() - self.N_SKIP:
+                raise RuntimeError("GradScaler: more than 12 optimisers")
             self._found[k] = self._flags[len(self._found) : len(self._found) + 1]
             self._steps[k] = torch.full((1,), int(getattr(opt, "_step", 0)), dtype=torch.int64, device=self.device)
             self._coef[k] = torch.zeros((max(1, len(opt.param_groups)), nb), dtype=torch.uint8, device=self.device)
         return self._found[k], self._steps[k], self._coef[k]
 
     def step(self, opt, grad_scale: float = 1.0):
-        """``opt.step()`` on the unscaled gradients unless one of them is inf / nan (decided and applied on the device)."""
+        """``opt.step()`` on the unscaled gradients unless one of ITS gradients is inf / nan (decided and applied on the device):
+        the per-optimiser form of torch's GradScaler.step.  A trainer whose optimisers are one HybridOptim uses ``step_all``."""
         if not self.enabled:
             return opt.step(grad_scale=grad_scale)
         if not hasattr(opt, "step_scaled"):
@@ -61,6 +62,37 @@ class GradScaler:
         for g in opt.grad_arenas():
             check(L.mm_grad_nonfinite(ptr(g), g.numel(), ptr(found), stream()), "grad_nonfinite")
         opt.step_scaled(self.scale_tensor, found, steps, coef, grad_scale)
+
+    N_SKIP = 4  # words [12, 16) of the flag buffer: the caller's extra skip words (ddp.GradAllReducer.skip_words)
+
+    def step_all(self, opts, grad_scale: float = 1.0, skip_words=None):
+        """The steps of ALL optimisers of a training step under one decision: the reference's HybridOptim is ONE
+        optimiser to Lightning's GradScaler (``param_groups`` is the concatenation, train.py:627-636), so a non-finite gradient
+        in either network skips both updates.  ``skip_words``: up to 4 more device int32 words that veto the step (the
+        data-parallel reducer's collective "gradients invalid" flags) - they do not touch the loss scale."""
+        if not self.enabled:
+            for o in opts:
+                o.step(grad_scale=grad_scale, skip_words=skip_words) if hasattr(o, "step_scaled") else o.step()
+            return
+        for o in opts:
+            if not hasattr(o, "step_scaled"):
+                raise TypeError("GradScaler.step: the optimiser must be a FlatAdamW (adamw); other optimisers have no device-side skip")
+        L = _lib.lib()
+        states = [self._state(o) for o in opts]
+        n = len(self._found)
+        if n > self._flags.numel() - self.N_SKIP:
+            raise RuntimeError("GradScaler: more than 12 optimisers")
+        self._flags.zero_()  # every optimiser's flag and the skip words: one fill
+        if skip_words is not None:
+            k = int(skip_words.numel())
+            if k > self.N_SKIP:
+                raise ValueError("GradScaler.step_all: at most 4 skip words")
+            self._flags[self._flags.numel() - self.N_SKIP : self._flags.numel() - self.N_SKIP + k].copy_(skip_words)
+        for o, (found, _, _) in zip(opts, states):
+            for g in o.grad_arenas():
+                check(L.mm_grad_nonfinite(ptr(g), g.numel(), ptr(found), stream()), "grad_nonfinite")
+        for o, (_, steps, coef) in zip(opts, states):
+            o.step_scaled(self.scale_tensor, self._flags, steps, coef, grad_scale)
 
     def update(self):
         if not self.enabled or not self._found:

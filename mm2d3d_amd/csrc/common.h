@@ -35,14 +35,18 @@ static inline int64_t mm_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t mm_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
 // Raising a kernel's dynamic-LDS limit (hipFuncSetAttribute) is a per-DEVICE attribute and idempotent: a call site remembers
-// the devices it has done it on in one word.  These words are the library's only process-wide memory - caches of an idempotent
+// the devices it has done it on in one word (mm_attr_todo asks, mm_attr_done records).  These words are the library's only process-wide memory - caches of an idempotent
 // driver call, no mode, no switch.
-static inline bool mm_attr_todo(unsigned* done) {
+static inline bool mm_attr_todo(const unsigned* done) {
   int d = 0;
   if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) return true;
-  if (__atomic_load_n(done, __ATOMIC_RELAXED) & (1u << d)) return false;
-  __atomic_fetch_or(done, 1u << d, __ATOMIC_RELAXED);
-  return true;
+  return !(__atomic_load_n(done, __ATOMIC_RELAXED) & (1u << d));
+}
+// ... and marks the device only AFTER every hipFuncSetAttribute of the call site has succeeded (a failed or a racing
+// first call must not leave the bit set with the limit not raised; two threads that both see "todo" both make the idempotent call)
+static inline void mm_attr_done(unsigned* done) {
+  int d = 0;
+  if (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 32) __atomic_fetch_or(done, 1u << d, __ATOMIC_RELAXED);
 }
 
 // bump allocator over a caller-provided workspace

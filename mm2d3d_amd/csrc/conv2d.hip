@@ -1795,6 +1795,7 @@ static int gemm_launch(ConvP p, int nz, int steps_max, hipStream_t s) {
     static unsigned once = 0;  // per-device bit: see mm_attr_todo (common.h)
     if (mm_attr_todo(&once)) {
       MM_HIP(hipFuncSetAttribute((const void*)k_conv_gemm<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * (128 * 64 + 128 * 64) * 2)));
+      mm_attr_done(&once);
     }
     hipLaunchKernelGGL(k_conv_gemm<128>, dim3((unsigned)mm_cdiv(M, 128), (unsigned)mm_cdiv(Cn, 128), nz), dim3(256), lds, s, p);
   }
@@ -1955,6 +1956,7 @@ static int c3_launch(C3P p, hipStream_t s) {
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+      mm_attr_done(&once_w);
     }
     if (Ca == 64 && Cn == 64) {  // weights resident in LDS
       const int hrows = tw == 16 ? 18 * 18 : 10 * 34;
@@ -1963,6 +1965,7 @@ static int c3_launch(C3P p, hipStream_t s) {
       if (mm_attr_todo(&once_r)) {
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        mm_attr_done(&once_r);
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
@@ -2035,6 +2038,7 @@ static int wgrad3x3_launch(const void* X, const void* X1, const void* dY, const 
   static unsigned attr9 = 0;  // per-device bit: see mm_attr_todo (common.h)
   if (mm_attr_todo(&attr9)) {
     MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3n, hipFuncAttributeMaxDynamicSharedMemorySize, lds9));
+    mm_attr_done(&attr9);
   }
   hipLaunchKernelGGL(k_wgrad3x3n, dim3((unsigned)(nsplit9 * np * q.ntile)), dim3(512), lds9, s, q);
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(np * Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,
@@ -2121,6 +2125,7 @@ int MM_SYM(mm_conv2d_stem7)(const void* xb, int B, int Hb, int Wb, int H, int W,
     MM_HIP(hipFuncSetAttribute((const void*)k_stem7<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
     MM_HIP(hipFuncSetAttribute((const void*)k_stem7<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
     MM_HIP(hipFuncSetAttribute((const void*)k_stem7<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 81920));
+    mm_attr_done(&once);
   }
   if (T == 1) hipLaunchKernelGGL(k_stem7<1>, dim3((unsigned)grid), dim3(512), lds, s, p);
   else if (T == 2) hipLaunchKernelGGL(k_stem7<2>, dim3((unsigned)grid), dim3(512), lds, s, p);

@@ -250,7 +250,12 @@ template <bool VEC, bool DEV = false>
 __global__ __launch_bounds__(T) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                               float* __restrict__ v, int64_t n, float decay, float omb1, float beta2,
                                               float omb2, float eps, float step_size, float bc2_sqrt, float grad_scale,
-                                              const AmpCoef* __restrict__ dc = nullptr) {
+                                              const AmpCoef* __restrict__ dc = nullptr, const int* __restrict__ skip = nullptr,
+                                              int nskip = 0) {
+  // skip words (the data-parallel reducer's collective "this step's gradients are invalid" flags, mm2d3d_amd/ddp.py): decided on
+  // the device, uniform - the host never reads them before queueing the update
+  for (int i = 0; i < nskip; i++)
+    if (skip[i]) return;
   if (DEV) {
     if (dc->skip) return;  // uniform
     decay = dc->decay, omb1 = dc->omb1, beta2 = dc->beta2, omb2 = dc->omb2, eps = dc->eps, step_size = dc->step_size;
@@ -305,10 +310,13 @@ __global__ __launch_bounds__(T) void k_grad_nonfinite(const float* __restrict__ 
 
 // one thread: the update coefficients of one parameter group from the device state.  t = *step + 1 is the step this update
 // would be; it is committed to *step only when the step is taken and ``advance`` is set (first group of an optimiser).
-__global__ void k_amp_prepare(const float* __restrict__ scale, const int* __restrict__ found, long long* __restrict__ step, int advance,
-                              double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+__global__ void k_amp_prepare(const float* __restrict__ scale, const int* __restrict__ found, int nfound, long long* __restrict__ step,
+                              int advance, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
                               AmpCoef* __restrict__ out) {
-  const int skip = found[0] != 0;
+  // ONE decision for every optimiser of the step (the reference's HybridOptim is one optimiser to Lightning's GradScaler:
+  // train.py:627-636 - a non-finite gradient in either network skips both updates) and for the caller's extra skip words
+  int skip = 0;
+  for (int i = 0; i < nfound; i++) skip |= found[i] != 0;
   const long long t = step[0] + (advance ? 1 : 0);
   if (!skip && advance) step[0] = t;
   const double tt = (double)(t > 0 ? t : 1);
@@ -434,8 +442,9 @@ int mm_eval_confusion(const float* logits2d, int ld2, const float* logits3d, int
 }
 
 int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
-                  double weight_decay, int64_t step, double grad_scale, hipStream_t s) {
+                  double weight_decay, int64_t step, double grad_scale, const int* skip_dev, int nskip, hipStream_t s) {
   MM_CHECK_ARG(step >= 1, "adamw: step counts from 1");
+  MM_CHECK_ARG(nskip >= 0 && nskip <= 16 && (nskip == 0 || skip_dev), "adamw: bad skip words");
   if (n == 0) return MM_OK;
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);
@@ -443,11 +452,11 @@ int mm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, doubl
   if (vec)
     hipLaunchKernelGGL(k_adamw<true>, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale, (const AmpCoef*)nullptr, skip_dev, nskip);
   else
     hipLaunchKernelGGL(k_adamw<false>, dim3((unsigned)mm_cdiv(n, (int64_t)T * 4)), dim3(T), 0, s, p, g, m, v, n,
                        (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                       (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale, (const AmpCoef*)nullptr, skip_dev, nskip);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
@@ -464,10 +473,10 @@ int mm_grad_nonfinite(const float* g, int64_t n, int* found_dev, hipStream_t s) 
 
 int mm_amp_coef_bytes(void) { return (int)sizeof(AmpCoef); }
 
-int mm_amp_prepare(const float* scale_dev, const int* found_dev, int64_t* step_dev, int advance, double lr, double beta1, double beta2,
-                   double eps, double weight_decay, double grad_scale, void* coef_dev, hipStream_t s) {
-  MM_CHECK_ARG(scale_dev && found_dev && step_dev && coef_dev, "amp_prepare: null argument");
-  hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(1), 0, s, scale_dev, found_dev, (long long*)step_dev, advance, lr, beta1, beta2, eps,
+int mm_amp_prepare(const float* scale_dev, const int* found_dev, int nfound, int64_t* step_dev, int advance, double lr, double beta1,
+                   double beta2, double eps, double weight_decay, double grad_scale, void* coef_dev, hipStream_t s) {
+  MM_CHECK_ARG(scale_dev && found_dev && step_dev && coef_dev && nfound >= 1 && nfound <= 32, "amp_prepare: bad argument");
+  hipLaunchKernelGGL(k_amp_prepare, dim3(1), dim3(1), 0, s, scale_dev, found_dev, nfound, (long long*)step_dev, advance, lr, beta1, beta2, eps,
                      weight_decay, grad_scale, (AmpCoef*)coef_dev);
   MM_LAUNCH_CHECK();
   return MM_OK;

@@ -47,6 +47,10 @@ struct OsP {
 };
 
 __device__ inline void split3(const f32x4& a, const f32x4& b, bf16x8 (&t)[3]) {
+#ifdef MM_DIAG_FAKESPLIT  // diagnostic build only (tools/diag_lib.sh): no VALU split - what operands stored pre-split would cost
+  t[0] = __builtin_bit_cast(bf16x8, a), t[1] = __builtin_bit_cast(bf16x8, b), t[2] = t[0];
+  return;
+#endif
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
   for (int i = 0; i < 8; i++) {

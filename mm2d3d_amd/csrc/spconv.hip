@@ -188,6 +188,11 @@ __device__ __attribute__((aligned(64))) const float g_zero128[128] = {0.f};  // 
 
 template <int NT>
 __device__ inline void split8(const f32x4& a, const f32x4& b, bf16x8 (&t)[NT]) {
+#ifdef MM_DIAG_FAKESPLIT  // diagnostic build only (tools/diag_lib.sh): no VALU split - what operands stored pre-split would cost
+#pragma unroll
+  for (int n = 0; n < NT; n++) t[n] = __builtin_bit_cast(bf16x8, (n & 1) ? b : a);
+  return;
+#endif
   float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
   for (int i = 0; i < 8; i++) {

@@ -70,8 +70,9 @@ class GradAllReducer:
         self._tick = 0
         self._arenas = []
         self._in_finish = False
-        self._flag = None
+        self._flag = None  # device int32[2] after finish(): [graph changed on some rank, batch-norm fault on some rank] (MAX over ranks)
         self._flag_host, self._flag_event, self._finished = None, None, 0
+        self._void_before = 0  # flags of reducer steps < this one were already acted upon (a re-learn is under way)
         self.stats = {"bytes": 0, "buckets": 0, "early": 0}  # of the last finished step
         self._step_stats = {"bytes": 0, "buckets": 0, "early": 0}
         self.bn_path = "as configured (no data-parallel group)"  # which batch-norm kernels run beside the collectives (bench line)
@@ -201,8 +202,17 @@ class GradAllReducer:
             self.order = list(self.buckets)
         self.learned = True
 
-    def finish(self):
-        """Call after backward: launches what is left, waits, resets the countdowns."""
+    def skip_words(self):
+        """Device int32 words of the LAST ``finish()``: nonzero = that step's reduced gradients are invalid on every rank (a
+        parameter learned as unused received a gradient somewhere, so its bucket was not reduced; or a rank reported a batch-norm
+        fault).  The optimiser kernels test them ON THE DEVICE (FlatAdamW.step(skip_words=) / GradScaler.step_all(skip_words=)):
+        the bad step is never applied on any rank, although the host learns the value one step late."""
+        return self._flag if (self.active and self._flag is not None) else None
+
+    def finish(self, fault=False):
+        """Call after backward: launches what is left, waits, resets the countdowns.  ``fault``: this rank's gradients are invalid
+        for a local reason (a single-launch batch norm gave up at its grid barrier): it travels with the collective flag, so every
+        rank skips the step and every rank raises together instead of this one alone."""
         if not self.active:
             return
         self._in_finish = True
@@ -216,18 +226,19 @@ class GradAllReducer:
                     self._send(b)
         # "a parameter learned as unused received a gradient" is a LOCAL observation (a data-dependent branch may take it on
         # some ranks only).  The decision to re-learn must be collective, or the ranks' collective sequences diverge in the
-        # next step: one int, MAX over the ranks.  It goes out AFTER the last bucket, at a fixed position of the
-        # sequence: which buckets were sent early is a per-rank fact, and a flag issued before the leftovers would sit at different
-        # positions of different ranks' sequences.
+        # next step: one word, MAX over the ranks (a second one carries ``fault``).  It goes out AFTER the last bucket,
+        # at a fixed position of the sequence: which buckets were sent early is a per-rank fact, and a flag issued before the
+        # leftovers would sit at different positions of different ranks' sequences.
         if self._flag is None:
-            self._flag = torch.zeros(1, dtype=torch.int32, device=self.buckets[0].arena.device)
-        self._flag.fill_(1 if self._late else 0)
+            self._flag = torch.zeros(2, dtype=torch.int32, device=self.buckets[0].arena.device)
+        self._flag[0:1].fill_(1 if self._late else 0)
+        self._flag[1:2].fill_(1 if fault else 0)
         flag_work = dist.all_reduce(self._flag, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
         for b in self.buckets:
             if b.work is not None:
                 b.work.wait()
         flag_work.wait()
-        late_anywhere, late_step = self._read_flag()
+        (late_anywhere, fault_anywhere), flag_step = self._read_flag()
         n_late = len(self._late)
         if not self.learned:
             self._learn()
@@ -236,51 +247,65 @@ class GradAllReducer:
         self._fired, self._late, self._tick = set(), [], 0
         self.stats, self._step_stats = self._step_stats, {"bytes": 0, "buckets": 0, "early": 0}
         self._in_finish = False
+        cur = self._finished  # the step this call finishes
         self._finished += 1
+        if flag_step < self._void_before:  # a flag from before the re-learn that is under way: already acted upon
+            late_anywhere = fault_anywhere = False
+        skipped = "the optimiser kernels of that step tested the flag on the device: no rank applied it"
         if late_anywhere:  # every rank takes this branch together: all re-learn in the next step, all raise now
             self.learned, self.unused = False, set()
             for b in self.buckets:
                 b.n_used = b.pending = len(b.params)
             self.order = list(self.buckets)
-            when = "this step's" if late_step == self._finished - 1 else f"the gradients of reducer step {late_step} (and of every step since)"
+            # flags of the steps up to and including this one were raised against the old unused set: the next finish() (the
+            # re-learn step's) must not raise for them a second time
+            self._void_before = cur + 1
+            same = flag_step == cur
             raise RuntimeError(
                 f"GradAllReducer: a parameter learned as unused received a gradient on some rank ({n_late} on this one now; the graph "
-                f"changed); {when} gradients are not reduced correctly on any rank - "
-                + ("skip the optimiser step everywhere; " if late_step == self._finished - 1 else "restore the last checkpoint; ")
-                + "the next step re-learns the unused set")
+                f"changed) in {'this step' if same else f'reducer step {flag_step}'}: its gradients were not reduced correctly on any "
+                "rank - " + ("skip the optimiser step everywhere; " if same else skipped + "; ") + "the next step re-learns the unused set")
+        if fault_anywhere:
+            raise RuntimeError(
+                f"GradAllReducer: a rank reported a batch-norm grid-barrier fault in {'this step' if flag_step == cur else f'reducer step {flag_step}'}: "
+                "that step's gradients are invalid on every rank - "
+                + ("skip the optimiser step everywhere" if flag_step == cur else skipped)
+                + "; the faulting process now uses the three-kernel batch norms")
 
     def _read_flag(self):
-        """(value, reducer step it belongs to) of the collective "graph changed" flag WITHOUT making the host wait for the GPU.
+        """((graph changed, fault), reducer step they belong to) of the collective flag WITHOUT making the host wait for the GPU.
         On the CPU (gloo) the value is there after ``wait()``.  On the GPU ``wait()`` only orders streams: the flag is copied to
         pinned memory behind the collective and read ONE STEP LATE, when the copy has long landed (the pattern of
-        ``scn.metadata._Readback``) - the host keeps queueing the optimiser while backward and the reductions still run.  The
-        condition is exceptional (the training graph of this path is static) and every rank sees the same value at the same
-        step, so the ranks still raise and re-learn together."""
+        ``scn.metadata._Readback``) - the host keeps queueing the optimiser while backward and the reductions still run, and the
+        optimiser kernels read the flag on the device (``skip_words``), so a flagged step is not applied in the meantime.  Every
+        rank sees the same value at the same step: the ranks still raise and re-learn together."""
         if self._flag.device.type != "cuda":
-            return bool(int(self._flag.item())), self._finished
+            v = self._flag.tolist()
+            return (bool(v[0]), bool(v[1])), self._finished
         if self._flag_host is None:
-            self._flag_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self._flag_host = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(2)]
             self._flag_event = [None, None]
         cur = self._finished & 1
-        prev_value, prev_step = False, self._finished - 1
+        prev_value, prev_step = (False, False), self._finished - 1
         if self._flag_event[cur ^ 1] is not None:
             self._flag_event[cur ^ 1].synchronize()  # recorded a whole step ago: returns at once
-            prev_value = bool(int(self._flag_host[cur ^ 1][0]))
+            prev_value = (bool(int(self._flag_host[cur ^ 1][0])), bool(int(self._flag_host[cur ^ 1][1])))
             self._flag_event[cur ^ 1] = None
         self._flag_host[cur].copy_(self._flag, non_blocking=True)
         self._flag_event[cur] = torch.cuda.current_stream(self._flag.device).record_event()
         return prev_value, prev_step
 
     def drain_flag(self):
-        """The flag of the LAST finished step (a host wait: end of training / before a checkpoint)."""
+        """True if the LAST finished step was flagged (graph changed / batch-norm fault on some rank; its optimiser step was skipped
+        on the device).  A host wait: end of training / before a checkpoint (TrainModel.checkpoint raises on it)."""
         if not self.active or self._flag is None or self._flag.device.type != "cuda" or self._flag_host is None:
             return False
         cur = (self._finished - 1) & 1
-        if self._flag_event[cur] is None:
+        if self._flag_event[cur] is None or self._finished - 1 < self._void_before:
             return False
         self._flag_event[cur].synchronize()
         self._flag_event[cur] = None
-        return bool(int(self._flag_host[cur][0]))
+        return bool(int(self._flag_host[cur][0])) or bool(int(self._flag_host[cur][1]))
 
     def broadcast_buffers(self, modules, src=0):
         """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a

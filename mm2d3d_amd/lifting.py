@@ -45,6 +45,10 @@ class PixelIndex:
         dev = torch.device(device)
         self.H, self.W, self.device = H, W, device
         self._joint = {}  # joint gradient buffers of maps that are channel slices of one NHWC buffer (see _LiftFn.backward)
+        # per-channel sums of the gradient maps the lifting backward passes of THIS batch produced, keyed by the map's address
+        # (nn2d._HeadsFn.backward takes them for the 1x1 heads' bias gradients).  Scoped to the batch's index object (a
+        # process-wide address-keyed table could hand a stale sum to an unrelated map the allocator placed at the same address)
+        self._colsums = {}
         self._err = None  # device flag: an index was outside the map (device-side lists only; host lists are checked on the host)
         if len(img_indices) and all(isinstance(ix, torch.Tensor) and ix.is_cuda for ix in img_indices):
             counts = [int(ix.shape[0]) for ix in img_indices]
@@ -134,19 +138,15 @@ class _LiftFn(torch.autograd.Function):
                                     dseg.stride(3), dseg.stride(1), ptr(dseg), stream()), "lift_scatter")
         # the per-channel sum of the dense gradient map = the sum over the points (what a bias behind the map needs): [N, C] instead
         # of a reduction over the whole map
-        COLSUMS[dseg.data_ptr()] = (dout.sum(0), dseg.shape)
+        index._colsums[dseg.data_ptr()] = (dout.sum(0), dseg.shape)
         return dseg, None
 
 
-# per-channel sums of the gradient maps produced by the last lifting backward passes, keyed by the map's address
-# (nn2d._HeadsFn.backward takes them for the 1x1 heads' bias gradients; popped on use, bounded)
-COLSUMS = {}
-
-
-def pop_colsum(dmap):
-    hit = COLSUMS.pop(dmap.data_ptr(), None)
-    if len(COLSUMS) > 16:
-        COLSUMS.clear()
+def pop_colsum(index, dmap):
+    """The per-channel sum the lifting backward of ``index``'s batch filed for gradient map ``dmap`` (popped), or None."""
+    if index is None:
+        return None
+    hit = index._colsums.pop(dmap.data_ptr(), None)
     if hit is None or tuple(hit[1]) != tuple(dmap.shape):
         return None
     return hit[0]

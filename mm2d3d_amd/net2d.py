@@ -338,8 +338,8 @@ class Net2DSeg(nn.Module):
         x = up(self.dec_t_conv_stage2, x, cb[0])
         x = self.dec_conv_stage1(cb[0].cat([d[0], x, r[0]]))
         segm_last = x[:, :, 0:h, 0:w]  # crop of the padding (a view; the heads read the padded map with bounds h, w)
-        segm, avg = nn2d.fused_heads(x, h, w, self.con1_1_avg, self.aux.con1_1_avg)
-        pix = _pixel_index(data_batch, h, w, segm.device)
+        pix = _pixel_index(data_batch, h, w, x.device)
+        segm, avg = nn2d.fused_heads(x, h, w, self.con1_1_avg, self.aux.con1_1_avg, pix)
         preds = {"seg_logit": lift(segm, pix), "seg_logit_2d": segm}
         return preds, segm_last, img_indices, self.aux(segm_last, pix, avg)
 

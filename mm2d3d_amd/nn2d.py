@@ -586,8 +586,10 @@ class _HeadsFn(torch.autograd.Function):
     """[main | aux] = Conv1x1(AvgPool5x5(x[:, :, :h, :w])) for both heads in one pass (csrc/misc2d.hip header)."""
 
     @staticmethod
-    def forward(ctx, x, h, w, w1, b1, w2, b2):
+    def forward(ctx, x, h, w, w1, b1, w2, b2, index=None):
+        """``index``: the batch's lifting.PixelIndex - its backward passes file the gradient maps' per-channel sums there."""
         L = _c2d.lib2d()
+        ctx.index = index
         x = _c2d.as_nhwc_bf16(x)
         B, C, Hp, Wp = x.shape
         nc = w1.shape[0]
@@ -622,17 +624,18 @@ class _HeadsFn(torch.autograd.Function):
               "head_bwd")
         from . import lifting
 
-        s1, s2 = lifting.pop_colsum(d1), lifting.pop_colsum(d2)
+        s1, s2 = lifting.pop_colsum(ctx.index, d1), lifting.pop_colsum(ctx.index, d2)
         if s1 is not None and s2 is not None:  # bias gradients = sums over the points (lifting backward), not over the maps
             db1, db2 = s1, s2
         else:
             db = dout.sum((0, 1, 2))
             db1, db2 = db[:nc], db[nc:]
-        return dx, None, None, dWj[:nc].reshape(wshape), db1, dWj[nc:].reshape(wshape), db2
+        return dx, None, None, dWj[:nc].reshape(wshape), db1, dWj[nc:].reshape(wshape), db2, None
 
 
-def fused_heads(x, h, w, conv_main: nn.Conv2d, conv_aux: nn.Conv2d):
-    """(seg_logit_2d, seg_logit_avg_2d), each fp32 [B, num_classes, h, w], from the decoder output x (NHWC bf16, padded)."""
+def fused_heads(x, h, w, conv_main: nn.Conv2d, conv_aux: nn.Conv2d, index=None):
+    """(seg_logit_2d, seg_logit_avg_2d), each fp32 [B, num_classes, h, w], from the decoder output x (NHWC bf16, padded).
+    ``index``: the lifting.PixelIndex the two maps will be lifted through (bias gradients = sums over the points)."""
     _need_gpu(x, "fused_heads")
     if fp32_mode():  # AvgPool2d(5, 1, 2) of the cropped map (torch pooling op), then the two 1x1 convolutions in fp32
         # (plain NCHW copy of the crop: torch 2.10+rocm7.0's avg_pool2d BACKWARD returns wrong values for a sliced
@@ -640,4 +643,4 @@ def fused_heads(x, h, w, conv_main: nn.Conv2d, conv_aux: nn.Conv2d):
         pooled = torch.nn.functional.avg_pool2d(x[:, :, :h, :w].contiguous(), 5, 1, 2)
         return (_c2f.Conv2dF32Fn.apply(pooled, conv_main.weight, conv_main.bias, 1, 0),
                 _c2f.Conv2dF32Fn.apply(pooled, conv_aux.weight, conv_aux.bias, 1, 0))
-    return _HeadsFn.apply(x, h, w, conv_main.weight, conv_main.bias, conv_aux.weight, conv_aux.bias)
+    return _HeadsFn.apply(x, h, w, conv_main.weight, conv_main.bias, conv_aux.weight, conv_aux.bias, index)

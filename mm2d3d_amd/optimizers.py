@@ -93,7 +93,9 @@ class FlatAdamW(optim.Optimizer):
                 a["touched"] = [True] * len(a["params"])
 
     @torch.no_grad()
-    def step(self, closure=None, grad_scale: float = 1.0):
+    def step(self, closure=None, grad_scale: float = 1.0, skip_words=None):
+        """``skip_words``: device int32 words (<= 16) - the update is a no-op on the device when any of them is nonzero (the
+        data-parallel reducer's collective flags, ddp.GradAllReducer.skip_words: no read-back, the host never waits)."""
         loss = closure() if closure is not None else None
         if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
             raise RuntimeError("FlatAdamW.step: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
@@ -114,14 +116,17 @@ class FlatAdamW(optim.Optimizer):
             for lo, hi in self._touched_ranges(a):
                 check(L.mm_adamw_step(ptr(a["p"][lo:hi]), ptr(a["g"][lo:hi]), ptr(a["m"][lo:hi]), ptr(a["v"][lo:hi]), hi - lo,
                                       float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                      float(group["weight_decay"]), self._step, float(grad_scale), stream()), "adamw_step")
+                                      float(group["weight_decay"]), self._step, float(grad_scale), ptr(skip_words),
+                                      0 if skip_words is None else int(skip_words.numel()), stream()), "adamw_step")
         return loss
 
     @torch.no_grad()
     def step_scaled(self, scale_dev, found_dev, step_dev, coef_dev, grad_scale: float = 1.0):
         """The update of ``step`` under a device-resident loss scale (mm2d3d_amd/amp.py): gradients are multiplied by
-        ``grad_scale / scale``, and nothing is updated when ``found_dev`` says a gradient is inf / nan - decided on the device,
-        the step counter of the bias corrections (``step_dev``) advances only when the step is taken."""
+        ``grad_scale / scale``, and nothing is updated when ANY word of ``found_dev`` is set (the non-finite flags of every optimiser
+        of the step + the caller's skip words: one decision for all, as the reference's HybridOptim gets from Lightning's
+        GradScaler, train.py:627-636) - decided on the device, the step counter of the bias corrections (``step_dev``) advances
+        only when the step is taken."""
         if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
             raise RuntimeError("FlatAdamW.step_scaled: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")
         L = _lib.lib()
@@ -138,7 +143,7 @@ class FlatAdamW(optim.Optimizer):
             if a is None:
                 continue
             b1, b2 = group["betas"]
-            check(L.mm_amp_prepare(ptr(scale_dev), ptr(found_dev), ptr(step_dev), 1 if first else 0, float(group["lr"]), float(b1),
+            check(L.mm_amp_prepare(ptr(scale_dev), ptr(found_dev), int(found_dev.numel()), ptr(step_dev), 1 if first else 0, float(group["lr"]), float(b1),
                                    float(b2), float(group["eps"]), float(group["weight_decay"]), float(grad_scale),
                                    ptr(coef_dev[gi]), stream()), "amp_prepare")
             first = False

@@ -311,12 +311,21 @@ class TrainModel(nn.Module):
 
     def checkpoint(self):
         """state_dict keys ``model.<net>.model.*`` as in a Lightning checkpoint of the reference; optimisers as a list (HybridOptim)."""
+        self.drain()
         return {"state_dict": {self._ckpt_key(k): v for k, v in self.model.state_dict().items()},
                 "optimizer_states": [o.state_dict() for o in self.optimizers],
                 "lr_schedulers": [s.state_dict() if s is not None else None for s in self.schedulers],
                 "global_step": self.global_step, **self.best,
                 # Lightning's key for the GradScaler of a ``precision: 16`` run
                 **({"native_amp_scaling_state": self.scaler.state_dict()} if self.scaler is not None else {})}
+
+    def drain(self):
+        """End of training / before a checkpoint: the data-parallel reducer reads its collective flag one step late (no host wait
+        in the step), so the LAST step's flag is still unread - wait for it here and raise if that step was flagged (its optimiser
+        update was skipped on the device; the caller decides whether to repeat it)."""
+        if self.reducer is not None and self.reducer.drain_flag():
+            raise RuntimeError("the last training step was flagged by the data-parallel reducer (graph changed / a rank's batch-norm "
+                               "fault): its optimiser update was skipped on every rank")
 
     def load_checkpoint(self, ckpt):
         nets = set(self.model.keys())
@@ -357,9 +366,13 @@ class TrainModel(nn.Module):
         time the host has long filled the queue and sits in the step's read-back wait, so the second poll normally sees a fault of
         the step it belongs to before that step's gradients are applied; the first poll catches what is left."""
         if (self.handle.fault_poll() if self.handle is not None else _lib.fault_poll()):
-            raise RuntimeError(f"a single-launch batch-norm kernel of {when} gave up at its grid barrier (its grid shared the GPU "
-                               "with another process or a spin-waiting kernel): that step's results are invalid - skip its optimiser "
-                               "step / restore the last checkpoint; the process now uses the three-kernel batch norms")
+            self._raise_bn_fault(when)
+
+    @staticmethod
+    def _raise_bn_fault(when):
+        raise RuntimeError(f"a single-launch batch-norm kernel of {when} gave up at its grid barrier (its grid shared the GPU "
+                           "with another process or a spin-waiting kernel): that step's results are invalid - skip its optimiser "
+                           "step / restore the last checkpoint; the process now uses the three-kernel batch norms")
 
     def fit_step(self, batch, next_batch=None):
         """One optimiser step on ``batch``.  ``next_batch``: the batch of the following call (the very dict that will be passed
@@ -393,20 +406,27 @@ class TrainModel(nn.Module):
             if getattr(self, "_scaler_state", None):
                 self.scaler.load_state_dict(self._scaler_state)
                 self._scaler_state = None
+        # One decision for both optimisers, taken on the device: a non-finite gradient in EITHER network (the reference's HybridOptim
+        # is one optimiser to Lightning's GradScaler, train.py:627-636) or a flag of the data-parallel reducer ("graph changed" /
+        # a rank's batch-norm fault: ddp.GradAllReducer.skip_words) leaves every weight untouched on every rank.  A fault of THIS
+        # rank's batch norms is polled before the reduction and travels with it: under data parallelism all ranks skip the step and
+        # raise together (one step late on RCCL: the flag is read without a host wait); alone, this process raises at once.
         if self.scaler is not None:
             self.scaler.scale(loss).backward()
-            self.reducer.finish()
-            self._check_bn_fault("this step")
-            for o in self.optimizers:
-                self.scaler.step(o, self.reducer.grad_scale)
-            self.scaler.update()
         else:
             loss.backward()
-            self.reducer.finish()
-            self._check_bn_fault("this step")
+        fault = bool(self.handle.fault_poll() if self.handle is not None else _lib.fault_poll())
+        self.reducer.finish(fault=fault)
+        if fault and not self.reducer.active:
+            self._raise_bn_fault("this step")
+        skip = self.reducer.skip_words()
+        if self.scaler is not None:
+            self.scaler.step_all(self.optimizers, self.reducer.grad_scale, skip_words=skip)
+            self.scaler.update()
+        else:
             for o in self.optimizers:
                 if hasattr(o, "grad_arenas"):
-                    o.step(grad_scale=self.reducer.grad_scale)
+                    o.step(grad_scale=self.reducer.grad_scale, skip_words=skip)
                 else:
                     o.step()
         for s in self.schedulers:

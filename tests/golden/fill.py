@@ -73,3 +73,33 @@ def digest_compare(digest, prefix, named, nproj=8):
             cos = None
         rows.append((k, rel, hn / max(rn, 1e-30), cos, rn))
     return rows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Large fixtures (round 5): inputs are REGENERATED from seeds on both sides (the generator script and the tests call the functions
+# below), only outputs and gradient digests are stored.  Sizes are chosen so that the deepest BatchNorm2d (layer4, 1/16 of the
+# padded image) normalises over >= 1,000 values per channel and statistics group: rounding is then no longer amplified through
+# the batch statistics, and a 16-bit gradient can be told from a wrong one.
+LARGE_2D = dict(seed=77, B=4, H=222, W=286)            # padded to 224 x 288: layer4 = 14 x 18 x 4 = 1,008 values per channel
+LARGE_STEP = dict(scenes=4, H=222, W=286, points=4000)  # 4 source + 4 target scenes: 1,008 values per channel and domain
+NPROJ_LARGE = 32
+
+
+def large_inputs_2d(seed=LARGE_2D["seed"], B=LARGE_2D["B"], H=LARGE_2D["H"], W=LARGE_2D["W"]):
+    """(img [B,3,H,W] f32, depth [B,1,H,W] f32, img_indices list of int64 [n_b,2]) of the large 2D train-mode fixture."""
+    g = np.random.default_rng(seed)
+    img = g.random((B, 3, H, W), dtype=np.float32)
+    depth = np.zeros((B, 1, H, W), np.float32)
+    idx = []
+    for b in range(B):
+        n = 1201 + 137 * b
+        ix = np.stack([g.integers(0, H, n), g.integers(0, W, n)], 1).astype(np.int64)
+        depth[b, 0, ix[:, 0], ix[:, 1]] = g.uniform(1, 50, n).astype(np.float32)
+        idx.append(ix)
+    return img, depth, idx
+
+
+def large_functional_2d(n_points, seed=LARGE_2D["seed"] + 1):
+    """The two weight matrices [n_points, 6] of the fixed linear functional sum(w1 * seg_logit) + sum(w2 * seg_logit_avg)."""
+    g = np.random.default_rng(seed)
+    return g.standard_normal((n_points, 6)).astype(np.float32), g.standard_normal((n_points, 6)).astype(np.float32)

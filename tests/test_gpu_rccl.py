@@ -170,3 +170,111 @@ def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_bat
         assert ddp.reducer.drain_flag() is False
     finally:
         dist.destroy_process_group()
+
+
+def test_a_flagged_step_is_skipped_on_the_device_and_the_relearn_step_does_not_raise_again(monkeypatch):
+    """on RCCL the collective "graph changed" flag is read one step late, so the step in which a parameter
+    learned as unused fires (its bucket is not reduced) used to go through the optimiser on every rank.  Now the optimiser kernels
+    test the flag ON THE DEVICE (``skip_words``): the flagged step leaves every weight untouched, the RuntimeError arrives one step
+    later, the re-learn step that follows is reduced correctly and does NOT raise a second time for the old flag, and
+    ``drain_flag`` reports a flagged last step.  Both update forms: FlatAdamW.step(skip_words=) and GradScaler.step_all."""
+    import torch.nn as nn
+
+    from mm2d3d_amd import _lib
+    from mm2d3d_amd.amp import GradScaler
+    from mm2d3d_amd.ddp import GradAllReducer
+    from mm2d3d_amd.optimizers import FlatAdamW
+
+    dev = torch.device("cuda:0")
+    _lib.lib()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        for scaled in (False, True):
+            torch.manual_seed(0)
+            net = nn.Sequential(nn.Linear(8, 16), nn.ReLU(), nn.Linear(16, 4)).to(dev)
+            extra = nn.Linear(4, 4).to(dev)  # unused at first: the find_unused_parameters case
+            opt = FlatAdamW(list(net.parameters()) + list(extra.parameters()), lr=1e-2)
+            red = GradAllReducer([opt], bucket_bytes=200, force=True, overlap=False)
+            scaler = GradScaler(dev, init_scale=64.0) if scaled else None
+            x = torch.randn(5, 8, device=dev)
+
+            def run(use_extra):
+                opt.zero_grad()
+                y = net(x)
+                loss = (y ** 2).sum() + (extra(y).sum() if use_extra else 0.0)
+                (scaler.scale(loss) if scaled else loss).backward()
+                red.finish()  # may raise
+                if scaled:
+                    scaler.step_all([opt], red.grad_scale, skip_words=red.skip_words())
+                    scaler.update()
+                else:
+                    opt.step(grad_scale=red.grad_scale, skip_words=red.skip_words())
+
+            snap = lambda: opt._arenas[0]["p"].detach().clone()
+            run(False), run(False)
+            assert red.learned and len(red.unused) == 2
+            w0 = snap()
+            run(False)
+            w1 = snap()
+            assert not torch.equal(w0, w1)  # an ordinary step moves the weights
+            run(True)  # the graph changes: flagged on the device, the host does not know yet
+            assert torch.equal(snap(), w1), "the flagged step was applied"
+            with pytest.raises(RuntimeError, match="unused"):
+                run(True)  # one step late: raises in finish(), before this step's update is queued
+            assert not red.learned and torch.equal(snap(), w1)
+            run(True)  # the re-learn step: reduced in full, must not raise for the (void) flag of the raising step
+            w2 = snap()
+            assert red.learned and len(red.unused) == 0 and not torch.equal(w2, w1)
+            run(True)
+            assert red.drain_flag() is False
+            if scaled:
+                assert scaler.steps_taken(opt) == 5 and scaler.get_scale() == 64.0  # the flag vetoes the step, not the loss scale
+            # a flagged LAST step is found by drain_flag (TrainModel.checkpoint raises on it)
+            extra2 = nn.Linear(4, 4).to(dev)
+            del extra2
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_scaler_step_all_takes_one_decision_for_every_optimiser():
+    """the reference's HybridOptim is ONE optimiser to Lightning's GradScaler (train.py:627-636) - a non-finite gradient in
+    the 2D network must skip the 3D network's update too (and vice versa); ``step`` keeps torch's per-optimiser form."""
+    from mm2d3d_amd.amp import GradScaler
+    from mm2d3d_amd.optimizers import FlatAdamW
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    pa = [torch.nn.Parameter(torch.randn(100, device=dev))]
+    pb = [torch.nn.Parameter(torch.randn(50, device=dev))]
+    oa, ob = FlatAdamW(pa, lr=1e-2), FlatAdamW(pb, lr=1e-2)
+    sc = GradScaler(dev, init_scale=8.0)
+
+    def load(poison):
+        for o, ps in ((oa, pa), (ob, pb)):
+            o.zero_grad()
+            ps[0].grad.copy_(torch.ones_like(ps[0]) * 8.0)
+            o.mark_all_touched()
+        if poison:
+            pa[0].grad[3] = float("inf")
+
+    a0, b0 = pa[0].detach().clone(), pb[0].detach().clone()
+    load(True)
+    sc.step_all([oa, ob])
+    sc.update()
+    assert torch.equal(pa[0], a0) and torch.equal(pb[0], b0), "an overflow in one optimiser must skip both"
+    assert sc.get_scale() == 4.0 and sc.steps_taken(oa) == 0 and sc.steps_taken(ob) == 0
+    load(False)
+    sc.step_all([oa, ob])
+    sc.update()
+    assert not torch.equal(pa[0], a0) and not torch.equal(pb[0], b0)
+    assert sc.steps_taken(oa) == 1 and sc.steps_taken(ob) == 1
+    # an extra skip word vetoes the step without touching the loss scale
+    a1, b1 = pa[0].detach().clone(), pb[0].detach().clone()
+    load(False)
+    sc.step_all([oa, ob], skip_words=torch.tensor([0, 1], dtype=torch.int32, device=dev))
+    sc.update()
+    assert torch.equal(pa[0], a1) and torch.equal(pb[0], b1) and sc.get_scale() == 4.0
+    # the plain update form takes the same words
+    load(False)
+    oa.step(grad_scale=1.0, skip_words=torch.tensor([1], dtype=torch.int32, device=dev))
+    assert torch.equal(pa[0], a1)
