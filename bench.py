@@ -239,14 +239,15 @@ def conv2d_roofline(tm, batch, dev):
     (mm_conv2d_3x3s1 / mm_conv2d_3x3s1_pair = k_conv3x3w/r fwd + dgrad - one problem / the same layer of both encoders per launch -,
     mm_conv2d_wgrad3x3_pair = the pairs' weight gradients, mm_conv2d_gemm = stems / strided / 1x1 / transposed convs fwd + dgrad,
     mm_conv2d_dgrad_s2 = the stride-2 data gradients by output parity, mm_conv2d_stem7 = the two 7x7 stems,
-    mm_conv2d_wgrad = weight gradients incl. their slab reduction) of one step bracketed by HIP events on the launch stream,
+    mm_conv2d_wgrad = weight gradients incl. their slab reduction; mm_conv2d_wgrad_slabs / mm_conv2d_wgrad3x3_pair_slabs = the slab
+    kernels alone, mm_conv2d_wgrad_reduce_batch = ONE slab-sum launch for all of them) of one step bracketed by HIP events on the launch stream,
     against the algorithmic FLOPs of BASELINE.md section 3 (fwd x 3 for fwd + dgrad + wgrad) and the dense bf16 matrix peak."""
     from mm2d3d_amd import _lib
     from mm2d3d_amd import conv2d as c2d
 
     L = _lib.lib()
     base = ("mm_conv2d_3x3s1", "mm_conv2d_3x3s1_pair", "mm_conv2d_gemm", "mm_conv2d_dgrad_s2", "mm_conv2d_stem7", "mm_conv2d_wgrad",
-            "mm_conv2d_wgrad3x3_pair")
+            "mm_conv2d_wgrad3x3_pair", "mm_conv2d_wgrad_slabs", "mm_conv2d_wgrad3x3_pair_slabs", "mm_conv2d_wgrad_reduce_batch")
     # the IEEE fp16 build exports the same entry points under the suffix _f16 (csrc/h16.h); hook the ones this run calls
     f16 = c2d.HALF[0] == torch.float16
     names = tuple(_lib.H16_2D[n] if f16 else n for n in base)

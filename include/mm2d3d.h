@@ -402,6 +402,21 @@ int mm_conv2d_wgrad(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const
 int mm_conv2d_wgrad3x3_pair(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1, int Cn,
                             int ldy, float* dW0, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
                             mm_stream_t stream);
+/* The same two weight-gradient forms WITHOUT their slab sums (round 5): ``slabs`` (mm_conv2d_wgrad_ws_bytes bytes; the caller keeps
+ * it until the sum has run) receives the fp32 partial slabs [*nsplit][Cn][ntaps][Ck] (pair: [2][*nsplit][Cn][9][Ck]), and ONE
+ * mm_conv2d_wgrad_reduce_batch launch later sums the slabs of every layer of a backward pass into their gradients - the per-layer
+ * sums were ~50 launches of ~14 us per training step.  Same sums in the same order: bit-identical with mm_conv2d_wgrad.
+ * descs_dev: n descriptors of mm_conv2d_wgrad_reduce_desc_bytes() bytes on the device: {const float* slabs; float* dW; float* dW1
+ * (the pair's second gradient, else NULL); int64 sn, st, sk; int32 nsplit, Cn, ntaps, Ck, accumulate, blk_first}, blk_first = the
+ * running sum of mm_conv2d_wgrad_reduce_blocks(Cn, Ck, pair) over the preceding descriptors, total_blocks = the sum over all. */
+int mm_conv2d_wgrad_slabs(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+                          int sa, int ntaps, const int* ty, const int* tx, void* slabs, size_t slab_bytes, int* nsplit,
+                          mm_stream_t stream);
+int mm_conv2d_wgrad3x3_pair_slabs(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1,
+                                  int Cn, int ldy, void* slabs, size_t slab_bytes, int* nsplit, mm_stream_t stream);
+int mm_conv2d_wgrad_reduce_desc_bytes(void);
+int64_t mm_conv2d_wgrad_reduce_blocks(int Cn, int Ck, int pair);
+int mm_conv2d_wgrad_reduce_batch(const void* descs_dev, int n, int64_t total_blocks, mm_stream_t stream);
 /* The 7x7 stride-1 stems (EXP/2d_net/backbones.py:23-25) on the staged image of mm_stem_prep: xb [B][Hb][Wb][8] with R = 8 / C image
  * rows stacked per buffer pixel, T = ceil(7 / R) taps of 8 pixels x 8 slots, Wp [64][T][64]; output O [B][H][W][64] (pitch ldo).
  * One persistent kernel with the weights resident in LDS and the RAW strip of a 16 x 16 tile staged once - the generic implicit GEMM
@@ -530,6 +545,14 @@ size_t mm_conv2d_wgrad_ws_bytes_f16(int64_t M, int Cn, int Ck, int ntaps);
 int mm_conv2d_wgrad_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn,
                     int ldy, int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st,
                     int64_t sk, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_conv2d_wgrad_slabs_f16(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+                          int sa, int ntaps, const int* ty, const int* tx, void* slabs, size_t slab_bytes, int* nsplit,
+                          mm_stream_t stream);
+int mm_conv2d_wgrad3x3_pair_slabs_f16(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1,
+                                  int Cn, int ldy, void* slabs, size_t slab_bytes, int* nsplit, mm_stream_t stream);
+int mm_conv2d_wgrad_reduce_desc_bytes_f16(void);
+int64_t mm_conv2d_wgrad_reduce_blocks_f16(int Cn, int Ck, int pair);
+int mm_conv2d_wgrad_reduce_batch_f16(const void* descs_dev, int n, int64_t total_blocks, mm_stream_t stream);
 int64_t mm_conv2d_stem7_stat_rows_f16(int B, int H, int W);
 int mm_conv2d_stem7_f16(const void* xb, int B, int Hb, int Wb, int H, int W, int R, int T, void* O, int ldo, const void* Wp, float* stats,
                     int split_b, mm_stream_t stream);

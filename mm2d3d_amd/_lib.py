@@ -119,6 +119,11 @@ _PROTOS = {
     "mm_conv2d_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, i64, i64, i32, vp, sz,
                               vp]),
     "mm_conv2d_wgrad3x3_pair": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, i64, i64, i64, i32, vp, sz, vp]),
+    "mm_conv2d_wgrad_slabs": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, sz, vp, vp]),
+    "mm_conv2d_wgrad3x3_pair_slabs": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, sz, vp, vp]),
+    "mm_conv2d_wgrad_reduce_desc_bytes": (i32, []),
+    "mm_conv2d_wgrad_reduce_blocks": (i64, [i32, i32, i32]),
+    "mm_conv2d_wgrad_reduce_batch": (i32, [vp, i32, i64, vp]),
     "mm_conv2d_f32": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64, vp, vp]),
     "mm_conv2d_f32_wgrad_ws_bytes": (sz, [i64, i32, i32, i32, i32]),
     "mm_conv2d_f32_wgrad": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, i64, i64, i64, i64,
@@ -182,6 +187,11 @@ H16_2D = {
     "mm_conv2d_wgrad_ws_bytes": "mm_conv2d_wgrad_ws_bytes_f16",
     "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",
     "mm_conv2d_wgrad3x3_pair": "mm_conv2d_wgrad3x3_pair_f16",
+    "mm_conv2d_wgrad_slabs": "mm_conv2d_wgrad_slabs_f16",
+    "mm_conv2d_wgrad3x3_pair_slabs": "mm_conv2d_wgrad3x3_pair_slabs_f16",
+    "mm_conv2d_wgrad_reduce_desc_bytes": "mm_conv2d_wgrad_reduce_desc_bytes_f16",
+    "mm_conv2d_wgrad_reduce_blocks": "mm_conv2d_wgrad_reduce_blocks_f16",
+    "mm_conv2d_wgrad_reduce_batch": "mm_conv2d_wgrad_reduce_batch_f16",
     "mm_stem_prep": "mm_stem_prep_f16",
     "mm_conv2d_stem7_stat_rows": "mm_conv2d_stem7_stat_rows_f16",
     "mm_conv2d_stem7": "mm_conv2d_stem7_f16",

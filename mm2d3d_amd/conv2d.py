@@ -231,6 +231,86 @@ def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz
     )
 
 
+# The weight gradient of a layer = a "partial slabs" kernel + a small slab-sum kernel (csrc/conv2d.hip).  With a gradient sink
+# (FlatAdamW's arena) the slab sums of ALL layers of a backward pass are deferred into ONE launch (mm_conv2d_wgrad_reduce_batch,
+# issued from an end-of-backward callback of the autograd engine): ~50 launches of ~14 us per step, each behind a dependent-launch
+# gap, become one; every layer keeps its slabs (<= 40 MB) in a buffer of its own until then - ~1.4 GB per step of 288 GB.  Same
+# slabs, same summation order: bit-identical.  MM_CONV_WGRAD_BATCH=0: the per-layer form (also what the data-parallel reducer
+# selects when its buckets go out DURING backward, ddp.GradAllReducer(overlap=True): a deferred sum would hold every bucket back).
+WGRAD_BATCH = [True]  # (set from the environment below, next to the other A/B switches)
+
+
+class _WgBatch:
+    def __init__(self):
+        self.items = []  # (slabs, dW, dW1, sn, st, sk, nsplit, Cn, ntaps, Ck, params)
+        self.cb_queued = False
+
+    def add(self, item):
+        self.items.append(item)
+        if not self.cb_queued:
+            self.cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+
+    def reset(self):
+        """Forget slabs whose backward pass never reached its end (an exception in between): called by FlatAdamW.zero_grad."""
+        self.items = []
+
+    def flush(self):
+        self.cb_queued = False
+        items, self.items = self.items, []
+        if not items:
+            return
+        # A weight that took part in the forward pass twice (the literal two-call sequence of the two domains, train.py:186-292)
+        # has two slab sets that ADD into one gradient: they must not share a launch (two blocks would read-modify-write the same
+        # words) - a new launch starts whenever a destination repeats.  The joint-domain step uses every weight once: one launch.
+        groups, seen = [[]], set()
+        for it in items:
+            dst = {it[1].data_ptr()} | ({it[2].data_ptr()} if it[2] is not None else set())
+            if dst & seen:
+                groups.append([])
+                seen = set()
+            seen |= dst
+            groups[-1].append(it)
+        for g in groups:
+            self._launch(g)
+        for it in items:
+            for prm in it[10]:
+                gradsink.done(prm)
+
+    @staticmethod
+    def _launch(items):
+        import numpy as np
+
+        L = lib2d()
+        nb = int(L.mm_conv2d_wgrad_reduce_desc_bytes())
+        assert nb == 72
+        tab = np.zeros((len(items), nb // 4), dtype=np.int32)
+        p64 = tab[:, :12].view(np.int64)  # {slabs, dW, dW1, sn, st, sk}
+        first = 0
+        for i, (slabs, dW, dW1, sn, st, sk, nsplit, Cn, ntaps, Ck, _) in enumerate(items):
+            p64[i, :] = (slabs.data_ptr(), dW.data_ptr(), 0 if dW1 is None else dW1.data_ptr(), sn, st, sk)
+            tab[i, 12:18] = (nsplit, Cn, ntaps, Ck, 1, first)
+            first += int(L.mm_conv2d_wgrad_reduce_blocks(Cn, Ck, 0 if dW1 is None else 1))
+        dev = items[0][0].device
+        descs = torch.from_numpy(tab.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+        check(L.mm_conv2d_wgrad_reduce_batch(ptr(descs), len(items), first, stream()), "conv2d_wgrad_reduce_batch")
+
+
+_WGB = _WgBatch()
+gradsink.RESETTERS.append(_WGB.reset)
+
+
+def _wgrad_deferred(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, param, sn, st, sk, ldx=None, ldy=None):
+    """The slabs of one weight gradient now, their sum into ``param._mm_sink`` with every other layer's at the end of backward."""
+    L = lib2d()
+    nbytes = int(L.mm_conv2d_wgrad_ws_bytes(Bn * Hg * Wg, Cn, Ck, len(ty)))
+    slabs = torch.empty(nbytes, dtype=torch.uint8, device=X.device)
+    nsplit = C.c_int(0)
+    check(L.mm_conv2d_wgrad_slabs(ptr(X), Bn, Hi, Wi, Ck, ldx or Ck, ptr(dY), Hg, Wg, Cn, ldy or Cn, sa, len(ty), _arr(ty), _arr(tx), ptr(slabs),
+                                  nbytes, C.byref(nsplit), stream()), "conv2d_wgrad_slabs")
+    _WGB.add((slabs, param._mm_sink, None, sn, st, sk, nsplit.value, Cn, len(ty), Ck, (param,)))
+
+
 def _wgrad(X, Bn, Hi, Wi, Ck, dY, Hg, Wg, Cn, sa, ty, tx, dW, sn, st, sk, accumulate=0, ldx=None, ldy=None):
     L = lib2d()
     ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * Hg * Wg, Cn, Ck, len(ty))), X.device)
@@ -325,7 +405,9 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]
             tx = [kw - padding for _ in range(KH) for kw in range(KW)]
-            if ctx.wparam is not None:  # accumulate straight into the optimiser's gradient arena
+            if ctx.wparam is not None and WGRAD_BATCH[0]:  # slabs now, summed into the arena with every other layer's (_WgBatch)
+                _wgrad_deferred(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam, Cin * T, 1, T, ldx=ldx, ldy=ldy)
+            elif ctx.wparam is not None:  # accumulate straight into the optimiser's gradient arena
                 _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam._mm_sink, Cin * T, 1, T, accumulate=1, ldx=ldx,
                        ldy=ldy)
                 gradsink.done(ctx.wparam)
@@ -350,6 +432,7 @@ STEM7 = [_os.environ.get("MM_CONV_STEM7", "1") != "0"]  # the 7x7 stems on their
 DGRAD_S2 = [_os.environ.get("MM_CONV_DGRAD_S2", "1") != "0"]  # stride-2 data gradients by output parity (A/B switch)
 PAIR = [_os.environ.get("MM_CONV_PAIR", "1") != "0"]
 PAIR_WGRAD = [_os.environ.get("MM_CONV_PAIR_WGRAD", "1") != "0"]  # the pairs' weight gradients in one launch too
+WGRAD_BATCH[0] = _os.environ.get("MM_CONV_WGRAD_BATCH", "1") != "0"
 
 
 def pairable(x1, x2, w1, w2):
@@ -419,6 +502,14 @@ class Conv2dPairFn(torch.autograd.Function):
             # both weight gradients in the two launches one of them takes (mm_conv2d_wgrad3x3_pair)
             L = lib2d()
             sink = ctx.wparams[0] is not None
+            if sink and WGRAD_BATCH[0]:  # both problems' slabs now, their sums with every other layer's (_WgBatch)
+                nbytes = int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, Cin, 9))
+                slabs = torch.empty(nbytes, dtype=torch.uint8, device=x1.device)
+                nsplit = C.c_int(0)
+                check(L.mm_conv2d_wgrad3x3_pair_slabs(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(dys[0]), ptr(dys[1]), Cout, Cout, ptr(slabs), nbytes,
+                                                      C.byref(nsplit), stream()), "conv2d_wgrad3x3_pair_slabs")
+                _WGB.add((slabs, ctx.wparams[0]._mm_sink, ctx.wparams[1]._mm_sink, Cin * 9, 1, 9, nsplit.value, Cout, 9, Cin, tuple(ctx.wparams)))
+                return dx[0], dx[1], None, None, None, None
             tgt = [wp._mm_sink for wp in ctx.wparams] if sink else [torch.empty_like(w) for w in wfs]
             ws = _lib.workspace.get(int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, Cin, 9)), x1.device)
             check(L.mm_conv2d_wgrad3x3_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(dys[0]), ptr(dys[1]), Cout, Cout, ptr(tgt[0]), ptr(tgt[1]),
@@ -432,7 +523,9 @@ class Conv2dPairFn(torch.autograd.Function):
         for i in range(2):
             if not ctx.needs_input_grad[2 + i]:
                 continue
-            if ctx.wparams[i] is not None:  # straight into the optimiser's gradient arena
+            if ctx.wparams[i] is not None and WGRAD_BATCH[0]:
+                _wgrad_deferred(xs[i], Bn, H, W, Cin, dys[i], H, W, Cout, 1, ty, tx, ctx.wparams[i], Cin * 9, 1, 9)
+            elif ctx.wparams[i] is not None:  # straight into the optimiser's gradient arena
                 _wgrad(xs[i], Bn, H, W, Cin, dys[i], H, W, Cout, 1, ty, tx, ctx.wparams[i]._mm_sink, Cin * 9, 1, 9, accumulate=1)
                 gradsink.done(ctx.wparams[i])
             else:
@@ -477,7 +570,9 @@ class ConvTranspose2dFn(torch.autograd.Function):
             _gemm(dy, Bn, 2 * H, 2 * W, Cout, dx, H, W, Cin, H, W, 1, 2, 1, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
             # roles: "dY" := x (base grid H x W, n = ci), "X" := dy (source pixel (2y+a, 2x+b), k = co)
-            if ctx.wparam is not None:  # straight into the optimiser's gradient arena
+            if ctx.wparam is not None and WGRAD_BATCH[0]:
+                _wgrad_deferred(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, ctx.wparam, Cout * 4, 1, 4)
+            elif ctx.wparam is not None:  # straight into the optimiser's gradient arena
                 _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, ctx.wparam._mm_sink, Cout * 4, 1, 4, accumulate=1)
                 gradsink.done(ctx.wparam)
             else:

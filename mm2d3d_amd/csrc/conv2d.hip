@@ -1540,9 +1540,10 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
 }
 
 // phase 1 of k_wgrad_reduce for a compile-time tap count: two slabs x NT taps = up to 18 independent loads per thread and pass
+typedef const __attribute__((address_space(1))) float* gcf32;  // global pointers, also when they come out of a descriptor table
+typedef __attribute__((address_space(1))) float* gf32;        // (a generic pointer would make every access a FLAT one)
 template <int NT>
-__device__ inline void wgrad_reduce_slices(const float* __restrict__ src, int64_t ne, int Ck, int nsplit, int sl, int kl,
-                                           float (*red)[16][33]) {
+__device__ inline void wgrad_reduce_slices(gcf32 src, int64_t ne, int Ck, int nsplit, int sl, int kl, float (*red)[16][33]) {
   float s[NT];
 #pragma unroll
   for (int tp = 0; tp < NT; tp++) s[tp] = 0.f;
@@ -1565,27 +1566,25 @@ __device__ inline void wgrad_reduce_slices(const float* __restrict__ src, int64_
 }
 
 // dW_torch[idx(n,tap,k)] (+)= sum_splits partial[s][n][tap][k];  out strides (sn, st, sk) express the torch layout
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
-                                                       float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
-                                                       int accumulate, float* __restrict__ dW1 = nullptr) {
+__device__ inline void wgrad_reduce_block(gcf32 partial, int nsplit, int Cn, int ntaps, int Ck, gf32 dW, int64_t sn, int64_t st, int64_t sk,
+                                          int accumulate, gf32 dW1, int bx, float (*red)[16][33]) {
   // dW1 (pair mode): blocks [Cn * Ck / 32, 2 Cn * Ck / 32) sum the slabs of the second problem (they follow the first's) into dW1
-  if (dW1 && (int)blockIdx.x >= Cn * (Ck >> 5)) {
+  if (dW1 && bx >= Cn * (Ck >> 5)) {
     partial += (int64_t)nsplit * Cn * ntaps * Ck;
     dW = dW1;
   }
-  const int blk = dW1 ? (int)blockIdx.x % (Cn * (Ck >> 5)) : (int)blockIdx.x;
+  const int blk = dW1 ? bx % (Cn * (Ck >> 5)) : bx;
   // A workgroup owns (n, 32 consecutive k) for ALL taps.  Phase 1: thread (k, slice) adds the slabs i = slice, slice + 8, ...
   // of every tap (4-byte loads, 128-byte segments per 32 lanes, all independent).  Phase 2: the 8 slices are combined in a
   // fixed order (bit-stable) and the 32 x ntaps results are written in the ORDER OF THE DESTINATION: for a Conv2d weight
   // [Cn][Ck][3][3] (st = 1, sk = 9) that is one contiguous 1,152-byte run.  (Writing four k of one tap per thread, as the
   // first version did, touched every 36-byte weight row nine times from nine workgroups: the read-modify-write of the gradient
   // arena cost more than reading the slabs.)
-  __shared__ float red[8][16][33];
   const int kl = threadIdx.x & 31, sl = threadIdx.x >> 5;
   const int nkb = Ck >> 5;
   const int n = blk / nkb, k0 = (blk - n * nkb) << 5;
   const int64_t ne = (int64_t)Cn * ntaps * Ck;
-  const float* src = partial + ((int64_t)n * ntaps) * Ck + k0 + kl;
+  gcf32 src = partial + ((int64_t)n * ntaps) * Ck + k0 + kl;
   if (ntaps == 9) wgrad_reduce_slices<9>(src, ne, Ck, nsplit, sl, kl, red);
   else if (ntaps == 4) wgrad_reduce_slices<4>(src, ne, Ck, nsplit, sl, kl, red);
   else if (ntaps == 1) wgrad_reduce_slices<1>(src, ne, Ck, nsplit, sl, kl, red);
@@ -1603,9 +1602,40 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     float t = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; i++) t += red[i][tp][k];
-    float* d = dW + n * sn + tp * st + (int64_t)(k0 + k) * sk;
+    gf32 d = dW + n * sn + tp * st + (int64_t)(k0 + k) * sk;
     *d = accumulate ? *d + t : t;
   }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, int nsplit, int Cn, int ntaps, int Ck,
+                                                       float* __restrict__ dW, int64_t sn, int64_t st, int64_t sk,
+                                                       int accumulate, float* __restrict__ dW1 = nullptr) {
+  __shared__ float red[8][16][33];
+  wgrad_reduce_block((gcf32)partial, nsplit, Cn, ntaps, Ck, (gf32)dW, sn, st, sk, accumulate, (gf32)dW1, (int)blockIdx.x, red);
+}
+
+// The slab sums of EVERY weight gradient of a backward pass in one launch (round 5): the per-layer k_wgrad_reduce was 51 launches of
+// ~14 us per step, each behind a dependent-launch gap.  The slabs of a layer stay in their own buffer until the end of the
+// backward pass (288 GB of HBM: ~1.4 GB of slabs per step); a block finds its layer by binary search over the first-block column
+// and then IS the per-layer kernel's block: same sums, same order - bit-identical.
+struct WgRedD {
+  const float* partial;
+  float* dW;
+  float* dW1;
+  int64_t sn, st, sk;
+  int nsplit, Cn, ntaps, Ck, accumulate, blk_first;
+};
+__global__ __launch_bounds__(256) void k_wgrad_reduce_batch(const WgRedD* __restrict__ descs, int n) {
+  __shared__ float red[8][16][33];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].blk_first <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const WgRedD d = descs[lo];
+  wgrad_reduce_block((gcf32)d.partial, d.nsplit, d.Cn, d.ntaps, d.Ck, (gf32)d.dW, d.sn, d.st, d.sk, d.accumulate, (gf32)d.dW1,
+                     (int)blockIdx.x - d.blk_first, red);
 }
 
 #define MM_PACK_CHUNK 4096
@@ -2004,9 +2034,10 @@ size_t MM_SYM(mm_conv2d_wgrad_ws_bytes)(int64_t M, int Cn, int Ck, int ntaps) {
 // dW[n*sn + t*st + k*sk] (+)= sum_m dY[m][n] * X[src(m,t)][k];   base grid = dY pixels (B,Hg,Wg), src = (gy*sa+ty, gx*sa+tx)
 // 3x3 stride-1 pad-1 weight gradient from halo tiles (k_wgrad3x3n + k_wgrad_reduce); X1 / dY1 / dW1 != NULL: a second problem of the
 // same shape in the same two launches (the same layer of the two encoders: twice the patches per workgroup, half the slabs each)
+// nsplit_out != NULL: slabs only (mm_conv2d_wgrad_slabs: their sum is left to mm_conv2d_wgrad_reduce_batch), *nsplit_out = slab count
 static int wgrad3x3_launch(const void* X, const void* X1, const void* dY, const void* dY1, int B, int Hg, int Wg, int Ck, int ldx, int Cn,
                            int ldy, float* dW, float* dW1, int64_t sn, int64_t st, int64_t sk, int accumulate, void* ws, size_t ws_bytes,
-                           hipStream_t s) {
+                           hipStream_t s, int* nsplit_out = nullptr) {
   const int np = X1 ? 2 : 1;
   Wg9P q;
   q.X = (const u16*)X; q.DY = (const u16*)dY; q.X1 = (const u16*)X1; q.DY1 = (const u16*)dY1;
@@ -2041,15 +2072,17 @@ static int wgrad3x3_launch(const void* X, const void* X1, const void* dY, const 
     mm_attr_done(&attr9);
   }
   hipLaunchKernelGGL(k_wgrad3x3n, dim3((unsigned)(nsplit9 * np * q.ntile)), dim3(512), lds9, s, q);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(np * Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,
-                     dW, sn, st, sk, accumulate, dW1);
+  if (nsplit_out) *nsplit_out = nsplit9;
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(np * Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit9, Cn, 9, Ck,
+                       dW, sn, st, sk, accumulate, dW1);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }
 
-int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
-                    int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st, int64_t sk,
-                    int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+static int wgrad_any(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+                     int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st, int64_t sk,
+                     int accumulate, void* ws, size_t ws_bytes, hipStream_t s, int* nsplit_out) {
   MM_CHECK_ARG(Ck % 64 == 0 && Cn % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ntaps <= MAXT, "conv2d_wgrad: bad shape");
   MM_CHECK_ARG(Cn % 64 == 0, "conv2d_wgrad: Cn must be a multiple of 64");
   WgP p;
@@ -2063,7 +2096,7 @@ int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ld
   bool is3x3 = (ntaps == 9 && sa == 1 && Hi == Hg && Wi == Wg);
   for (int i = 0; i < 9 && is3x3; i++) is3x3 = (ty[i] == i / 3 - 1) && (tx[i] == i % 3 - 1);
   if (is3x3 && M > 0)
-    return wgrad3x3_launch(X, nullptr, dY, nullptr, B, Hg, Wg, Ck, ldx, Cn, ldy, dW, nullptr, sn, st, sk, accumulate, ws, ws_bytes, s);
+    return wgrad3x3_launch(X, nullptr, dY, nullptr, B, Hg, Wg, Ck, ldx, Cn, ldy, dW, nullptr, sn, st, sk, accumulate, ws, ws_bytes, s, nsplit_out);
   p.mchunk = wgrad_chunk(M, Cn, Ck, ntaps);
   const int nsplit = (int)mm_cdiv(M, p.mchunk);
   if ((size_t)nsplit * Cn * ntaps * Ck * sizeof(float) > ws_bytes) {
@@ -2081,8 +2114,47 @@ int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ld
       hipLaunchKernelGGL(k_conv_wgrad2<64>, dim3(nsplit, (Cn / 64) * nkt, ntaps), dim3(256), lds, s, p);
     }
   }
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, p.partial,
-                     M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
+  if (nsplit_out) *nsplit_out = M > 0 ? nsplit : 0;
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, p.partial,
+                       M > 0 ? nsplit : 0, Cn, ntaps, Ck, dW, sn, st, sk, accumulate);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+int MM_SYM(mm_conv2d_wgrad)(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+                    int sa, int ntaps, const int* ty, const int* tx, float* dW, int64_t sn, int64_t st, int64_t sk,
+                    int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  return wgrad_any(X, B, Hi, Wi, Ck, ldx, dY, Hg, Wg, Cn, ldy, sa, ntaps, ty, tx, dW, sn, st, sk, accumulate, ws, ws_bytes, s, nullptr);
+}
+
+// The partial slabs of mm_conv2d_wgrad WITHOUT their sum: ``slabs`` (mm_conv2d_wgrad_ws_bytes bytes, the caller keeps it until the
+// sum has run) receives [*nsplit][Cn][ntaps][Ck] fp32; mm_conv2d_wgrad_reduce_batch later sums the slabs of every layer of a
+// backward pass in ONE launch (same sums, same order: bit-identical with mm_conv2d_wgrad).
+int MM_SYM(mm_conv2d_wgrad_slabs)(const void* X, int B, int Hi, int Wi, int Ck, int ldx, const void* dY, int Hg, int Wg, int Cn, int ldy,
+                          int sa, int ntaps, const int* ty, const int* tx, void* slabs, size_t slab_bytes, int* nsplit, hipStream_t s) {
+  MM_CHECK_ARG(nsplit != nullptr, "conv2d_wgrad_slabs: nsplit is NULL");
+  return wgrad_any(X, B, Hi, Wi, Ck, ldx, dY, Hg, Wg, Cn, ldy, sa, ntaps, ty, tx, nullptr, 0, 0, 0, 0, slabs, slab_bytes, s, nsplit);
+}
+
+// ... of mm_conv2d_wgrad3x3_pair: slabs = [2][*nsplit][Cn][9][Ck] (problem 1's follow problem 0's)
+int MM_SYM(mm_conv2d_wgrad3x3_pair_slabs)(const void* X0, const void* X1, int B, int H, int W, int Ck, int ldx, const void* dY0, const void* dY1,
+                                  int Cn, int ldy, void* slabs, size_t slab_bytes, int* nsplit, hipStream_t s) {
+  MM_CHECK_ARG(Ck % 64 == 0 && Cn % 64 == 0 && ldx % 8 == 0 && ldy % 8 == 0, "conv2d_wgrad3x3_pair_slabs: bad shape");
+  MM_CHECK_ARG(X0 && X1 && dY0 && dY1 && nsplit, "conv2d_wgrad3x3_pair_slabs: null pointer");
+  *nsplit = 0;
+  if ((int64_t)B * H * W == 0) return MM_OK;
+  return wgrad3x3_launch(X0, X1, dY0, dY1, B, H, W, Ck, ldx, Cn, ldy, nullptr, nullptr, 0, 0, 0, 0, slabs, slab_bytes, s, nsplit);
+}
+
+// One launch for the slab sums of n weight gradients.  descs_dev: n descriptors of mm_conv2d_wgrad_reduce_desc_bytes() bytes on
+// the device = {const float* slabs; float* dW; float* dW1 (pair: second problem, else NULL); int64 sn, st, sk; int32 nsplit, Cn,
+// ntaps, Ck, accumulate, blk_first}, blk_first = running sum of mm_conv2d_wgrad_reduce_blocks over the preceding descriptors.
+int MM_SYM(mm_conv2d_wgrad_reduce_desc_bytes)(void) { return (int)sizeof(WgRedD); }
+int64_t MM_SYM(mm_conv2d_wgrad_reduce_blocks)(int Cn, int Ck, int pair) { return (int64_t)(pair ? 2 : 1) * Cn * (Ck / 32); }
+int MM_SYM(mm_conv2d_wgrad_reduce_batch)(const void* descs_dev, int n, int64_t total_blocks, hipStream_t s) {
+  MM_CHECK_ARG(descs_dev && n > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "conv2d_wgrad_reduce_batch: bad arguments");
+  hipLaunchKernelGGL(k_wgrad_reduce_batch, dim3((unsigned)total_blocks), dim3(256), 0, s, (const WgRedD*)descs_dev, n);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

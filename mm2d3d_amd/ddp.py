@@ -94,7 +94,9 @@ class GradAllReducer:
             import os
 
             from . import _lib
+            from . import conv2d as _c2d
 
+            _c2d.WGRAD_BATCH[0] = False  # a deferred slab sum would hold every 2D bucket back until the end of backward
             keep = 1 if os.environ.get("MM_DDP_BN_FUSED", "1") != "0" else 0
             was2d = _lib.bn2d_set_fused(0)
             was3d = _lib.bn3d_set_fused(0)

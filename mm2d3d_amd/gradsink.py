@@ -24,3 +24,13 @@ def done(param):
     if param._mm_pending == 0:
         for h in param._mm_hooks:
             h(param)
+
+
+# deferred gradient work (conv2d._WgBatch: slab sums of a whole backward pass in one launch) registers a reset here; FlatAdamW.zero_grad
+# calls them, so that what an aborted backward pass left behind never reaches the next step's gradients
+RESETTERS = []
+
+
+def reset_deferred():
+    for r in RESETTERS:
+        r()

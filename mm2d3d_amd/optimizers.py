@@ -77,6 +77,9 @@ class FlatAdamW(optim.Optimizer):
         return [a["g"] for a in self._arenas if a is not None]
 
     def zero_grad(self, set_to_none: bool = False):
+        from . import gradsink
+
+        gradsink.reset_deferred()
         for a in self._arenas:
             if a is None:
                 continue

@@ -103,3 +103,19 @@ def large_functional_2d(n_points, seed=LARGE_2D["seed"] + 1):
     """The two weight matrices [n_points, 6] of the fixed linear functional sum(w1 * seg_logit) + sum(w2 * seg_logit_avg)."""
     g = np.random.default_rng(seed)
     return g.standard_normal((n_points, 6)).astype(np.float32), g.standard_normal((n_points, 6)).astype(np.float32)
+
+
+def digest_vs_digest(digest, prefix_a, prefix_b, keys):
+    """{key: estimated relative L2 difference of the tensor recorded under ``prefix_a`` from the one under ``prefix_b``} - two stored
+    digests against each other (e.g. the reference's own fp16-autocast gradients against its fp32 ones)."""
+    out = {}
+    for k in keys:
+        nb = float(digest[f"{prefix_b}{k}/norm"])
+        if f"{prefix_b}{k}/full" in digest and f"{prefix_a}{k}/full" in digest:
+            a = digest[f"{prefix_a}{k}/full"].astype(np.float64).ravel()
+            b = digest[f"{prefix_b}{k}/full"].astype(np.float64).ravel()
+            out[k] = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+        else:
+            d = digest[f"{prefix_a}{k}/proj"] - digest[f"{prefix_b}{k}/proj"]
+            out[k] = float(np.sqrt((d * d).mean()) / max(nb, 1e-30))
+    return out

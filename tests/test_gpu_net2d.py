@@ -562,3 +562,60 @@ def test_backbone_pair_equals_two_separate_backbones_bit_for_bit(split, bn_pairs
                 assert float((a.grad - b.grad).norm() / b.grad.norm()) < 2e-6, n
             else:
                 assert torch.equal(a.grad, b.grad), n
+
+
+def test_deferred_weight_gradient_slab_sums_equal_the_per_layer_sums_bit_for_bit(half2d):
+    """conv2d._WgBatch: with gradient sinks the slab sums of every 2D weight gradient of a backward pass wait for ONE launch at the end
+    of backward (mm_conv2d_wgrad_reduce_batch) instead of one k_wgrad_reduce launch per layer.  Same slabs, same order of every sum:
+    the gradient arena must be bit-identical with the per-layer form (MM_CONV_WGRAD_BATCH=0) - the whole Net2DSeg (3x3 pairs, single
+    3x3, strided, 1x1, transposed convolutions), and a weight used TWICE in one graph (two slab sets adding into one gradient: they
+    must not share a launch)."""
+    import copy
+
+    import mm2d3d_amd.conv2d as c2d
+    from mm2d3d_amd import nn2d
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.optimizers import FlatAdamW
+
+    dev = _dev()
+    torch.manual_seed(3)
+    net = Net2DSeg(6, pretrained=False).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net0 = copy.deepcopy(net)
+    g = np.random.default_rng(0)
+    B, H, W = 2, 64, 96
+    img, depth = torch.randn(B, 3, H, W, device=dev), torch.rand(B, 1, H, W, device=dev)
+    idx = [np.stack([g.integers(0, H, 300), g.integers(0, W, 300)], 1).astype(np.int64) for _ in range(B)]
+    w = torch.randn(600, 6, device=dev)
+    arenas = []
+    was = c2d.WGRAD_BATCH[0]
+    try:
+        for n_, batch in ((net, True), (net0, False)):
+            c2d.WGRAD_BATCH[0] = batch
+            opt = FlatAdamW(n_.parameters(), lr=1e-3)
+            opt.zero_grad()
+            preds, _, _, aux = n_({"img": img, "depth": depth, "img_indices": idx})
+            ((preds["seg_logit"] * w).sum() + (aux["seg_logit_avg"] * w).sum()).backward()
+            torch.cuda.synchronize()
+            assert not c2d._WGB.items  # flushed by the end-of-backward callback
+            arenas.append((opt.grad_arenas()[0].clone(), list(opt._arenas[0]["touched"])))
+        assert arenas[0][1] == arenas[1][1]
+        assert float(arenas[1][0].abs().sum()) > 0 and torch.equal(arenas[0][0], arenas[1][0])
+        # one weight, two uses in one graph
+        res = []
+        for batch in (True, False):
+            c2d.WGRAD_BATCH[0] = batch
+            torch.manual_seed(1)
+            conv = nn2d.Conv2d(64, 64, 3, 1, 1, bias=False).to(dev)
+            opt = FlatAdamW(conv.parameters(), lr=1e-3)
+            opt.zero_grad()
+            x = torch.randn(2, 64, 32, 48, device=dev).to(half2d).contiguous(memory_format=CL).requires_grad_(True)
+            y = conv(conv(x))
+            (y.float() * torch.linspace(-1, 1, y.numel(), device=dev).view_as(y)).sum().backward()
+            torch.cuda.synchronize()
+            res.append(opt.grad_arenas()[0].clone())
+        assert float(res[1].abs().sum()) > 0 and torch.equal(res[0], res[1])
+    finally:
+        c2d.WGRAD_BATCH[0] = was
