@@ -55,6 +55,16 @@ def build_trainer(dev, total_steps=49047, num_classes=6, class_weights=None, tra
     return tm
 
 
+def _graph_state(tm):
+    """Was the 2D trunk replayed as two HIP graphs in the timed loop (mm2d3d_amd/graph2d.py)?"""
+    from mm2d3d_amd import graph2d
+
+    st = graph2d._STATE.get(id(tm.model[tm.modules_name[0]]))
+    n = len(st["graphs"]) if st else 0
+    return {"captured": n > 0, "what": "stems ... heads of the 2D branch, forward and backward, as two hipGraph launches per step "
+            "(MM_GRAPH2D=0: eager launches)" if n else "eager launches (MM_GRAPH2D=0, a data-parallel reducer, or fewer than 3 steps)"}
+
+
 def fresh(batch):
     """A loader hands over new tensors every step; the 3D net gates ``x[1]`` in place, so clone the features."""
     out = {}
@@ -267,13 +277,17 @@ def conv2d_roofline(tm, batch, dev):
     b = fresh(batch)
     n_img = b["source"]["img"].shape[0] + b["target"]["img"].shape[0]
     torch.cuda.synchronize()
+    from mm2d3d_amd import graph2d
+
     try:
+        graph2d.SUSPEND[0] = True  # this leg brackets every launch of the eager trunk (the timed loop replays it as two HIP graphs)
         for n in names:
             setattr(L, n, timed(n, saved[n]))
         torch.cuda._sleep(int(2.0e9 * 0.25))  # a GPU backlog: the event pairs then bracket kernel execution, not launch cadence
         tm.fit_step(b)
         torch.cuda.synchronize()
     finally:
+        graph2d.SUSPEND[0] = False
         for n in names:
             setattr(L, n, saved[n])
     n_launch = sum(len(v) for v in rec.values())
@@ -327,6 +341,42 @@ def conv2d_roofline(tm, batch, dev):
             "kernel": "2D convolution set: k_conv3x3w<*> / k_conv3x3r (3x3 s1 fwd + dgrad), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
                       "k_wgrad3x3n / k_conv_wgrad2 + k_wgrad_reduce (weight gradients)",
             "mfma_busy_cycles_per_wave_cycle": busy, "mfma_busy_source": busy_src}
+
+
+def metadata_build_ms(tm, batch, dev, iters=5):
+    """The sparse metadata build of one joint [source | target] batch alone (voxel dedupe chain of every level, submanifold and
+    strided rulebooks, output-stationary tile tables): GPU time between HIP events, median of ``iters`` (the two small
+    read-backs are waited for inside, as a step that builds its metadata in line would)."""
+    from mm2d3d_amd import domains
+    from mm2d3d_amd.scn.metadata import Metadata
+    from mm2d3d_amd.train import TrainModel
+
+    both, B = TrainModel._join(batch["source"], batch["target"])
+    coords = both["x"][0].contiguous()
+    net3d = tm.model[tm.modules_name[1]]
+    act16 = False
+    try:
+        from mm2d3d_amd import scn
+
+        act16 = scn.ACTIVATION_DTYPE[0] != torch.float32
+    except Exception:
+        pass
+    ts, sizes = [], None
+    for _ in range(iters + 1):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        with domains.split(B):
+            md = Metadata(dev, 4096, 7, act16=act16)
+            md.build_levels(coords)
+            md.build_rulebooks()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+        sizes = {"rows_per_level": [int(lv.n) for lv in md.levels], "subm_rules_per_level": [int(lv.subm.n_rules) for lv in md.levels]}
+    ts = sorted(ts[1:])
+    return {"ms": round(ts[len(ts) // 2], 3), "what": "voxel dedupe chain + rulebooks + tile tables of one joint batch, in line (incl. its two "
+            "read-back waits), HIP events, median of 5", "points": int(coords.shape[0]), **sizes}
 
 
 def branch_rates(tm, batch, dev, iters=5):
@@ -461,8 +511,9 @@ def main(argv=None):
                          "precision: 16 = fp16 autocast + GradScaler, run/train.yaml:11) or bf16")
     ap.add_argument("--batches", type=int, default=4, help="distinct batches rotated through the warm-up and the timed loop (different "
                     "scene seeds -> different point / voxel / rule counts per level every step)")
-    ap.add_argument("--sparse-act", default="bf16", choices=["bf16", "fp16"],
-                    help="--workload c5: kind of the 16-bit sparse rows (fp16 = IEEE half + loss scaling)")
+    ap.add_argument("--sparse-act", default="fp16", choices=["bf16", "fp16"],
+                    help="--workload c5: kind of the 16-bit sparse rows (default fp16 = IEEE half + loss scaling: BASELINE.json configs[4] "
+                         "says 'fp16 activations'; bf16 = bfloat16 rows, no loss scale)")
     a = ap.parse_args(argv)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -500,8 +551,8 @@ def main(argv=None):
         tm = build_trainer(dev, num_classes=10, class_weights=[1.0] * 10, train_kwargs={"precision": a.precision})
     elif a.workload == "c5":
         # source = KITTI-shaped sweeps downsampled to 10,000 points (datasets/virtual_kitti_semantic_kitti.yaml:27),
-        # target = full KITTI-shaped scans; sparse rows in bf16 between the stem and the OutputLayer (fp32 accumulation)
-        # (--sparse-act fp16: IEEE fp16 rows + the device-resident loss scale of mm2d3d_amd/amp.py)
+        # target = full KITTI-shaped scans; sparse rows in IEEE fp16 between the stem and the OutputLayer (fp32 accumulation) under the
+        # device-resident loss scale of mm2d3d_amd/amp.py (--sparse-act bf16: bfloat16 rows, no loss scale)
         shape, ncls, B, down_src = "kitti", 6, a.scenes, 10000
         tm = build_trainer(dev, train_kwargs={"sparse_activations": a.sparse_act, "precision": a.precision})
     else:
@@ -590,7 +641,8 @@ def main(argv=None):
                    "host_enqueue_ms_per_step": round(host_s / a.steps * 1e3, 3),
                    "host_enqueue_ms_empty_queue": round(idle_host[1], 3), "parallelism": f"dp{world}", "final_loss": float(loss.detach()),
                    "step_ms_p10_p50_p90": [round(per_step[int(q * (len(per_step) - 1))], 3) for q in (0.1, 0.5, 0.9)],
-                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2)},
+                   "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
+                   "hip_graph_2d_trunk": _graph_state(tm)},
     }
     if world > 1:
         st = tm.reducer.stats
@@ -600,6 +652,9 @@ def main(argv=None):
             "allreduce_bytes_per_step": st["bytes"], "allreduce_buckets_per_step": st["buckets"],
             "buckets_launched_before_finish": st["early"],  # sent from backward hooks, i.e. overlapped with the rest of backward
             "batch_norm_path": tm.reducer.bn_path,
+            "ddp_schedule": {False: "after: every bucket in finish()", True: "hooks: every bucket as soon as it is complete",
+                             "tail": "tail: buckets from the hooks once the last grid-barrier kernel of backward is queued"}[tm.reducer.overlap],
+            "grid_barrier_kernels_in_backward": st.get("barrier_kernels_bwd"),
         })
     if a.image != "480x302":
         out["config"]["workload"] = out["config"]["workload"].replace("480x302", a.image) + f" [image {a.image}: the reference YAML's size, not the headline]"
@@ -612,13 +667,18 @@ def main(argv=None):
         out["dtype"] = (f"{a.precision} MFMA, fp32 accumulate (2D branch) + {a.sparse_act} sparse activations / fp32 accumulate and statistics "
                         "(3D branch)" + (", loss scale 65536 on the device (GradScaler semantics)" if a.sparse_act == "fp16" else ""))
         out["config"]["workload"] = out["config"]["workload"].replace("sparse rows bf16", f"sparse rows {a.sparse_act}")
-    if rank == 0 and world == 1 and not a.no_extras and a.workload == "c5":
+    if rank == 0 and world == 1 and not a.no_extras and a.workload in ("c4", "c5"):
+        # configs[3] "stresses rulebook/hash build", configs[4] is the mixed-precision gather/scatter: the sparse-engine roofline of
+        # THIS workload (same accounting as the headline's; 16-bit rows are charged 2 bytes per element) and what one batch's
+        # sparse metadata build (voxel hash, rulebooks, tile tables) costs on the GPU
         out["roofline"] = conv_roofline(tm, batch, dev)
+        out["config"]["metadata_build"] = metadata_build_ms(tm, batch, dev)
     if rank == 0 and world == 1 and not a.no_extras and a.workload == "c2":
         print(f"[bench] timed region done: {ms:.2f} ms/step; roofline leg ...", file=sys.stderr, flush=True)
         out["roofline"] = conv_roofline(tm, batch, dev)
         out["roofline_2d"] = conv2d_roofline(tm, batch, dev)
         out["config"]["branch_only_fwd_bwd"] = branch_rates(tm, batch, dev)
+        out["config"]["metadata_build"] = metadata_build_ms(tm, batch, dev)
         if not os.environ.get("MM_BENCH_NO_CPU"):  # (diagnostic A/B runs skip the 20-40 s CPU leg; the default run never does)
             print("[bench] cpu_baseline leg (CPU oracle, about 20-40 s) ...", file=sys.stderr, flush=True)
             out["cpu_baseline"] = cpu_baseline()

@@ -355,6 +355,30 @@ def fault_poll(device=None) -> int:
     return bad
 
 
+# Listeners called right BEFORE a grid-barrier kernel (a single-launch batch norm: csrc/fused_bn.h) is queued, with backward = True /
+# False.  The data-parallel reducer keeps its collectives away from them (mm2d3d_amd/ddp.py, "tail" schedule): a barrier kernel
+# needs every workgroup resident at once and must not share the GPU with a kernel that holds CUs for as long as a peer is late.
+BARRIER_LISTENERS = []  # weakref.WeakMethod objects (a reducer that is gone stops listening)
+
+
+def add_barrier_listener(bound_method):
+    import weakref
+
+    BARRIER_LISTENERS.append(weakref.WeakMethod(bound_method))
+
+
+def before_barrier_kernel(backward):
+    dead = False
+    for ref in BARRIER_LISTENERS:
+        cb = ref()
+        if cb is None:
+            dead = True
+        else:
+            cb(backward)
+    if dead:
+        BARRIER_LISTENERS[:] = [r for r in BARRIER_LISTENERS if r() is not None]
+
+
 def exported_symbols():
     return sorted(_PROTOS)
 

@@ -240,6 +240,12 @@ def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz
 WGRAD_BATCH = [True]  # (set from the environment below, next to the other A/B switches)
 
 
+def _defer_wgrad():
+    """Deferred slab sums?  Not while the backward pass is being captured into a HIP graph (graph2d.py): the deferred form uploads its
+    descriptor table from the host per step, and inside a graph a per-layer launch costs the host nothing anyway."""
+    return WGRAD_BATCH[0] and not torch.cuda.is_current_stream_capturing()
+
+
 class _WgBatch:
     def __init__(self):
         self.items = []  # (slabs, dW, dW1, sn, st, sk, nsplit, Cn, ntaps, Ck, params)
@@ -405,7 +411,7 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             ty = [kh - padding for kh in range(KH) for _ in range(KW)]
             tx = [kw - padding for _ in range(KH) for kw in range(KW)]
-            if ctx.wparam is not None and WGRAD_BATCH[0]:  # slabs now, summed into the arena with every other layer's (_WgBatch)
+            if ctx.wparam is not None and _defer_wgrad():  # slabs now, summed into the arena with every other layer's (_WgBatch)
                 _wgrad_deferred(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam, Cin * T, 1, T, ldx=ldx, ldy=ldy)
             elif ctx.wparam is not None:  # accumulate straight into the optimiser's gradient arena
                 _wgrad(x, Bn, H, W, Cin, dy, Ho, Wo, Cout, stride, ty, tx, ctx.wparam._mm_sink, Cin * T, 1, T, accumulate=1, ldx=ldx,
@@ -502,7 +508,7 @@ class Conv2dPairFn(torch.autograd.Function):
             # both weight gradients in the two launches one of them takes (mm_conv2d_wgrad3x3_pair)
             L = lib2d()
             sink = ctx.wparams[0] is not None
-            if sink and WGRAD_BATCH[0]:  # both problems' slabs now, their sums with every other layer's (_WgBatch)
+            if sink and _defer_wgrad():  # both problems' slabs now, their sums with every other layer's (_WgBatch)
                 nbytes = int(L.mm_conv2d_wgrad_ws_bytes(Bn * H * W, Cout, Cin, 9))
                 slabs = torch.empty(nbytes, dtype=torch.uint8, device=x1.device)
                 nsplit = C.c_int(0)
@@ -523,7 +529,7 @@ class Conv2dPairFn(torch.autograd.Function):
         for i in range(2):
             if not ctx.needs_input_grad[2 + i]:
                 continue
-            if ctx.wparams[i] is not None and WGRAD_BATCH[0]:
+            if ctx.wparams[i] is not None and _defer_wgrad():
                 _wgrad_deferred(xs[i], Bn, H, W, Cin, dys[i], H, W, Cout, 1, ty, tx, ctx.wparams[i], Cin * 9, 1, 9)
             elif ctx.wparams[i] is not None:  # straight into the optimiser's gradient arena
                 _wgrad(xs[i], Bn, H, W, Cin, dys[i], H, W, Cout, 1, ty, tx, ctx.wparams[i]._mm_sink, Cin * 9, 1, 9, accumulate=1)
@@ -570,7 +576,7 @@ class ConvTranspose2dFn(torch.autograd.Function):
             _gemm(dy, Bn, 2 * H, 2 * W, Cout, dx, H, W, Cin, H, W, 1, 2, 1, ty, tx, Wd)
         if ctx.needs_input_grad[1]:
             # roles: "dY" := x (base grid H x W, n = ci), "X" := dy (source pixel (2y+a, 2x+b), k = co)
-            if ctx.wparam is not None and WGRAD_BATCH[0]:
+            if ctx.wparam is not None and _defer_wgrad():
                 _wgrad_deferred(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, ctx.wparam, Cout * 4, 1, 4)
             elif ctx.wparam is not None:  # straight into the optimiser's gradient arena
                 _wgrad(dy, Bn, 2 * H, 2 * W, Cout, x, H, W, Cin, 2, ty, tx, ctx.wparam._mm_sink, Cout * 4, 1, 4, accumulate=1)
@@ -587,6 +593,11 @@ class ConvTranspose2dFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+# While graph2d captures the trunk's backward pass, the two stems take this tensor as an extra input (no arithmetic on it): it is the
+# ONE input torch.autograd.grad is asked for, every node of the trunk lies on a path to it, and no parameter's AccumulateGrad node
+# (created long ago on the default stream: it would pull that stream into the capture) is ever visited - every parameter of the
+# trunk receives its gradient through its sink.
+CAPTURE_ANCHOR = [None]
 _STEM_IDX = {}
 
 
@@ -623,9 +634,10 @@ class StemConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, img, weight, stats=None, pad_to=None):
+    def forward(ctx, img, weight, stats=None, pad_to=None, anchor=None):
         """``pad_to`` = (Hp, Wp): the result of the convolution on the image zero-padded at the bottom / right to Hp x Wp
-        (2d_net/model.py:91-96 pads the inputs to multiples of 16) - the zeros are written by the staging kernel, no F.pad."""
+        (2d_net/model.py:91-96 pads the inputs to multiples of 16) - the zeros are written by the staging kernel, no F.pad.
+        ``anchor``: see CAPTURE_ANCHOR (no arithmetic; its gradient is None)."""
         _lib.require_cuda(img, "img")
         L = lib2d()
         img = img.float().contiguous()
@@ -660,6 +672,7 @@ class StemConvFn(torch.autograd.Function):
                                    _arr([0] * T), ptr(Wp), 1, 0, 0, None, ptr(slab), split_m, None, 0, stream()), "conv2d_gemm(stem)")
         ctx.save_for_backward(xb)
         ctx.dims = (Bn, C, H, W, Cout, Hb, Wb, weight.shape)
+        ctx.wparam = weight if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]) else None
         return y
 
     @staticmethod
@@ -676,6 +689,10 @@ class StemConvFn(torch.autograd.Function):
                                 ptr(dwp), T * 64, 64, 1, 0, ptr(ws), ws.numel(), stream()), "conv2d_wgrad(stem)")
         dw = torch.zeros((Cout, C * 49), dtype=torch.float32, device=dy.device)
         dw.index_copy_(1, src, dwp.index_select(1, valid))
-        return None, dw.view(wshape), None, None
+        if ctx.wparam is not None:  # into the optimiser's arena (what autograd's AccumulateGrad would do, in place)
+            ctx.wparam._mm_sink.add_(dw.view(wshape))
+            gradsink.done(ctx.wparam)
+            return None, None, None, None, None
+        return None, dw.view(wshape), None, None, None
 
 

@@ -18,6 +18,12 @@ fp32 gradient buckets (25 MB) all-reduced over NCCL during backward.  MI355X-fir
   * xGMI is point-to-point (7 links/GPU): fewer, larger messages are better than NVSwitch-style 25 MB buckets;
     default bucket = 64 MB (~196 MB of fp32 gradients -> 4 all-reduces per step);
   * the sum is averaged inside the fused AdamW kernel (grad_scale = 1/world), not by an extra pass.
+Schedules (``overlap``): "tail" (default, round 5) - the buckets go out from the hooks, beside backward, but only once the LAST
+grid-barrier kernel of the backward pass (the single-launch batch norms, csrc/fused_bn.h) has been queued: every batch norm keeps
+its single-launch kernel AND the collectives overlap the barrier-free tail of backward (layer1.0 / max-pool / stem backward of the
+two encoders, ~1.8 ms on the headline step) - what north_star asks for ("all-reduce overlapped with backward") without paying the
+2.8 ms of three-kernel batch norms; True ("hooks") - every bucket as soon as it is complete, backward batch norms on the three-kernel
+path; False ("after") - everything in finish().
 One process per GPU; backend "nccl" (= RCCL on ROCm) on GPU, "gloo" in the CPU tests.
 """
 from __future__ import annotations
@@ -41,17 +47,24 @@ class GradAllReducer:
         world of ONE rank - the only way to execute the RCCL path on a one-GPU box (a one-rank all-reduce is still an RCCL
         launch on RCCL's stream beside the backward pass).
 
-        ``overlap`` (default: MM_DDP_OVERLAP, "0"): True = buckets go out from the backward hooks, beside the rest of backward - the
-        backward batch norms must then leave their single-launch (grid-barrier) kernels, +2.8 ms per 36.3 ms step on one MI355X
-        (profiles/r04/bench_n1_bn_as_under_ddp.json).  False = every bucket goes out in ``finish()``, after backward: the
-        collectives never share the GPU with a grid barrier, every batch norm keeps its single-launch kernel, and what is paid
-        instead is the exposed all-reduce of the 196 MB of fp32 gradients - 1.0-1.7 ms by the link arithmetic of DESIGN.md
-        section 6 (8 / 4 / 2 GPUs).  The cheaper of the two by that arithmetic is the default; no multi-GPU node was available to
-        measure either (MM_DDP_OVERLAP=1 selects the overlapped form)."""
+        ``overlap`` (default: MM_DDP_OVERLAP, "tail"):
+        "tail" = buckets go out from the backward hooks, but only after the LAST grid-barrier kernel of the backward pass has been
+        queued (counted in the learning step through _lib.BARRIER_LISTENERS; the 3D branch runs its whole backward before the 2D
+        branch's, whose barrier-free tail is layer1.0.conv1 / max-pool / stem backward of both encoders): every batch norm keeps
+        its single-launch kernel and the collectives of all buckets but the last small one overlap that tail.  Safety does not rest
+        on the count: a barrier kernel that turns up AFTER buckets were launched makes the compute stream wait for them first
+        (stream order, no host wait) and the count is re-learned.
+        True / "hooks" = every bucket as soon as it is complete - the backward batch norms must then leave their single-launch
+        kernels, +2.8 ms per 36.3 ms step on one MI355X (profiles/r04/bench_n1_bn_as_under_ddp.json).
+        False / "after" = every bucket in ``finish()``, after backward: exposed all-reduce of the 196 MB of fp32 gradients, 1.0-1.7
+        ms by the link arithmetic of DESIGN.md section 6 (8 / 4 / 2 GPUs).  No multi-GPU node was available to measure any of them."""
         import os
 
         if overlap is None:
-            overlap = os.environ.get("MM_DDP_OVERLAP", "0") != "0"
+            overlap = os.environ.get("MM_DDP_OVERLAP", "tail")
+        overlap = {"0": False, "after": False, "1": True, "hooks": True, "tail": "tail", False: False, True: True}.get(overlap, overlap)
+        if overlap not in (False, True, "tail"):
+            raise ValueError('GradAllReducer(overlap=): False / "after", True / "hooks" or "tail"')
 
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -73,6 +86,8 @@ class GradAllReducer:
         self._flag = None  # device int32[2] after finish(): [graph changed on some rank, batch-norm fault on some rank] (MAX over ranks)
         self._flag_host, self._flag_event, self._finished = None, None, 0
         self._void_before = 0  # flags of reducer steps < this one were already acted upon (a re-learn is under way)
+        # "tail" schedule: grid-barrier kernels of the backward pass seen so far this step / in the step that was learned from
+        self._nbar, self._nbar_learned, self._early_this_step = 0, None, False
         self.stats = {"bytes": 0, "buckets": 0, "early": 0}  # of the last finished step
         self._step_stats = {"bytes": 0, "buckets": 0, "early": 0}
         self.bn_path = "as configured (no data-parallel group)"  # which batch-norm kernels run beside the collectives (bench line)
@@ -80,7 +95,15 @@ class GradAllReducer:
             return
         if not overlap:
             self.bn_path = "as configured: single-launch in both directions (collectives after backward, MM_DDP_OVERLAP=0)"
-        if overlap and torch.cuda.is_available():
+        if overlap == "tail":
+            self.bn_path = ("as configured: single-launch in both directions (collectives beside the barrier-free tail of backward, "
+                            "MM_DDP_OVERLAP=tail)")
+            from . import _lib
+            from . import conv2d as _c2d
+
+            _c2d.WGRAD_BATCH[0] = False  # a deferred slab sum would complete every 2D weight gradient only at the end of backward
+            _lib.add_barrier_listener(self._on_barrier)
+        if overlap is True and torch.cuda.is_available():
             # The single-launch batch-norm kernels (csrc/bn2d.hip, csrc/bn.hip) hold a grid barrier: every workgroup of the launch
             # must be resident at once.  BACKWARD runs beside the bucket all-reduces, whose kernels hold CUs for the length of a
             # collective: a barrier grid would sit half resident and spin until the collective ends, so the backward direction takes
@@ -153,6 +176,8 @@ class GradAllReducer:
         st["bytes"] += (b.hi - b.lo) * 4
         st["buckets"] += 1
         st["early"] += 0 if self._in_finish else 1
+        if not self._in_finish:
+            self._early_this_step = True
 
     def _launch_ready(self):
         for b in self.order:  # strict order: a bucket goes out only after every earlier one of the learned order
@@ -176,8 +201,24 @@ class GradAllReducer:
         b.pending -= 1
         self._tick += 1
         b.done_at = self._tick  # tick of the bucket's latest gradient = when it completes once unused parameters are known
-        if b.pending == 0 and self.overlap and self.learned and self.consistent:
-            self._launch_ready()
+        if not (self.learned and self.consistent):
+            return
+        if self.overlap is True:
+            if b.pending == 0:
+                self._launch_ready()
+        elif self.overlap == "tail" and self._nbar_learned is not None and self._nbar >= self._nbar_learned:
+            self._launch_ready()  # past the last grid-barrier kernel of backward: whatever is complete goes out, in the learned order
+
+    def _on_barrier(self, backward):
+        """_lib.BARRIER_LISTENERS: a grid-barrier kernel is about to be queued.  Backward ones are counted (the "tail" begins after the
+        last); one that turns up while buckets of this step are already in flight first makes the compute stream wait for them."""
+        if not self.active or not backward or self._in_finish:
+            return
+        self._nbar += 1
+        if self._early_this_step:
+            for b in self.buckets:
+                if b.work is not None:
+                    b.work.wait()  # orders the streams (no host wait on RCCL): the barrier kernel runs after the collectives
 
     def _learn(self):
         """End of the first step: agree on the unused set and on the launch order."""
@@ -248,6 +289,8 @@ class GradAllReducer:
             b.pending, b.launched, b.work, b.done_at = b.n_used, False, None, -1
         self._fired, self._late, self._tick = set(), [], 0
         self.stats, self._step_stats = self._step_stats, {"bytes": 0, "buckets": 0, "early": 0}
+        self.stats["barrier_kernels_bwd"] = self._nbar
+        self._nbar_learned, self._nbar, self._early_this_step = self._nbar, 0, False  # (re-)learned every step: the last step's count
         self._in_finish = False
         cur = self._finished  # the step this call finishes
         self._finished += 1

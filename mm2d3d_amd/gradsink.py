@@ -18,12 +18,30 @@ def claim(ctx, param, needs_grad):
     return use
 
 
+_COLLECT = [None]
+
+
 def done(param):
     """Call in Function.backward after the kernel accumulating into ``param._mm_sink`` has been enqueued."""
     param._mm_pending -= 1
     if param._mm_pending == 0:
+        if _COLLECT[0] is not None:  # a backward pass that is being CAPTURED into a HIP graph (graph2d.py): the hooks are per-step
+            _COLLECT[0].append(param)  # Python work - the caller fires them after every replay
+            return
         for h in param._mm_hooks:
             h(param)
+
+
+def collect_hooks():
+    """From now on ``done`` records the parameters whose last contribution has been issued instead of firing their hooks."""
+    _COLLECT[0] = []
+    return _COLLECT[0]
+
+
+def release_hooks(token):
+    """Ends ``collect_hooks``; returns the recorded parameters (in completion order)."""
+    _COLLECT[0] = None
+    return list(token)
 
 
 # deferred gradient work (conv2d._WgBatch: slab sums of a whole backward pass in one launch) registers a reset here; FlatAdamW.zero_grad

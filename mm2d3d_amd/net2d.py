@@ -298,17 +298,36 @@ class Net2DSeg(nn.Module):
         h, w = img.shape[2], img.shape[3]
         # the point -> pixel index first: its host arrays are uploaded asynchronously from pinned staging (lifting.PixelIndex)
         # before any of this forward is queued, so the host never waits for the convolutions to drain
-        _pixel_index(data_batch, h, w, img.device)
+        pix = _pixel_index(data_batch, h, w, img.device)
+        if nn2d.fp32_mode():
+            pad_h, pad_w = (-h) % 16, (-w) % 16
+            if pad_h or pad_w:
+                img = F.pad(img, [0, pad_w, 0, pad_h])
+                hints = F.pad(hints, [0, pad_w, 0, pad_h])
+            return self._forward_fp32(data_batch, img, hints, img_indices, h, w)
+        from . import graph2d
+
+        if graph2d.usable(self, img, hints):
+            # the static-shape trunk (stems ... heads) as two HIP graphs - forward and backward - replayed per step: ~600 launches of
+            # Python / autograd / ctypes work per step become two graph launches (mm2d3d_amd/graph2d.py)
+            x, segm, avg = graph2d.run(self, img, hints, h, w, pix)
+        else:
+            x, segm, avg = self._trunk(img, hints, h, w, pix)
+        segm_last = x[:, :, 0:h, 0:w]  # crop of the padding (a view; the heads read the padded map with bounds h, w)
+        preds = {"seg_logit": lift(segm, pix), "seg_logit_2d": segm}
+        return preds, segm_last, img_indices, self.aux(segm_last, pix, avg)
+
+    def _trunk(self, img, hints, h, w, pix):
+        """Images -> (decoder output map x [B, 64, Hp, Wp] 16-bit NHWC, main head logits, aux head logits [B, nc, h, w] fp32): every
+        layer whose shapes depend on the image size only (the lifting to points does not belong to it)."""
         pad_h, pad_w = (-h) % 16, (-w) % 16
-        fused_stems = not nn2d.fp32_mode() and self.rgb_backbone._fused and self.depth_backbone._fused
+        fused_stems = self.rgb_backbone._fused and self.depth_backbone._fused
         if (pad_h or pad_w) and not fused_stems:
             img = F.pad(img, [0, pad_w, 0, pad_h])
             hints = F.pad(hints, [0, pad_w, 0, pad_h])
         # The three full-resolution decoder concats [depth | up | rgb] are never copied: their buffers exist up front and
         # the producing BatchNorm layers (stem / layer1 / layer2 of both backbones, the transposed-conv stages) write
         # straight into their channel slices; the backbones keep reading those slices as pitched NHWC maps.
-        if nn2d.fp32_mode():
-            return self._forward_fp32(data_batch, img, hints, img_indices, h, w)
         Bn, Hp, Wp = img.shape[0], h + pad_h, w + pad_w
         pad_to = (Hp, Wp) if (fused_stems and (pad_h or pad_w)) else None  # the stems' staging kernels write the padding zeros
         cb = [nn2d.CatBuffer(Bn, (c, c, c), Hp >> l, Wp >> l, img.device) for l, c in enumerate(self.rgb_backbone.channels[:3])]
@@ -337,11 +356,8 @@ class Net2DSeg(nn.Module):
         x = self.dec_conv_stage2(cb[1].cat([d[1], x, r[1]]))
         x = up(self.dec_t_conv_stage2, x, cb[0])
         x = self.dec_conv_stage1(cb[0].cat([d[0], x, r[0]]))
-        segm_last = x[:, :, 0:h, 0:w]  # crop of the padding (a view; the heads read the padded map with bounds h, w)
-        pix = _pixel_index(data_batch, h, w, x.device)
         segm, avg = nn2d.fused_heads(x, h, w, self.con1_1_avg, self.aux.con1_1_avg, pix)
-        preds = {"seg_logit": lift(segm, pix), "seg_logit_2d": segm}
-        return preds, segm_last, img_indices, self.aux(segm_last, pix, avg)
+        return x, segm, avg
 
 
 Model = Net2DSeg

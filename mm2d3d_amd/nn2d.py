@@ -114,7 +114,7 @@ class Conv2d(nn.Conv2d):
         if k == (7, 7) and self.stride == (1, 1) and self.padding == (3, 3) and self.in_channels <= 8 and self.bias is None \
                 and self.out_channels % 64 == 0 and self.groups == 1:
             st = _wants_stats(self)
-            return _with_stats(_c2d.StemConvFn.apply(x, self.weight, st, pad_to), st)  # the two stems (backbones.py:23-25)
+            return _with_stats(_c2d.StemConvFn.apply(x, self.weight, st, pad_to, _c2d.CAPTURE_ANCHOR[0]), st)  # the two stems (backbones.py:23-25)
         raise NotImplementedError(f"mm2d3d_amd.nn2d.Conv2d: shape not on the hot path: {self}")  # (pad_to is the stems' alone)
 
 
@@ -242,6 +242,8 @@ class _BN2dFn(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device)
             db = dbt = torch.empty(C, dtype=F32, device=x.device)
             acc = 0
+        if _lib.BARRIER_LISTENERS and L.mm_bn2d_single_launch(ctx.hd.h, N, ctx.Ns, C, 1):
+            _lib.before_barrier_kernel(True)
         check(L.mm_bn2d_bwd(ctx.hd.h, ptr(x), ldx, ptr(dy), lddy, ptr(dy2), lddy2, ptr(ymask), ldy, 1 if ctx.relu else 0, N, ctx.Ns, C, ptr(weight),
                             ptr(bias),
                             ptr(stats[0]), ptr(stats[1]),
@@ -342,6 +344,8 @@ class _BN2dPairFn(torch.autograd.Function):
                 tgt.append((ctx.sinks[i][0]._mm_sink, ctx.sinks[i][1]._mm_sink))
             else:
                 tgt.append((torch.empty(C, dtype=F32, device=x1.device), torch.empty(C, dtype=F32, device=x1.device)))
+        if _lib.BARRIER_LISTENERS and L.mm_bn2d_single_launch(ctx.hd.h, N, ctx.Ns, C, 1):
+            _lib.before_barrier_kernel(True)
         args = [_lib.Bn2dBwdArgs(ptr(xs[i]), ldx[i], ptr(dys[i]), lddy[i], ptr(dy2s[i]), lddy2[i], ptr(ymask[i]), ldy[i], ptr(ws_[i]), ptr(bs[i]),
                                  ptr(sts[i][0]), ptr(sts[i][1]), ptr(dx[i]), C, ptr(dres[i]), C, ptr(tgt[i][0]), ptr(tgt[i][1])) for i in range(2)]
         check(L.mm_bn2d_bwd_pair(ctx.hd.h, C_.byref(args[0]), C_.byref(args[1]), 1 if ctx.relu else 0, N, ctx.Ns, C, 1 if both_sinks else 0,
@@ -600,6 +604,13 @@ class _HeadsFn(torch.autograd.Function):
         check(L.mm_head_fwd(ptr(x), B, Hp, Wp, C, h, w, C, ptr(Wj), ptr(bj), 2 * nc, ptr(out), ptr(ws), ws.numel(), stream()), "head_fwd")
         ctx.save_for_backward(x, Wj)
         ctx.dims = (h, w, nc, w1.shape)
+        # gradient sinks for the four head parameters (all or none): their gradients then go straight into the optimiser's arena
+        ps = (w1, b1, w2, b2)
+        ctx.sinks = None
+        if all(hasattr(q, "_mm_sink") for q in ps) and all(ctx.needs_input_grad[i] for i in (3, 4, 5, 6)):
+            for q in ps:
+                gradsink.claim(ctx, q, True)
+            ctx.sinks = ps
         o = out.permute(0, 3, 1, 2)
         return o[:, :nc], o[:, nc:]
 
@@ -630,6 +641,11 @@ class _HeadsFn(torch.autograd.Function):
         else:
             db = dout.sum((0, 1, 2))
             db1, db2 = db[:nc], db[nc:]
+        if ctx.sinks is not None:  # what autograd's AccumulateGrad would do (in place into the arena slices), then the sinks' hooks
+            for q, g in zip(ctx.sinks, (dWj[:nc].reshape(wshape), db1, dWj[nc:].reshape(wshape), db2)):
+                q._mm_sink.add_(g)
+                gradsink.done(q)
+            return dx, None, None, None, None, None, None, None
         return dx, None, None, dWj[:nc].reshape(wshape), db1, dWj[nc:].reshape(wshape), db2, None
 
 

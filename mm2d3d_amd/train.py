@@ -104,6 +104,10 @@ class TrainModel(nn.Module):
             self.optimizers.append(opt)
             self.schedulers.append(sched)
         self.reducer = GradAllReducer(self.optimizers)
+        # the 2D trunk runs as two HIP graphs (mm2d3d_amd/graph2d.py) unless the data-parallel reducer is active: its bucket hooks want
+        # the parameters' gradients to complete one by one during backward
+        n2d = self.model[self.modules_name[0]]
+        n2d._mm_no_graph = bool(self.reducer.active)
         # torch DDP broadcasts rank 0's parameters when it wraps a model (run.py:262-268): replicas start identical whatever
         # each rank's seed was
         self.reducer.sync_parameters(src=0)

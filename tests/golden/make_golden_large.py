@@ -81,7 +81,7 @@ def case_2d():
             sys.modules.pop(k, None)
 
 
-def case_step():
+def case_step(variants=("f32", "f16")):
     import types
 
     import torch.nn as nn
@@ -134,25 +134,69 @@ def case_step():
             if isinstance(m, nn.Dropout):
                 m.p = 0.0
         S = fill.LARGE_STEP
-        t0 = time.time()
         batch = {"source": collate([make_scene(93000 + i, "nuscenes", (S["H"], S["W"]), 6, downsample=S["points"]) for i in range(S["scenes"])]),
                  "target": collate([make_scene(94000 + i, "nuscenes", (S["H"], S["W"]), 6, downsample=S["points"]) for i in range(S["scenes"])])}
-        out = {"points": np.array([batch[d]["x"][0].shape[0] for d in ("source", "target")])}
-        with torch.autograd.graph.saved_tensors_hooks(lambda t: t.clone(), lambda t: t):  # see make_golden.py:step_case
-            total = tm._generic_step(batch, "train")
-        total.backward()
-        out["total"] = np.array(float(total.detach()))
-        out["log_keys"] = np.array(list(logged.keys()))
-        out["log_values"] = np.array([logged[k] for k in logged])
-        for k, v in tm.state_dict().items():
-            if k.endswith(("running_mean", "running_var")):
-                out[f"sd/{k}"] = v.numpy()
-        named = [(k, p_.grad) for k, p_ in tm.named_parameters() if p_.grad is not None]
-        out["grad_keys"] = np.array([k for k, _ in named])
-        for k, v in fill.grad_digest(named, nproj=fill.NPROJ_LARGE).items():
-            out[f"grad/{k}"] = v
-        np.savez_compressed(os.path.join(HERE, "step_ref_large.npz"), **out)
-        print(f"step large: {time.time() - t0:.0f} s", {k: round(v, 6) for k, v in logged.items()}, "total", float(total.detach()), flush=True)
+        path = os.path.join(HERE, "step_ref_large.npz")
+        out = dict(np.load(path)) if os.path.exists(path) else {}
+        out["points"] = np.array([batch[d]["x"][0].shape[0] for d in ("source", "target")])
+        initial = {k: v.clone() for k, v in tm.state_dict().items()}
+
+        def fresh():
+            b = {}
+            for dom, d in batch.items():
+                nb = dict(d)
+                nb["x"] = [d["x"][0], d["x"][1].clone()]  # the 3D net gates the features in place
+                b[dom] = nb
+            return b
+
+        if "f32" in variants:
+            t0 = time.time()
+            with torch.autograd.graph.saved_tensors_hooks(lambda t: t.clone(), lambda t: t):  # see make_golden.py:step_case
+                total = tm._generic_step(fresh(), "train")
+            total.backward()
+            out["total"] = np.array(float(total.detach()))
+            out["log_keys"] = np.array(list(logged.keys()))
+            out["log_values"] = np.array([logged[k] for k in logged])
+            for k, v in tm.state_dict().items():
+                if k.endswith(("running_mean", "running_var")):
+                    out[f"sd/{k}"] = v.numpy().copy()
+            named = [(k, p_.grad) for k, p_ in tm.named_parameters() if p_.grad is not None]
+            out["grad_keys"] = np.array([k for k, _ in named])
+            for k, v in fill.grad_digest(named, nproj=fill.NPROJ_LARGE).items():
+                out[f"grad/{k}"] = v
+            print(f"step large [f32]: {time.time() - t0:.0f} s", {k: round(v, 6) for k, v in logged.items()}, "total", float(total.detach()), flush=True)
+        if "f16" in variants:
+            # The reference's own training precision class (run/train.yaml:11 precision: 16 = Lightning native AMP): the same
+            # _generic_step under torch.autocast(float16), loss scaled by 1024 as a GradScaler would.  SparseConvNet's operators are
+            # not autocast-aware - under AMP they compute in fp32 while the nn.Linear layers around them run in fp16 - so the
+            # oracle primitives that stand in for them are kept out of autocast (a wrapper around the reference class's forward,
+            # in this process only; its source stays as it is).
+            t0 = time.time()
+            tm.load_state_dict(initial)
+            tm.zero_grad(set_to_none=True)
+            logged.clear()
+            unet = sys.modules["3d_net.scn_unet"].UNetSCN
+            orig_forward = unet.forward
+
+            def forward_fp32(self, x):
+                with torch.autocast("cpu", enabled=False):
+                    return orig_forward(self, [x[0], x[1].float()])
+
+            unet.forward = forward_fp32
+            try:
+                with torch.autograd.graph.saved_tensors_hooks(lambda t: t.clone(), lambda t: t):
+                    with torch.autocast("cpu", dtype=torch.float16):
+                        total = tm._generic_step(fresh(), "train")
+                (total.float() * 1024.0).backward()
+            finally:
+                unet.forward = orig_forward
+            out["f16/total"] = np.array(float(total.detach()))
+            out["f16/log_values"] = np.array([logged[k] for k in logged])
+            named = [(k, p_.grad / 1024.0) for k, p_ in tm.named_parameters() if p_.grad is not None]
+            for k, v in fill.grad_digest(named, nproj=fill.NPROJ_LARGE).items():
+                out[f"f16/grad/{k}"] = v
+            print(f"step large [f16]: {time.time() - t0:.0f} s", {k: round(v, 6) for k, v in logged.items()}, "total", float(total.detach()), flush=True)
+        np.savez_compressed(path, **out)
     finally:
         sys.path.remove(EXP)
         for k in list(mods) + ["train", "2d_net", "2d_net.model", "2d_net.backbones", "3d_net", "3d_net.model", "3d_net.scn_unet"]:
@@ -166,4 +210,6 @@ if __name__ == "__main__":
         case_2d()
     if "step" in which:
         case_step()
+    if "step_f16" in which:  # adds the fp16-autocast variant to an existing step_ref_large.npz
+        case_step(("f16",))
     print("large fixtures written to", HERE)

@@ -159,8 +159,9 @@ def _worker(rank, world, port, overlap, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("overlap", [True, False, "tail"])
 def test_bucketed_allreduce_world2_gloo(overlap):
+    # ("tail" without any grid-barrier kernel in the backward pass - this CPU model has none - is the hook-launched schedule)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -207,15 +208,111 @@ def test_paired_shards_max_size_cycle():
     assert not (a & b)
 
 
-def test_collectives_after_backward_is_the_default_form(monkeypatch):
-    """GradAllReducer(overlap=None): MM_DDP_OVERLAP decides, and its default is "every bucket in finish(), after backward" - the form
-    in which no collective shares the GPU with a grid-barrier batch norm (ddp.py)."""
-    import torch
-
+def test_the_tail_schedule_is_the_default_form(monkeypatch):
+    """GradAllReducer(overlap=None): MM_DDP_OVERLAP decides; its default is "tail" - buckets from the hooks once the last
+    grid-barrier kernel of the backward pass has been queued (ddp.py)."""
     from mm2d3d_amd.ddp import GradAllReducer
 
     monkeypatch.delenv("MM_DDP_OVERLAP", raising=False)
-    assert GradAllReducer([]).overlap is False
+    assert GradAllReducer([]).overlap == "tail"
     monkeypatch.setenv("MM_DDP_OVERLAP", "1")
     assert GradAllReducer([]).overlap is True
-    assert GradAllReducer([], overlap=False).overlap is False
+    monkeypatch.setenv("MM_DDP_OVERLAP", "0")
+    assert GradAllReducer([]).overlap is False
+    assert GradAllReducer([], overlap=False).overlap is False and GradAllReducer([], overlap="after").overlap is False
+    assert GradAllReducer([], overlap="hooks").overlap is True
+    with pytest.raises(ValueError):
+        GradAllReducer([], overlap="sometimes")
+
+
+def _worker_tail(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mm2d3d_amd import _lib
+        from mm2d3d_amd.ddp import GradAllReducer
+        from mm2d3d_amd.optimizers import FlatAdamW
+
+        torch.manual_seed(0)
+        l0, l1, l2 = nn.Linear(8, 16), nn.Linear(16, 16), nn.Linear(16, 4)
+        params = list(l0.parameters()) + list(l1.parameters()) + list(l2.parameters())
+        opt = FlatAdamW(params, lr=1e-3)
+        red = GradAllReducer([opt], bucket_bytes=300, overlap="tail", tail_bytes=600)
+        assert len(red.buckets) >= 3
+        torch.manual_seed(100 + rank)
+        x = torch.randn(5, 8)
+        seen = []  # (which barrier, buckets launched at that moment)
+
+        def barrier(tag):
+            def hook(g):
+                # what a single-launch batch norm's backward does right before it queues its kernel (nn2d._BN2dFn.backward)
+                _lib.before_barrier_kernel(True)
+                seen.append((tag, [b.launched for b in red.order]))
+                return g
+            return hook
+
+        def run(extra_barrier=False, barriers=True):
+            opt.zero_grad()
+            seen.clear()
+            a0 = torch.relu(l0(x))
+            a1 = torch.relu(l1(a0))
+            if barriers:  # backward order: l2's gradients, barrier "b1", l1's gradients, barrier "b0" (the LAST), l0's gradients
+                a0.register_hook(barrier("b0"))
+                a1.register_hook(barrier("b1"))
+            (l2(a1) ** 2).sum().backward()
+            early = [b.launched for b in red.order]
+            if extra_barrier:  # a barrier kernel AFTER buckets went out: the reducer makes the stream wait, then re-learns the count
+                _lib.before_barrier_kernel(True)
+            red.finish()
+            return early
+
+        early = run()  # learning step: nothing before finish()
+        assert not any(early) and red.learned and red.stats["barrier_kernels_bwd"] == 2
+        early = run()
+        # at barrier b1 (not the last) nothing may be in flight although l2's bucket(s) are complete; at b0 (the last one, called BEFORE
+        # its kernel is queued) still nothing; after it everything complete goes out from the next hook - all before finish()
+        assert [t for t, _ in seen] == ["b1", "b0"] and not any(seen[0][1]) and not any(seen[1][1]), seen
+        assert all(early) and red.stats["early"] == len(red.order), (early, red.stats)
+        # gradients are the sum over the ranks
+        ref = copy_grads = opt.grad_arenas()[0].clone()
+        opt.zero_grad()
+        (l2(torch.relu(l1(torch.relu(l0(x))))) ** 2).sum().backward()  # no barriers fire, hooks do: local gradients again
+        local = opt.grad_arenas()[0].clone()
+        red.finish()  # (reduces again: keeps the collective sequences of the ranks aligned)
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        # the reduced arena of THIS step = sum of locals; the earlier step computed the same function of the same inputs
+        assert torch.allclose(ref, sum(gathered), atol=1e-6)
+        # that step had no barrier: the count was re-learned as 0, so now every bucket goes as soon as it is complete
+        assert red.stats["barrier_kernels_bwd"] == 0
+        run()  # re-learns 2
+        early = run(extra_barrier=True)
+        assert all(early) and red.stats["barrier_kernels_bwd"] == 3
+        early = run()  # 3 expected, 2 come: the tail never opens, everything goes out in finish() - and 2 is learned again
+        assert not any(early) and red.stats["early"] == 0 and red.stats["buckets"] == len(red.order)
+        early = run()
+        assert all(early)
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tail_schedule_world2_gloo():
+    """The default data-parallel schedule: which buckets leave before finish().  Grid-barrier kernels are
+    emulated by tensor hooks that call _lib.before_barrier_kernel(True) where a single-launch batch norm's backward would."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_tail, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
