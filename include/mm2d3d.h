@@ -476,6 +476,19 @@ int mm_bn2d_fwd_train_pair(mm_handle_t h, const mm_bn2d_fwd_args* a, const mm_bn
                            float momentum, int relu, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_bwd_pair(mm_handle_t h, const mm_bn2d_bwd_args* a, const mm_bn2d_bwd_args* b, int relu, int64_t N, int64_t Ns, int C, int accumulate,
                      void* ws, size_t ws_bytes, mm_stream_t stream);
+/* The stems' BatchNorm2d + ReLU + MaxPool2d(3, 2, 1) (EXP/2d_net/backbones.py:43-47) as ONE pass over the map (after the slab reduce +
+ * finalize of mm_bn2d_fwd_train_pre): y = the normalised map [B][H][W][C] (pitch ld_y), ypool [B][H/2][W/2][C] its pooled version, idx
+ * the winning taps (the outputs of mm_maxpool3x3s2_fwd); H, W even; images [0, Bs) are statistics group 0.  Backward
+ * (mm_bn2d_bwd_pool): the gradient arrives as the POOLED map's gradient dyp + idx (gathered per pixel inside the reduce / apply passes,
+ * so no full-resolution gradient map is written or read) and optionally a second full-resolution contribution dy2; three launches,
+ * no grid barrier, same results as mm_maxpool3x3s2_bwd followed by mm_bn2d_bwd. */
+int mm_bn2d_fwd_train_pre_pool(const void* x, int ld_x, int B, int H, int W, int Bs, int C, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps, float momentum, void* y,
+                               int ld_y, void* ypool, void* idx, float* save_mean, float* save_invstd, const float* slab,
+                               int64_t slab_rows, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_bwd_pool(const void* x, int ld_x, const void* dyp, int ld_dyp, const void* idx, int B, int H, int W, int Bs, const void* dy2,
+                     int ld_dy2, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
+                     int ld_dx, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);
@@ -574,6 +587,13 @@ int mm_bn2d_fwd_train_pair_f16(mm_handle_t h, const mm_bn2d_fwd_args* a, const m
                            float momentum, int relu, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_bwd_pair_f16(mm_handle_t h, const mm_bn2d_bwd_args* a, const mm_bn2d_bwd_args* b, int relu, int64_t N, int64_t Ns, int C, int accumulate,
                      void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_fwd_train_pre_pool_f16(const void* x, int ld_x, int B, int H, int W, int Bs, int C, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps, float momentum, void* y,
+                               int ld_y, void* ypool, void* idx, float* save_mean, float* save_invstd, const float* slab,
+                               int64_t slab_rows, void* ws, size_t ws_bytes, mm_stream_t stream);
+int mm_bn2d_bwd_pool_f16(const void* x, int ld_x, const void* dyp, int ld_dyp, const void* idx, int B, int H, int W, int Bs, const void* dy2,
+                     int ld_dy2, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
+                     int ld_dx, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, mm_stream_t stream);
 int mm_bn2d_fwd_eval_f16(const void* x, int ld_x, const void* res, int ld_r, int64_t N, int C, const float* weight,
                      const float* bias, const float* running_mean, const float* running_var, float eps, int relu, void* y,
                      int ld_y, mm_stream_t stream);

@@ -138,6 +138,8 @@ _PROTOS = {
     "mm_bn2d_fwd_train": (i32, [vp, vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, sz, vp]),
     "mm_bn2d_single_launch": (i32, [vp, i64, i64, i32, i32]),
     "mm_bn2d_fwd_train_pre": (i32, [vp, i32, vp, i32, i64, i64, i32, vp, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, i64, vp, sz, vp]),
+    "mm_bn2d_fwd_train_pre_pool": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, i32, vp, vp, vp, vp, vp, i64, vp, sz, vp]),
+    "mm_bn2d_bwd_pool": (i32, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, sz, vp]),
     "mm_bn2d_fwd_train_pair": (i32, [vp, vp, vp, i64, i64, i32, f32, f32, i32, vp, sz, vp]),
     "mm_bn2d_bwd_pair": (i32, [vp, vp, vp, i32, i64, i64, i32, i32, vp, sz, vp]),
     "mm_bn2d_fwd_eval": (i32, [vp, i32, vp, i32, i64, i32, vp, vp, vp, vp, f32, i32, vp, i32, vp]),
@@ -183,6 +185,8 @@ H16_2D = {
     "mm_bn2d_fwd_train_pre": "mm_bn2d_fwd_train_pre_f16",
     "mm_bn2d_single_launch": "mm_bn2d_single_launch_f16",
     "mm_bn2d_fwd_train_pair": "mm_bn2d_fwd_train_pair_f16",
+    "mm_bn2d_fwd_train_pre_pool": "mm_bn2d_fwd_train_pre_pool_f16",
+    "mm_bn2d_bwd_pool": "mm_bn2d_bwd_pool_f16",
     "mm_bn2d_bwd_pair": "mm_bn2d_bwd_pair_f16",
     "mm_conv2d_wgrad_ws_bytes": "mm_conv2d_wgrad_ws_bytes_f16",
     "mm_conv2d_wgrad": "mm_conv2d_wgrad_f16",

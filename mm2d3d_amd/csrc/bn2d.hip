@@ -37,6 +37,46 @@ __device__ inline void st8(u16* p, const float (&v)[8]) {
   *(uint4*)p = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// ---- the stems' BatchNorm + ReLU + MaxPool(3, 2, 1) as one forward pass and one backward (round 5).  The stem maps are the largest of
+// the net (299 MB each at the bench's size): the separate max-pool read the normalised map again forward, and backward wrote a
+// full-resolution gradient map that the batch norm's two backward passes then read.  Backward here: the gradient that reaches a
+// full-resolution pixel through the pool is GATHERED from the pooled gradient and the winner indices (<= 4 windows per pixel) inside
+// the batch norm's reduce / apply passes - PoolSrc - so that map is never written or read.  The gathered sum is rounded to the 16-bit
+// storage format first, as the stored map was: the fused passes compute what the separate kernels computed.
+struct PoolSrc {
+  const u16* dyp;            // gradient of the pooled map [B][Ho][Wo][C] (pitch ld), NULL: off (the gradient comes as a full map)
+  const unsigned char* idx;  // winning tap (kh * 3 + kw) per pooled element [B][Ho][Wo][C]
+  int ld, H, W, Ho, Wo, C;
+};
+__device__ inline uint4 pool_grad8(const PoolSrc& ps, int64_t r, int cv) {
+  const unsigned ru = (unsigned)r, t = ru / (unsigned)ps.W;  // 32-bit index arithmetic (host: N < 2^31)
+  const int ix = (int)(ru - t * (unsigned)ps.W);
+  const int b = (int)(t / (unsigned)ps.H), iy = (int)(t - (unsigned)b * (unsigned)ps.H);
+  float sacc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) sacc[i] = 0.f;
+  for (int oy = iy / 2; oy <= (iy + 1) / 2; oy++) {  // windows with oy*2-1 <= iy <= oy*2+1 (as k_maxpool_bwd)
+    if (oy >= ps.Ho) continue;
+    const int kh = iy - (oy * 2 - 1);
+    for (int ox = ix / 2; ox <= (ix + 1) / 2; ox++) {
+      if (ox >= ps.Wo) continue;
+      const int kw = ix - (ox * 2 - 1);
+      const int64_t opix = (int64_t)(b * ps.Ho + oy) * ps.Wo + ox;
+      const unsigned long long iw = *(const unsigned long long*)(ps.idx + opix * ps.C + cv * 8);
+      const uint4 v = *(const uint4*)(ps.dyp + opix * ps.ld + cv * 8);
+      const unsigned wv[4] = {v.x, v.y, v.z, v.w};
+      const unsigned tap = (unsigned)(kh * 3 + kw);
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        if (((iw >> (8 * i)) & 0xFFull) == tap) sacc[i] += (i & 1) ? h_hi(wv[i >> 1]) : h_lo(wv[i >> 1]);
+    }
+  }
+  unsigned ow[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) ow[i] = (unsigned)f2bf(sacc[2 * i]) | ((unsigned)f2bf(sacc[2 * i + 1]) << 16);
+  return make_uint4(ow[0], ow[1], ow[2], ow[3]);
+}
+
 // MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * (yout > 0 if relu).  MODE 2: sum x only
 template <int MODE>
 __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
@@ -44,7 +84,7 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                                     double* __restrict__ partial, int64_t Ns, int nb0,
                                                     const float* __restrict__ weight = nullptr, const float* __restrict__ bias = nullptr,
-                                                    const u16* __restrict__ dy2 = nullptr, int ld_dy2 = 0) {
+                                                    const u16* __restrict__ dy2 = nullptr, int ld_dy2 = 0, PoolSrc ps = PoolSrc{}) {
   // rows [0, Ns) are statistics group 0 (blocks [0, nb0)), rows [Ns, N) group 1 (the other blocks): the two domains of a
   // jointly batched training step keep their own batch statistics.  Ns == N: one group.
   __shared__ float red[2][T];
@@ -118,7 +158,7 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
       for (int u = 0; u < U; u++) {
         const int64_t ru = r + (int64_t)u * rs;
         tx[u] = *(const uint4*)(x + ru * ld_x + cv * 8);
-        td[u] = MODE == 1 ? *(const uint4*)(dy + ru * ld_dy + cv * 8) : z4;
+        td[u] = MODE == 1 ? (ps.dyp ? pool_grad8(ps, ru, cv) : *(const uint4*)(dy + ru * ld_dy + cv * 8)) : z4;
         t2[u] = (MODE == 1 && dy2) ? *(const uint4*)(dy2 + ru * ld_dy2 + cv * 8) : z4;
         ty[u] = (MODE == 1 && relu && !remask) ? *(const uint4*)(yout + ru * ld_y + cv * 8) : z4;
       }
@@ -127,7 +167,7 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
     }
     for (; r < r1; r += rs) {
       const uint4 tx = *(const uint4*)(x + r * ld_x + cv * 8);
-      const uint4 td = MODE == 1 ? *(const uint4*)(dy + r * ld_dy + cv * 8) : z4;
+      const uint4 td = MODE == 1 ? (ps.dyp ? pool_grad8(ps, r, cv) : *(const uint4*)(dy + r * ld_dy + cv * 8)) : z4;
       const uint4 t2 = (MODE == 1 && dy2) ? *(const uint4*)(dy2 + r * ld_dy2 + cv * 8) : z4;
       const uint4 ty = (MODE == 1 && relu && !remask) ? *(const uint4*)(yout + r * ld_y + cv * 8) : z4;
       row_acc(tx, td, t2, ty);
@@ -322,13 +362,83 @@ __global__ __launch_bounds__(T) void k_bn2d_apply(const u16* __restrict__ x, int
   }
 }
 
+// y = relu((x - mean) * invstd * w + b) written at full resolution AND max-pooled 3x3 / stride 2 / pad 1 in the same pass: thread =
+// (pooled pixel, 8-channel group); it normalises the <= 9 pixels of its window (neighbouring windows share pixels: L1 / L2 hits),
+// stores the four it owns - (2 oy + {0,1}, 2 ox + {0,1}): H and W even, every pixel has exactly one owner - and keeps the first
+// maximum in scan order of the ROUNDED values (what k_maxpool_fwd does on the stored map).  Bs: images [0, Bs) are group 0.
+__global__ __launch_bounds__(T) void k_bn2d_apply_pool(const u16* __restrict__ x, int ld_x, int B, int H, int W, int C, int Bs,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ weight, const float* __restrict__ bias,
+                                                        u16* __restrict__ y, int ld_y, u16* __restrict__ yp,
+                                                        unsigned char* __restrict__ idx, int Ho, int Wo) {
+  const int C8 = C >> 3;
+  const unsigned gid = blockIdx.x * (unsigned)T + threadIdx.x;  // 32-bit index arithmetic (host: total < 2^32)
+  if ((int64_t)gid >= (int64_t)B * Ho * Wo * C8) return;
+  const unsigned pixu = gid / (unsigned)C8;
+  const int cv = (int)(gid - pixu * (unsigned)C8);
+  const unsigned tu = pixu / (unsigned)Wo;
+  const int ox = (int)(pixu - tu * (unsigned)Wo);
+  const int b = (int)(tu / (unsigned)Ho), oy = (int)(tu - (unsigned)b * (unsigned)Ho);
+  const int grp = b >= Bs ? 1 : 0;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int c = cv * 8 + i;
+    sc[i] = invstd[grp * C + c] * (weight ? weight[c] : 1.f);
+    sh[i] = (bias ? bias[c] : 0.f) - mean[grp * C + c] * sc[i];
+  }
+  float best[8];
+  unsigned char bi[8];
+  bool any = false;
+#pragma unroll
+  for (int kh = 0; kh < 3; kh++) {
+    const int iy = oy * 2 - 1 + kh;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) {
+      const int ix = ox * 2 - 1 + kw;
+      if (ix < 0 || ix >= W) continue;
+      const int64_t pix = (int64_t)(b * H + iy) * W + ix;
+      float xv[8], yv[8];
+      ld8(x + pix * ld_x + cv * 8, xv);
+      unsigned ow[4];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float v = fmaf(xv[i], sc[i], sh[i]);
+        yv[i] = !(v > 0.f) ? 0.f : v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) ow[i] = (unsigned)f2bf(yv[2 * i]) | ((unsigned)f2bf(yv[2 * i + 1]) << 16);
+      if (kh >= 1 && kw >= 1) *(uint4*)(y + pix * ld_y + cv * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float f = (i & 1) ? h_hi(ow[i >> 1]) : h_lo(ow[i >> 1]);  // the stored (rounded) value
+        if (!any || f > best[i]) {
+          best[i] = f;
+          bi[i] = (unsigned char)(kh * 3 + kw);
+        }
+      }
+      any = true;
+    }
+  }
+  unsigned pw[4];
+  unsigned long long iw = 0ull;
+#pragma unroll
+  for (int i = 0; i < 4; i++) pw[i] = (unsigned)f2bf(best[2 * i]) | ((unsigned)f2bf(best[2 * i + 1]) << 16);
+#pragma unroll
+  for (int i = 0; i < 8; i++) iw |= (unsigned long long)bi[i] << (8 * i);
+  *(uint4*)(yp + (int64_t)pixu * C + cv * 8) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
+  *(unsigned long long*)(idx + (int64_t)pixu * C + cv * 8) = iw;
+}
+
 // g = dy * relu'(yout); dx = w*invstd*(g - sum_g/N - xhat*sum_gx/N); dres = g
 __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
                                                        const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ weight, const float* __restrict__ sums,
                                                        u16* __restrict__ dx, int ld_dx, u16* __restrict__ dres, int ld_dr, int64_t Ns,
-                                                       int ab0, const float* __restrict__ bias, const u16* __restrict__ dy2, int ld_dy2) {
+                                                       int ab0, const float* __restrict__ bias, const u16* __restrict__ dy2, int ld_dy2,
+                                                       PoolSrc ps = PoolSrc{}) {
   const int CV = C >> 3;
   const int rs = T / CV;
   const int slot = threadIdx.x / CV, cv = threadIdx.x - slot * CV;
@@ -357,7 +467,8 @@ __global__ __launch_bounds__(T) void k_bn2d_bwd_apply(const u16* __restrict__ x,
     if (r >= gend) break;
     float xv[8], dv[8], yv[8], ov[8], gv[8];
     ld8(x + r * ld_x + cv * 8, xv);
-    ld8(dy + r * ld_dy + cv * 8, dv);
+    if (ps.dyp) cvt8(pool_grad8(ps, r, cv), dv);
+    else ld8(dy + r * ld_dy + cv * 8, dv);
     if (dy2) {
       float d2[8];
       ld8(dy2 + r * ld_dy2 + cv * 8, d2);
@@ -891,6 +1002,68 @@ int MM_SYM(mm_bn2d_fwd_train_pre)(const void* x, int ld_x, const void* res, int 
     hipLaunchKernelGGL(k_bn2d_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)res, ld_r, N, C, save_mean,
                        save_invstd, 0, eps, weight, bias, relu, (u16*)y, ld_y, Ns, ab0);
   }
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// mm_bn2d_fwd_train_pre (+ReLU, no residual) on a [B][H][W][C] map, H and W even, FUSED with MaxPool2d(3, 2, 1): y (pitch ld_y) receives
+// the normalised map, ypool [B][H/2][W/2][C] its pooled version and idx the winning taps (mm_maxpool3x3s2_fwd's outputs), in ONE pass
+// over x after the slab reduce + finalize launches (the stems: 2d_net/backbones.py:43-47).  Bs: images [0, Bs) are statistics group 0.
+int MM_SYM(mm_bn2d_fwd_train_pre_pool)(const void* x, int ld_x, int B, int H, int W, int Bs, int C, const float* weight, const float* bias,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked, float eps, float momentum, void* y,
+                               int ld_y, void* ypool, void* idx, float* save_mean, float* save_invstd, const float* slab, int64_t slab_rows,
+                               void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_y % 8 == 0, "bn2d_pool: C must be a multiple of 8, <= 2048");
+  MM_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "bn2d_pool: H and W must be even");
+  MM_CHECK_ARG(slab != nullptr && slab_rows > 0 && slab_rows % 2 == 0 && ((uintptr_t)slab % 16) == 0, "bn2d_pool: no statistics slab");
+  MM_CHECK_ARG(ws_bytes >= MM_SYM(mm_bn2d_ws_bytes)(C), "bn2d: workspace too small");
+  const int64_t N = (int64_t)B * H * W;
+  MM_CHECK_ARG(N * (C / 8) / 4 < (1ll << 32) && N < (1ll << 31), "bn2d_pool: map too large for 32-bit indices");
+  int64_t Ns = (Bs <= 0 || Bs >= B) ? N : (int64_t)Bs * H * W;
+  const int64_t nsub = slab_rows / 2;
+  int nb = (int)(nsub / 64 < 1 ? 1 : nsub / 64);
+  if (nb > 256) nb = 256;
+  if (nb > MAX_PART / 2) nb = MAX_PART / 2;
+  const int nb0 = nb, nb1 = Ns < N ? nb : 0;
+  double* partial = (double*)ws;
+  hipLaunchKernelGGL(k_bn2d_slab_reduce, dim3(nb0 + nb1), dim3(256), 0, s, slab, nsub, nb0, nb1, C, partial);
+  hipLaunchKernelGGL(k_bn2d_finalize_fwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, Ns, N, C, eps, momentum, running_mean, running_var,
+                     save_mean, save_invstd, num_batches_tracked);
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+  hipLaunchKernelGGL(k_bn2d_apply_pool, dim3((unsigned)mm_cdiv(total, T)), dim3(T), 0, s, (const u16*)x, ld_x, B, H, W, C, Ns < N ? Bs : B,
+                     save_mean, save_invstd, weight, bias, (u16*)y, ld_y, (u16*)ypool, (unsigned char*)idx, Ho, Wo);
+  MM_LAUNCH_CHECK();
+  return MM_OK;
+}
+
+// Its backward: mm_bn2d_bwd (ReLU mask recomputed from x, no residual output) whose incoming gradient is the pooled map's gradient
+// dyp [B][H/2][W/2][C] (pitch ld_dyp) + the winning taps idx (gathered per full-resolution pixel inside the reduce and apply passes:
+// PoolSrc) + optionally a second full-resolution contribution dy2 (the decoder's concat slice).  Three launches, no grid barrier.
+int MM_SYM(mm_bn2d_bwd_pool)(const void* x, int ld_x, const void* dyp, int ld_dyp, const void* idx, int B, int H, int W, int Bs, const void* dy2,
+                     int ld_dy2, int C, const float* weight, const float* bias, const float* save_mean, const float* save_invstd, void* dx,
+                     int ld_dx, float* dweight, float* dbias, int accumulate, void* ws, size_t ws_bytes, hipStream_t s) {
+  MM_CHECK_ARG(C % 8 == 0 && C / 8 <= T && ld_x % 8 == 0 && ld_dyp % 8 == 0 && ld_dx % 8 == 0 && (!dy2 || ld_dy2 % 8 == 0), "bn2d_bwd_pool: bad pitch");
+  MM_CHECK_ARG(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && x && dyp && idx && dx, "bn2d_bwd_pool: bad arguments");
+  const int64_t N = (int64_t)B * H * W;
+  MM_CHECK_ARG(N < (1ll << 31), "bn2d_bwd_pool: map too large for 32-bit indices");
+  size_t need = mm_align((size_t)MAX_PART * 2 * C * sizeof(double));
+  if (ws_bytes < need + 4 * C * sizeof(float)) {
+    mm_set_error("bn2d_bwd: workspace too small");
+    return MM_ERR_WORKSPACE;
+  }
+  double* partial = (double*)ws;
+  float* sums = (float*)((char*)ws + need);
+  int64_t Ns = (Bs <= 0 || Bs >= B) ? N : (int64_t)Bs * H * W;
+  PoolSrc ps{(const u16*)dyp, (const unsigned char*)idx, ld_dyp, H, W, H / 2, W / 2, C};
+  int nb0, nb1, ab0, ab1;
+  split_blocks(N, Ns, C, true, nb0, nb1);
+  hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)nullptr, 0, (const u16*)nullptr, 0, 1, N, C,
+                     save_mean, save_invstd, partial, Ns, nb0, weight, bias, (const u16*)dy2, ld_dy2, ps);
+  hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
+  split_blocks(N, Ns, C, false, ab0, ab1);
+  hipLaunchKernelGGL(k_bn2d_bwd_apply, dim3(ab0 + ab1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)nullptr, 0, (const u16*)nullptr, 0, 1, N, C,
+                     save_mean, save_invstd, weight, sums, (u16*)dx, ld_dx, (u16*)nullptr, 0, Ns, ab0, bias, (const u16*)dy2, ld_dy2, ps);
   MM_LAUNCH_CHECK();
   return MM_OK;
 }

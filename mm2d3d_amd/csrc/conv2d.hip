@@ -470,6 +470,22 @@ struct C3P {
 __device__ __attribute__((aligned(16))) unsigned int g_dump[256];  // sink for the stores of out-of-image pixels
 
 
+#ifdef MM_DIAG_CLOCK
+// diagnostic build only (tools/diag_lib.sh clock -DMM_DIAG_CLOCK): per-workgroup (s_memtime, s_memrealtime) deltas around a kernel's
+// main loop - the in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  Kernel ids:
+// 0 k_conv3x3w, 1 k_conv3x3r, 2 k_wgrad3x3n.  The stamps go to a buffer nothing else reads.
+__device__ unsigned long long g_clk[3][1024][2];
+#define MM_CLK_BEGIN() const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime()
+#define MM_CLK_END(kid)                                                                   \
+  if ((threadIdx.x & 511) == 0 && threadIdx.x < 512 && blockIdx.x < 1024) {               \
+    g_clk[kid][blockIdx.x][0] = __builtin_amdgcn_s_memtime() - clk_t0;                    \
+    g_clk[kid][blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - clk_r0;                \
+  }
+#else
+#define MM_CLK_BEGIN()
+#define MM_CLK_END(kid)
+#endif
+
 template <int N>
 __device__ inline void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -701,6 +717,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
   int c_k = 0, c_c = 0, c_half;    // consumer cursor
   int c_item = item_of(0, c_half);
   int slot = 0;                    // byte offset of the W ring slot of the current step
+  MM_CLK_BEGIN();
   for (int seg = 0; seg < nseg; seg++) {
     const int hb = (seg & 1) * HSZB;
 #pragma unroll
@@ -814,6 +831,7 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       if (MM_DIAG(p, 64)) g_dump[lane] = diag_sum;
     }
   }
+  MM_CLK_END(0);
 }
 
 // 64 -> 64 channel layers (layer1 of both backbones, 24 calls per step): the whole 3x3x64x64 weight tensor is 72 KB of
@@ -932,6 +950,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   issue_halo(0);
   bool st = false;
   int seg = 0;
+  MM_CLK_BEGIN();
   for (int item = it_begin; item < it_end; item += G8, seg++) {
     // this item's halo (and, the first time, the weights) must have landed; younger in the queue: the previous item's stores
     if (st) {
@@ -994,6 +1013,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
                   true);
     st = true;
   }
+  MM_CLK_END(1);
   wait_vm<0>();  // the dummy halo of the tail is still in flight: drain before the LDS is released
 }
 
@@ -1292,6 +1312,114 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad2(WgP p) {
       }
 }
 
+// Weight gradient of the 7x7 stems from the RAW strips of the staged image (round 5; the counterpart of k_stem7).  Through the generic
+// k_conv_wgrad2 every tap re-staged the dY tile and a [64 px][64 virtual channels] X tile whose rows - 8 neighbouring buffer pixels
+// x 8 slots - overlap in 7 of 8 pixels: 1 KB of L2 -> LDS traffic per output pixel for the RGB stem (4 taps), 2.4 GB per call,
+// 332 us against ~60 us for reading its 299 MB gradient map once.  Here a K'-step is 64 pixels of ONE image row: dY [64 px][64 n]
+// is staged once for all taps and per tap only the raw strip - buffer row y + t R, pixels x0 .. x0 + 71, 16 bytes each - is
+// fetched (1.1 KB); the virtual row of pixel px IS the 128 contiguous bytes starting at strip byte 16 px, so the transpose reads of
+// the X operand take their (pixel, channel) pieces at a row pitch of 16 bytes, without a swizzle (lanes of a read group touch
+// distinct banks or the same address).  4 waves = 2 (n halves) x 2 (k halves), NT accumulator tiles of 32 x 32 per wave.
+// Partial slabs [nsplit][64][NT][64] as k_conv_wgrad2 writes them; k_wgrad_reduce sums them.
+struct SwP {
+  const u16* xb;  // [B][Hb][Wb][8]
+  const u16* dy;  // [B][H][W][>= 64] (pitch ldy)
+  int B, Hb, Wb, H, W, ldy, R;
+  int steps_per_row, steps_per_wg;
+  int64_t nsteps;
+  float* partial;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k_stem_wgrad(SwP p) {
+  extern __shared__ __attribute__((aligned(16))) u16 smem[];
+  constexpr int YSZ = 64 * 64;    // elements of a dY stage
+  constexpr int XROW = 72 * 8;    // elements of one tap's strip (72 pixels)
+  constexpr int XSZ = NT * XROW;
+  u16* Ys = smem;                 // [2][64][64]
+  u16* Xs = smem + 2 * YSZ;       // [2][NT][72][8]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int64_t sb = (int64_t)blockIdx.x * p.steps_per_wg;
+  const int64_t se = sb + p.steps_per_wg < p.nsteps ? sb + p.steps_per_wg : p.nsteps;
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+  auto fy = [](int row) { return ((row >> 1) & 1) << 2; };
+  auto issue = [&](int64_t s, int buf) {
+    const int row = (int)(s / p.steps_per_row), x0 = (int)(s - (int64_t)row * p.steps_per_row) * 64;
+    const int b = row / p.H, y = row - b * p.H;
+    // dY: 8 one-KiB pieces (8 pixel rows x 128 B each), two per wave; source chunk swizzled as the transpose reads expect
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int piece = wave * 2 + i, prow = piece * 8 + (lane >> 3), pc = lane & 7;
+      const int px = x0 + prow;
+      const u16* g = px < p.W ? p.dy + ((int64_t)(b * p.H + y) * p.W + px) * p.ldy + ((pc ^ fy(prow)) << 3) : (const u16*)g_zero16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(Ys + buf * YSZ + piece * 512), 16, 0, 0);
+    }
+    // strips: tap t = buffer row y + t R, pixels x0 .. x0 + 71: wave w stages taps w, w + 4 (64 pixels by all lanes, 8 more by lanes 0-7)
+#pragma unroll
+    for (int i = 0; i < (NT + 3) / 4; i++) {
+      const int t = wave + 4 * i;
+      if (t < NT) {
+        const u16* rowp = p.xb + ((int64_t)(b * p.Hb + y + t * p.R) * p.Wb) * 8;
+        const int pa = x0 + lane;
+        const u16* ga = pa < p.Wb ? rowp + (int64_t)pa * 8 : (const u16*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                         (__attribute__((address_space(3))) void*)(Xs + buf * XSZ + t * XROW), 16, 0, 0);
+        if (lane < 8) {
+          const int pb = x0 + 64 + lane;
+          const u16* gb = pb < p.Wb ? rowp + (int64_t)pb * 8 : (const u16*)g_zero16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                           (__attribute__((address_space(3))) void*)(Xs + buf * XSZ + t * XROW + 512), 16, 0, 0);
+        }
+      }
+    }
+  };
+  const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  if (sb < se) issue(sb, 0);
+  int buf = 0;
+  for (int64_t s = sb; s < se; s++, buf ^= 1) {
+    __syncthreads();  // (vmcnt(0) + barrier) step s has landed; everyone is done with the other stage
+    if (s + 1 < se) issue(s + 1, buf ^ 1);
+    const u16* Yb = Ys + buf * YSZ;
+    const u16* Xb = Xs + buf * XSZ;
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      const int prow = kk * 16 + 8 * (g >> 1) + q;
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const int ca = (wn * 32 + 16 * (g & 1)) >> 3;
+      const int o0 = prow * 64 + (((ca + (pp >> 1)) ^ fy(prow)) << 3) + 4 * (pp & 1);
+      const int o1 = (prow + 4) * 64 + (((ca + (pp >> 1)) ^ fy(prow + 4)) << 3) + 4 * (pp & 1);
+      const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[o0]);
+      const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Yb[o1]);
+      const s16x8 av = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const bf16x8 af = __builtin_bit_cast(bf16x8, av);
+      const int cb = wk * 32 + 16 * (g & 1) + 8 * (pp >> 1) + 4 * (pp & 1);  // virtual channel of this lane's piece
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        const u16* Xt = Xb + t * XROW;
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xt[prow * 8 + cb]);
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)&Xt[(prow + 4) * 8 + cb]);
+        const s16x8 bv = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        acc[t] = MM_MFMA_32x32x16(af, __builtin_bit_cast(bf16x8, bv), acc[t]);
+      }
+    }
+  }
+  float* P = p.partial + (int64_t)blockIdx.x * 64 * NT * 64;
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int n = wn * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+      const int k = wk * 32 + (lane & 31);
+      P[((int64_t)n * NT + t) * 64 + k] = acc[t][reg];
+    }
+}
+
 // Weight gradient of a 3x3 stride-1 pad-1 convolution from halo tiles, ALL NINE taps in one workgroup, software-pipelined.
 // (The round-1 kernel ran one workgroup per filter row kh: a patch was 36 KB of LDS-DMA for 24 MFMAs per wave, nothing
 // overlapped inside a workgroup - request, wait, multiply - and the LDS capped the bytes in flight per CU, so a patch cost
@@ -1471,6 +1599,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
     MM_TR(Bu[0][kw], b0[kw], 0);
     MM_TR(Bw[0][kw], b0[kw], 512);
   }
+  MM_CLK_BEGIN();
   for (int patch = pb; patch < pe; patch++) {
     const int sb = stage * STG, sn = ((stage + 1) & (NSTG - 1)) * STG;
     const int A = a0 + sb;
@@ -1528,6 +1657,7 @@ __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
     stage = (stage + 1) & (NSTG - 1);
   }
 #undef MM_TR
+  MM_CLK_END(2);
   float* P = p.partial + (int64_t)((second ? p.nsplit : 0) + split) * p.Cn * 9 * p.Ck;
 #pragma unroll
   for (int t = 0; t < 9; t++)
@@ -1804,6 +1934,12 @@ int fill_taps(ConvP* p, const int* ty, const int* tx, int nt) {
 
 extern "C" {
 
+#ifdef MM_DIAG_CLOCK
+int MM_SYM(mm_diag_clock_read)(void* out_host, size_t bytes) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_clk), bytes < sizeof(g_clk) ? bytes : sizeof(g_clk)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 // launches k_conv_gemm for a filled ConvP; steps_max = the most (tap, 64-channel chunk) steps a workgroup walks
 static int gemm_launch(ConvP p, int nz, int steps_max, hipStream_t s) {
   const int B = p.B, Hg = p.Hg, Wg = p.Wg, Cn = p.Cn;
@@ -2008,6 +2144,10 @@ static int c3_launch(C3P p, hipStream_t s) {
   return MM_OK;
 }
 
+// k_stem_wgrad (the stems' weight gradient from raw strips): on by default; slabs = workgroups of its launch (4 per CU)
+constexpr bool STEM_WGRAD = true;
+constexpr int STEM_WGRAD_SPLITS = 1024;
+
 static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
   const int tn = (Cn % 128 == 0) ? 128 : 64;
   int64_t tiles = (int64_t)mm_cdiv(Cn, tn) * mm_cdiv(Ck, 128) * ntaps;
@@ -2023,6 +2163,10 @@ static int64_t wgrad_chunk(int64_t M, int Cn, int Ck, int ntaps) {
 size_t MM_SYM(mm_conv2d_wgrad_ws_bytes)(int64_t M, int Cn, int Ck, int ntaps) {
   int64_t c = wgrad_chunk(M, Cn, Ck, ntaps);
   size_t a = (size_t)mm_cdiv(M, c) * Cn * ntaps * Ck * sizeof(float);
+  if (Cn == 64 && Ck == 64 && ntaps <= 7) {  // k_stem_wgrad: up to STEM_WGRAD_SPLITS slabs of 16-112 KB
+    size_t b = (size_t)STEM_WGRAD_SPLITS * Cn * ntaps * Ck * sizeof(float);
+    if (b > a) a = b;
+  }
   if (ntaps == 9) {  // halo variant: at most ceil(1536 / tiles) + 1 pixel splits
     size_t nsp = (size_t)mm_cdiv(1024, (int64_t)mm_cdiv(Cn, 64) * mm_cdiv(Ck, 64)) + 1;
     size_t b = nsp * Cn * 9 * Ck * sizeof(float);
@@ -2097,6 +2241,40 @@ static int wgrad_any(const void* X, int B, int Hi, int Wi, int Ck, int ldx, cons
   for (int i = 0; i < 9 && is3x3; i++) is3x3 = (ty[i] == i / 3 - 1) && (tx[i] == i % 3 - 1);
   if (is3x3 && M > 0)
     return wgrad3x3_launch(X, nullptr, dY, nullptr, B, Hg, Wg, Ck, ldx, Cn, ldy, dW, nullptr, sn, st, sk, accumulate, ws, ws_bytes, s, nsplit_out);
+  // the 7x7 stems over the staged image (conv2d.py StemConvFn: 64 virtual channels at a pixel pitch of 8 elements, taps = whole
+  // buffer rows t R, no column offsets): k_stem_wgrad stages raw strips instead of overlapping virtual rows
+  bool stem = STEM_WGRAD && M > 0 && ldx == 8 && Ck == 64 && Cn == 64 && sa == 1 && (ntaps == 1 || ntaps == 2 || ntaps == 4 || ntaps == 7) &&
+              ldy >= 64 && Wi >= Wg + 7;
+  const int Rs = ntaps > 1 ? ty[1] : 8;
+  for (int i = 0; i < ntaps && stem; i++) stem = tx[i] == 0 && ty[i] == i * Rs;
+  stem = stem && Rs >= 1 && Hi >= Hg + (ntaps - 1) * Rs;
+  if (stem) {
+    SwP q;
+    q.xb = (const u16*)X; q.dy = (const u16*)dY; q.B = B; q.Hb = Hi; q.Wb = Wi; q.H = Hg; q.W = Wg; q.ldy = ldy; q.R = Rs;
+    q.steps_per_row = (int)mm_cdiv(Wg, 64);
+    q.nsteps = (int64_t)B * Hg * q.steps_per_row;
+    int64_t nsp = (int64_t)(ws_bytes / ((size_t)64 * ntaps * 64 * sizeof(float)));
+    if (nsp > STEM_WGRAD_SPLITS) nsp = STEM_WGRAD_SPLITS;
+    if (nsp > q.nsteps) nsp = q.nsteps;
+    if (nsp < 1) {
+      mm_set_error("conv2d_wgrad(stem): workspace too small");
+      return MM_ERR_WORKSPACE;
+    }
+    q.steps_per_wg = (int)mm_cdiv(q.nsteps, nsp);
+    const int nsplit = (int)mm_cdiv(q.nsteps, q.steps_per_wg);
+    q.partial = (float*)ws;
+    const size_t lds = (size_t)(2 * 64 * 64 + 2 * ntaps * 72 * 8) * 2;
+    if (ntaps == 1) hipLaunchKernelGGL(k_stem_wgrad<1>, dim3(nsplit), dim3(256), lds, s, q);
+    else if (ntaps == 2) hipLaunchKernelGGL(k_stem_wgrad<2>, dim3(nsplit), dim3(256), lds, s, q);
+    else if (ntaps == 4) hipLaunchKernelGGL(k_stem_wgrad<4>, dim3(nsplit), dim3(256), lds, s, q);
+    else hipLaunchKernelGGL(k_stem_wgrad<7>, dim3(nsplit), dim3(256), lds, s, q);
+    if (nsplit_out) *nsplit_out = nsplit;
+    else
+      hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)(Cn * (Ck / 32))), dim3(256), 0, s, q.partial, nsplit, Cn, ntaps, Ck, dW, sn, st, sk,
+                         accumulate);
+    MM_LAUNCH_CHECK();
+    return MM_OK;
+  }
   p.mchunk = wgrad_chunk(M, Cn, Ck, ntaps);
   const int nsplit = (int)mm_cdiv(M, p.mchunk);
   if ((size_t)nsplit * Cn * ntaps * Ck * sizeof(float) > ws_bytes) {

@@ -157,7 +157,7 @@ _STATE = {}  # id(net) -> {"calls": {key: n}, "graphs": {key: _Graph}, "anchor":
 def _key(net, img, hints):
     nf = domains.current()
     return (tuple(img.shape), tuple(hints.shape), img.dtype, nn2d.half_kind(), nf, img.device.index, nn2d._c2d.BN_PRE[0],
-            nn2d._c2d.PAIR[0], nn2d.BN_PAIR[0], nn2d._c2d.WGRAD_BATCH[0])
+            nn2d._c2d.PAIR[0], nn2d.BN_PAIR[0], nn2d._c2d.WGRAD_BATCH[0], nn2d.BN_POOL[0])
 
 
 def usable(net, img, hints):

@@ -163,11 +163,12 @@ class Backbone(nn.Module):
         feats = []
         o = (list(outs) + [None] * 3)[:3] if outs is not None else [None] * 3
         if self._fused:
-            x = self.bn1(self.conv1(x, pad_to=pad_to) if pad_to is not None else self.conv1(x), out=o[0])
+            x, xp = nn2d.bn_pool(self.bn1, self.maxpool, self.conv1(x, pad_to=pad_to) if pad_to is not None else self.conv1(x), out=o[0])
         else:
             x = self.relu(self.bn1(self.conv1(x)))
+            xp = self.maxpool(x)
         feats.append(x)
-        x = self._run(self.layer1, self.maxpool(x), o[1])
+        x = self._run(self.layer1, xp, o[1])
         feats.append(x)
         x = self._run(self.layer2, x, o[2])
         feats.append(x)
@@ -192,9 +193,9 @@ def backbone_pair(r, d, img, hints, outs_r=None, outs_d=None, pad_to=None):
     fr, fd = [], []
     xs = []
     for net, x, o, feats in ((r, img, o_r, fr), (d, hints, o_d, fd)):
-        x = net.bn1(net.conv1(x, pad_to=pad_to) if pad_to is not None else net.conv1(x), out=o[0])
+        x, xp = nn2d.bn_pool(net.bn1, net.maxpool, net.conv1(x, pad_to=pad_to) if pad_to is not None else net.conv1(x), out=o[0])
         feats.append(x)
-        xs.append(net.maxpool(x))
+        xs.append(xp)
     xr, xd = xs
 
     def run_pair(lr, ld, xr, xd, out_r, out_d):

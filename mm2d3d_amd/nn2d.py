@@ -485,6 +485,120 @@ class MaxPool2d(nn.MaxPool2d):
         return y
 
 
+# the stems' BatchNorm + ReLU + MaxPool as one pass: "1" forward and backward, "fwd" the forward pass only (backward = the separate
+# max-pool and batch-norm kernels), "0" (default) off.  Measured on the headline step (round 5, same box, p50 of 20 steps x 2):
+# off 35.19 / 35.17 ms, fwd 35.10 / 35.16, both 35.16 / 35.14 - bit-identical results, 0.7 GB less HBM traffic per encoder, no gain:
+# the fused passes trade the streaming access of the separate kernels for window gathers (k_bn2d_apply_pool 230 us against 132 +
+# 118 us; the gathering reduce / apply +76 / +77 us against the 151 us max-pool backward they replace).  Kept as an option.
+BN_POOL = [{"1": True, "fwd": "fwd"}.get(os.environ.get("MM_BN2D_POOL", "0"), False)]
+
+
+class _BnPoolFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d(+ReLU) whose batch statistics come from the producing convolution's epilogue, FUSED with the
+    MaxPool2d(3, 2, 1) that follows (the two stems, backbones.py:43-47): mm_bn2d_fwd_train_pre_pool / mm_bn2d_bwd_pool.  Returns (y,
+    pooled y); ``out``: the channel slice of the decoder's concat buffer that receives y.  Backward: the pooled map's gradient is
+    gathered inside the batch norm's backward passes - no full-resolution gradient map between the two layers."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, nbt, out, handoff, pre):
+        L = _c2d.lib2d()
+        ctx.handoff = handoff
+        ctx.set_materialize_grads(False)  # y's gradient normally arrives through the hand-off: no zero map in its place
+        x, ldx = _c2d.nhwc_pitch(x)
+        B, C, H, W = x.shape
+        if out is not None:
+            dst = out[0].detach()
+            y, ldy = _c2d.nhwc_pitch(dst)
+            if y.data_ptr() != dst.data_ptr() or tuple(y.shape) != tuple(x.shape) or y.dtype != _c2d.HALF[0]:
+                raise ValueError("BatchNorm2d(out=): destination must be an NHWC 16-bit channel slice of the output's shape")
+        else:
+            y, ldy = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x.device, memory_format=CL), C
+        Ho, Wo = H // 2, W // 2
+        yp = torch.empty((B, C, Ho, Wo), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
+        idx = torch.empty(B * Ho * Wo * C, dtype=torch.uint8, device=x.device)
+        nf = domains.current()
+        Bs = nf if (nf is not None and 0 < nf < B) else B
+        stats = torch.empty((2, 2 if Bs < B else 1, C), dtype=F32, device=x.device)
+        ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
+        check(L.mm_bn2d_fwd_train_pre_pool(ptr(x), ldx, B, H, W, Bs, C, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), ptr(nbt), eps,
+                                           momentum, ptr(y), ldy, ptr(yp), ptr(idx), ptr(stats[0]), ptr(stats[1]), ptr(pre[0]), pre[1], ptr(ws),
+                                           ws.numel(), stream()), "bn2d_fwd_train_pre_pool")
+        ctx.save_for_backward(x, weight, stats, bias, idx)
+        ctx.dims = (B, C, H, W, Bs, ldx)
+        ctx.sinks = None
+        if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]):
+            gradsink.claim(ctx, bias, True)
+            ctx.sinks = (weight, bias)
+        return y, yp
+
+    @staticmethod
+    def backward(ctx, dy, dyp):
+        L = _c2d.lib2d()
+        x, weight, stats, bias, idx = ctx.saved_tensors
+        B, C, H, W, Bs, ldx = ctx.dims
+        extra = []
+        if ctx.handoff is not None and ctx.handoff.extra:
+            extra, ctx.handoff.extra = ctx.handoff.extra, []
+        if dy is not None:
+            extra.append(dy)
+        dy2, lddy2 = None, 0
+        if extra:
+            acc_ = extra[0]
+            for e in extra[1:]:  # never more than one in this model; kept general
+                acc_ = acc_ + e
+            dy2, lddy2 = _c2d.nhwc_pitch(acc_)
+        if dyp is None:
+            dyp = torch.zeros((B, C, H // 2, W // 2), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
+        dyp, lddyp = _c2d.nhwc_pitch(dyp)
+        dx = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
+        ws = _lib.workspace.get(int(L.mm_bn2d_ws_bytes(C)), x.device)
+        if ctx.sinks is not None:
+            wp, bp = ctx.sinks
+            dw = db = None
+            dwt, dbt, acc = wp._mm_sink, bp._mm_sink, 1
+        else:
+            dw = dwt = torch.empty(C, dtype=F32, device=x.device)
+            db = dbt = torch.empty(C, dtype=F32, device=x.device)
+            acc = 0
+        if BN_POOL[0] == "fwd":  # the separate kernels: the pooled gradient scattered to a full-resolution map, then mm_bn2d_bwd
+            dxp = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
+            check(L.mm_maxpool3x3s2_bwd(ptr(dyp), lddyp, None, 0, ptr(idx), B, H, W, C, ptr(dxp), stream()), "maxpool_bwd")
+            Ns = Bs * H * W
+            check(L.mm_bn2d_bwd(_lib.handle(x.device).h, ptr(x), ldx, ptr(dxp), C, ptr(dy2), lddy2, None, C, 1, B * H * W, Ns, C, ptr(weight),
+                                ptr(bias), ptr(stats[0]), ptr(stats[1]), ptr(dx), C, None, C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
+                                stream()), "bn2d_bwd")
+        else:
+            check(L.mm_bn2d_bwd_pool(ptr(x), ldx, ptr(dyp), lddyp, ptr(idx), B, H, W, Bs, ptr(dy2), lddy2, C, ptr(weight), ptr(bias),
+                                     ptr(stats[0]), ptr(stats[1]), ptr(dx), C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(), stream()),
+                  "bn2d_bwd_pool")
+        if ctx.sinks is not None:
+            gradsink.done(wp)
+            gradsink.done(bp)
+        return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def bn_pool(bn, pool, x, out=None):
+    """(bn(x, out=out), pool(bn(x))) - one fused pass where the library has one (see _BnPoolFn), else the two modules."""
+    pre = getattr(x, "_mm_stats", None)
+    B, C, H, W = x.shape
+    nf = domains.current()
+    ok = (BN_POOL[0] and not fp32_mode() and isinstance(bn, BatchNorm2d) and isinstance(pool, MaxPool2d) and bn.training and bn.relu
+          and bn.track_running_stats and bn.affine and x.is_cuda and pre is not None and H % 2 == 0 and W % 2 == 0 and C % 8 == 0
+          and (pool.kernel_size, pool.stride, pool.padding, pool.dilation, pool.ceil_mode) == (3, 2, 1, 1, False)
+          and torch.is_grad_enabled() and x.requires_grad and not MAXPOOL_HANDOFF[0]
+          and pre[2] == (nf if (nf is not None and 0 < nf < B) else B) and pre[3] == B and pre[0].shape[2] == C)
+    if not ok:
+        y = bn(x, out=out)
+        return y, pool(y)
+    handoff = GradHandoff()
+    y, yp = _BnPoolFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps),
+                            float(bn.momentum if bn.momentum is not None else 0.1), bn.num_batches_tracked,
+                            [out] if out is not None else None, handoff, pre)
+    y._mm_handoff = handoff
+    x._mm_stats = None  # the slab has served
+    return y, yp
+
+
 class AvgPool2d(nn.AvgPool2d):
     """Only ever used fused with the 1x1 head convolution: see ``fused_heads``."""
 

@@ -75,13 +75,16 @@ def test_conv_transpose2d_fwd_bwd(cin, cout, hw, half2d):
     assert _rel(bh.grad, br.grad) < 5e-3
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 48), (2, 19, 150), (1, 40, 64), (3, 9, 209)])
 @pytest.mark.parametrize("cin", [3, 1])
-def test_stem_conv7x7_fwd_and_weight_grad(cin, half2d):
+def test_stem_conv7x7_fwd_and_weight_grad(cin, shape, half2d):
+    """k_stem7 forward and k_stem_wgrad (round 5: the weight gradient from the raw strips of the staged image, 64-pixel steps along
+    image rows) against torch on the same 16-bit-rounded operands: widths below, at and above the step length, not multiples of it."""
     from mm2d3d_amd.conv2d import StemConvFn
 
     dev = _dev()
     torch.manual_seed(cin)
-    B, H, W = 2, 32, 48
+    B, H, W = shape
     img = torch.rand(B, cin, H, W, device=dev)
     w = torch.randn(64, cin, 7, 7, device=dev) / (cin * 49) ** 0.5
     xr = img.to(half2d).float()

@@ -619,3 +619,54 @@ def test_deferred_weight_gradient_slab_sums_equal_the_per_layer_sums_bit_for_bit
         assert float(res[1].abs().sum()) > 0 and torch.equal(res[0], res[1])
     finally:
         c2d.WGRAD_BATCH[0] = was
+
+
+def test_fused_stem_batchnorm_maxpool_equals_the_two_kernels_bit_for_bit(half2d):
+    """nn2d.bn_pool (round 5): the stems' BatchNorm + ReLU + MaxPool(3, 2, 1) as one forward pass (mm_bn2d_fwd_train_pre_pool) and a
+    backward that gathers the pooled map's gradient inside the batch norm's passes (mm_bn2d_bwd_pool) instead of writing a
+    full-resolution gradient map.  Same arithmetic, same roundings: the whole Net2DSeg - outputs, running statistics, every
+    gradient - must equal the separate-kernel form (MM_BN2D_POOL=0) to the last bit, with one and with two statistics groups.  The
+    handle takes the three-kernel batch norms (bn2d_fused = 0): what the stems' 299 MB maps take at the bench's size."""
+    import copy
+
+    from mm2d3d_amd import _lib, domains, nn2d
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.optimizers import FlatAdamW
+
+    dev = _dev()
+    torch.manual_seed(7)
+    net = Net2DSeg(6, pretrained=False).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    g = np.random.default_rng(1)
+    B, H, W = 4, 62, 94  # padded to 64 x 96
+    img, depth = torch.randn(B, 3, H, W, device=dev), torch.rand(B, 1, H, W, device=dev)
+    idx = [np.stack([g.integers(0, H, 200), g.integers(0, W, 200)], 1).astype(np.int64) for _ in range(B)]
+    w = torch.randn(800, 6, device=dev)
+    hd = _lib.Handle(dev, bn2d_fused=0)
+    was = nn2d.BN_POOL[0]
+    try:
+        for split in (None, 2):
+            res = []
+            for fused in (True, False):
+                nn2d.BN_POOL[0] = fused
+                n_ = copy.deepcopy(net)
+                opt = FlatAdamW(n_.parameters(), lr=1e-3)
+                opt.zero_grad()
+                calls = []
+                orig = nn2d._BnPoolFn.forward
+                with _lib.use(hd), domains.split(split):
+                    preds, last, _, aux = n_({"img": img, "depth": depth, "img_indices": idx})
+                    ((preds["seg_logit"] * w).sum() + (aux["seg_logit_avg"] * w).sum()).backward()
+                torch.cuda.synchronize()
+                res.append((preds["seg_logit"].detach().clone(), last.detach().clone(), opt.grad_arenas()[0].clone(),
+                            {k: v.clone() for k, v in n_.state_dict().items()}))
+            (la, xa, ga, sa), (lb, xb, gb, sb) = res
+            assert torch.equal(la, lb) and torch.equal(xa, xb), split
+            assert float(gb.abs().sum()) > 0 and torch.equal(ga, gb), (split, float((ga - gb).abs().max()))
+            for k in sa:
+                assert torch.equal(sa[k], sb[k]), (split, k)
+    finally:
+        nn2d.BN_POOL[0] = was
+        hd.close()
