@@ -371,14 +371,15 @@ def add_barrier_listener(bound_method):
     BARRIER_LISTENERS.append(weakref.WeakMethod(bound_method))
 
 
-def before_barrier_kernel(backward):
+def before_barrier_kernel(backward, sparse=False):
+    """``sparse``: the kernel belongs to the sparse branch's batch norms (short: a few thousand rows to a few hundred thousand)."""
     dead = False
     for ref in BARRIER_LISTENERS:
         cb = ref()
         if cb is None:
             dead = True
         else:
-            cb(backward)
+            cb(backward, sparse)
     if dead:
         BARRIER_LISTENERS[:] = [r for r in BARRIER_LISTENERS if r() is not None]
 

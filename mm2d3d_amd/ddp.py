@@ -209,7 +209,7 @@ class GradAllReducer:
         elif self.overlap == "tail" and self._nbar_learned is not None and self._nbar >= self._nbar_learned:
             self._launch_ready()  # past the last grid-barrier kernel of backward: whatever is complete goes out, in the learned order
 
-    def _on_barrier(self, backward):
+    def _on_barrier(self, backward, sparse=False):
         """_lib.BARRIER_LISTENERS: a grid-barrier kernel is about to be queued.  Backward ones are counted (the "tail" begins after the
         last); one that turns up while buckets of this step are already in flight first makes the compute stream wait for them."""
         if not self.active or not backward or self._in_finish:

@@ -112,6 +112,8 @@ class _Graph:
     def forward(self, img, hints):
         self.img.copy_(img)
         self.hints.copy_(hints)
+        if _lib.BARRIER_LISTENERS:
+            _lib.before_barrier_kernel(False)
         self.fwd.replay()
         return self.x.detach(), self.segm.detach(), self.avg.detach()
 
@@ -129,6 +131,8 @@ class _Graph:
                 dst.copy_(s)
             else:
                 dst.copy_(src.sum((0, 2, 3)))
+        if _lib.BARRIER_LISTENERS:  # the captured backward contains grid-barrier kernels (single-launch batch norms)
+            _lib.before_barrier_kernel(True)
         self.bwd.replay()
         for p, g in self.auto:  # what AccumulateGrad does in the eager backward (in place into the arena slice)
             (p._mm_sink if hasattr(p, "_mm_sink") else p.grad).add_(g)

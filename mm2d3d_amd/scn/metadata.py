@@ -185,6 +185,19 @@ class Metadata:
             t.record_stream(cur)
         return md
 
+    @staticmethod
+    def _rulebook_tensors(rb):
+        for name in Rulebook.__slots__:
+            t = getattr(rb, name, None)
+            if torch.is_tensor(t):
+                yield t
+            elif isinstance(t, OsTable):
+                yield from (t.dst, t.nbrp, t.tmask)
+            elif isinstance(t, (list, tuple)):
+                for u in t:
+                    if torch.is_tensor(u):
+                        yield u
+
     def tensors(self):
         for lv in self.levels:
             for t in (lv.coords, lv.tkeys, lv.tvals, lv.item2vox, lv.csr_off, lv.csr_items):
@@ -192,16 +205,15 @@ class Metadata:
                     yield t
             for rb in (lv.subm, lv.down):
                 if rb is not None:
-                    for name in Rulebook.__slots__:
-                        t = getattr(rb, name, None)
-                        if torch.is_tensor(t):
-                            yield t
-                        elif isinstance(t, OsTable):
-                            yield from (t.dst, t.nbrp, t.tmask)
-                        elif isinstance(t, (list, tuple)):
-                            for u in t:
-                                if torch.is_tensor(u):
-                                    yield u
+                    yield from self._rulebook_tensors(rb)
+
+    def pending_tensors(self):
+        """Device tensors of rulebooks that begin_rulebooks has queued and finish_rulebooks has not yet attached to their levels."""
+        if self._pending_rulebooks is not None:
+            for _lv, subm, down in self._pending_rulebooks[1]:
+                for rb in (subm, down):
+                    if rb is not None:
+                        yield from self._rulebook_tensors(rb)
 
     def build_levels(self, coords_i64: torch.Tensor):
         """Dedupe chain: points -> level 0 -> level 1 ... (A.8 i, ii).  One host sync at the end."""

@@ -601,8 +601,9 @@ class BatchNormActFunction(torch.autograd.Function):
             dw = dwt = torch.empty(C, dtype=F32, device=x.device) if weight is not None else None
             db = dbt = torch.empty(C, dtype=F32, device=x.device) if bias is not None else None
             acc = 0
-        if _lib.BARRIER_LISTENERS:  # the row kernels decide inside the library whether they take the single-launch form: assume so
-            _lib.before_barrier_kernel(True)
+        if _lib.BARRIER_LISTENERS and ctx.hd.get(_lib.OPT_BN3D_FUSED) & 2:
+            # the row kernels decide inside the library whether they take the single-launch form: assume so when the handle allows it
+            _lib.before_barrier_kernel(True, sparse=True)
         if ctx.act16 and weight is not None:
             _bn16_bwd(L, ctx.hd.h, x, C, ptr(dy), C, N, ctx.Ns, C, ptr(weight), ptr(bias), stats, ctx.leak, dx, ptr(dwt), ptr(dbt), acc)
         else:
@@ -680,8 +681,8 @@ class BatchNormActJoinFunction(torch.autograd.Function):
             db = dbt = torch.empty(C, dtype=F32, device=dy.device)
             acc = 0
         bwd = _bn_entry(L, xs[0].dtype, ctx.hd.h)[2]
-        if _lib.BARRIER_LISTENERS:
-            _lib.before_barrier_kernel(True)
+        if _lib.BARRIER_LISTENERS and ctx.hd.get(_lib.OPT_BN3D_FUSED) & 2:
+            _lib.before_barrier_kernel(True, sparse=True)
         dxs, off = [], 0
         for x, st, c in zip(xs, stats, ctx.widths):
             dx = torch.empty_like(x)

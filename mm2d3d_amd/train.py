@@ -65,6 +65,17 @@ class TrainModel(nn.Module):
         # forward, bit 1 = backward single-launch kernels (default: the environment's MM_BN2D_FUSED / MM_BN_FUSED, else 3).
         self._handle_cfg = (train_kwargs.get("bn2d_fused"), train_kwargs.get("bn3d_fused"))
         self.handle = None
+        # The rulebook / tile-table half of the NEXT batch's sparse metadata (~100 small kernels, ~1.9 ms of the step when it runs in
+        # line) on a side stream BESIDE THIS STEP'S 3D BACKWARD PASS (round 5): both are latency-bound small-kernel work that leaves
+        # most of the chip empty; measured -1.0 ms per step (34.27 -> 33.29 ms, same box).  Nothing on the side stream spin-waits
+        # across workgroups (metadata.NO_SPIN), so a single-launch batch norm of the sparse branch beside it can at worst wait a few
+        # microseconds for CUs (csrc/fused_bn.h); the main stream waits for the side stream before the first grid-barrier kernel of
+        # the 2D backward (_lib.BARRIER_LISTENERS / graph2d) - by stream order, no host wait - so the big kernels of the 2D branch
+        # and the data-parallel buckets that follow them (ddp.py "tail") never share the GPU with it.  The dedupe chain stays on the main stream at
+        # the start of the step: moving it too (beside the 2D forward) measured no further gain.  Results are bit-identical
+        # (tests/test_gpu_step.py::test_metadata_built_one_step_ahead_gives_the_same_steps).
+        self.overlap_rulebooks = bool(int(train_kwargs.get("overlap_rulebooks", os.environ.get("MM_META_SIDE", "1"))))
+        self._meta_stream, self._meta_event = None, None
         self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
@@ -256,8 +267,45 @@ class TrainModel(nn.Module):
     def _prefetch_rulebooks(self):
         pre = self._pipelined
         if pre is not None and pre["phase"] == 1:
-            pre["md"].begin_rulebooks()  # reads the level sizes (no wait: queued before this step's forward), queues phase two
+            if self.overlap_rulebooks and pre["md"].device.type == "cuda":
+                self._rulebooks_on_side_stream(pre["md"])
+            else:
+                pre["md"].begin_rulebooks()  # reads the level sizes (no wait: queued before this step's forward), queues phase two
             pre["phase"] = 2
+
+    def _rulebooks_on_side_stream(self, md):
+        from .scn import metadata as _md
+
+        dev = md.device
+        main = torch.cuda.current_stream(dev)
+        if self._meta_stream is None:
+            self._meta_stream = torch.cuda.Stream(dev)
+            _lib.add_barrier_listener(self._join_meta_stream)
+        side = self._meta_stream
+        if md._pending_levels is not None:
+            md.finish_levels()  # host half (the level sizes were read back long ago)
+        side.wait_stream(main)  # the level tensors (main stream) are complete; this step's backward is queued AFTER this point
+
+        prev, _md.NO_SPIN[0] = _md.NO_SPIN[0], 1  # nothing on a side stream may spin-wait across workgroups (Metadata.prebuild)
+        try:
+            with torch.cuda.stream(side), _lib.workspace_slot("meta"):
+                for t in md.tensors():
+                    t.record_stream(side)  # allocated on the main stream, read by the side stream's kernels
+                md.begin_rulebooks()
+                md.ready = side.record_event()
+        finally:
+            _md.NO_SPIN[0] = prev
+        for t in md.pending_tensors():
+            t.record_stream(main)  # allocated on the side stream, consumed by the next step's 3D branch on the main stream
+        self._meta_event = md.ready
+
+    def _join_meta_stream(self, backward, sparse=False):
+        """_lib.BARRIER_LISTENERS: a grid-barrier kernel is about to be queued on the current stream - the side stream's work first."""
+        if sparse:
+            return  # the sparse branch's own batch norms run beside it (see __init__)
+        ev, self._meta_event = self._meta_event, None
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
 
     # ------------------------------------------------------------------ validation / test (train.py:297-365, 374-458)
     def _iou(self, stage, device, num_classes):
