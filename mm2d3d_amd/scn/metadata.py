@@ -7,6 +7,7 @@ row counts (two small D2H copies per batch: one after the dedupe chain, one afte
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 import weakref
@@ -22,6 +23,16 @@ I32 = torch.int32
 # points (include/mm2d3d.h) - only kernels whose workgroups never wait for each other.  An explicit argument of every call: the
 # library keeps no switch.
 NO_SPIN = [0]
+
+
+@contextlib.contextmanager
+def no_spin():
+    """Metadata built inside uses only kernels that never wait across workgroups (merge sort, three-kernel scans)."""
+    prev, NO_SPIN[0] = NO_SPIN[0], 1
+    try:
+        yield
+    finally:
+        NO_SPIN[0] = prev
 
 
 class _Readback:

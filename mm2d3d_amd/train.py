@@ -76,7 +76,9 @@ class TrainModel(nn.Module):
         # (tests/test_gpu_step.py::test_metadata_built_one_step_ahead_gives_the_same_steps).
         self.overlap_rulebooks = bool(int(train_kwargs.get("overlap_rulebooks", os.environ.get("MM_META_SIDE", "1"))))
         self._meta_stream, self._meta_event = None, None
-        self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
+        # 0: one stream; 1: the 3D branch on its own stream, three-kernel batch norms everywhere (round 2); 2 (default, round 5): the
+        # 3D branch on its own stream with three-kernel SPARSE batch norms only - see _generic_step.  Not under data parallelism.
+        self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "2")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
         self._s3d = None
@@ -180,22 +182,35 @@ class TrainModel(nn.Module):
                 # works through it (the build's two host read-backs would otherwise drain the queue)
                 if prep is not None and self.overlap_metadata:
                     prep(both, self._side, step_start)
-                if self.overlap_branches:
+                if self.overlap_branches and not (self.reducer is not None and self.reducer.active):
                     # the 3D branch (gathers, HBM-bound) on its own stream beside the 2D branch (MFMA / LDS-bound persistent
                     # workgroups): autograd runs each branch's backward on the stream of its forward
                     if self._s3d is None:
-                        self._s3d = torch.cuda.Stream(dev)
+                        self._s3d = torch.cuda.Stream(dev, priority=int(os.environ.get("MM_S3D_PRIO", "0")))
                         # the single-launch BatchNorm2d kernels need every CU at once and would starve behind the other
                         # stream's workgroups (csrc/bn2d.hip): three-kernel path while the branches share the GPU
                         from . import _lib
 
-                        _lib.bn2d_set_fused(0)
+                        if self.overlap_branches == 1:
+                            _lib.bn2d_set_fused(0)
+                        # mode 2 (round 5): the 2D branch keeps its single-launch kernels (and its HIP graphs).  Beside them the 3D
+                        # branch launches nothing that waits across workgroups - three-kernel batch norms, merge sort / three-
+                        # kernel scans in whatever metadata it still has to build - so a grid barrier of the 2D branch can at
+                        # worst wait for the short kernels that hold CUs when it starts (csrc/fused_bn.h), never deadlock.
                         _lib.bn3d_set_fused(0)
                     main = torch.cuda.current_stream(dev)
                     self._s3d.wait_event(step_start)
-                    with torch.cuda.stream(self._s3d):
+                    md = getattr(both["x"][0], "_mm_metadata", None)
+                    from .scn import metadata as _md
+
+                    with torch.cuda.stream(self._s3d), _md.no_spin():
                         for t in both["x"]:
                             t.record_stream(self._s3d)
+                        if md is not None:
+                            for t in md.tensors():
+                                t.record_stream(self._s3d)
+                            for t in md.pending_tensors():
+                                t.record_stream(self._s3d)
                         p3d, _, aux3d = self(both, model_name=n3d)
                     main.wait_stream(self._s3d)
                     for t in (p3d["seg_logit"], aux3d["seg_logit_point"]):
@@ -467,6 +482,10 @@ class TrainModel(nn.Module):
             self.scaler.scale(loss).backward()
         else:
             loss.backward()
+        if self._s3d is not None:
+            # gradient sinks: the 3D branch's weight gradients were accumulated into the arenas by kernels of ITS stream (no
+            # AccumulateGrad node whose stream the engine would join at the end of backward)
+            torch.cuda.current_stream().wait_stream(self._s3d)
         fault = bool(self.handle.fault_poll() if self.handle is not None else _lib.fault_poll())
         self.reducer.finish(fault=fault)
         if fault and not self.reducer.active:

@@ -334,3 +334,45 @@ def test_stem_kernel_is_bit_identical_with_the_generic_implicit_gemm(cin, B, hw,
         assert float(((t - want).abs() / scale).max()) < 2e-6
     yr = F.conv2d(img.to(half2d).float(), w.to(half2d).float(), None, 1, 3)
     assert _rel(outs[0], yr) < 1e-2
+
+
+def test_conv3x3_results_do_not_depend_on_kernels_of_other_streams():
+    """Round 5: k_conv3x3w<64, *> (the decoder's 192 -> 64 convolutions: 96 registers per wave and 139 KB of LDS then, i.e. room on
+    the CU for another kernel's workgroups) computed wrong tiles whenever small LDS-using workgroups of ANOTHER stream were launched
+    onto its CU while its LDS-DMA ring was in flight - the sparse metadata kernels did it in 15 of 24 launches
+    (tools/conv_corun.py, tools/corun_units.py).  The kernel now owns its CU (whole LDS, 128 registers per
+    wave).  Here: the convolution and its data gradient on the main stream, the metadata build of a 280k-point batch on a second
+    stream beside them, every output compared with the kernel's own output when it runs alone - bit for bit."""
+    from mm2d3d_amd import nn2d
+    from mm2d3d_amd.scn import metadata as md_mod
+    from mm2d3d_amd.synthetic import make_batch
+
+    dev = _dev()
+    torch.manual_seed(5)
+    conv = nn2d.Conv2d(192, 64, kernel_size=3, padding=1).to(dev)
+    x = torch.randn(16, 192, 304, 480, device=dev).half().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    coords = make_batch(6, 8, "nuscenes", (302, 480), 6, device=dev)["x"][0].contiguous()
+    g = torch.randn(16, 64, 304, 480, device=dev).half().contiguous(memory_format=torch.channels_last)
+
+    def fwd_bwd():
+        x.grad = None
+        y = conv(x)
+        y.backward(g)
+        return y.detach(), x.grad
+
+    ref_y, ref_dx = [t.clone() for t in fwd_bwd()]
+    torch.cuda.synchronize()
+    main, side = torch.cuda.current_stream(), torch.cuda.Stream(dev)
+    bad = []
+    for rep in range(4):
+        side.wait_stream(main)
+        outs = [fwd_bwd() for _ in range(3)]
+        with torch.cuda.stream(side), md_mod.no_spin():
+            md = md_mod.Metadata(dev, 4096, 7)
+            md.build_levels(coords)
+            md.build_rulebooks()
+        outs += [fwd_bwd() for _ in range(3)]
+        main.wait_stream(side)
+        torch.cuda.synchronize()
+        bad += [(rep, i) for i, (y, dx) in enumerate(outs) if not (torch.equal(y, ref_y) and torch.equal(dx, ref_dx))]
+    assert not bad, f"convolution outputs changed beside another stream's kernels: launches {bad}"

@@ -280,10 +280,12 @@ def test_joint_domain_pass_equals_the_two_call_sequence(bf16_mode):
         cos = torch.nn.functional.cosine_similarity(p.grad.flatten().double(), q.grad.flatten().double(), dim=0).item()
         assert cos > 0.98 or q.grad.norm() < 1e-3, (name, cos)
 
-def test_branches_on_two_streams_equal_the_single_stream_step():
+@pytest.mark.parametrize("mode", [1, 2])
+def test_branches_on_two_streams_equal_the_single_stream_step(mode):
     """train_kwargs["overlap_branches"]: the 3D branch runs on its own stream (forward and, through autograd's stream rules,
     backward).  Same kernels, same order within each branch: every loss term and every gradient must be BIT-identical to the
-    single-stream step with the same (three-kernel) batch norm - a missing stream dependency shows up as a difference."""
+    single-stream step with the same batch-norm kernels (mode 1: three-kernel everywhere; mode 2, the default: three-kernel in the
+    sparse branch, single-launch in the 2D branch) - a missing stream dependency shows up as a difference."""
     import copy
 
     from mm2d3d_amd import _lib
@@ -305,9 +307,9 @@ def test_branches_on_two_streams_equal_the_single_stream_step():
         n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
         mk = lambda: {"source": make_batch(5, 2, "nuscenes", (96, 128), device=dev), "target": make_batch(6, 2, "nuscenes", (96, 128), device=dev)}
         loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {"weight": W}}])
-        kwargs = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False, bn2d_fused=0, bn3d_fused=0)  # three-kernel batch norms on both handles
-        one = TrainModel({"2d_net": n2, "3d_net": n3}, None, loss, dict(kwargs))
-        two = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(kwargs, overlap_branches=1))
+        kwargs = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False, bn2d_fused=0 if mode == 1 else 3, bn3d_fused=0)
+        one = TrainModel({"2d_net": n2, "3d_net": n3}, None, loss, dict(kwargs, overlap_branches=0))
+        two = TrainModel({"2d_net": n2b, "3d_net": n3b}, None, loss, dict(kwargs, overlap_branches=mode))
         for _ in range(3):  # several steps: the stream handoffs repeat with recycled allocator blocks
             for tm in (one, two):
                 for p in tm.model.parameters():
