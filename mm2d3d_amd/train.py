@@ -76,9 +76,14 @@ class TrainModel(nn.Module):
         # (tests/test_gpu_step.py::test_metadata_built_one_step_ahead_gives_the_same_steps).
         self.overlap_rulebooks = bool(int(train_kwargs.get("overlap_rulebooks", os.environ.get("MM_META_SIDE", "1"))))
         self._meta_stream, self._meta_event = None, None
-        # 0: one stream; 1: the 3D branch on its own stream, three-kernel batch norms everywhere (round 2); 2 (default, round 5): the
-        # 3D branch on its own stream with three-kernel SPARSE batch norms only - see _generic_step.  Not under data parallelism.
-        self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "2")))
+        # 0 (default): one stream; 1: the 3D branch on its own stream, three-kernel batch norms everywhere (round 2); 2 (round 5): the
+        # 3D branch on its own stream with three-kernel SPARSE batch norms only - the 2D branch keeps its single-launch kernels and
+        # its HIP graphs.  Mode 2 measured -1.07 ms per step (33.69 -> 32.61 ms, two runs each on one box, final loss repeatable)
+        # and is bit-identical with the one-stream step on the same kernels (tests/test_gpu_step.py), but it is NOT the default: in
+        # a 49-test sequence on one process a single-launch BatchNorm2d grid ran into its 10 s barrier bound beside the 3D stream
+        # (the dispatcher kept feeding the other queue's workgroups onto the CUs the grid's missing workgroups were waiting for -
+        # csrc/fused_bn.h).  Never under data parallelism.
+        self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
         self._s3d = None
