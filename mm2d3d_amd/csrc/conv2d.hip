@@ -494,7 +494,9 @@ __device__ inline void wait_vm() {
 template <int BN, int TW, int DIAG = 0>
 __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
   extern __shared__ __attribute__((aligned(16))) char smemc[];
+#ifndef MM_DIAG_SHARED_CU
   asm volatile("" ::: "v127");  // the wave allocates all 128 registers it may have: see c3_launch (the CU is owned by this workgroup)
+#endif
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
   constexpr int HSZB = 344 * 128;  // bytes per halo buffer: 43 one-KiB DMA pieces (5 rounds of 8 waves + waves 0..2 of a sixth)
   constexpr int RW = BN == 128 ? 4 : 6;  // W ring depth: tiles are requested RW - 1 tap steps ahead
@@ -842,7 +844,9 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
 template <int TW>
 __global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
   extern __shared__ __attribute__((aligned(16))) char smemc[];
+#ifndef MM_DIAG_SHARED_CU
   asm volatile("" ::: "v127");  // the wave allocates all 128 registers it may have: see c3_launch (the CU is owned by this workgroup)
+#endif
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
   constexpr int HSZB = ((HROWS + 7) / 8) * 8 * 128;  // bytes per halo buffer, whole 1-KiB DMA pieces
   constexpr int NPIECE = (HROWS + 63) / 64;          // DMA rounds of 64 rows; the last one is partial (fewer waves issue it)
@@ -2121,7 +2125,11 @@ static int c3_launch(C3P p, hipStream_t s) {
     // LDS-using workgroups of another stream were LAUNCHED onto its CU while its LDS-DMA ring was in flight - the sparse
     // metadata kernels beside the decoder's 192 -> 64 convolutions, in practice any RCCL kernel of a data-parallel run; every
     // other kernel of the library (and <128, *>, whose waves already take 127 registers) came through that stress unchanged.
+#ifdef MM_DIAG_SHARED_CU  // diagnostic build (tools/diag_lib.sh sharedcu -DMM_DIAG_SHARED_CU): the round-4 resource request, for tools/corun_units.py
+    const size_t ldsw = (size_t)(2 * 344 * 64 + (bn == 128 ? 4 : 6) * bn * 64) * 2 + (bias ? (size_t)mm_cdiv(Cn, 512) * 512 * 4 : 0);
+#else
     const size_t ldsw = 163840;
+#endif
     int64_t grid = mm_cdiv(nitems, 8) * 8;  // a multiple of the 8 XCDs
     if (grid > 256) grid = 256;             // one resident 8-wave workgroup per CU
     static unsigned once_w = 0;  // per-device bit: see mm_attr_todo (common.h)

@@ -197,7 +197,7 @@ def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W, half2d):
 
 
 @pytest.mark.parametrize("workload", ["c2", "c4"])
-def test_full_joint_step_at_bench_size(workload, bf16_mode):
+def test_full_joint_step_at_bench_size(workload, half2d):
     """One whole two-domain training step at BASELINE.json's sizes - configs[1]: 8 + 8 NuScenes-shaped scenes, 6 classes;
     configs[3]: 4 + 4 KITTI-shaped scans of 121,600 points, 10 classes (datasets/a2d2_semantic_kitti.yaml:19), both at
     480x302.  The jointly batched step (one pass per network over [source | target], per-domain batch-norm statistics)
@@ -239,7 +239,8 @@ def test_full_joint_step_at_bench_size(workload, bf16_mode):
     logs2 = {k: float(v) for k, v in two.last_logs.items()}
     assert len(logs1) == 6 and all(np.isfinite(v) for v in logs1.values())
     for k, v in logs2.items():
-        tol = 1e-5 if k.endswith("segmentation_3d") else 3e-3  # 3D: fp32 end to end; the others see the bf16 2D logits
+        # 3D: fp32 end to end; the others see the 16-bit 2D logits (round 5: both formats - IEEE fp16, the default, rounds 8x finer)
+        tol = 1e-5 if k.endswith("segmentation_3d") else (3e-3 if half2d == torch.bfloat16 else 1e-3)
         assert abs(logs1[k] - v) <= tol * max(1.0, abs(v)), (k, logs1[k], v)
     # run-to-run: a second joint step from the same weights and inputs (running statistics have moved, the training-mode
     # arithmetic does not read them) gives the same bits for the fp32 3D loss and the same 3D head gradient
