@@ -10,7 +10,7 @@ Workload = BASELINE.json configs[1]: NuScenes-shaped scenes (34,880 points, 5 cm
 Weak scaling: every rank processes its own 2*B scenes; the only collective is the gradient all-reduce.
 
 Extra legs (rank 0, N=1): `roofline` = sparse-conv engine kernels timed with HIP events against SURVEY.md 8d's
-algorithmic bytes; `cpu_baseline` = the CPU oracle timed on a bounded sample (1 source + 1 target scene).
+algorithmic bytes; `cpu_baseline` = the CPU oracle timed on a bounded sample (2 source + 2 target scenes).
 """
 from __future__ import annotations
 
@@ -406,7 +406,7 @@ def branch_rates(tm, batch, dev, iters=5):
 
 
 def cpu_baseline():
-    """The CPU oracle (a port, not the reference) on 1 source + 1 target scene of the same workload, fwd+bwd."""
+    """The CPU oracle (a port, not the reference) on 2 source + 2 target scenes of the same workload, fwd+bwd."""
     from mm2d3d_amd.net2d import Net2DSeg
     from mm2d3d_amd.synthetic import make_batch
     from oracle.net3d_ref import Net3DSegRef
@@ -419,8 +419,8 @@ def cpu_baseline():
     sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k and "num_batches" not in k)
           for k, v in Net2DSeg(6, pretrained=True).state_dict().items()}
     net3d = Net3DSegRef(6, True, NET3D_KW)
-    batch = {"source": make_batch(2, 1, "nuscenes", (302, 480)), "target": make_batch(3, 1, "nuscenes", (302, 480))}
-    reps, dts = 5, []  # 1 untimed warm-up (thread pools, allocator) + 4 timed passes: ~10-15 s of CPU work
+    batch = {"source": make_batch(2, 2, "nuscenes", (302, 480)), "target": make_batch(3, 2, "nuscenes", (302, 480))}
+    reps, dts = 4, []  # 1 untimed warm-up (thread pools, allocator) + 3 timed passes: ~15-20 s of CPU work
     for i in range(reps):
         for v in sd.values():
             v.grad = None
@@ -457,13 +457,13 @@ def cpu_baseline():
         F.cross_entropy(preds["seg_logit"], b8["seg_label"], weight=w6).backward()  # lib/losses.py:66-68
         if i:
             t3.append(time.perf_counter() - t0)
-    return {"value": round(2 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+    return {"value": round(4 / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
             "branch_3d_8_scenes_fwd_bwd": {"scenes_per_s": round(8 / min(t3), 4), "seconds_per_pass": round(min(t3), 3),
                                            "what": "CPU oracle of the 3D branch alone (oracle/net3d_ref.py) on the C2 per-GPU batch of 8 "
                                                    "NuScenes-shaped scenes, fwd+bwd with the weighted CE; best of 2 after 1 warm-up"},
-            "sample": "CPU oracle (torch-CPU 2D + oracle sparse ops): 1 source + 1 target NuScenes-shaped scene at 480x302 = 1/8 of the "
+            "sample": "CPU oracle (torch-CPU 2D + oracle sparse ops): 2 source + 2 target NuScenes-shaped scenes at 480x302 = 1/4 of the "
                       "C2 batch (8 + 8; the full batch needs ~18 GB of autograd state and ~20 s per pass on the host), fwd+bwd of the "
-                      "full two-domain step (no optimiser step), median of 4 passes after 1 warm-up; c1_fwd_only = BASELINE.md C1 "
+                      "full two-domain step (no optimiser step), median of 3 passes after 1 warm-up; c1_fwd_only = BASELINE.md C1 "
                       "(one scene, forward only, both networks, eval mode), best of 2 after 1 warm-up",
             "c1_fwd_only_scenes_per_s": round(1.0 / min(c1), 4),
             "seconds": round(sum(dts) + sum(c1) + sum(t3), 2)}
