@@ -842,8 +842,11 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
 // weight DMA, no per-tap barrier: one barrier per 256-pixel item (72 MFMAs per wave between barriers).  Same item
 // schedule, fragment layouts, halo swizzle and epilogue as k_conv3x3w<64, TW>.
 template <int TW>
-__global__ __launch_bounds__(512, 2) void k_conv3x3r(C3P p) {
+__global__ __launch_bounds__(512, 1) void k_conv3x3r(C3P p) {
   extern __shared__ __attribute__((aligned(16))) char smemc[];
+#ifndef MM_DIAG_SHARED_CU
+  asm volatile("" ::: "v255");  // 8 waves x 256 registers + the whole LDS: the CU is owned by this workgroup (see c3_launch)
+#endif
 #ifndef MM_DIAG_SHARED_CU
   asm volatile("" ::: "v127");  // the wave allocates all 128 registers it may have: see c3_launch (the CU is owned by this workgroup)
 #endif
@@ -1458,6 +1461,9 @@ struct Wg9P {
 
 __global__ __launch_bounds__(512, 1) void k_wgrad3x3n(Wg9P p) {
   extern __shared__ __attribute__((aligned(16))) char smw[];
+#ifndef MM_DIAG_SHARED_CU
+  asm volatile("" ::: "v255");  // 8 waves x 256 registers + the whole LDS: the CU is owned by this workgroup (see c3_launch)
+#endif
   constexpr int YB = 128 * 128;   // dY patch [8*16 px][64 n]
   constexpr int HB = 184 * 128;   // halo [10*18 = 180 px (+4 of the last DMA piece)][64 k]
   constexpr int STG = YB + HB;    // one stage (39,936 B)
@@ -2143,7 +2149,12 @@ static int c3_launch(C3P p, hipStream_t s) {
     }
     if (Ca == 64 && Cn == 64) {  // weights resident in LDS
       const int hrows = tw == 16 ? 18 * 18 : 10 * 34;
+#ifdef MM_DIAG_SHARED_CU
       const size_t ldsr = (size_t)9 * 64 * 128 + 2 * (size_t)((hrows + 7) / 8) * 8 * 128 + 256;
+#else
+      (void)hrows;  // used: 9 * 64 * 128 + 2 * ceil(hrows / 8) * 1024 + 256 = 154-158 KB; requested: the CU's whole LDS (CU ownership, above)
+      const size_t ldsr = 163840;
+#endif
       static unsigned once_r = 0;  // per-device bit: see mm_attr_todo (common.h)
       if (mm_attr_todo(&once_r)) {
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3r<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
@@ -2226,7 +2237,11 @@ static int wgrad3x3_launch(const void* X, const void* X1, const void* dY, const 
     return MM_ERR_WORKSPACE;
   }
   q.partial = (float*)ws;
+#ifdef MM_DIAG_SHARED_CU
   constexpr int lds9 = 4 * (128 + 184) * 128;
+#else
+  constexpr int lds9 = 163840;  // used: 4 * (128 + 184) * 128 = 159,744 B; requested: the CU's whole LDS (CU ownership, see c3_launch)
+#endif
   static unsigned attr9 = 0;  // per-device bit: see mm_attr_todo (common.h)
   if (mm_attr_todo(&attr9)) {
     MM_HIP(hipFuncSetAttribute((const void*)k_wgrad3x3n, hipFuncAttributeMaxDynamicSharedMemorySize, lds9));
