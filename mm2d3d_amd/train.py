@@ -76,13 +76,15 @@ class TrainModel(nn.Module):
         # (tests/test_gpu_step.py::test_metadata_built_one_step_ahead_gives_the_same_steps).
         self.overlap_rulebooks = bool(int(train_kwargs.get("overlap_rulebooks", os.environ.get("MM_META_SIDE", "1"))))
         self._meta_stream, self._meta_event = None, None
-        # 0 (default): one stream; 1: the 3D branch on its own stream, three-kernel batch norms everywhere (round 2); 2 (round 5): the
-        # 3D branch on its own stream with three-kernel SPARSE batch norms only - the 2D branch keeps its single-launch kernels and
-        # its HIP graphs.  Mode 2 measured -1.07 ms per step (33.69 -> 32.61 ms, two runs each on one box, final loss repeatable)
-        # and is bit-identical with the one-stream step on the same kernels (tests/test_gpu_step.py), but it is NOT the default: in
-        # a 49-test sequence on one process a single-launch BatchNorm2d grid ran into its 10 s barrier bound beside the 3D stream
-        # (the dispatcher kept feeding the other queue's workgroups onto the CUs the grid's missing workgroups were waiting for -
-        # csrc/fused_bn.h).  Never under data parallelism.
+        # 0 (default): one stream; 1: the 3D branch on its own stream, three-kernel batch norms everywhere (round 2); 2 (round 5,
+        # EXPERIMENTAL): the 3D branch on its own stream with three-kernel SPARSE batch norms only - the 2D branch keeps its
+        # single-launch kernels and its HIP graphs.  Mode 2 measured -0.9 to -1.07 ms per step on the C2 workload (same-box pairs,
+        # final loss repeatable) and is bit-identical with the one-stream step on the same kernels (tests/test_gpu_step.py), but it
+        # is NOT the default and not safe at every size: at the C5 size (1 M points) inside a 49-test sequence a single-launch
+        # BatchNorm2d grid ran into its 10 s barrier bound beside the 3D stream (under a debugger: the fault word, as designed;
+        # without: the process was aborted while the grid spun) - the grid's missing workgroups need EMPTY CUs and the other queue
+        # keeps refilling them; what exactly keeps them from ever draining at that size was not found.
+        # Never under data parallelism.
         self.overlap_branches = int(train_kwargs.get("overlap_branches", os.environ.get("MM_OVERLAP_BRANCHES", "0")))
         self.gc_freeze = bool(train_kwargs.get("gc_freeze", True))
         self._side = None
@@ -203,6 +205,15 @@ class TrainModel(nn.Module):
                         # kernel scans in whatever metadata it still has to build - so a grid barrier of the 2D branch can at
                         # worst wait for the short kernels that hold CUs when it starts (csrc/fused_bn.h), never deadlock.
                         _lib.bn3d_set_fused(0)
+                        if self.overlap_branches == 2:
+                            # ... and for good, not only around the forward call: a rulebook's destination-row CSR is built lazily
+                            # by the first BACKWARD that needs it (Rulebook.ensure_csr) - with rocPRIM's look-back scan that
+                            # is a spin-waiting kernel of the 3D stream beside the grid barriers of the 2D backward, the one
+                            # combination csrc/fused_bn.h rules out (the 10 s barrier bound fired once in a 49-test sequence
+                            # before this line existed).  Process-wide: metadata builds of this process stay spin-free.
+                            from .scn import metadata as _md0
+
+                            _md0.NO_SPIN[0] = 1
                     main = torch.cuda.current_stream(dev)
                     self._s3d.wait_event(step_start)
                     md = getattr(both["x"][0], "_mm_metadata", None)
