@@ -55,6 +55,12 @@ def build_trainer(dev, total_steps=49047, num_classes=6, class_weights=None, tra
     return tm
 
 
+def _lib_opt(name):
+    from mm2d3d_amd import _lib
+
+    return getattr(_lib, name)
+
+
 def _graph_state(tm):
     """Was the 2D trunk replayed as two HIP graphs in the timed loop (mm2d3d_amd/graph2d.py)?"""
     from mm2d3d_amd import graph2d
@@ -481,6 +487,12 @@ def launch_ranks(a, argv):
         # fewer cards than ranks: a rehearsal with several ranks per card, which RCCL refuses - gradients go through gloo
         print(f"[bench] {a.gpus} ranks on {n_dev} GPU(s): rehearsal over the gloo backend (MM_BENCH_BACKEND=gloo)", file=sys.stderr, flush=True)
         env["MM_BENCH_BACKEND"] = "gloo"
+    if n_dev < a.gpus:
+        # several PROCESSES on one card: their single-launch batch-norm grids (one workgroup per CU, every workgroup resident at once)
+        # starve each other (csrc/fused_bn.h; a two-rank rehearsal ran into the 10 s barrier bound within two steps) - the
+        # three-kernel batch norms for a rehearsal, as the header prescribes for a shared GPU
+        env.setdefault("MM_BN2D_FUSED", "0")
+        env.setdefault("MM_BN_FUSED", "0")
     with socket.socket() as sock:  # a free rendezvous port on the loopback interface
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
@@ -655,6 +667,8 @@ def main(argv=None):
             "ddp_schedule": {False: "after: every bucket in finish()", True: "hooks: every bucket as soon as it is complete",
                              "tail": "tail: buckets from the hooks once the last grid-barrier kernel of backward is queued"}[tm.reducer.overlap],
             "grid_barrier_kernels_in_backward": st.get("barrier_kernels_bwd"),
+            "single_launch_batch_norms": {"2d": int(tm.handle.get(_lib_opt("OPT_BN2D_FUSED"))), "3d": int(tm.handle.get(_lib_opt("OPT_BN3D_FUSED"))),
+                                          "what": "handle options at the end of the run: bit 0 forward, bit 1 backward (0 = three-kernel path)"},
         })
     if a.image != "480x302":
         out["config"]["workload"] = out["config"]["workload"].replace("480x302", a.image) + f" [image {a.image}: the reference YAML's size, not the headline]"

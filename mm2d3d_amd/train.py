@@ -298,7 +298,9 @@ class TrainModel(nn.Module):
     def _prefetch_rulebooks(self):
         pre = self._pipelined
         if pre is not None and pre["phase"] == 1:
-            if self.overlap_rulebooks and pre["md"].device.type == "cuda":
+            # (not under an active data-parallel reducer: that path has never run on more than one GPU, and a two-rank rehearsal on
+            # ONE GPU showed the two processes' grid barriers starving each other far more often with the extra queue in play)
+            if self.overlap_rulebooks and pre["md"].device.type == "cuda" and not (self.reducer is not None and self.reducer.active):
                 self._rulebooks_on_side_stream(pre["md"])
             else:
                 pre["md"].begin_rulebooks()  # reads the level sizes (no wait: queued before this step's forward), queues phase two
