@@ -280,7 +280,10 @@ def test_joint_domain_pass_equals_the_two_call_sequence(bf16_mode):
         cos = torch.nn.functional.cosine_similarity(p.grad.flatten().double(), q.grad.flatten().double(), dim=0).item()
         assert cos > 0.98 or q.grad.norm() < 1e-3, (name, cos)
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, pytest.param(2, marks=pytest.mark.skipif(
+    os.environ.get("MM_TEST_EXPERIMENTAL", "0") == "0",
+    reason="overlap_branches=2 is experimental (a BatchNorm2d grid barrier can starve beside the 3D stream: DESIGN.md section 4); "
+           "set MM_TEST_EXPERIMENTAL=1 to run it"))])
 def test_branches_on_two_streams_equal_the_single_stream_step(mode):
     """train_kwargs["overlap_branches"]: the 3D branch runs on its own stream (forward and, through autograd's stream rules,
     backward).  Same kernels, same order within each branch: every loss term and every gradient must be BIT-identical to the
