@@ -77,6 +77,8 @@ import os as _os
 
 # mm_conv2d_3x3s1's flip argument, bit 1: whole work items only (A/B of the half-item last round; MM_CONV_WHOLE_ITEMS=1)
 WHOLE_ITEMS = [2 if _os.environ.get("MM_CONV_WHOLE_ITEMS", "0") != "0" else 0]
+# ... bit 2: the round-2 kernel k_conv3x3w instead of the register-tile kernel k_conv3x3v (A/B and bit-identity tests; MM_CONV3X3_LEGACY=1)
+LEGACY3X3 = [4 if _os.environ.get("MM_CONV3X3_LEGACY", "0") != "0" else 0]
 PARAM_EPOCH = [0]  # bumped by FlatAdamW.step(): packed bf16 copies of the fp32 master weights are valid for one epoch
 
 
@@ -359,7 +361,7 @@ class Conv2dFn(torch.autograd.Function):
             if stats is not None and bn_pre_wanted(x.device, Bn, H, W, Cout):
                 nf = _stat_group_split(Bn)
                 slab = _stat_slab(stats, int(lib2d().mm_conv2d_3x3s1_stat_rows(Bn, H, W)), Cout, nf, Bn, x.device)
-            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0 | WHOLE_ITEMS[0], ptr(slab), nf,
+            check(lib2d().mm_conv2d_3x3s1(ptr(x), Bn, H, W, Cin, ldx, ptr(y), Cout, Cout, ptr(Wp), ptr(b), 0 | WHOLE_ITEMS[0] | LEGACY3X3[0], ptr(slab), nf,
                                           stream()), "conv2d_3x3s1")
         else:
             _gemm(x, Bn, H, W, Cin, y, Ho, Wo, Cout, Ho, Wo, 1, stride, 1, ty, tx, Wp, bias=b, lda=ldx, stats=stats)
@@ -386,7 +388,7 @@ class Conv2dFn(torch.autograd.Function):
             Wd = _pack(w, 1, Cin, T, Cout, 0, T, 1, Cin * T, ctx.wowner, "dgrad")  # [ci][t][co]
             dx = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x.device, memory_format=CL)
             if (KH, KW, stride, padding) == (3, 3, 1, 1):
-                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1 | WHOLE_ITEMS[0], None, 0,
+                check(lib2d().mm_conv2d_3x3s1(ptr(dy), Bn, H, W, Cout, ldy, ptr(dx), Cin, Cin, ptr(Wd), None, 1 | WHOLE_ITEMS[0] | LEGACY3X3[0], None, 0,
                                               stream()), "conv2d_3x3s1")
             else:
                 ty = [padding - kh for kh in range(KH) for _ in range(KW)]
@@ -474,7 +476,7 @@ class Conv2dPairFn(torch.autograd.Function):
         # (64 -> 64: the weights-resident kernel pairs when the item list splits at an XCD boundary, else the entry point runs the
         # two problems one after the other)
         check(lib2d().mm_conv2d_3x3s1_pair(ptr(x1), ptr(x2), Bn, H, W, Cin, Cin, ptr(y[0]), ptr(y[1]), Cout, Cout, ptr(Wp[0]), ptr(Wp[1]),
-                                           0 | WHOLE_ITEMS[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
+                                           0 | WHOLE_ITEMS[0] | LEGACY3X3[0], ptr(slabs[0]), ptr(slabs[1]), nf, stream()), "conv2d_3x3s1_pair")
         ctx.save_for_backward(x1, x2, wf[0], wf[1])
         ctx.owners = (w1, w2)
         ctx.wparams = tuple(w if gradsink.claim(ctx, w, ctx.needs_input_grad[2 + i]) else None for i, w in enumerate((w1, w2)))
@@ -494,13 +496,13 @@ class Conv2dPairFn(torch.autograd.Function):
             if need[0] and need[1]:
                 dx = [torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x1.device, memory_format=CL) for _ in range(2)]
                 check(lib2d().mm_conv2d_3x3s1_pair(ptr(dys[0]), ptr(dys[1]), Bn, H, W, Cout, Cout, ptr(dx[0]), ptr(dx[1]), Cin, Cin,
-                                                   ptr(Wd[0]), ptr(Wd[1]), 1 | WHOLE_ITEMS[0], None, None, 0, stream()), "conv2d_3x3s1_pair")
+                                                   ptr(Wd[0]), ptr(Wd[1]), 1 | WHOLE_ITEMS[0] | LEGACY3X3[0], None, None, 0, stream()), "conv2d_3x3s1_pair")
             else:
                 for i in range(2):
                     if need[i]:
                         dx[i] = torch.empty((Bn, Cin, H, W), dtype=HALF[0], device=x1.device, memory_format=CL)
                         check(lib2d().mm_conv2d_3x3s1(ptr(dys[i]), Bn, H, W, Cout, Cout, ptr(dx[i]), Cin, Cin, ptr(Wd[i]), None,
-                                                      1 | WHOLE_ITEMS[0], None, 0, stream()), "conv2d_3x3s1")
+                                                      1 | WHOLE_ITEMS[0] | LEGACY3X3[0], None, 0, stream()), "conv2d_3x3s1")
         dw = [None, None]
         ty = [kh - 1 for kh in range(3) for _ in range(3)]
         tx = [kw - 1 for _ in range(3) for kw in range(3)]

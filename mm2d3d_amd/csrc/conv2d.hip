@@ -15,6 +15,8 @@
 //       read ds_read_b64_tr_b16; split over pixel chunks into fp32 partial slabs, reduced in a fixed order.
 #include <hip/hip_bf16.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "h16.h"  // bf16 (default) or IEEE fp16 (-DMM_ACT_FP16) storage: this file is built once for each
 
@@ -429,6 +431,7 @@ struct C3P {
   const float* bias;
   int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
   int whole; // != 0: never cut a ragged last round into half items (A/B measurements)
+  int legacy;  // != 0: the round-2 kernel k_conv3x3w instead of k_conv3x3v (A/B measurements, bit-identity tests)
   float* stats;  // BatchNorm statistics slab (see stats_accum), or NULL
   int split_b;   // images [0, split_b) are statistics group 0, the others group 1
   int tiles_y, tiles_x;
@@ -834,6 +837,393 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
       if (MM_DIAG(p, 64)) g_dump[lane] = diag_sum;
     }
   }
+  MM_CLK_END(0);
+}
+
+// Round 6: the same convolution with 128-pixel x 64-cout REGISTER TILES.  k_conv3x3w above reads 1 KiB of LDS
+// fragments per MFMA (a wave owns 64 pixels x BN / 2 couts: 2 + 2 fragment reads for 4 MFMAs) and runs two multiplying waves per
+// SIMD in lockstep behind one barrier per tap step: its step takes 0.8-0.9 us against 0.43 us of MFMA time, 0.63 us of it with
+// every DMA switched off (tools/conv3x3_diag.hip), i.e. the fragment reads and the two waves' shared matrix pipe are what bounds it.
+// Here a workgroup is 8 waves at 256 registers: FOUR multiplying waves, one per SIMD, each with a 128-pixel x 64-cout accumulator
+// block (128 registers; BN = 64: 64 pixels x 64 couts), and four loader waves that issue every LDS-DMA.  Per 16-deep K slice a
+// multiplying wave reads 4 pixel fragments + 2 cout fragments for 8 MFMAs (0.75 KiB per MFMA, BN = 64: 1 KiB against 1.5), its
+// reads of slice kk + 1 are requested before the MFMAs of slice kk (two fragment sets), and the pixel fragments of the NEXT tap
+// step are requested before the barrier that ends the current one (the halo has landed long before; only the weight tile needs
+// the barrier).  Item list, halo / weight images, swizzles, ring protocol, half items, pair mode and epilogue are k_conv3x3w's:
+// every output element is the same chain of the same MFMAs in the same order - the results are bit-identical
+// (tests/test_gpu_conv2d.py::test_conv3x3_register_tile_kernel_is_bit_identical_with_the_first_kernel), statistics slab included.
+// DIAG (tools/conv3x3_diag.hip only; the library instantiates 0): 1 no MFMA (fragment reads kept)  2 no fragment reads, no MFMA
+// 4 W DMA from the zero line  8 halo DMA from the zero line  32 no epilogue (accumulators consumed by an empty asm)
+template <int BN, int TW, int DIAG = 0>
+__global__ __launch_bounds__(512, 1) void k_conv3x3v(C3P p) {
+  extern __shared__ __attribute__((aligned(16))) char smemc[];
+#ifndef MM_DIAG_SHARED_CU
+  asm volatile("" ::: "v255");  // 8 waves x 256 registers + the whole LDS: the CU is owned by this workgroup (see c3_launch)
+#endif
+  constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;  // 324 or 340 halo pixels
+  constexpr int HSZB = 344 * 128;          // bytes per halo buffer: 43 one-KiB DMA pieces
+  constexpr int RW = BN == 128 ? 4 : 8;    // W ring depth (64 KB either way): tiles are requested RW - 1 tap steps ahead
+  constexpr int BSZB = BN * 128;           // bytes per W buffer
+  constexpr int NB = BN / 32;              // W DMA instructions per loader thread and tile
+  constexpr int PF = BN == 128 ? 4 : 2;    // 32-pixel fragments per multiplying wave (x 2 cout fragments)
+  static_assert(HROWS <= 344, "halo does not fit its 43 DMA pieces");
+  static_assert(RW - 2 <= 8 && (RW - 2) * NB + 11 < 64, "ring protocol / vmcnt range");
+  constexpr int HS0 = RW * BSZB;  // LDS map (bytes): W ring at 0 (65,536), halo ring [2][HSZB], bias
+  char* const lds = smemc;
+  float* biasl = (float*)(lds + HS0 + 2 * HSZB);  // [Cn <= 1024] when p.bias
+  const bool loader = threadIdx.x >= 256;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;  // wave = index within the role
+  const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
+  const int pixbase = BN == 128 ? 128 * wm : 64 * wm;  // this wave's first pixel of the 256-pixel tile
+  const int cc = tid & 7, r0 = tid >> 3;
+  const int nchunk = p.Ca >> 6, ncb = p.Cn / BN;
+  if (p.bias) {  // staged once by DMA (loaders)
+    if (loader) {
+      for (int k0 = 0; k0 < p.Cn; k0 += 256) {
+        const int k = k0 + tid < p.Cn ? k0 + tid : p.Cn - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + k),
+                                         (__attribute__((address_space(3))) void*)(biasl + k0 + wave * 64), 4, 0, 0);
+      }
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // item schedule: exactly k_conv3x3w's (XCD-contiguous ranges, round-robin inside an XCD, half items in a ragged last round)
+  const int nitems = p.B * p.tiles_y * p.tiles_x * ncb;
+  const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per = (nitems + 7) >> 3;
+  const int x_begin = xcd * per;
+  const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
+  const int n_x = it_end > x_begin ? it_end - x_begin : 0;
+  const int r_full = n_x / G8, rem = n_x - r_full * G8;
+  const bool halfmode = BN == 128 && rem > 0 && 2 * rem <= G8 && !p.whole;
+  const int my_items = r_full + ((halfmode ? local < 2 * rem : local < rem) ? 1 : 0);
+  if (my_items == 0) return;
+  const int nseg = my_items * nchunk;
+  auto item_of = [&](int k, int& half) {
+    if (halfmode && k == r_full) {
+      half = local & 1;
+      return x_begin + r_full * G8 + (local >> 1);
+    }
+    half = -1;
+    return x_begin + local + k * G8;
+  };
+  auto decode = [&](int item, int& b, int& ty0, int& tx0, int& n0) {
+    n0 = (item % ncb) * BN;
+    int t = item / ncb;
+    tx0 = (t % p.tiles_x) * TW;
+    t /= p.tiles_x;
+    ty0 = (t % p.tiles_y) * TH;
+    b = t / p.tiles_y;
+  };
+
+  if (loader) {
+    // ---- the four loader waves: thread (r0 = 0..31, cc) fetches 16-byte chunk cc of rows r0 + 32 i.  (Measured and dropped: weight tiles
+    // and halos on separate waves, two each, so that a tile never queues behind a slower halo request - a wave sustains only ~16-25 GB/s
+    // of LDS-DMA, and two waves for the 16 KB per step of weights were slower than four sharing everything: 1.14 against 1.10 us per step.)
+    int hl[11], hyx[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+      const int row = r0 + 32 * i, hy = row / HC, hx = row - hy * HC;
+      const bool used = row < HROWS;
+      hyx[i] = used ? ((hy - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
+      hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ ((hx >> 1) & 7)) << 3);  // swizzle by the halo column (k_conv3x3w)
+    }
+    int wl[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int row = r0 + 32 * i;
+      wl[i] = row * 9 * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3);
+    }
+    int h_k = 0, h_c = 0, h_b, h_ty0, h_tx0, h_n0, h_half;
+    decode(item_of(0, h_half), h_b, h_ty0, h_tx0, h_n0);
+    auto issue_halo = [&](int buf) {  // 11 DMA instructions (10 for wave 3), always; then advance the cursor
+      const bool live = h_k < my_items && !MM_DIAG(p, 8);
+      const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
+      const u16* base = (h_b < p.B1 ? p.A + (int64_t)h_b * p.H * p.W * p.lda : p.A1 + (int64_t)(h_b - p.B1) * p.H * p.W * p.lda) +
+                        ((int64_t)h_ty0 * p.W + h_tx0) * p.lda + h_c * 64;
+      char* dst = lds + HS0 + buf * HSZB + wave * 1024;
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < 11; i++)
+          if (i < 10 || wave < 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+          if (i == 10 && wave >= 3) break;
+          const int y = h_ty0 + (hyx[i] >> 16), x = h_tx0 + (short)(hyx[i] & 0xFFFF);
+          const bool ok = live && y >= 0 && y < p.H && x >= 0 && x < p.W;
+          const u16* g = ok ? base + hl[i] : (const u16*)g_zero16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                           (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+        }
+      }
+      if (++h_c == nchunk) {
+        h_c = 0;
+        if (++h_k < my_items) decode(item_of(h_k, h_half), h_b, h_ty0, h_tx0, h_n0);
+      }
+    };
+    int w_k = 0, w_c = 0, w_tap = 0, w_half, w_n0;
+    const int items0 = p.B1 * p.tiles_y * p.tiles_x * ncb;  // items of problem 0 (pair mode; all of them otherwise)
+    const u16* w_src;
+    {
+      const int it = item_of(0, w_half);
+      w_n0 = (it % ncb) * BN + (w_half > 0 ? 64 : 0);
+      w_src = it < items0 ? p.Wp : p.Wp1;
+    }
+    auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
+      const bool live = w_k < my_items && !MM_DIAG(p, 4);
+      const u16* base = live ? w_src + ((int64_t)w_n0 * 9 + w_tap) * p.Ca + w_c * 64 : (const u16*)g_zero16;
+      char* dst = lds + buf * BSZB + wave * 1024;
+#pragma unroll
+      for (int i = 0; i < NB; i++) {
+        const bool real = live && !(i >= 2 && w_half >= 0);  // a half item: rows 64.. of the tile are not read, their DMA reads the zero line
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(real ? base + wl[i] : (const u16*)g_zero16),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+      }
+      if (++w_tap == 9) {
+        w_tap = 0;
+        if (++w_c == nchunk) {
+          w_c = 0;
+          if (++w_k < my_items) {
+            const int it = item_of(w_k, w_half);
+            w_n0 = (it % ncb) * BN + (w_half > 0 ? 64 : 0);
+            w_src = it < items0 ? p.Wp : p.Wp1;
+          }
+        }
+      }
+    };
+    // Ring protocol of k_conv3x3w (one barrier per step g = (segment, tap); a loader passes it once ITS pieces of W(g) have landed;
+    // W(g + RW - 1) and, at tap 0, the next segment's halo are requested right behind it), plus ONE barrier ahead of the first step
+    // that publishes the first halo: the multiplying waves request their first pixel fragments behind it.
+    issue_halo(0);
+#pragma unroll
+    for (int d = 0; d < RW - 1; d++) issue_w(d);
+    wait_vm<(RW - 1) * NB>();  // the first halo is the oldest request: everything younger may still be in flight
+    __builtin_amdgcn_s_barrier();
+    int wslot = RW - 1;
+    for (int seg = 0; seg < nseg; seg++) {
+#pragma unroll
+      for (int tap = 0; tap < 9; tap++) {
+        if (tap >= 1 && tap <= RW - 2) {  // the halo requested at tap 0 is younger than W(g)
+          if (wave < 3) wait_vm<(RW - 2) * NB + 11>();
+          else wait_vm<(RW - 2) * NB + 10>();
+        } else {
+          wait_vm<(RW - 2) * NB>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (tap == 0) issue_halo((seg + 1) & 1);
+        issue_w(wslot);
+        wslot = wslot + 1 == RW ? 0 : wslot + 1;
+      }
+    }
+    wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
+    return;
+  }
+
+  // ---- the four multiplying waves
+  const int fr_ = lane & 31, fh = lane >> 5;
+  const int schunk = frag_chunk(lane);
+  const int rstep = p.flip ? -(HC * 128) : HC * 128, rbase = p.flip ? 2 * HC * 128 : 0;  // halo row offset of filter row kh: rbase + kh * rstep
+
+  f32x16 acc[PF][2];
+#pragma unroll
+  for (int i = 0; i < PF; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+
+  int c_k = 0, c_c = 0, c_half;  // consumer cursor
+  int c_item = item_of(0, c_half);
+  int slot = 0;                  // byte offset of the W ring slot of the current step
+  bf16x8 Af[2][PF], Bf[2][2];    // two fragment sets: slice kk + 1 is requested before slice kk is multiplied
+  // Fragment reads are inline asm with hand-counted waits: left to the compiler, the waits in front of slices 0 and 2 came out as
+  // lgkmcnt(0) - they drained the requests of the NEXT slice too, so nothing was in flight under the MFMAs.  Addresses are absolute LDS
+  // bytes (this kernel has no static LDS: the dynamic segment starts at 0).
+#define MM_LDSR(dst, addr)                                                        \
+  do {                                                                            \
+    if (MM_DIAG(p, 2)) asm volatile("" : "=v"(dst) : "v"(addr));                  \
+    else asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));             \
+  } while (0)
+  __builtin_amdgcn_s_barrier();  // the first halo has landed
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < PF; i++) {  // slice 0 of the first step's pixel fragments (tap 0: filter column 0)
+    const int pix = pixbase + 32 * i + fr_, py = pix / TW, hx = pix % TW + (p.flip ? 2 : 0);
+    MM_LDSR(Af[0][i], HS0 + (py * HC + hx) * 128 + ((fh ^ ((hx >> 1) & 7)) << 4) + rbase);
+  }
+  MM_CLK_BEGIN();
+  // One segment = the 9 tap steps of one (item, 64-channel chunk), fully unrolled, in two instantiations: whole items (4 x 2 fragments
+  // per wave) and half items (4 x 1: a runtime branch around the second cout fragment cut every step into eight basic blocks, and the
+  // compiler then waits for ALL outstanding LDS reads - the just-requested next slice included - at each of them).
+  auto run_segment = [&](auto half_c, const int hb) {
+    constexpr bool HALF = decltype(half_c)::value;
+    constexpr int NJ = HALF ? 1 : 2;
+    const int hbn = HSZB - hb;
+    // Fragment addresses, formed anew per segment from an opaque copy of the lane index (~90 vector instructions per 9 tap steps): as
+    // kernel-lifetime values the register allocator spilled them around the epilogue and re-loaded them from scratch in this loop.
+    int ab[PF][3];  // pixel fragment i at filter column kw, halo row offset 0, K slice 0: byte offset inside a halo buffer (+ HS0)
+    int bb[2];      // cout fragment j, K slice 0, inside a W buffer (a half item: ONE fragment, rows wn * 32 .. of the tile's 64 valid rows)
+    {
+      int lo = lane;
+      asm volatile("" : "+v"(lo));
+      const int fr_ = lo & 31, fh = lo >> 5;
+#pragma unroll
+      for (int i = 0; i < PF; i++) {
+        const int pix = pixbase + 32 * i + fr_, py = pix / TW, px = pix % TW;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          const int hx = px + (p.flip ? 2 - kw : kw);
+          ab[i][kw] = HS0 + (py * HC + hx) * 128 + ((fh ^ ((hx >> 1) & 7)) << 4);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int row = (HALF ? wn * 32 : wn * 64 + j * 32) + fr_;
+        bb[j] = row * 128 + ((fh ^ ((row >> 1) & 7)) << 4);
+      }
+    }
+    const int bsel0 = bb[0];
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int kh = tap / 3, kw = tap % 3, nkh = tap == 8 ? 0 : (tap + 1) / 3, nkw = tap == 8 ? 0 : (tap + 1) % 3;
+      int so = hb + rbase + kh * rstep;                          // this step's halo rows
+      int nso = (tap == 8 ? hbn : hb) + rbase + nkh * rstep;     // the next step's (the other buffer behind tap 8)
+      // (opaque scalars: otherwise the 144 fragment addresses of all (tap, slice, fragment) are formed ahead of the loop and spilled)
+      asm volatile("" : "+s"(so), "+s"(nso));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // W(g) has landed; every wave has finished step g - 1
+      asm volatile("" ::: "memory");
+      const int b0 = bsel0 + slot, b1 = bb[1] + slot;
+      MM_LDSR(Bf[0][0], b0);
+      if (NJ > 1) MM_LDSR(Bf[0][1], b1);
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int cur = kk & 1, nxt = cur ^ 1;
+        if (kk < 3) {
+#pragma unroll
+          for (int i = 0; i < PF; i++) MM_LDSR(Af[nxt][i], (ab[i][kw] + so) ^ ((kk + 1) << 5));
+          MM_LDSR(Bf[nxt][0], b0 ^ ((kk + 1) << 5));
+          if (NJ > 1) MM_LDSR(Bf[nxt][1], b1 ^ ((kk + 1) << 5));
+        } else {  // slice 0 of the NEXT step's pixel fragments (behind the last step: a harmless read of the idle buffer)
+#pragma unroll
+          for (int i = 0; i < PF; i++) MM_LDSR(Af[nxt][i], ab[i][nkw] + nso);
+        }
+        // LDS reads return in order: everything but the requests just made (PF + NJ of them, PF behind slice 3) has arrived.  The wait
+        // names the fragments it guards, which orders the MFMAs that consume them behind it (cdna_hip_programming.md rule 18).
+        if (PF == 4 && NJ == 2) {
+          if (kk < 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(Af[cur][0]), "+v"(Af[cur][1]), "+v"(Af[cur][2]), "+v"(Af[cur][3]), "+v"(Bf[cur][0]), "+v"(Bf[cur][1]));
+          else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Af[cur][0]), "+v"(Af[cur][1]), "+v"(Af[cur][2]), "+v"(Af[cur][3]), "+v"(Bf[cur][0]), "+v"(Bf[cur][1]));
+        } else if (PF == 4) {
+          if (kk < 3) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(Af[cur][0]), "+v"(Af[cur][1]), "+v"(Af[cur][2]), "+v"(Af[cur][3]), "+v"(Bf[cur][0]));
+          else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Af[cur][0]), "+v"(Af[cur][1]), "+v"(Af[cur][2]), "+v"(Af[cur][3]), "+v"(Bf[cur][0]));
+        } else {
+          if (kk < 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Af[cur][0]), "+v"(Af[cur][1]), "+v"(Bf[cur][0]), "+v"(Bf[cur][1]));
+          else asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(Af[cur][0]), "+v"(Af[cur][1]), "+v"(Bf[cur][0]), "+v"(Bf[cur][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the requests of slice kk + 1 stay ahead of the MFMAs of slice kk, and no further ahead
+        if (!MM_DIAG(p, 3)) {
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int i = 0; i < PF; i++) acc[i][j] = MM_MFMA_32x32x16(Bf[cur][j], Af[cur][i], acc[i][j]);  // D[cout][pixel]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      slot = slot + BSZB == RW * BSZB ? 0 : slot + BSZB;
+    }
+    // The next segment's first pixel fragments have arrived by now (requested before the last 8 MFMAs were issued): the wait makes
+    // that a fact for the compiler, which may move registers at the loop edge and in the epilogue - never while a read is in flight.
+    if (PF == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]), "+v"(Af[0][2]), "+v"(Af[0][3]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Af[0][0]), "+v"(Af[0][1]));
+  };
+  // An item is finished: D row (reg&3) + 8*(reg>>2) + 4*fh = output channel, column fr_ = pixel (the epilogue of k_conv3x3w)
+  auto finish_item = [&](auto half_c) {
+    constexpr bool HALF = decltype(half_c)::value;
+    constexpr int NJ = HALF ? 1 : 2;  // cout fragments of this item per wave
+    int b, ty0, tx0, n0;
+    decode(c_item, b, ty0, tx0, n0);
+    const int cbase = n0 + (HALF ? c_half * 64 + wn * 32 : wn * 64);  // this wave's first channel
+    const bool second = b >= p.B1;  // pair mode: the item belongs to problem 1
+    const int bl = second ? b - p.B1 : b;
+    u16* const Obase = second ? p.O1 : p.O;
+    float* const slab = second ? p.stats1 : p.stats;
+    // statistics slab rows: two per 64-pixel sub-block of the tile (k_conv3x3w's wave = one sub-block; this wave has PF / 2)
+    const int64_t srow0 = 2 * ((int64_t)(c_item / ncb - (second ? p.B1 * p.tiles_y * p.tiles_x : 0)) * 4 + pixbase / 64) + (bl >= p.split_b ? 1 : 0);
+    c_c = 0;
+    if (++c_k < my_items) c_item = item_of(c_k, c_half);
+    if (MM_DIAG(p, 32)) {  // the accumulators are consumed (the MFMAs stay) but nothing of the epilogue runs
+#pragma unroll
+      for (int i = 0; i < PF; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            asm volatile("" ::"v"(acc[i][j][r]));
+            acc[i][j][r] = 0.f;
+          }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+#pragma unroll
+      for (int sbl = 0; sbl < PF / 2; sbl++) {
+        float st[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) st[t] = 0.f;
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+          const int i = 2 * sbl + ii;
+          unsigned D[4][2];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              v[e] = acc[i][j][4 * q + e];
+              if (p.bias) v[e] += biasl[cbase + 32 * j + 8 * q + 4 * fh + e];
+              acc[i][j][4 * q + e] = 0.f;
+            }
+            D[q][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            D[q][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          }
+          uint4 xa, xb;
+          frag_rows(D, xa, xb);  // rows of pixels pa = pixbase + 32 i + (lane & 15) (xa) and pa + 16 (xb), 16-byte chunk schunk
+          const int pa = pixbase + 32 * i + (lane & 15), pb = pa + 16;
+          const int ya = ty0 + pa / TW, xa_ = tx0 + pa % TW, yb = ty0 + pb / TW, xb_ = tx0 + pb % TW;
+          const bool ina = ya < p.H && xa_ < p.W, inb = yb < p.H && xb_ < p.W;
+          if (slab) {
+            stats_accum(xa, ina, st);
+            stats_accum(xb, inb, st);
+          }
+          u16* const rowa = Obase + ((int64_t)(bl * p.H + ya) * p.W + xa_) * p.ldo + cbase + 8 * schunk + 32 * j;
+          u16* const rowb = Obase + ((int64_t)(bl * p.H + yb) * p.W + xb_) * p.ldo + cbase + 8 * schunk + 32 * j;
+          *(uint4*)(ina ? rowa : (u16*)g_dump + lane * 8) = xa;
+          *(uint4*)(inb ? rowb : (u16*)g_dump + lane * 8) = xb;
+        }
+        if (slab) stats_store(slab, srow0 + 2 * sbl, p.Cn, cbase + 32 * j, lane, row_reduce_scatter16(st, lane & 15), true);
+      }
+    }
+  };
+  // whole items first, then (a ragged last round, BN = 128) this workgroup's one half item: two loops, not a branch per segment - the
+  // two instantiations keep their accumulators in different registers, and a join per segment moved them through scratch
+  const int nseg_whole = (halfmode && my_items > r_full) ? r_full * nchunk : nseg;
+  int seg = 0;
+  for (; seg < nseg_whole; seg++) {
+    run_segment(std::false_type{}, (seg & 1) * HSZB);
+    if (++c_c == nchunk) finish_item(std::false_type{});
+  }
+  if (BN == 128) {
+    for (; seg < nseg; seg++) {
+      run_segment(std::true_type{}, (seg & 1) * HSZB);
+      if (++c_c == nchunk) finish_item(std::true_type{});
+    }
+  }
+#undef MM_LDSR
   MM_CLK_END(0);
 }
 
@@ -2071,6 +2461,7 @@ int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda,
   C3P p;
   p.A = (const u16*)A; p.B = B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O; p.Cn = Cn; p.ldo = ldo;
   p.Wp = (const u16*)Wp; p.bias = bias; p.flip = flip & 1; p.whole = (flip >> 1) & 1;  // flip bit 1: whole items only
+  p.legacy = (flip >> 2) & 1;                                                            // flip bit 2: k_conv3x3w
   p.stats = stats; p.split_b = split_b;
   p.B1 = B; p.A1 = nullptr; p.O1 = nullptr; p.Wp1 = nullptr; p.stats1 = nullptr;
   return c3_launch(p, s);
@@ -2099,7 +2490,7 @@ int MM_SYM(mm_conv2d_3x3s1_pair)(const void* A0, const void* A1, int B, int H, i
   MM_CHECK_ARG((stats0 == nullptr) == (stats1 == nullptr), "conv2d_3x3s1_pair: statistics for both problems or for neither");
   C3P p;
   p.A = (const u16*)A0; p.B = 2 * B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O0; p.Cn = Cn; p.ldo = ldo;
-  p.Wp = (const u16*)Wp0; p.bias = nullptr; p.flip = flip & 1; p.whole = (flip >> 1) & 1;
+  p.Wp = (const u16*)Wp0; p.bias = nullptr; p.flip = flip & 1; p.whole = (flip >> 1) & 1; p.legacy = (flip >> 2) & 1;
   p.stats = stats0; p.split_b = split_b;
   p.B1 = B; p.A1 = (const u16*)A1; p.O1 = (u16*)O1; p.Wp1 = (const u16*)Wp1; p.stats1 = stats1;
   return c3_launch(p, s);
@@ -2163,6 +2554,19 @@ static int c3_launch(C3P p, hipStream_t s) {
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
+    } else if (!p.legacy) {  // 128-pixel x 64-cout register tiles, four multiplying + four loader waves (round 6)
+      static unsigned once_v = 0;  // per-device bit: see mm_attr_todo (common.h)
+      if (mm_attr_todo(&once_v)) {
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        mm_attr_done(&once_v);
+      }
+      if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3v<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+      else if (bn == 64) hipLaunchKernelGGL((k_conv3x3v<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+      else if (tw == 16) hipLaunchKernelGGL((k_conv3x3v<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+      else hipLaunchKernelGGL((k_conv3x3v<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
     } else if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
     else if (bn == 64) hipLaunchKernelGGL((k_conv3x3w<64, 32>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
     else if (tw == 16) hipLaunchKernelGGL((k_conv3x3w<128, 16>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);

@@ -376,3 +376,58 @@ def test_conv3x3_results_do_not_depend_on_kernels_of_other_streams():
         torch.cuda.synchronize()
         bad += [(rep, i) for i, (y, dx) in enumerate(outs) if not (torch.equal(y, ref_y) and torch.equal(dx, ref_dx))]
     assert not bad, f"convolution outputs changed beside another stream's kernels: launches {bad}"
+
+
+@pytest.mark.parametrize("cin,cout,B,hw,split", [
+    (128, 128, 20, (64, 64), True),    # <128, 16>, 320 items: ragged last round -> half items; two statistics groups
+    (128, 256, 9, (48, 80), False),    # two cout blocks per tile, half items
+    (256, 128, 17, (64, 64), True),    # four input chunks per item
+    (256, 256, 4, (8, 30), False),     # <128, 32>, image smaller than a tile
+    (512, 512, 6, (19, 30), True),     # layer4's shape: 8 x 32 tiles, eight chunks
+    (192, 64, 3, (40, 56), True),      # <64, 16>: the decoder's concat convolutions
+    (64, 192, 2, (33, 47), False),     # <64, .> with three cout blocks (their data gradient)
+    (128, 64, 5, (8, 100), False),     # <64, 32>
+])
+def test_conv3x3_register_tile_kernel_is_bit_identical_with_the_first_kernel(cin, cout, B, hw, split, half2d):
+    """Round 6: k_conv3x3v (128-pixel x 64-cout register tiles, four multiplying + four loader waves) against k_conv3x3w (flip | 4):
+    every output element is the same chain of the same MFMAs in the same order, so forward (with bias), data gradient and the
+    BatchNorm statistics slab of the epilogue must agree bit for bit - whole items, half items, one or two statistics groups, pair
+    mode.  (k_conv3x3w itself is compared with torch above.)"""
+    from mm2d3d_amd import conv2d as c2, domains
+    from mm2d3d_amd.conv2d import Conv2dFn, Conv2dPairFn
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(cin * 3 + cout + B)
+    H, W = hw
+    mk = lambda *s: torch.randn(*s, generator=g)
+    xs = [mk(B, cin, H, W).to(half2d).to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for _ in range(2)]
+    ws = [(mk(cout, cin, 3, 3) * (2.0 / (9 * cin)) ** 0.5).to(dev).requires_grad_(True) for _ in range(2)]
+    b = mk(cout).to(dev)
+    gys = [mk(B, cout, H, W).to(half2d).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    old_pre = c2.BN_PRE[0]
+    c2.BN_PRE[0] = True  # file the statistics whatever the map size
+
+    def run(legacy):
+        c2.LEGACY3X3[0] = 4 if legacy else 0
+        out = []
+        with domains.split(B // 2 if split else None):
+            st = [None]
+            y = Conv2dFn.apply(xs[0], ws[0], b, 1, 1, None, st)
+            (dx,) = torch.autograd.grad(y, [xs[0]], gys[0])
+            out += [y.detach(), dx, st[0][0]]
+            if (cin, cout) != (64, 64):
+                s1, s2 = [None], [None]
+                y1, y2 = Conv2dPairFn.apply(xs[0], xs[1], ws[0], ws[1], s1, s2)
+                d1, d2 = torch.autograd.grad([y1, y2], xs, gys)
+                out += [y1.detach(), y2.detach(), d1, d2, s1[0][0], s2[0][0]]
+        return out
+
+    try:
+        new, ref = run(False), run(True)
+    finally:
+        c2.LEGACY3X3[0] = 0
+        c2.BN_PRE[0] = old_pre
+    for i, (a, r) in enumerate(zip(new, ref)):
+        assert a.shape == r.shape and torch.equal(a, r), f"output {i} differs: {int((a != r).sum())} of {a.numel()} elements"
+    yr = F.conv2d(xs[0].detach().float(), ws[0].detach().to(half2d).float(), b, 1, 1)
+    assert float((new[0].float() - yr).norm() / yr.norm()) < 4e-3
