@@ -431,7 +431,7 @@ struct C3P {
   const float* bias;
   int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
   int whole; // != 0: never cut a ragged last round into half items (A/B measurements)
-  int legacy;  // != 0: the round-2 kernel k_conv3x3w instead of k_conv3x3v (A/B measurements, bit-identity tests)
+  int legacy;  // 0: k_conv3x3s (16x16x32 MFMAs)  1: the round-2 kernel k_conv3x3w  2: k_conv3x3v (32x32x16 MFMAs, bit-identical with 1) - A/B, tests
   float* stats;  // BatchNorm statistics slab (see stats_accum), or NULL
   int split_b;   // images [0, split_b) are statistics group 0, the others group 1
   int tiles_y, tiles_x;
@@ -852,6 +852,161 @@ __global__ __launch_bounds__(1024, 1) void k_conv3x3w(C3P p) {
 // the barrier).  Item list, halo / weight images, swizzles, ring protocol, half items, pair mode and epilogue are k_conv3x3w's:
 // every output element is the same chain of the same MFMAs in the same order - the results are bit-identical
 // (tests/test_gpu_conv2d.py::test_conv3x3_register_tile_kernel_is_bit_identical_with_the_first_kernel), statistics slab included.
+// ---- pieces shared by the two 8-wave kernels k_conv3x3v / k_conv3x3s: the item schedule (k_conv3x3w's: XCD-contiguous ranges,
+// round-robin inside an XCD, half items in a ragged last round) and the loader role
+struct C3Sched {
+  int nchunk, ncb, x_begin, local, G8, r_full, my_items, nseg;
+  bool halfmode;
+  __device__ int item_of(int k, int& half) const {  // k-th item of this workgroup; half = -1: the whole BN-cout block, 0 / 1: its 64-cout halves
+    if (halfmode && k == r_full) {
+      half = local & 1;
+      return x_begin + r_full * G8 + (local >> 1);
+    }
+    half = -1;
+    return x_begin + local + k * G8;
+  }
+};
+template <int BN>
+__device__ inline C3Sched c3_sched(const C3P& p) {
+  C3Sched sc;
+  sc.nchunk = p.Ca >> 6, sc.ncb = p.Cn / BN;
+  const int nitems = p.B * p.tiles_y * p.tiles_x * sc.ncb;
+  sc.G8 = gridDim.x >> 3, sc.local = blockIdx.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int per = (nitems + 7) >> 3;
+  sc.x_begin = xcd * per;
+  const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
+  const int n_x = it_end > sc.x_begin ? it_end - sc.x_begin : 0;
+  sc.r_full = n_x / sc.G8;
+  const int rem = n_x - sc.r_full * sc.G8;
+  sc.halfmode = BN == 128 && rem > 0 && 2 * rem <= sc.G8 && !p.whole;
+  sc.my_items = sc.r_full + ((sc.halfmode ? sc.local < 2 * rem : sc.local < rem) ? 1 : 0);
+  sc.nseg = sc.my_items * sc.nchunk;
+  return sc;
+}
+template <int BN, int TW>
+__device__ inline void c3_decode(const C3P& p, const C3Sched& sc, int item, int& b, int& ty0, int& tx0, int& n0) {
+  n0 = (item % sc.ncb) * BN;
+  int t = item / sc.ncb;
+  tx0 = (t % p.tiles_x) * TW;
+  t /= p.tiles_x;
+  ty0 = (t % p.tiles_y) * (256 / TW);
+  b = t / p.tiles_y;
+}
+// The four loader waves (tid = 0..255 within the role): thread (r0 = 0..31, cc) fetches 16-byte chunk cc of rows r0 + 32 i.  HSWZ: the
+// bank swizzle of the halo rows, by the halo column hx: 1 = chunk ^ ((hx >> 1) & 7) (k_conv3x3w's, for the 32x32x16 fragment reads),
+// 0 = chunk ^ (hx & 7) (for the 16x16x32 reads of k_conv3x3s).  (Measured and dropped: weight tiles and halos on separate waves, two
+// each, so that a tile never queues behind a slower halo request - a wave sustains only ~16-25 GB/s of LDS-DMA, and two waves for the
+// 16 KB per step of weights were slower than four sharing everything: 1.14 against 1.10 us per step.)
+template <int BN, int TW, int HSWZ, int DIAG>
+__device__ inline void c3_loader(const C3P& p, const C3Sched& sc, char* const lds, const int tid) {
+  constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;
+  constexpr int HSZB = 344 * 128, RW = BN == 128 ? 4 : 8, BSZB = BN * 128, NB = BN / 32, HS0 = RW * BSZB;
+  const int wave = tid >> 6, cc = tid & 7, r0 = tid >> 3;
+  const int nchunk = sc.nchunk, ncb = sc.ncb, my_items = sc.my_items, nseg = sc.nseg;
+  auto item_of = [&](int k, int& half) { return sc.item_of(k, half); };
+  auto decode = [&](int item, int& b, int& ty0, int& tx0, int& n0) { c3_decode<BN, TW>(p, sc, item, b, ty0, tx0, n0); };
+  int hl[11], hyx[11];
+#pragma unroll
+  for (int i = 0; i < 11; i++) {
+    const int row = r0 + 32 * i, hy = row / HC, hx = row - hy * HC;
+    const bool used = row < HROWS;
+    hyx[i] = used ? ((hy - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
+    hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ (HSWZ ? (hx >> 1) & 7 : hx & 7)) << 3);
+  }
+  int wl[NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int row = r0 + 32 * i;
+    wl[i] = row * 9 * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3);
+  }
+  int h_k = 0, h_c = 0, h_b, h_ty0, h_tx0, h_n0, h_half;
+  decode(item_of(0, h_half), h_b, h_ty0, h_tx0, h_n0);
+  auto issue_halo = [&](int buf) {  // 11 DMA instructions (10 for wave 3), always; then advance the cursor
+    const bool live = h_k < my_items && !MM_DIAG(p, 8);
+    const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
+    const u16* base = (h_b < p.B1 ? p.A + (int64_t)h_b * p.H * p.W * p.lda : p.A1 + (int64_t)(h_b - p.B1) * p.H * p.W * p.lda) +
+                      ((int64_t)h_ty0 * p.W + h_tx0) * p.lda + h_c * 64;
+    char* dst = lds + HS0 + buf * HSZB + wave * 1024;
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < 11; i++)
+        if (i < 10 || wave < 3)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
+                                           (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 11; i++) {
+        if (i == 10 && wave >= 3) break;
+        const int y = h_ty0 + (hyx[i] >> 16), x = h_tx0 + (short)(hyx[i] & 0xFFFF);
+        const bool ok = live && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const u16* g = ok ? base + hl[i] : (const u16*)g_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+      }
+    }
+    if (++h_c == nchunk) {
+      h_c = 0;
+      if (++h_k < my_items) decode(item_of(h_k, h_half), h_b, h_ty0, h_tx0, h_n0);
+    }
+  };
+  int w_k = 0, w_c = 0, w_tap = 0, w_half, w_n0;
+  const int items0 = p.B1 * p.tiles_y * p.tiles_x * ncb;  // items of problem 0 (pair mode; all of them otherwise)
+  const u16* w_src;
+  {
+    const int it = item_of(0, w_half);
+    w_n0 = (it % ncb) * BN + (w_half > 0 ? 64 : 0);
+    w_src = it < items0 ? p.Wp : p.Wp1;
+  }
+  auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
+    const bool live = w_k < my_items && !MM_DIAG(p, 4);
+    const u16* base = live ? w_src + ((int64_t)w_n0 * 9 + w_tap) * p.Ca + w_c * 64 : (const u16*)g_zero16;
+    char* dst = lds + buf * BSZB + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const bool real = live && !(i >= 2 && w_half >= 0);  // a half item: rows 64.. of the tile are not read, their DMA reads the zero line
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(real ? base + wl[i] : (const u16*)g_zero16),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+    }
+    if (++w_tap == 9) {
+      w_tap = 0;
+      if (++w_c == nchunk) {
+        w_c = 0;
+        if (++w_k < my_items) {
+          const int it = item_of(w_k, w_half);
+          w_n0 = (it % ncb) * BN + (w_half > 0 ? 64 : 0);
+          w_src = it < items0 ? p.Wp : p.Wp1;
+        }
+      }
+    }
+  };
+  // Ring protocol of k_conv3x3w (one barrier per step g = (segment, tap); a loader passes it once ITS pieces of W(g) have landed;
+  // W(g + RW - 1) and, at tap 0, the next segment's halo are requested right behind it), plus ONE barrier ahead of the first step
+  // that publishes the first halo: the multiplying waves request their first pixel fragments behind it.
+  issue_halo(0);
+#pragma unroll
+  for (int d = 0; d < RW - 1; d++) issue_w(d);
+  wait_vm<(RW - 1) * NB>();  // the first halo is the oldest request: everything younger may still be in flight
+  __builtin_amdgcn_s_barrier();
+  int wslot = RW - 1;
+  for (int seg = 0; seg < nseg; seg++) {
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      if (tap >= 1 && tap <= RW - 2) {  // the halo requested at tap 0 is younger than W(g)
+        if (wave < 3) wait_vm<(RW - 2) * NB + 11>();
+        else wait_vm<(RW - 2) * NB + 10>();
+      } else {
+        wait_vm<(RW - 2) * NB>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (tap == 0) issue_halo((seg + 1) & 1);
+      issue_w(wslot);
+      wslot = wslot + 1 == RW ? 0 : wslot + 1;
+    }
+  }
+  wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
+}
+
 // DIAG (tools/conv3x3_diag.hip only; the library instantiates 0): 1 no MFMA (fragment reads kept)  2 no fragment reads, no MFMA
 // 4 W DMA from the zero line  8 halo DMA from the zero line  32 no epilogue (accumulators consumed by an empty asm)
 template <int BN, int TW, int DIAG = 0>
@@ -889,138 +1044,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3v(C3P p) {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  // item schedule: exactly k_conv3x3w's (XCD-contiguous ranges, round-robin inside an XCD, half items in a ragged last round)
-  const int nitems = p.B * p.tiles_y * p.tiles_x * ncb;
-  const int G8 = gridDim.x >> 3, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int per = (nitems + 7) >> 3;
-  const int x_begin = xcd * per;
-  const int it_end = (xcd + 1) * per < nitems ? (xcd + 1) * per : nitems;
-  const int n_x = it_end > x_begin ? it_end - x_begin : 0;
-  const int r_full = n_x / G8, rem = n_x - r_full * G8;
-  const bool halfmode = BN == 128 && rem > 0 && 2 * rem <= G8 && !p.whole;
-  const int my_items = r_full + ((halfmode ? local < 2 * rem : local < rem) ? 1 : 0);
+  const C3Sched sc = c3_sched<BN>(p);
+  const int my_items = sc.my_items, nseg = sc.nseg, r_full = sc.r_full;
+  const bool halfmode = sc.halfmode;
   if (my_items == 0) return;
-  const int nseg = my_items * nchunk;
-  auto item_of = [&](int k, int& half) {
-    if (halfmode && k == r_full) {
-      half = local & 1;
-      return x_begin + r_full * G8 + (local >> 1);
-    }
-    half = -1;
-    return x_begin + local + k * G8;
-  };
-  auto decode = [&](int item, int& b, int& ty0, int& tx0, int& n0) {
-    n0 = (item % ncb) * BN;
-    int t = item / ncb;
-    tx0 = (t % p.tiles_x) * TW;
-    t /= p.tiles_x;
-    ty0 = (t % p.tiles_y) * TH;
-    b = t / p.tiles_y;
-  };
-
+  auto item_of = [&](int k, int& half) { return sc.item_of(k, half); };
+  auto decode = [&](int item, int& b, int& ty0, int& tx0, int& n0) { c3_decode<BN, TW>(p, sc, item, b, ty0, tx0, n0); };
   if (loader) {
-    // ---- the four loader waves: thread (r0 = 0..31, cc) fetches 16-byte chunk cc of rows r0 + 32 i.  (Measured and dropped: weight tiles
-    // and halos on separate waves, two each, so that a tile never queues behind a slower halo request - a wave sustains only ~16-25 GB/s
-    // of LDS-DMA, and two waves for the 16 KB per step of weights were slower than four sharing everything: 1.14 against 1.10 us per step.)
-    int hl[11], hyx[11];
-#pragma unroll
-    for (int i = 0; i < 11; i++) {
-      const int row = r0 + 32 * i, hy = row / HC, hx = row - hy * HC;
-      const bool used = row < HROWS;
-      hyx[i] = used ? ((hy - 1) << 16) | ((hx - 1) & 0xFFFF) : 0;
-      hl[i] = (used ? ((hy - 1) * p.W + (hx - 1)) * p.lda : 0) + ((cc ^ ((hx >> 1) & 7)) << 3);  // swizzle by the halo column (k_conv3x3w)
-    }
-    int wl[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-      const int row = r0 + 32 * i;
-      wl[i] = row * 9 * p.Ca + ((cc ^ ((row >> 1) & 7)) << 3);
-    }
-    int h_k = 0, h_c = 0, h_b, h_ty0, h_tx0, h_n0, h_half;
-    decode(item_of(0, h_half), h_b, h_ty0, h_tx0, h_n0);
-    auto issue_halo = [&](int buf) {  // 11 DMA instructions (10 for wave 3), always; then advance the cursor
-      const bool live = h_k < my_items && !MM_DIAG(p, 8);
-      const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
-      const u16* base = (h_b < p.B1 ? p.A + (int64_t)h_b * p.H * p.W * p.lda : p.A1 + (int64_t)(h_b - p.B1) * p.H * p.W * p.lda) +
-                        ((int64_t)h_ty0 * p.W + h_tx0) * p.lda + h_c * 64;
-      char* dst = lds + HS0 + buf * HSZB + wave * 1024;
-      if (interior) {
-#pragma unroll
-        for (int i = 0; i < 11; i++)
-          if (i < 10 || wave < 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 11; i++) {
-          if (i == 10 && wave >= 3) break;
-          const int y = h_ty0 + (hyx[i] >> 16), x = h_tx0 + (short)(hyx[i] & 0xFFFF);
-          const bool ok = live && y >= 0 && y < p.H && x >= 0 && x < p.W;
-          const u16* g = ok ? base + hl[i] : (const u16*)g_zero16;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                           (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-        }
-      }
-      if (++h_c == nchunk) {
-        h_c = 0;
-        if (++h_k < my_items) decode(item_of(h_k, h_half), h_b, h_ty0, h_tx0, h_n0);
-      }
-    };
-    int w_k = 0, w_c = 0, w_tap = 0, w_half, w_n0;
-    const int items0 = p.B1 * p.tiles_y * p.tiles_x * ncb;  // items of problem 0 (pair mode; all of them otherwise)
-    const u16* w_src;
-    {
-      const int it = item_of(0, w_half);
-      w_n0 = (it % ncb) * BN + (w_half > 0 ? 64 : 0);
-      w_src = it < items0 ? p.Wp : p.Wp1;
-    }
-    auto issue_w = [&](int buf) {  // NB DMA instructions, always; then advance the cursor
-      const bool live = w_k < my_items && !MM_DIAG(p, 4);
-      const u16* base = live ? w_src + ((int64_t)w_n0 * 9 + w_tap) * p.Ca + w_c * 64 : (const u16*)g_zero16;
-      char* dst = lds + buf * BSZB + wave * 1024;
-#pragma unroll
-      for (int i = 0; i < NB; i++) {
-        const bool real = live && !(i >= 2 && w_half >= 0);  // a half item: rows 64.. of the tile are not read, their DMA reads the zero line
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(real ? base + wl[i] : (const u16*)g_zero16),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
-      }
-      if (++w_tap == 9) {
-        w_tap = 0;
-        if (++w_c == nchunk) {
-          w_c = 0;
-          if (++w_k < my_items) {
-            const int it = item_of(w_k, w_half);
-            w_n0 = (it % ncb) * BN + (w_half > 0 ? 64 : 0);
-            w_src = it < items0 ? p.Wp : p.Wp1;
-          }
-        }
-      }
-    };
-    // Ring protocol of k_conv3x3w (one barrier per step g = (segment, tap); a loader passes it once ITS pieces of W(g) have landed;
-    // W(g + RW - 1) and, at tap 0, the next segment's halo are requested right behind it), plus ONE barrier ahead of the first step
-    // that publishes the first halo: the multiplying waves request their first pixel fragments behind it.
-    issue_halo(0);
-#pragma unroll
-    for (int d = 0; d < RW - 1; d++) issue_w(d);
-    wait_vm<(RW - 1) * NB>();  // the first halo is the oldest request: everything younger may still be in flight
-    __builtin_amdgcn_s_barrier();
-    int wslot = RW - 1;
-    for (int seg = 0; seg < nseg; seg++) {
-#pragma unroll
-      for (int tap = 0; tap < 9; tap++) {
-        if (tap >= 1 && tap <= RW - 2) {  // the halo requested at tap 0 is younger than W(g)
-          if (wave < 3) wait_vm<(RW - 2) * NB + 11>();
-          else wait_vm<(RW - 2) * NB + 10>();
-        } else {
-          wait_vm<(RW - 2) * NB>();
-        }
-        __builtin_amdgcn_s_barrier();
-        if (tap == 0) issue_halo((seg + 1) & 1);
-        issue_w(wslot);
-        wslot = wslot + 1 == RW ? 0 : wslot + 1;
-      }
-    }
-    wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
+    c3_loader<BN, TW, 1, DIAG>(p, sc, lds, tid);
     return;
   }
 
@@ -1224,6 +1255,250 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3v(C3P p) {
     }
   }
 #undef MM_LDSR
+  MM_CLK_END(0);
+}
+
+// The same kernel on the OTHER matrix instruction, v_mfma_f32_16x16x32 (k_conv3x3s).  Why: the convolution is bound by the clock the
+// chip holds, not by issue slots - tools/conv3x3_diag.hip with s_memtime / s_memrealtime stamps: 2.2 GHz in the multiply loop with
+// every DMA switched off, 1.6-1.9 GHz with the real weight and halo streams beside it, whatever the loop's schedule (k_conv3x3v reads
+// a quarter fewer LDS bytes than k_conv3x3w, waits for nothing, and takes the same time) - and on random data the chip holds a higher
+// clock on the 16x16x32 shape than on 32x32x16 at the same cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15 x).
+// A wave's 128 x 64 block is 8 x 4 accumulator tiles of 16 x 16; per 32-deep K slice it reads 8 pixel + 4 cout fragments (the same
+// bytes per MFMA cycle as k_conv3x3v) in quads, each requested one 16-MFMA group ahead.  A lane holds row (lane & 15), K chunk
+// (lane >> 4) of a fragment, so the fragments of one image row / of 16 consecutive couts differ by constant LDS offsets (immediates:
+// 3 base addresses instead of 24), and the halo swizzle is chunk ^ (hx & 7): conflict-free for these reads at every filter column
+// (chunk ^ (hx >> 1) is 2-way at odd columns).  D = W x X^T again: a lane ends with 4 consecutive couts of one pixel per tile; ONE
+// v_permlane16_swap per packed pair of two neighbouring cout tiles makes 16-byte chunks - (tile j + (g & 1), couts 8 (g >> 1)..) in
+// lane group g = frag_chunk's order - so stores are 16 x 64-byte segments and stats_accum / stats_store apply unchanged.  Results
+// differ from k_conv3x3w in the last bits (one 32-deep MFMA instead of two 16-deep ones); tests compare it with torch.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int BN, int TW, int DIAG = 0>
+__global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
+  extern __shared__ __attribute__((aligned(16))) char smemc[];
+#ifndef MM_DIAG_SHARED_CU
+  asm volatile("" ::: "v255");  // 8 waves x 256 registers + the whole LDS: the CU is owned by this workgroup (see c3_launch)
+#endif
+  constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;
+  constexpr int HSZB = 344 * 128, RW = BN == 128 ? 4 : 8, BSZB = BN * 128, NB = BN / 32, HS0 = RW * BSZB;
+  constexpr int NQ = BN == 128 ? 2 : 1;  // quads of 16-pixel fragments per multiplying wave
+  constexpr int NF = 4 * NQ;             // 16-pixel fragments per wave (x 4 cout fragments of 16)
+  constexpr int NC = TW == 16 ? 1 : 2;   // column groups of a wave's pixel fragments (TW = 32: fragment f sits at columns 16 (f & 1) ..)
+  static_assert(HROWS <= 344 && RW - 2 <= 8 && (RW - 2) * NB + 11 < 64, "halo pieces / ring protocol / vmcnt range");
+  char* const lds = smemc;
+  float* biasl = (float*)(lds + HS0 + 2 * HSZB);  // [Cn <= 1024] when p.bias
+  const bool loader = threadIdx.x >= 256;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63;  // wave = index within the role
+  const int wm = BN == 128 ? wave >> 1 : wave, wn = BN == 128 ? wave & 1 : 0;
+  const int pixbase = BN == 128 ? 128 * wm : 64 * wm;  // this wave's first pixel of the 256-pixel tile
+  if (p.bias) {  // staged once by DMA (loaders)
+    if (loader) {
+      for (int k0 = 0; k0 < p.Cn; k0 += 256) {
+        const int k = k0 + tid < p.Cn ? k0 + tid : p.Cn - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.bias + k),
+                                         (__attribute__((address_space(3))) void*)(biasl + k0 + wave * 64), 4, 0, 0);
+      }
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  const C3Sched sc = c3_sched<BN>(p);
+  const int my_items = sc.my_items, nseg = sc.nseg, r_full = sc.r_full, nchunk = sc.nchunk, ncb = sc.ncb;
+  if (my_items == 0) return;
+  if (loader) {
+    c3_loader<BN, TW, 0, DIAG>(p, sc, lds, tid);
+    return;
+  }
+
+  // ---- the four multiplying waves
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int schunk = frag_chunk(lane);
+  const int rstep = p.flip ? -(HC * 128) : HC * 128, rbase = p.flip ? 2 * HC * 128 : 0;  // halo row offset of filter row kh: rbase + kh * rstep
+  f32x4 acc[NF][4];
+#pragma unroll
+  for (int f = 0; f < NF; f++)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[f][j][r] = 0.f;
+  int c_k = 0, c_c = 0, c_half;  // consumer cursor
+  int c_item = sc.item_of(0, c_half);
+  int slot = 0;                  // byte offset of the W ring slot of the current step
+  bf16x8 Aq[2][4], Bq[2][4];     // pixel fragment quads (alternating sets) and the cout fragments of K slice 0 / 1
+  // inline-asm fragment reads with hand-counted waits (see k_conv3x3v); absolute LDS addresses, constant parts as immediates
+#define MM_LDSO(dst, addr, off)                                                                   \
+  do {                                                                                            \
+    if (MM_DIAG(p, 2)) asm volatile("" : "=v"(dst) : "v"(addr));                                  \
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));        \
+  } while (0)
+#define MM_FROW(f) ((TW == 16 ? (f) : (f) >> 1) * HC * 128)  /* halo rows of fragment f below the wave's first pixel row */
+#define MM_FCOL(f) (TW == 16 ? 0 : (f) & 1)                   /* its column group */
+  __builtin_amdgcn_s_barrier();  // the first halo has landed
+  asm volatile("" ::: "memory");
+  {  // the first quad of the first step (tap 0: filter column 0, K slice 0)
+    int a0[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      const int hx = 16 * c + l15 + (p.flip ? 2 : 0);
+      a0[c] = HS0 + ((pixbase / TW) * HC + hx) * 128 + ((g4 ^ (hx & 7)) << 4) + rbase;
+    }
+#pragma unroll
+    for (int ff = 0; ff < 4; ff++) MM_LDSO(Aq[0][ff], a0[MM_FCOL(ff)], MM_FROW(ff));
+  }
+  MM_CLK_BEGIN();
+  auto run_segment = [&](auto half_c, const int hb) {
+    constexpr bool HALF = decltype(half_c)::value;
+    constexpr int NJ = HALF ? 2 : 4;  // 16-cout fragments per wave
+    const int hbn = HSZB - hb;
+    int ab[NC][3];  // column group c at filter column kw, K slice 0, the wave's first pixel row: byte offset inside a halo buffer (+ HS0)
+    int bq;         // cout fragment 0, K slice 0, inside a W buffer (fragment j: + j * 2048)
+    {
+      int lo = lane;  // (opaque: formed anew per segment, see k_conv3x3v)
+      asm volatile("" : "+v"(lo));
+      const int l = lo & 15, g = lo >> 4;
+#pragma unroll
+      for (int c = 0; c < NC; c++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          const int hx = 16 * c + l + (p.flip ? 2 - kw : kw);
+          ab[c][kw] = HS0 + ((pixbase / TW) * HC + hx) * 128 + ((g ^ (hx & 7)) << 4);
+        }
+      bq = ((HALF ? wn * 32 : wn * 64) + l) * 128 + ((g ^ ((l >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const int kh = tap / 3, kw = tap % 3, nkh = tap == 8 ? 0 : (tap + 1) / 3, nkw = tap == 8 ? 0 : (tap + 1) % 3;
+      int so = hb + rbase + kh * rstep;                          // this step's halo rows
+      int nso = (tap == 8 ? hbn : hb) + rbase + nkh * rstep;     // the next step's (the other buffer behind tap 8)
+      asm volatile("" : "+s"(so), "+s"(nso));
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // W(g) has landed; every wave has finished step g - 1
+      asm volatile("" ::: "memory");
+      const int tb = bq + slot;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) MM_LDSO(Bq[0][j], tb, j * 2048);
+      int ta[NC], tn[NC];
+#pragma unroll
+      for (int c = 0; c < NC; c++) ta[c] = ab[c][kw] + so, tn[c] = ab[c][nkw] + nso;
+#pragma unroll
+      for (int n = 0; n < 2 * NQ; n++) {  // group n = (K slice s, quad q): 4 x NJ MFMAs
+        const int s = n / NQ, q = n % NQ, set = n & 1;
+        int issued = 4;
+        if (n + 1 < 2 * NQ) {  // the next group's quad, and the cout fragments of its slice when it opens one
+          const int s2 = (n + 1) / NQ, q2 = (n + 1) % NQ;
+#pragma unroll
+          for (int ff = 0; ff < 4; ff++) MM_LDSO(Aq[set ^ 1][ff], ta[MM_FCOL(4 * q2 + ff)] ^ (s2 << 6), MM_FROW(4 * q2 + ff));
+          if (q2 == 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) MM_LDSO(Bq[s2][j], tb ^ (s2 << 6), j * 2048);
+            issued += NJ;
+          }
+        } else {  // the first quad of the NEXT step (behind the last step: a harmless read of the idle buffer)
+#pragma unroll
+          for (int ff = 0; ff < 4; ff++) MM_LDSO(Aq[set ^ 1][ff], tn[MM_FCOL(ff)], MM_FROW(ff));
+        }
+        // LDS reads return in order: everything but the `issued` requests just made has arrived
+        if (issued == 4) {
+          if (NJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]), "+v"(Bq[s][2]), "+v"(Bq[s][3]));
+          else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]));
+        } else if (NJ == 4) {
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]), "+v"(Bq[s][2]), "+v"(Bq[s][3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!MM_DIAG(p, 3)) {
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int ff = 0; ff < 4; ff++) acc[4 * q + ff][j] = MM_MFMA_16x16x32(Bq[s][j], Aq[set][ff], acc[4 * q + ff][j]);  // D[cout][pixel]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      slot = slot + BSZB == RW * BSZB ? 0 : slot + BSZB;
+    }
+    // the next segment's first quad has arrived by now: make it a fact for the compiler (see k_conv3x3v)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[0][0]), "+v"(Aq[0][1]), "+v"(Aq[0][2]), "+v"(Aq[0][3]));
+  };
+  auto finish_item = [&](auto half_c) {
+    constexpr bool HALF = decltype(half_c)::value;
+    constexpr int NP = HALF ? 1 : 2;  // pairs of 16-cout tiles = 32-channel runs of this item per wave
+    int b, ty0, tx0, n0;
+    c3_decode<BN, TW>(p, sc, c_item, b, ty0, tx0, n0);
+    const int cbase = n0 + (HALF ? c_half * 64 + wn * 32 : wn * 64);  // this wave's first channel
+    const bool second = b >= p.B1;  // pair mode: the item belongs to problem 1
+    const int bl = second ? b - p.B1 : b;
+    u16* const Obase = second ? p.O1 : p.O;
+    float* const slab = second ? p.stats1 : p.stats;
+    const int64_t srow0 = 2 * ((int64_t)(c_item / ncb - (second ? p.B1 * p.tiles_y * p.tiles_x : 0)) * 4 + pixbase / 64) + (bl >= p.split_b ? 1 : 0);
+    c_c = 0;
+    if (++c_k < my_items) c_item = sc.item_of(c_k, c_half);
+    if (MM_DIAG(p, 32)) {
+#pragma unroll
+      for (int f = 0; f < NF; f++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            asm volatile("" ::"v"(acc[f][j][r]));
+            acc[f][j][r] = 0.f;
+          }
+      return;
+    }
+#pragma unroll
+    for (int jp = 0; jp < NP; jp++) {
+#pragma unroll
+      for (int sbl = 0; sbl < NQ; sbl++) {  // a 64-pixel sub-block = one quad
+        float st[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) st[t] = 0.f;
+#pragma unroll
+        for (int ff = 0; ff < 4; ff++) {
+          const int f = 4 * sbl + ff;
+          unsigned d[2][2];  // [tile 2 jp + u][packed pair]: couts 16 (2 jp + u) + 4 g4 + (0,1 | 2,3) of this lane's pixel
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              v[r] = acc[f][2 * jp + u][r];
+              if (p.bias) v[r] += biasl[cbase + 16 * (2 * jp + u) + 4 * g4 + r];
+              acc[f][2 * jp + u][r] = 0.f;
+            }
+            d[u][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            d[u][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+          }
+          // rows of 16 lanes: [tile 0 c0-3 | tile 0 c4-7 | tile 0 c8-11 | tile 0 c12-15] x [tile 1 ...] -> lane group g: 8 couts
+          // (16-byte chunk) 16 (g & 1) + 8 (g >> 1) of the 32-channel run = chunk frag_chunk(lane)
+          const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
+          const uint4 x = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+          const int pix = pixbase + 16 * f + l15;
+          const int y = ty0 + pix / TW, xx = tx0 + pix % TW;
+          const bool in = y < p.H && xx < p.W;
+          if (slab) stats_accum(x, in, st);
+          u16* const row = Obase + ((int64_t)(bl * p.H + y) * p.W + xx) * p.ldo + cbase + 32 * jp + 8 * schunk;
+          *(uint4*)(in ? row : (u16*)g_dump + lane * 8) = x;
+        }
+        if (slab) stats_store(slab, srow0 + 2 * sbl, p.Cn, cbase + 32 * jp, lane, row_reduce_scatter16(st, l15), true);
+      }
+    }
+  };
+  const int nseg_whole = (sc.halfmode && my_items > r_full) ? r_full * nchunk : nseg;
+  int seg = 0;
+  for (; seg < nseg_whole; seg++) {
+    run_segment(std::false_type{}, (seg & 1) * HSZB);
+    if (++c_c == nchunk) finish_item(std::false_type{});
+  }
+  if (BN == 128) {
+    for (; seg < nseg; seg++) {
+      run_segment(std::true_type{}, (seg & 1) * HSZB);
+      if (++c_c == nchunk) finish_item(std::true_type{});
+    }
+  }
+#undef MM_LDSO
+#undef MM_FROW
+#undef MM_FCOL
   MM_CLK_END(0);
 }
 
@@ -2461,7 +2736,7 @@ int MM_SYM(mm_conv2d_3x3s1)(const void* A, int B, int H, int W, int Ca, int lda,
   C3P p;
   p.A = (const u16*)A; p.B = B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O; p.Cn = Cn; p.ldo = ldo;
   p.Wp = (const u16*)Wp; p.bias = bias; p.flip = flip & 1; p.whole = (flip >> 1) & 1;  // flip bit 1: whole items only
-  p.legacy = (flip >> 2) & 1;                                                            // flip bit 2: k_conv3x3w
+  p.legacy = (flip >> 2) & 3;                                                            // flip bits 2-3: kernel choice (C3P::legacy)
   p.stats = stats; p.split_b = split_b;
   p.B1 = B; p.A1 = nullptr; p.O1 = nullptr; p.Wp1 = nullptr; p.stats1 = nullptr;
   return c3_launch(p, s);
@@ -2490,7 +2765,7 @@ int MM_SYM(mm_conv2d_3x3s1_pair)(const void* A0, const void* A1, int B, int H, i
   MM_CHECK_ARG((stats0 == nullptr) == (stats1 == nullptr), "conv2d_3x3s1_pair: statistics for both problems or for neither");
   C3P p;
   p.A = (const u16*)A0; p.B = 2 * B; p.H = H; p.W = W; p.Ca = Ca; p.lda = lda; p.O = (u16*)O0; p.Cn = Cn; p.ldo = ldo;
-  p.Wp = (const u16*)Wp0; p.bias = nullptr; p.flip = flip & 1; p.whole = (flip >> 1) & 1; p.legacy = (flip >> 2) & 1;
+  p.Wp = (const u16*)Wp0; p.bias = nullptr; p.flip = flip & 1; p.whole = (flip >> 1) & 1; p.legacy = (flip >> 2) & 3;
   p.stats = stats0; p.split_b = split_b;
   p.B1 = B; p.A1 = (const u16*)A1; p.O1 = (u16*)O1; p.Wp1 = (const u16*)Wp1; p.stats1 = stats1;
   return c3_launch(p, s);
@@ -2554,19 +2829,30 @@ static int c3_launch(C3P p, hipStream_t s) {
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
-    } else if (!p.legacy) {  // 128-pixel x 64-cout register tiles, four multiplying + four loader waves (round 6)
+    } else if (p.legacy != 1) {  // 128-pixel x 64-cout register tiles, four multiplying + four loader waves (round 6)
       static unsigned once_v = 0;  // per-device bit: see mm_attr_todo (common.h)
       if (mm_attr_todo(&once_v)) {
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3s<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3s<64, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3s<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3s<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
         mm_attr_done(&once_v);
       }
-      if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3v<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
-      else if (bn == 64) hipLaunchKernelGGL((k_conv3x3v<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
-      else if (tw == 16) hipLaunchKernelGGL((k_conv3x3v<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
-      else hipLaunchKernelGGL((k_conv3x3v<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+      if (p.legacy == 2) {
+        if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3v<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv3x3v<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+        else if (tw == 16) hipLaunchKernelGGL((k_conv3x3v<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+        else hipLaunchKernelGGL((k_conv3x3v<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+      } else {
+        if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3s<64, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+        else if (bn == 64) hipLaunchKernelGGL((k_conv3x3s<64, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+        else if (tw == 16) hipLaunchKernelGGL((k_conv3x3s<128, 16>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+        else hipLaunchKernelGGL((k_conv3x3s<128, 32>), dim3((unsigned)grid), dim3(512), ldsw, s, p);
+      }
     } else if (bn == 64 && tw == 16) hipLaunchKernelGGL((k_conv3x3w<64, 16>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
     else if (bn == 64) hipLaunchKernelGGL((k_conv3x3w<64, 32>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);
     else if (tw == 16) hipLaunchKernelGGL((k_conv3x3w<128, 16>), dim3((unsigned)grid), dim3(1024), ldsw, s, p);

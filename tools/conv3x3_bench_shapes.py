@@ -1,6 +1,6 @@
 """The 3x3 stride-1 convolutions of the headline step at the BENCH's shapes (16 images per encoder; layers 2-4 as encoder pairs):
-k_conv3x3v (round 6) against k_conv3x3w (flip | 4), forward and data gradient, interleaved in one process (medians of --reps
-launches each).  Direct C-ABI calls on random 16-bit data.  usage: python tools/conv3x3_bench_shapes.py [--reps 15] [--half bf16]"""
+the round-6 kernels k_conv3x3s (flip bits 2-3 = 0, the default) and k_conv3x3v (8) against k_conv3x3w (4), interleaved in one
+process (medians of --reps launches each).  Direct C-ABI calls on random 16-bit data.  usage: python tools/conv3x3_bench_shapes.py [--reps 15] [--half bf16]"""
 import argparse
 import os
 import statistics
@@ -36,7 +36,8 @@ SHAPES = [
     ("dec1 dgrad 64->192", False, 64, 192, 304, 480, 1),
 ]
 B = 16
-tot = {0: 0.0, 4: 0.0}
+FLAGS = (0, 8, 4)
+tot = {f: 0.0 for f in FLAGS}
 for name, pair, Ca, Cn, H, W, per_step in SHAPES:
     xs = [torch.randn(B, H, W, Ca, device=dev).to(dt) for _ in range(2)]
     ws = [(torch.randn(Cn, 9, Ca, device=dev) * (2.0 / (9 * Ca)) ** 0.5).to(dt) for _ in range(2)]
@@ -49,13 +50,13 @@ for name, pair, Ca, Cn, H, W, per_step in SHAPES:
         else:
             check(L.mm_conv2d_3x3s1(ptr(xs[0]), B, H, W, Ca, Ca, ptr(ys[0]), Cn, Cn, ptr(ws[0]), None, flag, None, B, stream()), "single")
 
-    ts = {0: [], 4: []}
-    for flag in (0, 4):
+    ts = {f: [] for f in FLAGS}
+    for flag in FLAGS:
         launch(flag)
     torch.cuda.synchronize()
     ref = None
     for r in range(args.reps):
-        for flag in (0, 4):
+        for flag in FLAGS:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             launch(flag)
@@ -64,15 +65,14 @@ for name, pair, Ca, Cn, H, W, per_step in SHAPES:
             ts[flag].append(e0.elapsed_time(e1) * 1e3)
             if r == 0:
                 out = [y.clone() for y in (ys if pair else ys[:1])]
-                if ref is None:
-                    ref = out
-                else:
-                    same = all(torch.equal(a, b) for a, b in zip(out, ref))
-                    ref = None
+                if flag == 8:
+                    outv = out
+                elif flag == 4:
+                    same = all(torch.equal(a, b) for a, b in zip(outv, out))
     gf = 2.0 * B * (2 if pair else 1) * H * W * Ca * Cn * 9 / 1e9
     m = {f: statistics.median(ts[f]) for f in ts}
     for f in m:
         tot[f] += m[f] * per_step
-    print(f"{name:24s} {H:3d}x{W:3d}  new {m[0]:7.1f} us {gf / m[0] * 1e3:6.0f} TF/s | old {m[4]:7.1f} us {gf / m[4] * 1e3:6.0f} TF/s | "
-          f"{m[0] / m[4]:.3f}  identical={same}", flush=True)
-print(f"per step (launch counts of the headline step): new {tot[0] / 1e3:.3f} ms, old {tot[4] / 1e3:.3f} ms")
+    print(f"{name:24s} {H:3d}x{W:3d}  s {m[0]:7.1f} us {gf / m[0] * 1e3:5.0f} TF/s | v {m[8]:7.1f} us {gf / m[8] * 1e3:5.0f} TF/s | w {m[4]:7.1f} us {gf / m[4] * 1e3:5.0f} TF/s | "
+          f"s/w {m[0] / m[4]:.3f} v/w {m[8] / m[4]:.3f}  v==w {same}", flush=True)
+print(f"per step (launch counts of the headline step): s {tot[0] / 1e3:.3f} ms, v {tot[8] / 1e3:.3f} ms, w {tot[4] / 1e3:.3f} ms")

@@ -95,8 +95,10 @@ int main() {
     const double cw = last_clock();                                                                                                        \
     const float mv = big ? time_kernel(k_conv3x3v<128, 16, D>, 512, p) : time_kernel(k_conv3x3v<128, 32, D>, 512, p);                     \
     const double cv = last_clock();                                                                                                        \
-    printf("  diag %3d %-44s w %8.1f us %6.3f us/step %4.2f GHz | v %8.1f us %6.3f us/step %4.2f GHz\n", D, what, mw * 1e3,              \
-           mw * 1e3 / steps, cw, mv * 1e3, mv * 1e3 / steps, cv);                                                                          \
+    const float ms = big ? time_kernel(k_conv3x3s<128, 16, D>, 512, p) : time_kernel(k_conv3x3s<128, 32, D>, 512, p);                     \
+    const double cs = last_clock();                                                                                                        \
+    printf("  diag %3d %-36s w %7.1f us %5.3f /step %4.2f GHz | v %7.1f us %5.3f /step %4.2f GHz | s %7.1f us %5.3f /step %4.2f GHz\n",  \
+           D, what, mw * 1e3, mw * 1e3 / steps, cw, mv * 1e3, mv * 1e3 / steps, cv, ms * 1e3, ms * 1e3 / steps, cs);                       \
     fflush(stdout);                                                                                                                        \
   }
     ONE(0, "full kernel")
