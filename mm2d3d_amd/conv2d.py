@@ -83,6 +83,9 @@ LEGACY3X3 = [{"1": 4, "2": 8}.get(_os.environ.get("MM_CONV3X3_LEGACY", "0"), 0)]
 PARAM_EPOCH = [0]  # bumped by FlatAdamW.step(): packed bf16 copies of the fp32 master weights are valid for one epoch
 
 
+PACK_GEN = [0]  # bumped whenever a pack registry drops an entry (a parameter moved - load_checkpoint, .to() - or died)
+
+
 class _PackEntry:
     __slots__ = ("owner", "kind", "out", "key", "in_ptr", "args", "nblk")
 
@@ -117,6 +120,7 @@ class _PackRegistry:
             keep.append(e)
         self.entries = keep
         self.table = None
+        PACK_GEN[0] += 1  # a registered weight moved or died: whatever captured the old table / the old pointers (graph2d) is void
 
     def repack_all(self, device):
         self._alive()
@@ -130,13 +134,24 @@ class _PackRegistry:
             self.table = torch.tensor(rows, dtype=torch.int64).to(device)
             self.table_n, self.total_blocks = len(rows), blk
         check(lib2d().mm_pack_weights_bf16_batch(ptr(self.table), self.table_n, self.total_blocks, stream()), "pack_weights_batch")
+        self.mark_fresh()
+
+    def mark_fresh(self):
+        """Every registered pack now holds the current weights (after repack_all, or after the replay of a HIP graph whose first node
+        is that launch: graph2d.py)."""
         ep = PARAM_EPOCH[0]
         for e in self.entries:
             o = e.owner()
-            e.key = (o._version, ep, o.data_ptr())
+            if o is not None:
+                e.key = (o._version, ep, o.data_ptr())
 
 
 _REGISTRIES = {}
+
+
+def registry(device, half=None):
+    """The pack registry of (device, storage format), or None when nothing is registered yet."""
+    return _REGISTRIES.get((device.index if device.index is not None else torch.cuda.current_device(), half or HALF[0]))
 
 
 def _pack(w, Z, N, T, K, sz, sn, st, sk, owner=None, kind=None):
@@ -261,8 +276,12 @@ class _WgBatch:
             torch.autograd.Variable._execution_engine.queue_callback(self.flush)
 
     def reset(self):
-        """Forget slabs whose backward pass never reached its end (an exception in between): called by FlatAdamW.zero_grad."""
+        """Forget slabs whose backward pass never reached its end (an exception in between): called by FlatAdamW.zero_grad.  The
+        autograd engine skips the final callbacks of a graph task that raised, so ``flush`` never ran and never cleared ``cb_queued``:
+        left set, no later backward pass would queue it again (the deferred sums would never launch, the conv weight
+        gradients stay zero and their hooks never fire)."""
         self.items = []
+        self.cb_queued = False
 
     def flush(self):
         self.cb_queued = False

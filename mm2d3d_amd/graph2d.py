@@ -61,6 +61,9 @@ class _Graph:
         nc = net.con1_1_avg.out_channels
         B = img.shape[0]
         # gradient of the two heads' maps: ONE [B, h, w, 2 nc] fp32 buffer (the layout lifting._LiftFn.backward fills, nn2d._HeadsFn.backward reads)
+        self.inflight = False  # a replayed forward whose backward has not run yet owns the static buffers
+        self.pack_gen = nn2d._c2d.PACK_GEN[0]
+        self.reg = self.table = None
         self.dout = torch.zeros((B, h, w, 2 * nc), dtype=torch.float32, device=dev)
         self.s1 = torch.zeros(nc, dtype=torch.float32, device=dev)
         self.s2 = torch.zeros(nc, dtype=torch.float32, device=dev)
@@ -76,6 +79,9 @@ class _Graph:
         # capture_error_mode "thread_local": other threads of the process (an RCCL watchdog polling its events, a loader) may keep making
         # calls that a "global" capture forbids; launches into the capturing stream are captured from whichever thread they come
         c2d = nn2d._c2d
+        reg0 = c2d.registry(self.img.device)
+        if reg0 is not None:
+            reg0.repack_all(self.img.device)  # eagerly, once: the descriptor table exists (its upload must not happen inside the capture)
         try:
             with torch.cuda.graph(self.fwd, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                 with torch.enable_grad():
@@ -83,7 +89,21 @@ class _Graph:
                     # capture stream, so its gradient accumulator belongs to that stream
                     self.anchor = torch.zeros(1, device=self.img.device, requires_grad=True)
                     c2d.CAPTURE_ANCHOR[0] = self.anchor
+                    # The weight repack is an UNCONDITIONAL first node of the captured forward.  Left to the lazy host-side
+                    # test of conv2d._pack it was only recorded when a pack happened to be stale at capture time (not after
+                    # training_step x2 + fit_step, an eval forward between the warm-up calls, gradient accumulation): every replay
+                    # then multiplied with the capture-time 16-bit weights while AdamW kept updating the fp32 masters.  The table
+                    # tensor is pinned here: the registry re-creates (and frees) its table whenever the entry count changes.
+                    self.reg = c2d.registry(self.img.device)
+                    if self.reg is None or not self.reg.entries:
+                        raise RuntimeError("graph2d: no packed weights registered - capture before the trunk ever ran eagerly?")
+                    n_before = len(self.reg.entries)
+                    self.reg.repack_all(self.img.device)
+                    self.table = self.reg.table
                     x, segm, avg = net._trunk(self.img, self.hints, self.h, self.w, self.proxy)
+                    if len(self.reg.entries) != n_before:
+                        raise RuntimeError("graph2d: a weight was packed for the first time inside the capture (the trunk must have run "
+                                           "eagerly in this configuration before)")
         finally:
             c2d.CAPTURE_ANCHOR[0] = None
         self.x, self.segm, self.avg = x, segm, avg
@@ -109,12 +129,18 @@ class _Graph:
         self.proxy._colsums.clear()
         torch.cuda.synchronize()
 
+    def valid(self):
+        """Still what the eager trunk would launch?  No registered weight has moved or died since the capture."""
+        return self.pack_gen == nn2d._c2d.PACK_GEN[0]
+
     def forward(self, img, hints):
         self.img.copy_(img)
         self.hints.copy_(hints)
         if _lib.BARRIER_LISTENERS:
             _lib.before_barrier_kernel(False)
+        self.inflight = True
         self.fwd.replay()
+        self.reg.mark_fresh()  # the replay's first node repacked every registered weight: an eager use need not do it again
         return self.x.detach(), self.segm.detach(), self.avg.detach()
 
     def backward(self, d_segm, d_avg, pix):
@@ -134,6 +160,7 @@ class _Graph:
         if _lib.BARRIER_LISTENERS:  # the captured backward contains grid-barrier kernels (single-launch batch norms)
             _lib.before_barrier_kernel(True)
         self.bwd.replay()
+        self.inflight = False
         for p, g in self.auto:  # what AccumulateGrad does in the eager backward (in place into the arena slice)
             (p._mm_sink if hasattr(p, "_mm_sink") else p.grad).add_(g)
         for p in self.params:  # what gradsink.done() / the post-accumulate hooks do per parameter in the eager backward
@@ -160,8 +187,12 @@ _STATE = {}  # id(net) -> {"calls": {key: n}, "graphs": {key: _Graph}, "anchor":
 
 def _key(net, img, hints):
     nf = domains.current()
+    # the handle the batch norms launch through and its single-launch switch are part of what a capture records (after a
+    # barrier fault zeroed the switch, or a bn2d_set_fused(), the old graphs kept replaying the grid-barrier kernels)
+    hd = _lib.handle(img.device)
     return (tuple(img.shape), tuple(hints.shape), img.dtype, nn2d.half_kind(), nf, img.device.index, nn2d._c2d.BN_PRE[0],
-            nn2d._c2d.PAIR[0], nn2d.BN_PAIR[0], nn2d._c2d.WGRAD_BATCH[0], nn2d.BN_POOL[0])
+            nn2d._c2d.PAIR[0], nn2d.BN_PAIR[0], nn2d._c2d.WGRAD_BATCH[0], nn2d.BN_POOL[0], id(hd), hd.get(_lib.OPT_BN2D_FUSED),
+            nn2d._c2d.LEGACY3X3[0], nn2d._c2d.WHOLE_ITEMS[0])
 
 
 def usable(net, img, hints):
@@ -177,8 +208,16 @@ def usable(net, img, hints):
         return False  # no gradient sinks (no FlatAdamW): the eager path hands gradients to autograd, a replay could not
     st = _STATE.setdefault(id(net), {"calls": {}, "graphs": {}, "anchor": None, "net": None})
     k = _key(net, img, hints)
-    if k in st["graphs"]:
-        return True
+    g = st["graphs"].get(k)
+    if g is not None:
+        if not g.valid():  # a parameter moved (load_checkpoint, .to()): capture again, after the usual eager calls
+            del st["graphs"][k]
+            st["calls"][k] = 0
+        else:
+            # One set of static buffers per graph: a second forward of the same key BEFORE the first one's backward (the literal
+            # two-call sequence source / target of train.py:242-251, gradient accumulation) runs eagerly - its replay would overwrite
+            # the activations the pending backward differentiates and scatter into the same gradient buffer.
+            return not g.inflight
     st["calls"][k] = st["calls"].get(k, 0) + 1
     return st["calls"][k] > WARMUP_CALLS
 
@@ -199,6 +238,16 @@ def run(net, img, hints, h, w, pix):
         g.dout.zero_()
         pix._joint[base] = g.dout
     return _TrunkFn.apply(st["anchor"], g, img, hints, pix)
+
+
+def _forget_pending():
+    """FlatAdamW.zero_grad: a new step begins, no backward pass of the previous one is coming any more (it ran, or it raised)."""
+    for st in _STATE.values():
+        for g in st["graphs"].values():
+            g.inflight = False
+
+
+gradsink.RESETTERS.append(_forget_pending)
 
 
 def reset(net=None):

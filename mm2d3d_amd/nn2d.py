@@ -525,6 +525,7 @@ class _BnPoolFn(torch.autograd.Function):
                                            ws.numel(), stream()), "bn2d_fwd_train_pre_pool")
         ctx.save_for_backward(x, weight, stats, bias, idx)
         ctx.dims = (B, C, H, W, Bs, ldx)
+        ctx.hd = _lib.handle(x.device)
         ctx.sinks = None
         if gradsink.claim(ctx, weight, ctx.needs_input_grad[1]):
             gradsink.claim(ctx, bias, True)
@@ -564,7 +565,11 @@ class _BnPoolFn(torch.autograd.Function):
             dxp = torch.empty((B, C, H, W), dtype=_c2d.HALF[0], device=x.device, memory_format=CL)
             check(L.mm_maxpool3x3s2_bwd(ptr(dyp), lddyp, None, 0, ptr(idx), B, H, W, C, ptr(dxp), stream()), "maxpool_bwd")
             Ns = Bs * H * W
-            check(L.mm_bn2d_bwd(_lib.handle(x.device).h, ptr(x), ldx, ptr(dxp), C, ptr(dy2), lddy2, None, C, 1, B * H * W, Ns, C, ptr(weight),
+            hd = ctx.hd  # the forward's handle (the stem's batch norm is the LAST one of the backward pass: exactly the "tail" in which
+            # ddp.GradAllReducer(overlap="tail") has buckets in flight - the listeners must hear of this barrier kernel too)
+            if _lib.BARRIER_LISTENERS and L.mm_bn2d_single_launch(hd.h, B * H * W, Ns, C, 1):
+                _lib.before_barrier_kernel(True)
+            check(L.mm_bn2d_bwd(hd.h, ptr(x), ldx, ptr(dxp), C, ptr(dy2), lddy2, None, C, 1, B * H * W, Ns, C, ptr(weight),
                                 ptr(bias), ptr(stats[0]), ptr(stats[1]), ptr(dx), C, None, C, ptr(dwt), ptr(dbt), acc, ptr(ws), ws.numel(),
                                 stream()), "bn2d_bwd")
         else:

@@ -98,7 +98,10 @@ class FlatAdamW(optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, skip_words=None):
         """``skip_words``: device int32 words (<= 16) - the update is a no-op on the device when any of them is nonzero (the
-        data-parallel reducer's collective flags, ddp.GradAllReducer.skip_words: no read-back, the host never waits)."""
+        data-parallel reducer's collective flags, ddp.GradAllReducer.skip_words: no read-back, the host never waits).  The HOST step
+        counter (Adam's bias correction) advances even when the device skipped the update: the host learns of a flagged step one step
+        late and the trainer raises then (train.py), so training does not continue on that counter; ``step_scaled`` (the fp16 path)
+        keeps its counter on the device and does not advance it for a skipped step."""
         loss = closure() if closure is not None else None
         if any(a is not None and a["p"].device.type != "cuda" for a in self._arenas):
             raise RuntimeError("FlatAdamW.step: parameters must be on the GPU (the update is a HIP kernel, no CPU fallback)")

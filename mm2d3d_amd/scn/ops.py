@@ -270,6 +270,24 @@ class _DwBatch:
         items, self.items = self.items, []
         if not items:
             return
+        # A weight that went forward twice (the literal two-call sequence of the two domains, train.py:186-292; gradient accumulation)
+        # has two slab sets that ADD into one gradient: they must not share a launch - two workgroups would read-modify-write the
+        # same words (round 6: found as run-to-run differences of the 3D gradients in that mode; the joint-domain step uses every
+        # weight once).  A new launch starts whenever a destination repeats, as conv2d._WgBatch does.
+        groups, seen = [[]], set()
+        for it in items:
+            dst = it[1].data_ptr()
+            if dst in seen:
+                groups.append([])
+                seen = set()
+            seen.add(dst)
+            groups[-1].append(it)
+        for g in groups:
+            self._launch(g)
+        for it in items:
+            gradsink.done(it[5])
+
+    def _launch(self, items):
         L = _lib.lib()
         n, nr = len(items), self.rows()
         tab = np.zeros((n, 8 + nr), dtype=np.int32)  # {int64 partial, int64 dW, int32 ne, K, accumulate, blk_first, blk_start[nr]}
@@ -296,8 +314,6 @@ class _DwBatch:
             keep = items  # the replay reads the same slabs
             PROFILE.append(dict(kind="dW", R=0, cin=0, cout=0, K=0, e0=e0, e1=e1, bytes=0,
                                 fn=(lambda: (keep, run())[1]) if PROFILE_KEEP_CALLS else None))
-        for it in items:
-            gradsink.done(it[5])
 
 
 _DWB = _DwBatch()
