@@ -43,7 +43,7 @@ const char* mm_last_error(void);
 /* ---------------------------------------------------------------- per-device handle (csrc/handle.hip)
  * The reference keeps the equivalent state inside torch / cuDNN / SparseConvNet handles; this ABI exposes it. */
 typedef void* mm_handle_t;
-size_t mm_handle_sync_bytes(void);  /* device memory, zero-filled by the caller: 64 barrier slots of 512 B (one per stream) */
+size_t mm_handle_sync_bytes(void);  /* device memory, zero-filled by the caller: 64 barrier slots of 2 KB (one per stream) */
 size_t mm_handle_fault_bytes(void); /* pinned, device-mapped host memory (hipHostMalloc / torch pinned), zero-filled */
 int mm_create(int device_id, void* sync_dev, size_t sync_bytes, void* fault_host, size_t fault_bytes, mm_handle_t* out);
 int mm_destroy(mm_handle_t h);

@@ -86,8 +86,9 @@ enum {
   MM_OPT_DW_WIDE = 4,     // sparse dW: wide channel tiles on rule lists >= 200k (default 1)
   MM_OPT_COUNT = 8
 };
-constexpr int MM_SYNC_SLOTS = 64;           // one 512-B barrier slot (arrival counter | release word) per stream
-constexpr size_t MM_SYNC_BYTES = (size_t)MM_SYNC_SLOTS * 512;
+constexpr int MM_SYNC_SLOTS = 64;           // one barrier slot per stream: top arrival counter | release word | 8 group counters,
+constexpr size_t MM_SYNC_SLOT_BYTES = 2048;  // each on a 128-byte line of its own (fused_bn.h fused_barrier)
+constexpr size_t MM_SYNC_BYTES = (size_t)MM_SYNC_SLOTS * MM_SYNC_SLOT_BYTES;
 constexpr size_t MM_FAULT_BYTES = 64;
 
 struct MMHandle {

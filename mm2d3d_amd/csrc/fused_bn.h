@@ -129,16 +129,22 @@ __device__ inline void fused_wave_sums(const double* partial, int b0, int b1, in
   q = fused_wave_sum((vq[0] + vq[1]) + (vq[2] + vq[3]));
 }
 
-// Grid barrier (every workgroup of the launch is resident, see the header).  The last workgroup to arrive (its increment wraps
-// the counter to 0) advances the release word from flag_old to flag_old + 1; the others poll the release word.
+// Grid barrier (every workgroup of the launch is resident, see the header), in two levels (round 6).  Agent-scope atomics execute at
+// the memory side, one after the other per address (~12 ns each): 256 arrivals on ONE word are ~3 us of every barrier, and a
+// single-launch batch norm has two of them, ~370 times per step.  The workgroups therefore arrive in eight groups (blockIdx & 7 - the
+// blocks that share an XCD under round-robin dispatch; any grouping is correct) on eight counters, each on a line of its own; the last
+// arrival of a group (its increment wraps the group's counter to 0) arrives at the top counter, and the last of those advances the
+// release word from flag_old to flag_old + 1; everybody else polls the release word.  G = gridDim.x.
+constexpr int FUSED_GROUP0 = 128, FUSED_GROUP_STRIDE = 32;  // group counters at sync[128 + 32 g], g = 0..7
 __device__ inline void fused_barrier(unsigned* sync, unsigned* fault, unsigned G, unsigned flag_old) {
   stores_acked();   // this thread's xcd_store()s have reached the coherence point
   __syncthreads();  // ... and so have the whole workgroup's
   if (threadIdx.x == 0) {
-    // wrapping increment: the G-th arrival (old value G - 1) sets the counter back to 0 in the same atomic - the separate
-    // reset (an atomicExch whose return the release had to wait for) was one more round trip to the coherence point per barrier
-    const unsigned t = atomicInc(&sync[0], G - 1u);
-    if (t == G - 1) {
+    // wrapping increments: the n-th arrival (old value n - 1) sets its counter back to 0 in the same atomic
+    const unsigned grp = blockIdx.x & 7u, ng = (G - grp + 7u) >> 3, ngroups = G < 8u ? G : 8u;
+    bool last = atomicInc(&sync[FUSED_GROUP0 + FUSED_GROUP_STRIDE * grp], ng - 1u) == ng - 1u;
+    if (last) last = atomicInc(&sync[0], ngroups - 1u) == ngroups - 1u;
+    if (last) {
       xcd_store(&sync[FUSED_FLAG], flag_old + 1u);
     } else {
       const unsigned long long t0 = wall_clock64();
@@ -285,7 +291,7 @@ static inline int fused_plan(MMHandle* H, int opt, int unit, int64_t N, int64_t 
   if (R > rmax) return MM_OK;
   pl->ok = true;
   pl->G0 = G0, pl->G1 = G1, pl->R = (int)R;
-  pl->sync = H->sync + slot * 128;
+  pl->sync = H->sync + slot * (MM_SYNC_SLOT_BYTES / 4);
   pl->fault = H->fault_dev;
   return MM_OK;
 }

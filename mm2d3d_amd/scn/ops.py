@@ -34,9 +34,12 @@ def _timed(kind, rb, cin, cout, fn, esize=4):
     out = fn()
     e1.record()
     R = rb.n_rules
-    PROFILE.append(dict(kind=kind, R=R, cin=cin, cout=cout, K=rb.K, e0=e0, e1=e1,
+    PROFILE.append(dict(kind=kind, R=R, cin=cin, cout=cout, K=rb.K, e0=e0, e1=e1, eng=_ENG[0],
                         bytes=R * (cin + cout) * esize + 8 * R + rb.K * cin * cout * esize, fn=fn if PROFILE_KEEP_CALLS else None))
     return out
+
+
+_ENG = [""]  # which engine the last call took (per-layer listings: tools/sparse_layers.py)
 
 
 def _c(t):
@@ -56,6 +59,7 @@ def _apply(x, w_kcc, rb, src, dst, n_out, cout, unique, transpose_w, kflip, use_
     else:
         s_ci, s_co = cw_out, 1
     out = torch.empty((n_out, cout), dtype=F32, device=x.device)
+    _ENG[0] = "G" if unique else "G+R"
     if not unique:
         rb.ensure_csr()
     ws = _lib.workspace.get(int(L.mm_spconv_ws_bytes(rb.n_rules, cin, cout, K)), x.device)
@@ -177,6 +181,7 @@ def _os_usable(table, x, cin, cout):
 def _apply_os(x, weight, w_kcc, table, cout, transpose, kflip):
     """Output-stationary engine: out[dst] = sum_k x[nbr_k(dst)] . W[k], offsets ascending, no tmp rows."""
     L = _lib.lib()
+    _ENG[0] = "F"
     Wf = _os_fragments(weight, w_kcc, transpose, kflip)
     out = torch.empty((table.n_dst, cout), dtype=F32, device=x.device)
     check(L.mm_spconv_os_apply(ptr(x), x.stride(0), x.shape[1], ptr(out), cout, cout, ptr(Wf), table.K, ptr(table.dst),
@@ -201,6 +206,7 @@ def _apply_os_bf16(x, weight, w_kcc, table, cout, transpose, kflip):
     if x.shape[1] % 16 or cout % 16 or x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
         raise RuntimeError("16-bit activation mode: channel counts must be multiples of 16 and rows 16-byte aligned")
     f16 = x.dtype == F16
+    _ENG[0] = "F16"
     Wf = _os_fragments(weight, w_kcc, transpose, kflip, bf16="f16" if f16 else True)
     out = torch.empty((table.n_dst, cout), dtype=x.dtype, device=x.device)
     check((L.mm_spconv_os_apply_f16 if f16 else L.mm_spconv_os_apply_bf16)(
@@ -323,6 +329,7 @@ def _dw_partial(x, dout, rb, src, dst, cin, cout, sink, param, bf16, partial=Non
     """The slabs of one layer now, their sum with every other layer's later (``_DwBatch``)."""
     L = _lib.lib()
     nbytes = int(L.mm_spconv_dw_ws_bytes(rb.offsets_ptr, rb.K, cin, cout))
+    _ENG[0] = "dW"
     if partial is None:
         partial = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     row = np.empty(_DWB.rows(), dtype=np.int32)

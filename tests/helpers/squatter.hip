@@ -1,6 +1,6 @@
 // Diagnostic (round 5): a kernel that merely OCCUPIES part of every CU for a while - `lds_bytes` of LDS per workgroup, 64 threads, a
 // handful of registers - so that the workgroups of a kernel launched on another stream are placed beside it.  mode 0: sleeps;
-// mode 1: hammers its LDS; mode 2: streams global memory (buf, n floats).  Used by tools/conv_corun.py to find out what a
+// mode 1: hammers its LDS; mode 2: streams global memory (buf, n floats).  Used by tools/conv_corun.py and tests/test_gpu_corun.py to find out what a
 // co-resident foreign workgroup does to the LDS-DMA convolution kernels (DESIGN_LOG.md, round 5).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

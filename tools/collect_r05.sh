@@ -53,7 +53,7 @@ for f in sorted(glob.glob("gpurun_out/r05/final/ab_*.json") + glob.glob("gpurun_
         print(f, "unreadable:", e)
 PY
 # co-residency stress: the product build, then the diagnostic build with the round-4 resource request of k_conv3x3w
-[ -f tools/_bin/libsquat.so ] || hipcc -O2 --offload-arch=gfx950 -shared -fPIC tools/squatter.hip -o tools/_bin/libsquat.so
+[ -f tools/_bin/libsquat.so ] || hipcc -O2 --offload-arch=gfx950 -shared -fPIC tests/helpers/squatter.hip -o tools/_bin/libsquat.so
 timeout -k 10 300 python tools/corun_units.py > $O/corun_units_product.txt 2>&1
 [ -f tools/_bin/libmm2d3d_hip_sharedcu.so ] && MM_LIB_PATH=tools/_bin/libmm2d3d_hip_sharedcu.so timeout -k 10 300 python tools/corun_units.py > $O/corun_units_round4_request.txt 2>&1
 timeout -k 10 300 python tools/corun_net.py 1 1024 1024 20000 400 > $O/corun_net_product.txt 2>&1

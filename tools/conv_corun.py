@@ -1,6 +1,6 @@
 """Diagnostic (round 5): does a CO-RESIDENT foreign workgroup change what the LDS-DMA convolution kernels compute?
 The last decoder convolution (192 -> 64 at 304 x 480, k_conv3x3w<64, 16>: 96 VGPRs, 139 KB of LDS - room for another kernel's
-workgroups on the CU) runs on the main stream while tools/squatter.hip occupies every CU from a second stream; every output is
+workgroups on the CU) runs on the main stream while tests/helpers/squatter.hip occupies every CU from a second stream; every output is
 compared with the kernel's own output when it runs alone.  Usage: python tools/conv_corun.py  (needs tools/_bin/libsquat.so)."""
 import ctypes, os, sys
 import torch

@@ -1,4 +1,4 @@
-"""Diagnostic (round 5): the whole training step (2D + 3D, forward + backward, one stream) with tools/squatter.hip hammering
+"""Diagnostic (round 5): the whole training step (2D + 3D, forward + backward, one stream) with tests/helpers/squatter.hip hammering
 the LDS of every CU from a second stream, against the same step alone.  Any kernel whose result depends on what else is
 resident on its CU shows up as a loss / gradient that differs.  Usage: python tools/corun_net.py [mode] [lds_bytes] [grid]"""
 import ctypes, os, sys

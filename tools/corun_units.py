@@ -1,5 +1,5 @@
 """Diagnostic (round 5): which kernels of the 2D branch change their results when small LDS-using workgroups of ANOTHER stream are
-launched onto their CUs while they run (tools/squatter.hip, mode 1, many short launches)?  One layer at a time, forward + backward,
+launched onto their CUs while they run (tests/helpers/squatter.hip, mode 1, many short launches)?  One layer at a time, forward + backward,
 against the same layer alone.  Usage: python tools/corun_units.py [mode] [lds_bytes] [ticks] [nsquat]"""
 import ctypes, os, sys
 import torch
@@ -10,7 +10,7 @@ lds = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
 nsquat = int(sys.argv[4]) if len(sys.argv) > 4 else 60
 dev = torch.device("cuda:0")
-sq = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libsquat.so"))
+sq = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_bin", "libsquat.so")  # hipcc -shared -fPIC tests/helpers/squatter.hip)
 sq.squat.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_void_p]
 buf = torch.randn(16 << 20, device=dev)
 main, side = torch.cuda.current_stream(), torch.cuda.Stream(dev)
