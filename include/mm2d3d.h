@@ -146,6 +146,8 @@ size_t mm_spconv_ws_bytes(int64_t n_rules, int Cin, int Cout, int K);
 #define MM_SPCONV_FP32 1
 #define MM_SPCONV_TWO_TERMS 2
 #define MM_SPCONV_DW_NARROW 4
+#define MM_SPCONV_DW16_ELEM 8 /* 16-bit rows: the weight gradient gathers single elements (the round-3 kernel) instead of whole rows
+                              * through LDS and transpose reads (round 6, same slab sums): A/B measurements */
 int mm_spconv_apply(const float* in, int ld_in, int Cin, float* out, int ld_out, int Cout, int64_t n_out,
                     const int32_t* src, const int32_t* dst, const int32_t* offsets_dev, const int32_t* offsets_host,
                     int K, const int32_t* csr_off, const int32_t* csr_pos, int unique_dst, const float* W,

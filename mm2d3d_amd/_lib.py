@@ -245,7 +245,7 @@ def lib():
 # the single-launch batch norms, their switches) lives in a handle over memory supplied from here.  The environment variables
 # that used to be read inside the library are read HERE, once, and passed on explicitly.
 OPT_BN2D_FUSED, OPT_BN3D_FUSED = 0, 1
-SPCONV_DEFAULT, SPCONV_FP32, SPCONV_TWO_TERMS, SPCONV_DW_NARROW = 0, 1, 2, 4
+SPCONV_DEFAULT, SPCONV_FP32, SPCONV_TWO_TERMS, SPCONV_DW_NARROW, SPCONV_DW16_ELEM = 0, 1, 2, 4, 8
 
 
 def _env_int(name, default):
@@ -261,6 +261,8 @@ def spconv_mode_from_env():
     mode = SPCONV_FP32 if os.environ.get("MM_SPCONV_FP32") else (SPCONV_TWO_TERMS if _env_int("MM_SPCONV_SPLIT", 3) == 2 else SPCONV_DEFAULT)
     if _env_int("MM_DW_WIDE", 1) == 0:
         mode |= SPCONV_DW_NARROW
+    if _env_int("MM_DW16_ELEM", 0):
+        mode |= SPCONV_DW16_ELEM
     return mode
 
 

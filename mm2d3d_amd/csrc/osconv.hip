@@ -76,15 +76,18 @@ __device__ inline void split3(const f32x4& a, const f32x4& b, bf16x8 (&t)[3]) {
 // MODE 1 / 2: the 16-bit activation modes - rows are bf16 / IEEE fp16 (in and out), the weights one
 // 16-bit term per element ([K][nq][ncb][64 lanes] x 16 B fragments), one MFMA per block (v_mfma_f32_16x16x32_bf16 / _f16) and no
 // operand splitting; accumulation stays fp32.  MODE 0: fp32 rows, three-term split.
-template <int NCB, int MODE>
-__global__ __launch_bounds__(256) void k_osconv4(OsP p) {
+// NW (round 6): waves per tile.  4 everywhere until now; a tile with all 27 offsets is then a chain of 7 rounds of (neighbour ids ->
+// row gathers -> MFMAs -> LDS exchange), and on the small deep levels - a few hundred tiles for 256 CUs - that chain, not bandwidth, is
+// the layer's time (53 us for 34 MB at 112 -> 112 channels).  There 8 or 16 waves share a tile's offsets: 4 or 2 rounds.
+template <int NCB, int MODE, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_osconv4(OsP p) {
   constexpr bool BF = MODE != 0;
-  constexpr int NW = 4, MT = 64;
+  constexpr int MT = 64;
   constexpr int NTW = BF ? 1 : 3;             // bf16 terms per weight
   constexpr int FRB = NTW * 1024 / 16;        // 16-B pieces per (k, q, cb) fragment block
   extern __shared__ __attribute__((aligned(16))) char lds[];  // [NW producers][4 sub-blocks][NCB][64 lanes] f32x4
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
-  const int t = gridDim.x - 1 - blockIdx.x, cb0 = p.cb_first;
+  const int t = gridDim.x - 1 - blockIdx.x, cb0 = p.cb_first + blockIdx.y * NCB;  // blockIdx.y: further groups of NCB output-channel blocks
   const int nq = p.nq;
   const int64_t j0 = (int64_t)t * MT + rl;
   f32x4 acc[NCB];
@@ -173,12 +176,15 @@ __global__ __launch_bounds__(256) void k_osconv4(OsP p) {
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) slot[((wave * 4 + sb) * NCB + cb) * 64 + lane] = accP[sb][cb];
     __syncthreads();
+    if (wave < 4) {  // wave w adds the partials of sub-block w in wave order = ascending k
 #pragma unroll
-    for (int w = 0; w < NW; w++)
+      for (int w = 0; w < NW; w++)
 #pragma unroll
-      for (int cb = 0; cb < NCB; cb++) acc[cb] += slot[((w * 4 + wave) * NCB + cb) * 64 + lane];
+        for (int cb = 0; cb < NCB; cb++) acc[cb] += slot[((w * 4 + wave) * NCB + cb) * 64 + lane];
+    }
     __syncthreads();
   }
+  if (wave >= 4) return;
   const int d = p.dst[j0 + wave * 16];
   if (d >= 0) {
     if constexpr (BF) {
@@ -250,13 +256,25 @@ __global__ __launch_bounds__(256) void k_os_pack_batch(const PackD* __restrict__
   pack_one<NT, H>(d, ((int64_t)blockIdx.x - blk0) * 256 + threadIdx.x);
 }
 
-template <int NCB>
-int launch_os4(const OsP& p, int64_t n_tiles, int nchunk, int bf, hipStream_t s) {
-  constexpr int LDSB = 4 * 4 * NCB * 1024;
-  if (bf == 2) hipLaunchKernelGGL((k_osconv4<NCB, 2>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
-  else if (bf) hipLaunchKernelGGL((k_osconv4<NCB, 1>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
-  else hipLaunchKernelGGL((k_osconv4<NCB, 0>), dim3((unsigned)n_tiles, nchunk), dim3(256), LDSB, s, p);
+template <int NCB, int NW>
+int launch_os4w(const OsP& p, int64_t n_tiles, int nchunk, int bf, hipStream_t s) {
+  constexpr int LDSB = NW * 4 * NCB * 1024;
+  static_assert(LDSB <= 65536, "LDS partials of one workgroup");
+  if (bf == 2) hipLaunchKernelGGL((k_osconv4<NCB, 2, NW>), dim3((unsigned)n_tiles, nchunk), dim3(64 * NW), LDSB, s, p);
+  else if (bf) hipLaunchKernelGGL((k_osconv4<NCB, 1, NW>), dim3((unsigned)n_tiles, nchunk), dim3(64 * NW), LDSB, s, p);
+  else hipLaunchKernelGGL((k_osconv4<NCB, 0, NW>), dim3((unsigned)n_tiles, nchunk), dim3(64 * NW), LDSB, s, p);
   return MM_OK;
+}
+// nw: waves per tile (4, or 8 / 16 on small levels: only the one- and two-block instances exist in those forms)
+template <int NCB>
+int launch_os4(const OsP& p, int64_t n_tiles, int nchunk, int bf, int nw, hipStream_t s) {
+  if constexpr (NCB <= 2) {
+    if (nw == 8) return launch_os4w<NCB, 8>(p, n_tiles, nchunk, bf, s);
+  }
+  if constexpr (NCB == 1) {
+    if (nw == 16) return launch_os4w<NCB, 16>(p, n_tiles, nchunk, bf, s);
+  }
+  return launch_os4w<NCB, 4>(p, n_tiles, nchunk, bf, s);
 }
 
 }  // namespace
@@ -354,17 +372,30 @@ static int os_apply(int bf, const void* in_, int ld_in, int Cin, void* out_, int
   int parts = (ncb + maxw - 1) / maxw;
   // small levels: more, narrower launches (each re-gathers its rows) until the grid covers the chip
   while (n_tiles * parts < 1024 && parts < ncb && (ncb + parts) / (parts + 1) >= 2) parts++;
+  // ... and more waves per tile (k_osconv4 NW): a level that cannot fill the chip with tiles is bound by the chain of rounds per tile
+  int nw = 4;
+  if (n_tiles * parts < 2048) {
+    while (n_tiles * parts < 2048 && parts < ncb) parts++;  // one-block parts: the 16-wave form exists for them
+    nw = (ncb + parts - 1) / parts == 1 ? (K > 8 ? 16 : 8) : ((ncb + parts - 1) / parts == 2 ? 8 : 4);
+  }
+  // Parts of equal width share ONE launch (blockIdx.y = part).  Round 6: as one launch per part a small level paid its latency chain
+  // (7 rounds of neighbour ids -> row gathers -> MFMAs -> LDS exchange per tile, ~15 us however few tiles there are) once per part, one
+  // after the other: 112 -> 112 channels on a 72k-rule level = 7 launches = 114 us for 34 MB (tools/sparse_layers.py, configs[4]:
+  // the 16-bit mode runs every level on this engine).
   int rc = MM_OK;
-  for (int i = 0, cb = 0; i < parts && rc == MM_OK; i++) {
+  for (int i = 0, cb = 0; i < parts && rc == MM_OK;) {
     const int w = (ncb - cb + (parts - i) - 1) / (parts - i);  // near-equal parts, the wider ones first
+    int cnt = 1, cbn = cb + w;
+    while (i + cnt < parts && (ncb - cbn + (parts - i - cnt) - 1) / (parts - i - cnt) == w) cnt++, cbn += w;
     p.cb_first = cb;
     switch (w) {
-      case 1: rc = launch_os4<1>(p, n_tiles, 1, bf, s); break;
-      case 2: rc = launch_os4<2>(p, n_tiles, 1, bf, s); break;
-      case 3: rc = launch_os4<3>(p, n_tiles, 1, bf, s); break;
-      default: rc = launch_os4<4>(p, n_tiles, 1, bf, s); break;
+      case 1: rc = launch_os4<1>(p, n_tiles, cnt, bf, nw, s); break;
+      case 2: rc = launch_os4<2>(p, n_tiles, cnt, bf, nw, s); break;
+      case 3: rc = launch_os4<3>(p, n_tiles, cnt, bf, nw, s); break;
+      default: rc = launch_os4<4>(p, n_tiles, cnt, bf, nw, s); break;
     }
-    cb += w;
+    cb = cbn;
+    i += cnt;
   }
   if (rc) return rc;
   MM_LAUNCH_CHECK();

@@ -682,6 +682,147 @@ __global__ __launch_bounds__(256) void k_dw_direct_s3(const E* __restrict__ in, 
   }
 }
 
+// dW over 16-BIT rows (round 6; BASELINE.json configs[4]): whole rows through LDS and the hardware transpose read.  k_dw_direct_s3
+// gathers one ELEMENT per rule and lane - the MFMA's K dimension (the rules) lies along a lane's register vector - i.e. 2-byte loads
+// for 16-bit rows: 8 (TI + TJ) load instructions per 32 rules and wave, the instructions that bound the kernel; halving the row bytes
+// did not shorten it (2.5 TB/s of the 16-bit algorithmic bytes on configs[4], against 3.2-4.1 of the fp32 ones on configs[1]).  Here a
+// wave gathers the 32 rows of a group with 16-byte loads (TI + TJ instructions), writes them as a [32 rules][channels] tile of its
+// own LDS region and reads the MFMA operands back transposed with ds_read_b64_tr_b16 (4 rules x 16 channels per 16 lanes: two reads
+// per 16-channel block) - no split (the rows are 16-bit already), no workgroup barrier in the loop (a wave's LDS operations execute in
+// order), the next group's rows in flight under the current group's MFMAs.  Tile rows are padded to an odd multiple of 32 bytes: the
+// eight rows a 32-lane half reads then cover all 64 banks.  Same channel tiles, slabs, cross-wave sum and summation order per slab
+// as k_dw_direct_s3<.., 1, E> (the 32 rules of a group are summed by ONE MFMA either way): the slab sums are unchanged.
+template <int TI, int TJ, typename E>
+__global__ __launch_bounds__(256) void k_dw_tr16(const E* __restrict__ in, int ld_in, const E* __restrict__ dout, int ld_do,
+                                                  const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int Cin, int Cout, int K,
+                                                  KSeg seg, int chunk, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char ldsb[];
+  constexpr int SA = ((TI * 32 + 31) / 32 | 1) * 32, SB = ((TJ * 32 + 31) / 32 | 1) * 32;  // row pitch (bytes): odd multiples of 32
+  constexpr int WREG = 32 * (SA + SB);                                                     // bytes of one wave's two tiles
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  typedef std::conditional_t<std::is_same_v<E, _Float16>, f16x8, bf16x8> HV;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rl = lane & 15, sl = lane >> 4;
+  const int k = find_k(seg, blockIdx.x, K);
+  const int r_begin = seg.rule_off[k] + (blockIdx.x - seg.blk_start[k]) * chunk;
+  const int r_end = min(seg.rule_off[k + 1], r_begin + chunk);
+  const int ncib = Cin >> 4, ncob = Cout >> 4;
+  const int nrj = (ncob + TJ - 1) / TJ;
+  const int ci0 = (blockIdx.y / nrj) * TI, co0 = (blockIdx.y % nrj) * TJ;
+  char* const At = ldsb + wave * WREG;
+  char* const Bt = At + 32 * SA;
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // gather geometry: a row of the input tile is 2 TI 16-byte chunks, lanes walk (rule, chunk) pairs: pair e = lane + 64 it
+  constexpr int CA = 2 * TI, CB = 2 * TJ, ITA = CA / 2, ITB = CB / 2;  // 32 CA / 64 iterations
+  typedef const __attribute__((address_space(1))) u4* gq;
+  auto load_idx = [&](int r0, int& si, int& di) {  // lane l (and l + 32) holds rule r0 + (l & 31)
+    const int r = r0 + (lane & 31);
+    const bool ok = r < r_end;
+    si = ok ? src[ok ? r : r_begin] : -1;
+    di = ok ? dst[ok ? r : r_begin] : 0;
+  };
+  u4 ra[ITA], rb[ITB];  // the gathered chunks of one group
+  auto gather = [&](int si, int di) {
+#pragma unroll
+    for (int it = 0; it < ITA; it++) {
+      const int e = lane + 64 * it, rule = e / CA, ch = e % CA;
+      const int s = __shfl(si, rule, 64);
+      const bool live = s >= 0 && ci0 * 16 + ch * 8 < Cin;
+      const gq pq = live ? (gq)(in + (int64_t)s * ld_in + ci0 * 16 + ch * 8) : (gq)(const void*)g_zero128;
+      ra[it] = *pq;
+    }
+#pragma unroll
+    for (int it = 0; it < ITB; it++) {
+      const int e = lane + 64 * it, rule = e / CB, ch = e % CB;
+      const int s = __shfl(si, rule, 64), d = __shfl(di, rule, 64);
+      const bool live = s >= 0 && co0 * 16 + ch * 8 < Cout;
+      const gq pq = live ? (gq)(dout + (int64_t)d * ld_do + co0 * 16 + ch * 8) : (gq)(const void*)g_zero128;
+      rb[it] = *pq;
+    }
+  };
+  // transpose-read address of this lane inside a tile: lane group g = sl reads rules 8 g + 4 h + q, piece pp (8 bytes) of a 32-byte block
+  const int q = (lane >> 2) & 3, pp = lane & 3;
+  const int ta = (8 * sl + q) * SA + pp * 8, tb = (8 * sl + q) * SB + pp * 8;
+  int r0 = r_begin + wave * 32;
+  int si = -1, di = 0, sn = -1, dn = 0;
+  if (r0 < r_end) {
+    load_idx(r0, si, di);
+    gather(si, di);
+    if (r0 + 128 < r_end) load_idx(r0 + 128, sn, dn);
+  }
+  for (; r0 < r_end; r0 += 128) {
+    // this group's rows -> the wave's tiles (the previous group's transpose reads have returned: their MFMAs were issued)
+#pragma unroll
+    for (int it = 0; it < ITA; it++) {
+      const int e = lane + 64 * it;
+      *(u4*)(At + (e / CA) * SA + (e % CA) * 16) = ra[it];
+    }
+#pragma unroll
+    for (int it = 0; it < ITB; it++) {
+      const int e = lane + 64 * it;
+      *(u4*)(Bt + (e / CB) * SB + (e % CB) * 16) = rb[it];
+    }
+    // the next group's rows are requested now and land under this group's reads and MFMAs; its successor's indices behind them
+    const bool more = r0 + 128 < r_end;
+    if (more) {
+      gather(sn, dn);
+      if (r0 + 256 < r_end) load_idx(r0 + 256, sn, dn);
+    }
+    HV at[TI], bt[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++) {
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(At + ta + i * 32));
+      const s16x4 w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(At + ta + 4 * SA + i * 32));
+      const s16x8 o = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+      at[i] = __builtin_bit_cast(HV, o);
+    }
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+      const s16x4 u = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Bt + tb + j * 32));
+      const s16x4 w = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Bt + tb + 4 * SB + j * 32));
+      const s16x8 o = {u.x, u.y, u.z, u.w, w.x, w.y, w.z, w.w};
+      bt[j] = __builtin_bit_cast(HV, o);
+    }
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) {
+        if constexpr (std::is_same_v<E, _Float16>) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(at[i], bt[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[i], bt[j], acc[i][j], 0, 0, 0);
+      }
+  }
+  // cross-wave sum in wave order (k_dw_direct_s3's), through the same LDS: every wave has left its tiles first
+  float* red = (float*)ldsb;
+  __syncthreads();
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) *(f32x4*)&red[(((wave - 1) * TI * TJ + i * TJ + j) * 64 + lane) * 4] = acc[i][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* P = partial + (int64_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+      for (int j = 0; j < TJ; j++) {
+        f32x4 v = acc[i][j];
+#pragma unroll
+        for (int w = 0; w < 3; w++) v += *(const f32x4*)&red[((w * TI * TJ + i * TJ + j) * 64 + lane) * 4];
+        if (ci0 + i < ncib && co0 + j < ncob) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) P[(int64_t)((ci0 + i) * 16 + sl * 4 + r) * Cout + (co0 + j) * 16 + rl] = v[r];
+        }
+      }
+  }
+}
+
 // generic dW: thread = (ci, co) pairs strided over the block; rules staged in LDS 64 at a time
 __global__ __launch_bounds__(256) void k_dw_generic(const float* __restrict__ in, int ld_in,
                                                      const float* __restrict__ dout, int ld_do,
@@ -1106,7 +1247,8 @@ int dw_partial(int bf, int mode, const void* in, int ld_in, int Cin, const void*
   KSeg& seg = *seg_out;
   const bool mfma_ok = (Cin % 16 == 0) && (Cout % 16 == 0);
   const int nt = bf ? -bf : (mfma_ok && Cin >= split_min_cin(true) ? split_terms(mode) : 0);  // matrix-rate-bound widths, as in mm_spconv_apply
-  const bool wide_ok = nt != 0 && !(mode & 4) && offsets_host[K] >= DW_WIDE_MIN_RULES;  // the wide tiles exist for the split / 16-bit kernels
+  // the wide tiles exist for the split kernels (they save 4-byte gathers); 16-bit rows are gathered whole (k_dw_tr16): <= 4 x 4 there
+  const bool wide_ok = nt > 0 && !(mode & 4) && offsets_host[K] >= DW_WIDE_MIN_RULES;
   const int chunk = dw_chunk(offsets_host[K], Cin, Cout, wide_ok);
   int nb = make_seg(offsets_host, K, chunk, &seg);
   const int ne = Cin * Cout;
@@ -1123,11 +1265,19 @@ int dw_partial(int bf, int mode, const void* in, int ld_in, int Cin, const void*
     const size_t lds = (size_t)3 * ti * tj * 64 * 4 * sizeof(float);
 #define DWCASE(I, J)                                                                                                          \
   if (ti == I && tj == J) {                                                                                                   \
-    if (nt == -1)                                                                                                             \
+    constexpr size_t l16 = (size_t)4 * 32 * ((((I * 32 + 31) / 32 | 1) + ((J * 32 + 31) / 32 | 1)) * 32);                     \
+    const size_t lds16 = l16 > lds ? l16 : lds;                                                                               \
+    if (nt == -1 && (mode & 8))                                                                                               \
       hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, __bf16>), dim3(nb, ny), dim3(256), lds, s, (const __bf16*)in, ld_in,        \
                          (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                            \
-    else if (nt == -2)                                                                                                        \
+    else if (nt == -2 && (mode & 8))                                                                                          \
       hipLaunchKernelGGL((k_dw_direct_s3<I, J, 1, _Float16>), dim3(nb, ny), dim3(256), lds, s, (const _Float16*)in, ld_in,    \
+                         (const _Float16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                          \
+    else if (nt == -1)                                                                                                        \
+      hipLaunchKernelGGL((k_dw_tr16<I, J, __bf16>), dim3(nb, ny), dim3(256), lds16, s, (const __bf16*)in, ld_in,              \
+                         (const __bf16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                            \
+    else if (nt == -2)                                                                                                        \
+      hipLaunchKernelGGL((k_dw_tr16<I, J, _Float16>), dim3(nb, ny), dim3(256), lds16, s, (const _Float16*)in, ld_in,          \
                          (const _Float16*)dout, ld_do, src, dst, Cin, Cout, K, seg, chunk, partial);                          \
     else if (nt == 3)                                                                                                         \
       hipLaunchKernelGGL((k_dw_direct_s3<I, J, 3>), dim3(nb, ny), dim3(256), lds, s, (const float*)in, ld_in, (const float*)dout, \
