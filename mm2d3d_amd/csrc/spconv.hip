@@ -823,6 +823,10 @@ __global__ __launch_bounds__(256) void k_dw_tr16(const E* __restrict__ in, int l
   }
 }
 
+// (Measured and dropped, round 6: the same for fp32 rows - 16-byte row gathers into a per-wave fp32 tile, the eight rules of a lane's
+// channel read back with ds_read_b32, then split8 / mfma_split as k_dw_direct_s3: identical slabs, 1.0-1.8 x its time on the bench's
+// layers - the LDS round trip of 4-byte operands costs more than the 4-byte gathers it replaces, and the
+// tiles cap the occupancy at two workgroups per CU.)
 // generic dW: thread = (ci, co) pairs strided over the block; rules staged in LDS 64 at a time
 __global__ __launch_bounds__(256) void k_dw_generic(const float* __restrict__ in, int ld_in,
                                                      const float* __restrict__ dout, int ld_do,

@@ -1,3 +1,5 @@
+"""configs[4] weight gradient over 16-bit rows: k_dw_tr16 (rows through LDS + transpose reads, round 6) against k_dw_direct_s3 (element gathers;
+mode | 8) on random rulebooks of the bench's sizes: time, bit identity of the slab sums, error against fp64.  usage: python tools/dw16_ab.py"""
 import ctypes as C, os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from mm2d3d_amd import _lib
