@@ -222,7 +222,7 @@ def conv_roofline(tm, batch, dev):
         "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
         "traffic": traffic, "traffic_source": traffic_source,
         "kernel": "sparse-conv engines: k_osconv4<*> (fwd, dX of the levels >= 200k rows), k_gather_gemm<*> / "
-                  "k_gather_gemm_s3<*> + k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> per layer + ONE k_dw_reduce_batch per backward (dW)",
+                  "k_gather_gemm_s3<*> + k_csr_reduce (fwd, dX of the smaller levels), k_dw_direct<*> / k_dw_direct_s3<*> (16-bit rows: k_dw_tr16<*>) per layer + ONE k_dw_reduce_batch per backward (dW)",
         "algorithmic_bytes_per_step": int(alg_bytes), "kernel_ms_per_step": round(ms, 3), "launch_groups": len(rec),
         "event_pair_overhead_us": round(pair_us, 2),
         "how_timed": ("every engine launch of one step (second backward stream off) replayed back to back on the launch stream between ONE "
@@ -252,7 +252,7 @@ GFLOP_2D_FWD_BY_IMAGE = {(302, 480): 228.9, (225, 400): 150.6}  # SURVEY.md 8d: 
 
 def conv2d_roofline(tm, batch, dev):
     """MFMA side of the step (north_star: "MFMA utilisation on the 2D GEMMs"): every launch of the 2D convolution entry points
-    (mm_conv2d_3x3s1 / mm_conv2d_3x3s1_pair = k_conv3x3w/r fwd + dgrad - one problem / the same layer of both encoders per launch -,
+    (mm_conv2d_3x3s1 / mm_conv2d_3x3s1_pair = k_conv3x3s/r fwd + dgrad - one problem / the same layer of both encoders per launch -,
     mm_conv2d_wgrad3x3_pair = the pairs' weight gradients, mm_conv2d_gemm = stems / strided / 1x1 / transposed convs fwd + dgrad,
     mm_conv2d_dgrad_s2 = the stride-2 data gradients by output parity, mm_conv2d_stem7 = the two 7x7 stems,
     mm_conv2d_wgrad = weight gradients incl. their slab reduction; mm_conv2d_wgrad_slabs / mm_conv2d_wgrad3x3_pair_slabs = the slab
@@ -329,8 +329,9 @@ def conv2d_roofline(tm, batch, dev):
     for ppath in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_sq_step.json")), reverse=True):
         prec = json.load(open(ppath))
         if prec.get("conv2d_sources_sha256") != fingerprint:
-            busy_src = (f"none: {os.path.relpath(ppath, ROOT)} was taken on other 2D kernel sources (git {prec.get('git')}); "
-                        "re-run tools/pmc_sq.py")
+            if busy_src is None:  # records are walked newest first: name the NEWEST one that does not match
+                busy_src = (f"none: {os.path.relpath(ppath, ROOT)} was taken on other 2D kernel sources (git {prec.get('git')}); "
+                            "re-run tools/pmc_sq.py")
             continue
         k = prec.get("kernels", {})
         busy = {name: v["mfma_busy_cycles_per_wave_cycle"] for name, v in k.items() if name.startswith(("k_conv", "k_wgrad"))}
@@ -344,7 +345,7 @@ def conv2d_roofline(tm, batch, dev):
                                    "TFLOP/s": round(tflop / (net * 1e-3), 1), "frac_of_peak": round(tflop / (net * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4)},
             "ms_by_entry_point": {n: round(v, 3) for n, v in ms.items()}, "launches": {n: len(v) for n, v in rec.items()},
             "storage": kind + " maps and packed weights, fp32 accumulate (v_mfma_f32_32x32x16_" + kind + " / 16x16x32)",
-            "kernel": "2D convolution set: k_conv3x3w<*> / k_conv3x3r (3x3 s1 fwd + dgrad), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
+            "kernel": "2D convolution set: k_conv3x3s<*> / k_conv3x3r (3x3 s1 fwd + dgrad), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
                       "k_wgrad3x3n / k_conv_wgrad2 + k_wgrad_reduce (weight gradients)",
             "mfma_busy_cycles_per_wave_cycle": busy, "mfma_busy_source": busy_src}
 

@@ -129,3 +129,29 @@ def test_two_handles_with_different_modes_in_one_process():
     prev = plain.set(_lib.OPT_BN2D_FUSED, 1)
     assert prev == 0 and plain.get(_lib.OPT_BN2D_FUSED) == 1 and fused.get(_lib.OPT_BN2D_FUSED) == 3
     fused.close(), plain.close()
+
+
+def test_counter_records_belong_to_this_tree():
+    """Evidence hygiene: the newest offline counter records under profiles/ must have been taken on THIS tree's
+    kernel sources - bench.py reports them only then, and a README must never describe a stale record as current.  A kernel change
+    after tools/collect_rNN.sh therefore fails here until the records are re-taken (or removed: bench.py then reports null)."""
+    import glob
+    import hashlib
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def sha(files):
+        h = hashlib.sha256()
+        for f in files:
+            h.update(open(os.path.join(root, "mm2d3d_amd", "csrc", f), "rb").read())
+        return h.hexdigest()
+
+    for name, key, files in (("pmc_sq_step.json", "conv2d_sources_sha256", ("conv2d.hip", "h16.h")),
+                             ("traffic_3d.json", "engine_sources_sha256", ("spconv.hip", "osconv.hip", "ostable.hip"))):
+        recs = sorted(glob.glob(os.path.join(root, "profiles", "r*", name)))
+        if not recs or "r06" not in recs[-1]:
+            continue  # nothing collected this round (yet): nothing can be stale
+        rec = json.load(open(recs[-1]))
+        assert rec.get(key) == sha(files), (f"{os.path.relpath(recs[-1], root)} was taken on other kernel sources (git {rec.get('git')}): "
+                                            "re-run tools/collect_r06.sh after the last csrc/ commit, or delete the record")

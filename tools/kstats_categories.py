@@ -6,11 +6,11 @@ import re
 import sys
 
 CATS = [
-    ("2d conv 3x3 fwd+dgrad", r"k_conv3x3w|k_conv3x3r|k_c3"),
+    ("2d conv 3x3 fwd+dgrad", r"k_conv3x3w|k_conv3x3v|k_conv3x3s|k_conv3x3r|k_c3"),
     ("2d conv wgrad (+reduce)", r"k_wgrad3x3n|k_wgrad_reduce|k_conv_wgrad2|k_wg_"),
     ("2d conv gemm/stem/dgrad_s2", r"k_conv_gemm|k_stem7|k_stem_prep|k_conv_f32|k_wgrad_f32"),
     ("BatchNorm2d", r"k_bn2d|k_colsum"),
-    ("sparse engines", r"k_osconv|k_gather_gemm|k_csr_reduce|k_dw_direct|k_dw_reduce|k_rows_narrow"),
+    ("sparse engines", r"k_osconv|k_gather_gemm|k_csr_reduce|k_dw_direct|k_dw_tr16|k_dw_reduce|k_rows_narrow"),
     ("sparse batch norm", r"k_bn_"),
     ("sparse metadata (own)", r"k_insert|k_flag|k_assign|k_subm_nbr|k_down_nbr|k_up_nbr|k_emit_rules|k_row_fill|k_os_fill|k_row_mask|"
                               r"k_batch_lower|k_csr_|k_init_level|k_meta|k_hash|k_dedupe|k_scan|k_tile|k_bucket"),

@@ -27,7 +27,7 @@ def engine_sources_sha256():
         h.update(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
-ENGINE = ("k_gather_gemm", "k_csr_reduce", "k_dw_direct", "k_dw_reduce", "k_pack_frag", "k_rows_narrow", "k_generic", "k_osconv", "k_os_pack")
+ENGINE = ("k_gather_gemm", "k_csr_reduce", "k_dw_direct", "k_dw_tr16", "k_dw_reduce", "k_pack_frag", "k_rows_narrow", "k_generic", "k_osconv", "k_os_pack")
 
 
 def load(path, counter):
