@@ -88,7 +88,7 @@ def test_library_keeps_no_switches_and_reads_no_environment():
     for gone in ("mm_bn2d_set_fused", "mm_bn_set_fused", "mm_os_table_set_sort", "mm_bn2d_fused_fault", "mm_bn_fused_fault"):
         assert gone not in declared, f"{gone}: a process-wide switch"
     L = _lib.lib()
-    assert int(L.mm_handle_sync_bytes()) == 64 * 512 and int(L.mm_handle_fault_bytes()) >= 4
+    assert int(L.mm_handle_sync_bytes()) == 64 * 2048 and int(L.mm_handle_fault_bytes()) >= 4  # 64 stream slots of 2 KB (two-level grid barrier)
     # handle entry points refuse what is not a handle
     assert L.mm_destroy(None) != 0 and L.mm_set_option(None, 0, 0) < 0 and b"handle" in L.mm_last_error()
     src = "".join(open(os.path.join(ROOT, "mm2d3d_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "mm2d3d_amd", "csrc"))
