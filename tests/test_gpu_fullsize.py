@@ -196,6 +196,88 @@ def test_conv3x3_at_bench_shapes_vs_torch(cin, cout, H, W, half2d):
     assert float((y.detach().float() - yr.detach()).abs().max()) <= 2e-2 * float(yr.detach().abs().max())
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_batchnorm2d_three_kernel_path_at_full_resolution_vs_torch(split, half2d):
+    """a non-self comparison of a full-size 2D layer.  The three 299 MB maps of the headline step (16 x 64 x 304 x
+    480: stem outputs and the last decoder stage) are too large for the single-launch batch norm and take the reduce / finalize /
+    apply kernels; here that path at its own size, forward (+ReLU), running statistics and backward, one and two statistics groups,
+    against torch's fp32 BatchNorm2d on the same 16-bit-rounded input."""
+    import torch.nn.functional as F
+
+    from mm2d3d_amd import _lib, domains, nn2d
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(7)
+    B, C, H, W = 16, 64, 304, 480
+    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.25).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(B, C, H, W, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+    bn = nn2d.BatchNorm2d(C, relu=True).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    assert not _lib.lib().mm_bn2d_single_launch(_lib.handle(dev).h, B * H * W, B * H * W, C, 0), "this map must take the three-kernel path"
+    nf = 8 if split else None
+    xh = x.clone().requires_grad_(True)
+    with domains.split(nf):
+        yh = bn(xh)
+    yh.backward(gy)
+    groups = [(0, 8), (8, 16)] if split else [(0, 16)]
+    dxr, dwr, dbr = [], torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    for b0, b1 in groups:  # what two consecutive calls of the reference's BatchNorm2d do (the two domains)
+        xr = x[b0:b1].float().requires_grad_(True)
+        ref = torch.nn.BatchNorm2d(C).to(dev)
+        with torch.no_grad():
+            ref.weight.copy_(bn.weight), ref.bias.copy_(bn.bias), ref.running_mean.copy_(rm), ref.running_var.copy_(rv)
+        yr = F.relu(ref(xr))
+        err = float((yh[b0:b1].detach().float() - yr.detach()).abs().max() / yr.detach().abs().max())
+        assert err < 1e-2, err
+        yr.backward(gy[b0:b1].float())
+        dxr.append(xr.grad)
+        dwr += ref.weight.grad
+        dbr += ref.bias.grad
+        rm, rv = ref.running_mean.clone(), ref.running_var.clone()
+    dxr = torch.cat(dxr)
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())
+    assert rel(xh.grad, dxr) < 5e-3, rel(xh.grad, dxr)
+    assert rel(bn.weight.grad, dwr) < 2e-3 and rel(bn.bias.grad, dbr) < 2e-3, (rel(bn.weight.grad, dwr), rel(bn.bias.grad, dbr))
+    assert torch.allclose(bn.running_mean, rm, atol=1e-4) and torch.allclose(bn.running_var, rv, atol=1e-3)
+    assert int(bn.num_batches_tracked) == len(groups)
+
+
+def test_heads_at_full_resolution_vs_torch(half2d):
+    """... and the fused heads (5 x 5 average pool of the crop + two 1 x 1 convolutions, k_head_* / k_box5) on the decoder's map at the
+    bench's size, 16 x 64 x 304 x 480 cropped to 302 x 480, forward and backward against torch fp32 on the same 16-bit-rounded map."""
+    import torch.nn.functional as F
+
+    from mm2d3d_amd import nn2d
+
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, Hp, Wp, h, w = 16, 304, 480, 302, 480
+    x = torch.randn(B, 64, Hp, Wp, generator=g).to(half2d).to(dev).contiguous(memory_format=torch.channels_last)
+    c1, c2 = nn2d.Conv2d(64, 6, 1).to(dev), nn2d.Conv2d(64, 6, 1).to(dev)
+    xh = x.clone().requires_grad_(True)
+    o1, o2 = nn2d.fused_heads(xh, h, w, c1, c2)
+    g1, g2 = torch.randn(o1.shape, generator=g).to(dev), torch.randn(o2.shape, generator=g).to(dev)
+    (o1 * g1).sum().add((o2 * g2).sum()).backward()
+    # reference on a plain NCHW-contiguous fp32 copy (torch's NHWC avg-pool backward on a cropped view is not trusted), in two halves
+    gx = torch.empty(B, 64, h, w, device=dev)
+    gw = [torch.zeros_like(c1.weight), torch.zeros_like(c1.bias), torch.zeros_like(c2.weight), torch.zeros_like(c2.bias)]
+    for b0 in (0, 8):
+        xr = x[b0:b0 + 8, :, :h, :w].float().contiguous().requires_grad_(True)
+        pooled = F.avg_pool2d(xr, 5, 1, 2)
+        r1, r2 = F.conv2d(pooled, c1.weight, c1.bias), F.conv2d(pooled, c2.weight, c2.bias)
+        assert torch.allclose(o1[b0:b0 + 8], r1, atol=2e-4) and torch.allclose(o2[b0:b0 + 8], r2, atol=2e-4)
+        got = torch.autograd.grad((r1 * g1[b0:b0 + 8]).sum() + (r2 * g2[b0:b0 + 8]).sum(), [xr, c1.weight, c1.bias, c2.weight, c2.bias])
+        gx[b0:b0 + 8] = got[0]
+        for a, t in zip(gw, got[1:]):
+            a += t
+    rel = lambda a, b: float((a.float() - b).norm() / b.norm())
+    assert rel(xh.grad[:, :, :h, :w], gx) < 5e-3 and float(xh.grad[:, :, h:, :].float().abs().max()) == 0.0
+    assert rel(c1.weight.grad, gw[0]) < 1e-3 and rel(c1.bias.grad, gw[1]) < 1e-3 and rel(c2.weight.grad, gw[2]) < 1e-3 and rel(c2.bias.grad, gw[3]) < 1e-3
+
+
 @pytest.mark.parametrize("workload", ["c2", "c4"])
 def test_full_joint_step_at_bench_size(workload, half2d):
     """One whole two-domain training step at BASELINE.json's sizes - configs[1]: 8 + 8 NuScenes-shaped scenes, 6 classes;
