@@ -2829,7 +2829,10 @@ static int c3_launch(C3P p, hipStream_t s) {
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
-    } else if (p.legacy != 1) {  // 128-pixel x 64-cout register tiles, four multiplying + four loader waves (round 6)
+    } else if (p.legacy != 1 && !(p.legacy == 0 && bn == 64 && Ca == 64)) {  // 128 x 64 register tiles, four multiplying + four loader waves
+      // (Ca = 64 with 64-cout blocks - the data gradients of the decoder's 192 -> 64 convolutions - stays on k_conv3x3w: one chunk per
+      // item means an epilogue every nine steps, and the 16-wave kernel hides it better: 617 against 643 us at 304 x 480, 176 / 182 at
+      // 152 x 240, tools/conv3x3_bench_shapes.py)
       static unsigned once_v = 0;  // per-device bit: see mm_attr_todo (common.h)
       if (mm_attr_todo(&once_v)) {
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));

@@ -32,7 +32,7 @@ cp $O/kstats/ks_kernel_stats.csv $O/bench_n1_kernel_stats.csv 2>/dev/null; rm -r
 # per-call event times must agree with
 MM_SPCONV_BWD_OVERLAP=0 MM_META_SIDE=0 rocprofv3 --kernel-trace --stats -d $O/kstats_serial -o ks --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-extras > $O/bench_n1_serial_profiled.json 2> $O/bench_n1_serial_profiled.err; echo "rocprof serial rc=$?" | tee -a $O/summary.txt
 cp $O/kstats_serial/ks_kernel_stats.csv $O/bench_n1_serial_kernel_stats.csv 2>/dev/null; rm -rf $O/kstats_serial
-python tools/kstats_categories.py $O/bench_n1_serial_kernel_stats.csv 13 --top 45 > $O/kernel_families_serial.txt 2>&1
+python tools/kstats_categories.py $O/bench_n1_serial_kernel_stats.csv 16 --top 45 > $O/kernel_families_serial.txt 2>&1
 python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2>/dev/null; python bench.py --workload c5 --steps 10 --warmup 3 > $O/bench_c5.json 2>/dev/null
 python bench.py --precision bf16 --steps 20 --warmup 5 --no-extras > $O/bench_n1_bf16.json 2>/dev/null
 MM_BN2D_FUSED=1 MM_BN_FUSED=1 MM_GRAPH2D=0 MM_META_SIDE=0 python bench.py --steps 20 --warmup 5 --no-extras > $O/bench_n1_as_under_ddp.json 2>/dev/null
