@@ -547,7 +547,16 @@ def main(argv=None):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = None
-    if world > 1:
+    # MM_DDP_FORCE=1 with one rank: a process group of ONE rank over RCCL with the reducer forced on (ddp.GradAllReducer ``force``) -
+    # what the data-parallel machinery costs a step on the one GPU a measurement box has (buckets, hooks, stream ordering; no xGMI)
+    forced = world == 1 and os.environ.get("MM_DDP_FORCE", "0") != "0"
+    if forced:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sock.getsockname()[1]))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # "nccl" is RCCL on ROCm.  MM_BENCH_BACKEND=gloo is a rehearsal mode (several ranks sharing one GPU box).
         backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
@@ -657,9 +666,10 @@ def main(argv=None):
                    "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 2),
                    "hip_graph_2d_trunk": _graph_state(tm)},
     }
-    if world > 1:
+    if world > 1 or forced:
         st = tm.reducer.stats
         out["config"].update({
+            "hip_graph_2d_trunk_under_reducer": bool(tm.ddp_graph), "rulebook_side_stream_under_reducer": bool(tm.ddp_side_stream and tm.overlap_rulebooks),
             "backend": "rccl (torch.distributed 'nccl')" if backend == "nccl" else backend, "rccl_ranks": world if backend == "nccl" else 0,
             "ms_per_step_by_rank": [round(v, 3) for v in rank_ms],
             "allreduce_bytes_per_step": st["bytes"], "allreduce_buckets_per_step": st["buckets"],
@@ -699,7 +709,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

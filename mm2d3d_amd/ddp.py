@@ -28,6 +28,8 @@ One process per GPU; backend "nccl" (= RCCL on ROCm) on GPU, "gloo" in the CPU t
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -372,6 +374,14 @@ class GradAllReducer:
                 for b in bufs:
                     b.copy_(flat[off : off + b.numel()].view_as(b))
                     off += b.numel()
+
+
+def ranks_share_a_gpu() -> bool:
+    """More ranks on this node than it has GPUs (a rehearsal on one card): the launcher's LOCAL_WORLD_SIZE, else the world size."""
+    if not dist.is_initialized():
+        return False
+    local = int(os.environ.get("LOCAL_WORLD_SIZE", dist.get_world_size()))
+    return torch.cuda.is_available() and local > torch.cuda.device_count()
 
 
 def shard_indices(n_items: int, rank: int, world: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):

@@ -161,6 +161,8 @@ class _Graph:
             _lib.before_barrier_kernel(True)
         self.bwd.replay()
         self.inflight = False
+        # (the reducer's "tail" schedule: the call above is the LAST counted grid-barrier announcement of the trunk, and the hooks
+        # below run after the replay is queued - the trunk's buckets leave behind it, by stream order)
         for p, g in self.auto:  # what AccumulateGrad does in the eager backward (in place into the arena slice)
             (p._mm_sink if hasattr(p, "_mm_sink") else p.grad).add_(g)
         for p in self.params:  # what gradsink.done() / the post-accumulate hooks do per parameter in the eager backward

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, domains
-from .ddp import GradAllReducer
+from .ddp import GradAllReducer, ranks_share_a_gpu
 from .losses import Loss, cross_modal_loss
 from .metrics import SegIoU
 
@@ -75,6 +75,14 @@ class TrainModel(nn.Module):
         # the start of the step: moving it too (beside the 2D forward) measured no further gain.  Results are bit-identical
         # (tests/test_gpu_step.py::test_metadata_built_one_step_ahead_gives_the_same_steps).
         self.overlap_rulebooks = bool(int(train_kwargs.get("overlap_rulebooks", os.environ.get("MM_META_SIDE", "1"))))
+        # Under the data-parallel reducer (round 6): the side stream stays on while every rank has a GPU of its own (two processes on
+        # ONE card starve each other's grid barriers, more so with a third queue in play: off there).  ``ddp_graph`` (MM_DDP_GRAPH=1)
+        # additionally replays the 2D trunk as HIP graphs under the reducer: the same kernels as the one-GPU step, the buckets of the
+        # trunk then all leave after the backward replay (graph2d._Graph.backward brackets the replay for the "tail" schedule).  Off
+        # by default: the eager trunk's host enqueue (22-24 ms) still fits beside the 34 ms GPU step, and its buckets leave 2-3 ms
+        # before the end of backward instead of after it.
+        self.ddp_side_stream = train_kwargs.get("ddp_side_stream", os.environ.get("MM_DDP_META_SIDE"))
+        self.ddp_graph = bool(int(train_kwargs.get("ddp_graph", os.environ.get("MM_DDP_GRAPH", "0"))))
         self._meta_stream, self._meta_event = None, None
         # 0 (default): one stream; 1: the 3D branch on its own stream, three-kernel batch norms everywhere (round 2); 2 (round 5,
         # EXPERIMENTAL): the 3D branch on its own stream with three-kernel SPARSE batch norms only - the 2D branch keeps its
@@ -124,10 +132,17 @@ class TrainModel(nn.Module):
             self.optimizers.append(opt)
             self.schedulers.append(sched)
         self.reducer = GradAllReducer(self.optimizers)
-        # the 2D trunk runs as two HIP graphs (mm2d3d_amd/graph2d.py) unless the data-parallel reducer is active: its bucket hooks want
-        # the parameters' gradients to complete one by one during backward
+        # the 2D trunk runs as two HIP graphs (mm2d3d_amd/graph2d.py); under an active data-parallel reducer only on request
+        # (``ddp_graph``): its bucket hooks overlap more when the parameters' gradients complete one by one during backward
         n2d = self.model[self.modules_name[0]]
-        n2d._mm_no_graph = bool(self.reducer.active)
+        n2d._mm_no_graph = bool(self.reducer.active) and not self.ddp_graph
+        if self.reducer.active and self.ddp_graph:
+            from . import conv2d as _c2d
+
+            _c2d.WGRAD_BATCH[0] = True  # the reducer switched the deferred slab sum off for its hooks' sake: the graphs have it captured
+        if self.ddp_side_stream is None:
+            self.ddp_side_stream = not ranks_share_a_gpu()
+        self.ddp_side_stream = bool(int(self.ddp_side_stream))
         # torch DDP broadcasts rank 0's parameters when it wraps a model (run.py:262-268): replicas start identical whatever
         # each rank's seed was
         self.reducer.sync_parameters(src=0)
@@ -298,9 +313,10 @@ class TrainModel(nn.Module):
     def _prefetch_rulebooks(self):
         pre = self._pipelined
         if pre is not None and pre["phase"] == 1:
-            # (not under an active data-parallel reducer: that path has never run on more than one GPU, and a two-rank rehearsal on
-            # ONE GPU showed the two processes' grid barriers starving each other far more often with the extra queue in play)
-            if self.overlap_rulebooks and pre["md"].device.type == "cuda" and not (self.reducer is not None and self.reducer.active):
+            # (under an active data-parallel reducer only while every rank has its own GPU: a two-rank rehearsal on ONE GPU showed
+            # the two processes' grid barriers starving each other far more often with the extra queue in play)
+            ddp = self.reducer is not None and self.reducer.active
+            if self.overlap_rulebooks and pre["md"].device.type == "cuda" and (not ddp or self.ddp_side_stream):
                 self._rulebooks_on_side_stream(pre["md"])
             else:
                 pre["md"].begin_rulebooks()  # reads the level sizes (no wait: queued before this step's forward), queues phase two

@@ -180,6 +180,80 @@ def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_bat
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_the_rccl_step_keeps_the_one_gpu_step_s_side_stream_and_graphs(monkeypatch, graph):
+    """the step under the reducer is the one-GPU step.  The next batch's rulebooks are built on the side stream
+    beside the 3D backward (on by default while every rank has a GPU of its own), and with ``ddp_graph`` the 2D trunk is replayed as
+    its two HIP graphs; both give the plain trainer's losses and parameters bit for bit, and under the default "tail" schedule
+    every bucket still leaves before finish()."""
+    import copy
+
+    from mm2d3d_amd import _lib, graph2d
+    from mm2d3d_amd.losses import Loss
+    from mm2d3d_amd.net2d import Net2DSeg
+    from mm2d3d_amd.net3d import Net3DSeg
+    from mm2d3d_amd.optimizers import Optimizer
+    from mm2d3d_amd.synthetic import make_batch
+    from mm2d3d_amd.train import TrainModel
+
+    dev = torch.device("cuda:0")
+    _lib.lib()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    try:
+        torch.manual_seed(3)
+        kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
+        n2, n3 = Net2DSeg(6, pretrained=False).to(dev), Net3DSeg(6, True, kw).to(dev)
+        for m in n2.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        n2b, n3b = copy.deepcopy(n2), copy.deepcopy(n3)
+
+        def opts():
+            out = {}
+            for k in ("2d_net", "3d_net"):
+                o = Optimizer("adamw", lr=0.001)
+                o.set_scheduler("one_cycle", max_lr=0.005, total_steps=100)
+                out[k] = o
+            return out
+
+        def batches():
+            return [{"source": make_batch(5 + i, 2, "nuscenes", (96, 128), device=dev), "target": make_batch(40 + i, 2, "nuscenes", (96, 128), device=dev)}
+                    for i in range(7)]
+
+        loss = Loss([{"name": "cross_entropy", "target": "segmentation", "args": {}}])
+        tk = dict(lambda_xm_src=1.0, lambda_xm_trg=0.1, gc_freeze=False, overlap_branches=0)
+        monkeypatch.setenv("MM_DDP_FORCE", "1")
+        monkeypatch.delenv("MM_DDP_OVERLAP", raising=False)
+        monkeypatch.delenv("MM_DDP_META_SIDE", raising=False)
+        ddp = TrainModel({"2d_net": n2, "3d_net": n3}, opts(), loss, dict(tk, ddp_graph=graph))
+        ddp.configure_optimizers()
+        monkeypatch.setenv("MM_DDP_FORCE", "0")
+        plain = TrainModel({"2d_net": n2b, "3d_net": n3b}, opts(), loss, dict(tk))
+        plain.configure_optimizers()
+        assert ddp.reducer.active and ddp.reducer.overlap == "tail" and ddp.ddp_side_stream and not plain.reducer.active
+        ba, bb = batches(), batches()
+        for step in range(6):
+            la = ddp.fit_step(ba[step], next_batch=ba[step + 1])
+            lb = plain.fit_step(bb[step], next_batch=bb[step + 1])
+            torch.cuda.synchronize()
+            assert float(la) == float(lb), (step, float(la), float(lb))
+        assert ddp._meta_stream is not None, "the rulebooks of the next batch were not built on the side stream"
+        st2 = graph2d._STATE.get(id(n2))
+        assert bool(st2 and st2["graphs"]) == graph, "HIP graphs of the 2D trunk under the reducer: only with ddp_graph"
+        st = ddp.reducer.stats
+        assert st["buckets"] == len(ddp.reducer.order) and st["early"] >= st["buckets"] - 1 >= 1, st
+        assert ddp.reducer.drain_flag() is False
+        for a, b in zip(ddp.optimizers, plain.optimizers):
+            for x, y in zip(a._arenas, b._arenas):
+                if x is not None:
+                    assert torch.equal(x["p"], y["p"]), "parameters after 6 optimiser steps differ"
+    finally:
+        dist.destroy_process_group()
+        from mm2d3d_amd import conv2d as _c2d
+
+        _c2d.WGRAD_BATCH[0] = True
+
+
 def test_a_flagged_step_is_skipped_on_the_device_and_the_relearn_step_does_not_raise_again(monkeypatch):
     """on RCCL the collective "graph changed" flag is read one step late, so the step in which a parameter
     learned as unused fires (its bucket is not reduced) used to go through the optimiser on every rank.  Now the optimiser kernels

@@ -51,6 +51,14 @@ for i in 1 2 3; do
   MM_CONV3X3_LEGACY=2 python bench.py --steps 20 --warmup 5 --no-extras > $O/ab_conv3x3_v_32x32x16_$i.json 2>/dev/null
   MM_GRAPH2D=0 python bench.py --steps 20 --warmup 5 --no-extras > $O/ab_graph2d_off_$i.json 2>/dev/null
 done
+# the data-parallel step on the one GPU of this box: a one-rank RCCL group with the reducer forced on (no xGMI; buckets, hooks, stream
+# ordering are the real ones) - default (eager trunk + "tail" + rulebook side stream), with the trunk's graphs, and round 5's form
+for i in 1 2; do
+  MM_DDP_FORCE=1 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_default_$i.json 2>/dev/null
+  MM_DDP_FORCE=1 MM_DDP_GRAPH=1 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_graphs_$i.json 2>/dev/null
+  MM_DDP_FORCE=1 MM_DDP_META_SIDE=0 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_round5_form_$i.json 2>/dev/null
+  python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_none_$i.json 2>/dev/null
+done
 python - > $O/ab_summary.txt <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r06/final/ab_*.json") + glob.glob("gpurun_out/r06/final/bench_*.json")):
