@@ -258,16 +258,22 @@ def _gemm(A, Bn, Hi, Wi, Ca, out, Ho, Wo, Cn, Hg, Wg, so, sa, fr, ty, tx, Wp, nz
 WGRAD_BATCH = [True]  # (set from the environment below, next to the other A/B switches)
 
 
+WGRAD_BATCH_GRAPH = [True]  # ... also inside a captured backward pass (MM_CONV_WGRAD_BATCH_GRAPH=0: per-layer sums there, as in round 5)
+
+
 def _defer_wgrad():
-    """Deferred slab sums?  Not while the backward pass is being captured into a HIP graph (graph2d.py): the deferred form uploads its
-    descriptor table from the host per step, and inside a graph a per-layer launch costs the host nothing anyway."""
-    return WGRAD_BATCH[0] and not torch.cuda.is_current_stream_capturing()
+    """Deferred slab sums?  Also while the backward pass is being captured into a HIP graph (graph2d.py, round 6): the descriptor
+    table of a captured pass is constant (static slab buffers, static arena), so it is uploaded ONCE, after the capture
+    (_WgBatch.fill_captured), and the graph ends in one k_wgrad_reduce_batch node instead of ~45 dependent k_wgrad_reduce nodes."""
+    return WGRAD_BATCH[0] and (WGRAD_BATCH_GRAPH[0] or not torch.cuda.is_current_stream_capturing())
 
 
 class _WgBatch:
     def __init__(self):
         self.items = []  # (slabs, dW, dW1, sn, st, sk, nsplit, Cn, ntaps, Ck, params)
         self.cb_queued = False
+        self.captured = []  # (device table, host table) of launches recorded into a HIP graph, not yet filled in
+        self.cap_buf, self.cap_used = None, 0  # device memory for those tables, allocated OUTSIDE the graph's pool (begin_capture)
 
     def add(self, item):
         self.items.append(item)
@@ -282,6 +288,7 @@ class _WgBatch:
         gradients stay zero and their hooks never fire)."""
         self.items = []
         self.cb_queued = False
+        self.captured, self.cap_buf, self.cap_used = [], None, 0
 
     def flush(self):
         self.cb_queued = False
@@ -305,8 +312,22 @@ class _WgBatch:
             for prm in it[10]:
                 gradsink.done(prm)
 
-    @staticmethod
-    def _launch(items):
+    def begin_capture(self, device, nbytes=1 << 16):
+        """Before a backward pass is captured: memory for the descriptor tables of its batch launches.  NOT from the graph's pool
+        (allocated here, before the capture): the pool is shared with the forward graph, whose temporaries would overwrite a table
+        that is written once, outside the graphs."""
+        self.cap_buf, self.cap_used, self.captured = torch.empty(nbytes // 4, dtype=torch.int32, device=device), 0, []
+
+    def fill_captured(self):
+        """After the capture: upload the descriptor tables of the batch launches it recorded (constant: static slab buffers, static
+        arena).  Returns the table memory: the graph keeps it alive."""
+        done, self.captured = self.captured, []
+        for descs, tab in done:
+            descs.copy_(torch.from_numpy(tab))
+        buf, self.cap_buf, self.cap_used = self.cap_buf, None, 0
+        return buf
+
+    def _launch(self, items):
         import numpy as np
 
         L = lib2d()
@@ -320,7 +341,15 @@ class _WgBatch:
             tab[i, 12:18] = (nsplit, Cn, ntaps, Ck, 1, first)
             first += int(L.mm_conv2d_wgrad_reduce_blocks(Cn, Ck, 0 if dW1 is None else 1))
         dev = items[0][0].device
-        descs = torch.from_numpy(tab.reshape(-1)).pin_memory().to(dev, non_blocking=True)
+        if torch.cuda.is_current_stream_capturing():
+            # no host copy inside a capture: the node reads a static device table whose contents arrive right after the capture
+            if self.cap_buf is None or self.cap_used + tab.size > self.cap_buf.numel():
+                raise RuntimeError("conv2d: deferred weight-gradient sums inside a stream capture need _WgBatch.begin_capture() first")
+            descs = self.cap_buf[self.cap_used : self.cap_used + tab.size]
+            self.cap_used += (tab.size + 3) // 4 * 4  # tables stay 16-byte aligned
+            self.captured.append((descs, tab.reshape(-1).copy()))
+        else:
+            descs = torch.from_numpy(tab.reshape(-1)).pin_memory().to(dev, non_blocking=True)
         check(L.mm_conv2d_wgrad_reduce_batch(ptr(descs), len(items), first, stream()), "conv2d_wgrad_reduce_batch")
 
 
@@ -461,6 +490,7 @@ DGRAD_S2 = [_os.environ.get("MM_CONV_DGRAD_S2", "1") != "0"]  # stride-2 data gr
 PAIR = [_os.environ.get("MM_CONV_PAIR", "1") != "0"]
 PAIR_WGRAD = [_os.environ.get("MM_CONV_PAIR_WGRAD", "1") != "0"]  # the pairs' weight gradients in one launch too
 WGRAD_BATCH[0] = _os.environ.get("MM_CONV_WGRAD_BATCH", "1") != "0"
+WGRAD_BATCH_GRAPH[0] = _os.environ.get("MM_CONV_WGRAD_BATCH_GRAPH", "1") != "0"
 
 
 def pairable(x1, x2, w1, w2):

@@ -77,8 +77,12 @@ __device__ inline uint4 pool_grad8(const PoolSrc& ps, int64_t r, int cv) {
   return make_uint4(ow[0], ow[1], ow[2], ow[3]);
 }
 
-// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * (yout > 0 if relu).  MODE 2: sum x only
-template <int MODE>
+// MODE 0: (sum x, sum x^2).  MODE 1: (sum g, sum g*xhat) with g = dy * (yout > 0 if relu).  MODE 2: sum x only.
+// POOL: the gradient is gathered from the pooled map (PoolSrc) - a template parameter, not a run-time test of ps.dyp: the test sat
+// between the loads of a trip and kept the compiler from issuing them together (round 6: 165 -> see profiles/r06 stream_diag.txt).
+// HAS2 / YOUT (MODE 1 without POOL): a second gradient map / the forward output for the ReLU mask are read - compile-time, so that a
+// trip's load count is known to the compiler (with run-time tests it waited for vmcnt(0), i.e. also for the loads just issued).
+template <int MODE, bool POOL = false, bool HAS2 = false, bool YOUT = false>
 __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, int ld_x, const u16* __restrict__ dy, int ld_dy,
                                                     const u16* __restrict__ yout, int ld_y, int relu, int64_t N, int C,
                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -102,6 +106,9 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
   // relu without yout: the mask is recomputed from x exactly as the forward decided it (v = fma(x, sc, sh) > 0 in fp32),
   // which saves reading the output map back (layers without a residual input)
   const bool remask = MODE == 1 && relu && yout == nullptr;
+  constexpr bool STATIC = MODE == 1 && !POOL;
+  const bool has2 = STATIC ? HAS2 : dy2 != nullptr;          // host: HAS2 == (dy2 != NULL), YOUT == (relu && yout != NULL)
+  const bool use_y = STATIC ? YOUT : (relu && !remask);
   if (MODE == 1 && slot < rs) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
@@ -133,13 +140,13 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
       } else {
         float dv[8], yv[8];
         cvt8(td, dv);
-        if (dy2) {  // second gradient contribution of this map (residual / concat consumer), summed here instead of by an add kernel
+        if (has2) {  // second gradient contribution of this map (residual / concat consumer), summed here instead of by an add kernel
           float d2[8];
           cvt8(t2, d2);
 #pragma unroll
           for (int i = 0; i < 8; i++) dv[i] += d2[i];
         }
-        if (relu && !remask) cvt8(ty, yv);
+        if (use_y) cvt8(ty, yv);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
           if (remask) yv[i] = fmaf(xv[i], sc[i], sh[i]);
@@ -151,25 +158,53 @@ __global__ __launch_bounds__(T) void k_bn2d_reduce(const u16* __restrict__ x, in
     };
     const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
     constexpr int U = MODE == 1 ? 2 : 4;  // the backward reduction has up to four tensors per row: two rows keep the occupancy
-    int64_t r = r0 + slot;
-    for (; r + (U - 1) * (int64_t)rs < r1; r += U * (int64_t)rs) {
+    struct Trip {
       uint4 tx[U], td[U], t2[U], ty[U];
+    };
+    auto load_trip = [&](Trip& t, int64_t r) {
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const int64_t ru = r + (int64_t)u * rs;
-        tx[u] = *(const uint4*)(x + ru * ld_x + cv * 8);
-        td[u] = MODE == 1 ? (ps.dyp ? pool_grad8(ps, ru, cv) : *(const uint4*)(dy + ru * ld_dy + cv * 8)) : z4;
-        t2[u] = (MODE == 1 && dy2) ? *(const uint4*)(dy2 + ru * ld_dy2 + cv * 8) : z4;
-        ty[u] = (MODE == 1 && relu && !remask) ? *(const uint4*)(yout + ru * ld_y + cv * 8) : z4;
+        t.tx[u] = *(const uint4*)(x + ru * ld_x + cv * 8);
+        t.td[u] = MODE == 1 ? (POOL ? pool_grad8(ps, ru, cv) : *(const uint4*)(dy + ru * ld_dy + cv * 8)) : z4;
+        t.t2[u] = (MODE == 1 && has2) ? *(const uint4*)(dy2 + ru * ld_dy2 + cv * 8) : z4;
+        t.ty[u] = (MODE == 1 && use_y) ? *(const uint4*)(yout + ru * ld_y + cv * 8) : z4;
       }
+    };
+    auto acc_trip = [&](const Trip& t) {
 #pragma unroll
-      for (int u = 0; u < U; u++) row_acc(tx[u], td[u], t2[u], ty[u]);
+      for (int u = 0; u < U; u++) row_acc(t.tx[u], t.td[u], t.t2[u], t.ty[u]);
+    };
+    int64_t r = r0 + slot;
+    const int64_t step = U * (int64_t)rs, last = (U - 1) * (int64_t)rs;
+    if (MODE == 1 && !POOL) {
+      // software-pipelined (round 6): the next trip's loads are issued before this trip's rows are consumed - the one-deep form
+      // drained the memory pipe (s_waitcnt vmcnt(0)) before every trip's arithmetic.  Same rows in the same order: same bits.
+      if (r + last < r1) {
+        Trip cur;
+        load_trip(cur, r);
+        r += step;
+        while (r + last < r1) {
+          Trip nxt;
+          load_trip(nxt, r);
+          acc_trip(cur);
+          cur = nxt;
+          r += step;
+        }
+        acc_trip(cur);
+      }
+    } else {
+      for (; r + last < r1; r += step) {
+        Trip t;
+        load_trip(t, r);
+        acc_trip(t);
+      }
     }
     for (; r < r1; r += rs) {
       const uint4 tx = *(const uint4*)(x + r * ld_x + cv * 8);
-      const uint4 td = MODE == 1 ? (ps.dyp ? pool_grad8(ps, r, cv) : *(const uint4*)(dy + r * ld_dy + cv * 8)) : z4;
-      const uint4 t2 = (MODE == 1 && dy2) ? *(const uint4*)(dy2 + r * ld_dy2 + cv * 8) : z4;
-      const uint4 ty = (MODE == 1 && relu && !remask) ? *(const uint4*)(yout + r * ld_y + cv * 8) : z4;
+      const uint4 td = MODE == 1 ? (POOL ? pool_grad8(ps, r, cv) : *(const uint4*)(dy + r * ld_dy + cv * 8)) : z4;
+      const uint4 t2 = (MODE == 1 && has2) ? *(const uint4*)(dy2 + r * ld_dy2 + cv * 8) : z4;
+      const uint4 ty = (MODE == 1 && use_y) ? *(const uint4*)(yout + r * ld_y + cv * 8) : z4;
       row_acc(tx, td, t2, ty);
     }
   }
@@ -1058,7 +1093,7 @@ int MM_SYM(mm_bn2d_bwd_pool)(const void* x, int ld_x, const void* dyp, int ld_dy
   PoolSrc ps{(const u16*)dyp, (const unsigned char*)idx, ld_dyp, H, W, H / 2, W / 2, C};
   int nb0, nb1, ab0, ab1;
   split_blocks(N, Ns, C, true, nb0, nb1);
-  hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)nullptr, 0, (const u16*)nullptr, 0, 1, N, C,
+  hipLaunchKernelGGL((k_bn2d_reduce<1, true>), dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)nullptr, 0, (const u16*)nullptr, 0, 1, N, C,
                      save_mean, save_invstd, partial, Ns, nb0, weight, bias, (const u16*)dy2, ld_dy2, ps);
   hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   split_blocks(N, Ns, C, false, ab0, ab1);
@@ -1203,8 +1238,21 @@ int MM_SYM(mm_bn2d_bwd)(void* h, const void* x, int ld_x, const void* dy, int ld
     return MM_OK;
   }
   split_blocks(N, Ns, C, true, nb0, nb1);
-  hipLaunchKernelGGL(k_bn2d_reduce<1>, dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy, (const u16*)yout, ld_y,
-                     relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias, (const u16*)dy2, ld_dy2);
+#define MM_RED1(H2, YO)                                                                                                                \
+  hipLaunchKernelGGL((k_bn2d_reduce<1, false, H2, YO>), dim3(nb0 + nb1), dim3(T), 0, s, (const u16*)x, ld_x, (const u16*)dy, ld_dy,    \
+                     (const u16*)yout, ld_y, relu, N, C, save_mean, save_invstd, partial, Ns, nb0, weight, bias, (const u16*)dy2, ld_dy2, \
+                     PoolSrc{})
+  {
+    const bool yo = relu && yout != nullptr;
+    if (dy2) {
+      if (yo) MM_RED1(true, true);
+      else MM_RED1(true, false);
+    } else {
+      if (yo) MM_RED1(false, true);
+      else MM_RED1(false, false);
+    }
+  }
+#undef MM_RED1
   hipLaunchKernelGGL(k_bn2d_finalize_bwd, dim3(C), dim3(256), 0, s, partial, nb0, nb1, C, sums, dweight, dbias, accumulate);
   if (N > 0) {
     split_blocks(N, Ns, C, false, ab0, ab1);

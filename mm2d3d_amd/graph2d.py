@@ -114,11 +114,13 @@ class _Graph:
         # straight into the optimiser's arena), and gradsink.done - the per-step Python bookkeeping - is collected here, not fired,
         # and repeated after every replay.  Every node of the trunk lies on a path to the anchor (the stems), so none is pruned.
         hold = gradsink.collect_hooks()
+        c2d._WGB.begin_capture(self.img.device)
         try:
             with torch.cuda.graph(self.bwd, pool=self.pool, stream=self.stream, capture_error_mode="thread_local"):
                 torch.autograd.grad([segm, avg], [self.anchor], [self.d1, self.d2], allow_unused=True)
         finally:
             sunk = gradsink.release_hooks(hold)
+        self.wg_tables = c2d._WGB.fill_captured()  # descriptor tables of the captured slab-sum launch (constant: uploaded once, now)
         missing = [n for n, p in net.named_parameters() if p.requires_grad and hasattr(p, "_mm_sink") and not any(p is q for q in sunk)
                    and not n.startswith("aux.linear")]
         if missing:
