@@ -893,6 +893,17 @@ __device__ inline void c3_decode(const C3P& p, const C3Sched& sc, int item, int&
   ty0 = (t % p.tiles_y) * (256 / TW);
   b = t / p.tiles_y;
 }
+// Loader requests that may be in flight at the barrier of tap T (see c3_loader): halo parts of 2 instructions behind taps 0..4, the
+// eleventh instruction (absent in wave 3) behind tap 5, a weight tile of NB instructions behind every tap.
+constexpr int c3_halo_part(int t, bool wave3) { return t < 0 ? 0 : t < 5 ? 2 : t == 5 ? (wave3 ? 0 : 1) : 0; }
+constexpr int c3_allow(int T, int RW, int NB, bool wave3) {
+  // behind a barrier the halo part goes first, then the weight tile (the other order measured 1 % slower): W(g), requested at
+  // tap T - (RW - 1), is older than everything the later taps requested
+  int a = 0;
+  for (int v = T - (RW - 1) + 1; v <= T - 1; v++) a += NB + c3_halo_part(v, wave3);
+  if (T == 8 && a > 3 * NB) a = 3 * NB;  // the last halo part (tap 5) is followed by the tiles of taps 5, 6 and 7
+  return a;
+}
 // The four loader waves (tid = 0..255 within the role): thread (r0 = 0..31, cc) fetches 16-byte chunk cc of rows r0 + 32 i.  HSWZ: the
 // bank swizzle of the halo rows, by the halo column hx: 1 = chunk ^ ((hx >> 1) & 7) (k_conv3x3w's, for the 32x32x16 fragment reads),
 // 0 = chunk ^ (hx & 7) (for the 16x16x32 reads of k_conv3x3s).  (Measured and dropped: weight tiles and halos on separate waves, two
@@ -922,29 +933,42 @@ __device__ inline void c3_loader(const C3P& p, const C3Sched& sc, char* const ld
   }
   int h_k = 0, h_c = 0, h_b, h_ty0, h_tx0, h_n0, h_half;
   decode(item_of(0, h_half), h_b, h_ty0, h_tx0, h_n0);
-  auto issue_halo = [&](int buf) {  // 11 DMA instructions (10 for wave 3), always; then advance the cursor
-    const bool live = h_k < my_items && !MM_DIAG(p, 8);
-    const bool interior = live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
-    const u16* base = (h_b < p.B1 ? p.A + (int64_t)h_b * p.H * p.W * p.lda : p.A1 + (int64_t)(h_b - p.B1) * p.H * p.W * p.lda) +
-                      ((int64_t)h_ty0 * p.W + h_tx0) * p.lda + h_c * 64;
-    char* dst = lds + HS0 + buf * HSZB + wave * 1024;
-    if (interior) {
+  // One halo = 11 DMA instructions per thread (10 for wave 3), issued in PARTS (round 6): instructions 2t, 2t + 1 behind the barrier
+  // of tap t = 0..4 and the eleventh behind tap 5's.  Requested whole at tap 0 (rounds 2-5), the 41.5 KB of every workgroup left at
+  // once - 10 MB over the chip, from HBM - and the weight tiles requested behind them could not be published before they had
+  // landed (vmcnt is in order): tools/conv3x3_diag.hip showed 0.3-0.4 us per tap step going to the halo although it was a whole
+  // segment ahead.  In parts, 8 KB follow each weight tile and a tile waits for at most the part just ahead of it.
+  bool hb_live = false, hb_interior = false;
+  const u16* hb_base = nullptr;
+  char* hb_dst = nullptr;
+  auto halo_begin = [&](int buf) {
+    hb_live = h_k < my_items && !MM_DIAG(p, 8);
+    hb_interior = hb_live && h_ty0 >= 1 && h_ty0 + TH < p.H && h_tx0 >= 1 && h_tx0 + TW < p.W;
+    hb_base = (h_b < p.B1 ? p.A + (int64_t)h_b * p.H * p.W * p.lda : p.A1 + (int64_t)(h_b - p.B1) * p.H * p.W * p.lda) +
+              ((int64_t)h_ty0 * p.W + h_tx0) * p.lda + h_c * 64;
+    hb_dst = lds + HS0 + buf * HSZB + wave * 1024;
+  };
+  auto halo_part = [&](auto i0c, auto i1c) {  // instructions [I0, I1) of the halo begun last; always issued (dummy reads hit the zero line)
+    constexpr int I0 = decltype(i0c)::value, I1 = decltype(i1c)::value;
+    if (hb_interior) {
 #pragma unroll
-      for (int i = 0; i < 11; i++)
+      for (int i = I0; i < I1; i++)
         if (i < 10 || wave < 3)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + hl[i]),
-                                           (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(hb_base + hl[i]),
+                                           (__attribute__((address_space(3))) void*)(hb_dst + i * 4096), 16, 0, 0);
     } else {
 #pragma unroll
-      for (int i = 0; i < 11; i++) {
+      for (int i = I0; i < I1; i++) {
         if (i == 10 && wave >= 3) break;
         const int y = h_ty0 + (hyx[i] >> 16), x = h_tx0 + (short)(hyx[i] & 0xFFFF);
-        const bool ok = live && y >= 0 && y < p.H && x >= 0 && x < p.W;
-        const u16* g = ok ? base + hl[i] : (const u16*)g_zero16;
+        const bool ok = hb_live && y >= 0 && y < p.H && x >= 0 && x < p.W;
+        const u16* g = ok ? hb_base + hl[i] : (const u16*)g_zero16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(hb_dst + i * 4096), 16, 0, 0);
       }
     }
+  };
+  auto halo_end = [&]() {  // advance the cursor
     if (++h_c == nchunk) {
       h_c = 0;
       if (++h_k < my_items) decode(item_of(h_k, h_half), h_b, h_ty0, h_tx0, h_n0);
@@ -981,29 +1005,38 @@ __device__ inline void c3_loader(const C3P& p, const C3Sched& sc, char* const ld
     }
   };
   // Ring protocol of k_conv3x3w (one barrier per step g = (segment, tap); a loader passes it once ITS pieces of W(g) have landed;
-  // W(g + RW - 1) and, at tap 0, the next segment's halo are requested right behind it), plus ONE barrier ahead of the first step
-  // that publishes the first halo: the multiplying waves request their first pixel fragments behind it.
-  issue_halo(0);
+  // W(g + RW - 1) is requested right behind it, preceded at taps 0..5 by a part of the next segment's halo), plus ONE barrier ahead
+  // of the first step that publishes the first halo: the multiplying waves request their first pixel fragments behind it.
+  // C3_ALLOW(T): requests that may still be in flight at the barrier of tap T = those younger than W(g) (issued RW - 1 taps
+  // earlier; halo parts of the PREVIOUS segment are not counted: one count for every segment, the first included) - and at tap 8 at
+  // most the three weight tiles younger than the last halo part: the multiplying waves request the next segment's first pixel
+  // fragments before the next barrier.
+  halo_begin(0);
+  halo_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 11>{});
+  halo_end();
 #pragma unroll
   for (int d = 0; d < RW - 1; d++) issue_w(d);
   wait_vm<(RW - 1) * NB>();  // the first halo is the oldest request: everything younger may still be in flight
   __builtin_amdgcn_s_barrier();
   int wslot = RW - 1;
-  for (int seg = 0; seg < nseg; seg++) {
-#pragma unroll
-    for (int tap = 0; tap < 9; tap++) {
-      if (tap >= 1 && tap <= RW - 2) {  // the halo requested at tap 0 is younger than W(g)
-        if (wave < 3) wait_vm<(RW - 2) * NB + 11>();
-        else wait_vm<(RW - 2) * NB + 10>();
-      } else {
-        wait_vm<(RW - 2) * NB>();
-      }
-      __builtin_amdgcn_s_barrier();
-      if (tap == 0) issue_halo((seg + 1) & 1);
-      issue_w(wslot);
-      wslot = wslot + 1 == RW ? 0 : wslot + 1;
-    }
+#define C3_TAP(T)                                                                                        \
+  {                                                                                                      \
+    if (wave < 3) wait_vm<c3_allow(T, RW, NB, false)>();                                                 \
+    else wait_vm<c3_allow(T, RW, NB, true)>();                                                           \
+    __builtin_amdgcn_s_barrier();                                                                        \
+    if (T == 0) halo_begin((seg + 1) & 1);                                                               \
+    if (T < 5) halo_part(std::integral_constant<int, 2 * (T < 5 ? T : 0)>{}, std::integral_constant<int, 2 * (T < 5 ? T : 0) + 2>{}); \
+    if (T == 5) {                                                                                        \
+      halo_part(std::integral_constant<int, 10>{}, std::integral_constant<int, 11>{});                   \
+      halo_end();                                                                                        \
+    }                                                                                                    \
+    issue_w(wslot);                                                                                      \
+    wslot = wslot + 1 == RW ? 0 : wslot + 1;                                                             \
   }
+  for (int seg = 0; seg < nseg; seg++) {
+    C3_TAP(0) C3_TAP(1) C3_TAP(2) C3_TAP(3) C3_TAP(4) C3_TAP(5) C3_TAP(6) C3_TAP(7) C3_TAP(8)
+  }
+#undef C3_TAP
   wait_vm<0>();  // the dummy W tiles / dummy halo of the tail are still in flight: drain before the LDS is released
 }
 
@@ -1313,6 +1346,8 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
   // ---- the four multiplying waves
   const int l15 = lane & 15, g4 = lane >> 4;
   const int schunk = frag_chunk(lane);
+  // byte offset of this lane's 16-byte output chunk from the first element of (the wave's first pixel, the item's first channel)
+  const unsigned lane_boff = (unsigned)((((pixbase / TW) * p.W + l15) * p.ldo + 8 * schunk) * 2);
   const int rstep = p.flip ? -(HC * 128) : HC * 128, rbase = p.flip ? 2 * HC * 128 : 0;  // halo row offset of filter row kh: rbase + kh * rstep
   f32x4 acc[NF][4];
 #pragma unroll
@@ -1445,6 +1480,14 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
           }
       return;
     }
+    // Addresses (round 6): the item's first output element is wave-uniform (scalar arithmetic), fragment f adds a uniform row / column
+    // step, the lane a constant byte offset (lane_boff) - per store one scalar add and a compare.  The form before computed a 64-bit
+    // product per lane and store and tested p.bias per element: ~350 cycles per store, 5.8 us per item with the matrix pipe idle
+    // (tools/conv3x3_diag.hip "no epilogue").
+    u16* const item0 = Obase + ((int64_t)(bl * p.H + ty0) * p.W + tx0) * p.ldo + cbase;
+    const int y_first = ty0 + pixbase / TW;
+    const int xlane = tx0 + l15;
+    const bool has_bias = p.bias != nullptr;
 #pragma unroll
     for (int jp = 0; jp < NP; jp++) {
 #pragma unroll
@@ -1455,6 +1498,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
 #pragma unroll
         for (int ff = 0; ff < 4; ff++) {
           const int f = 4 * sbl + ff;
+          const int f_dy = (16 * f) / TW, f_dx = (16 * f) % TW;  // fragment f's first pixel relative to the wave's first pixel
           unsigned d[2][2];  // [tile 2 jp + u][packed pair]: couts 16 (2 jp + u) + 4 g4 + (0,1 | 2,3) of this lane's pixel
 #pragma unroll
           for (int u = 0; u < 2; u++) {
@@ -1462,8 +1506,11 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
               v[r] = acc[f][2 * jp + u][r];
-              if (p.bias) v[r] += biasl[cbase + 16 * (2 * jp + u) + 4 * g4 + r];
               acc[f][2 * jp + u][r] = 0.f;
+            }
+            if (has_bias) {
+              const float4 bv = *(const float4*)(biasl + cbase + 16 * (2 * jp + u) + 4 * g4);
+              v[0] += bv.x, v[1] += bv.y, v[2] += bv.z, v[3] += bv.w;
             }
             d[u][0] = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
             d[u][1] = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
@@ -1473,12 +1520,10 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
           const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
           const uint4 x = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-          const int pix = pixbase + 16 * f + l15;
-          const int y = ty0 + pix / TW, xx = tx0 + pix % TW;
-          const bool in = y < p.H && xx < p.W;
+          const bool in = y_first + f_dy < p.H && xlane + f_dx < p.W;
           if (slab) stats_accum(x, in, st);
-          u16* const row = Obase + ((int64_t)(bl * p.H + y) * p.W + xx) * p.ldo + cbase + 32 * jp + 8 * schunk;
-          *(uint4*)(in ? row : (u16*)g_dump + lane * 8) = x;
+          const char* const frag0 = (const char*)(item0 + ((int64_t)f_dy * p.W + f_dx) * p.ldo + 32 * jp);  // uniform
+          if (in) *(uint4*)(frag0 + lane_boff) = x;
         }
         if (slab) stats_store(slab, srow0 + 2 * sbl, p.Cn, cbase + 32 * jp, lane, row_reduce_scatter16(st, l15), true);
       }
