@@ -431,7 +431,7 @@ struct C3P {
   const float* bias;
   int flip;  // 0: tap (kh,kw) reads (y+kh-1, x+kw-1) (forward); 1: reads (y+1-kh, x+1-kw) (data gradient)
   int whole; // != 0: never cut a ragged last round into half items (A/B measurements)
-  int legacy;  // 0: k_conv3x3s (16x16x32 MFMAs)  1: the round-2 kernel k_conv3x3w  2: k_conv3x3v (32x32x16 MFMAs, bit-identical with 1) - A/B, tests
+  int legacy;  // 0: k_conv3x3s (16x16x32 MFMAs)  1: the round-2 kernel k_conv3x3w  2: k_conv3x3v (32x32x16 MFMAs, bit-identical with 1)  3: k_conv3x3s also for 64 -> 64 (instead of k_conv3x3r) - A/B, tests
   float* stats;  // BatchNorm statistics slab (see stats_accum), or NULL
   int split_b;   // images [0, split_b) are statistics group 0, the others group 1
   int tiles_y, tiles_x;
@@ -909,10 +909,13 @@ constexpr int c3_allow(int T, int RW, int NB, bool wave3) {
 // 0 = chunk ^ (hx & 7) (for the 16x16x32 reads of k_conv3x3s).  (Measured and dropped: weight tiles and halos on separate waves, two
 // each, so that a tile never queues behind a slower halo request - a wave sustains only ~16-25 GB/s of LDS-DMA, and two waves for the
 // 16 KB per step of weights were slower than four sharing everything: 1.14 against 1.10 us per step.)
-template <int BN, int TW, int HSWZ, int DIAG>
+// RES (64 -> 64 layers, k_conv3x3s<64, TW, DIAG, true>): the nine weight tiles stay RESIDENT in nine slots; the loaders fetch them once
+// and then only halos - one barrier per item (see the end of this function).
+template <int BN, int TW, int HSWZ, int DIAG, bool RES = false>
 __device__ inline void c3_loader(const C3P& p, const C3Sched& sc, char* const lds, const int tid) {
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;
-  constexpr int HSZB = 344 * 128, RW = BN == 128 ? 4 : 8, BSZB = BN * 128, NB = BN / 32, HS0 = RW * BSZB;
+  constexpr int HSZB = 344 * 128, RW = RES ? 9 : BN == 128 ? 4 : 8, BSZB = BN * 128, NB = BN / 32, HS0 = RW * BSZB;
+  static_assert(!RES || BN == 64, "resident weights: 64 -> 64 layers only");
   const int wave = tid >> 6, cc = tid & 7, r0 = tid >> 3;
   const int nchunk = sc.nchunk, ncb = sc.ncb, my_items = sc.my_items, nseg = sc.nseg;
   auto item_of = [&](int k, int& half) { return sc.item_of(k, half); };
@@ -1011,6 +1014,26 @@ __device__ inline void c3_loader(const C3P& p, const C3Sched& sc, char* const ld
   // earlier; halo parts of the PREVIOUS segment are not counted: one count for every segment, the first included) - and at tap 8 at
   // most the three weight tiles younger than the last halo part: the multiplying waves request the next segment's first pixel
   // fragments before the next barrier.
+  if (RES) {
+    // resident weights: tiles 0..8 once, then per item: its halo has landed -> barrier (the multiplying waves have left the other
+    // halo buffer) -> the next item's halo, whole (no weight tile can queue behind it)
+#pragma unroll
+    for (int t = 0; t < 9; t++) issue_w(t);
+    halo_begin(0);
+    halo_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 11>{});
+    halo_end();
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // publishes the weights and the first halo
+    for (int seg = 0; seg < nseg; seg++) {
+      wait_vm<0>();
+      __builtin_amdgcn_s_barrier();
+      halo_begin((seg + 1) & 1);
+      halo_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 11>{});
+      halo_end();
+    }
+    wait_vm<0>();
+    return;
+  }
   halo_begin(0);
   halo_part(std::integral_constant<int, 0>{}, std::integral_constant<int, 11>{});
   halo_end();
@@ -1305,18 +1328,22 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3v(C3P p) {
 // lane group g = frag_chunk's order - so stores are 16 x 64-byte segments and stats_accum / stats_store apply unchanged.  Results
 // differ from k_conv3x3w in the last bits (one 32-deep MFMA instead of two 16-deep ones); tests compare it with torch.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int BN, int TW, int DIAG = 0>
+// RES (round 6, the 64 -> 64 layers of layer1 - k_conv3x3r's job until then): Ca = Cn = 64, the nine 8 KB weight tiles RESIDENT in nine
+// slots (72 KB + 86 KB of halo ring), no weight DMA per item and ONE barrier per item instead of nine; a workgroup serves one problem of a
+// pair (item list split at an XCD boundary, as for k_conv3x3r).  The first pixel quad of an item is requested behind its barrier.
+template <int BN, int TW, int DIAG = 0, bool RES = false>
 __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
   extern __shared__ __attribute__((aligned(16))) char smemc[];
 #ifndef MM_DIAG_SHARED_CU
   asm volatile("" ::: "v255");  // 8 waves x 256 registers + the whole LDS: the CU is owned by this workgroup (see c3_launch)
 #endif
   constexpr int TH = 256 / TW, HC = TW + 2, HROWS = (TH + 2) * HC;
-  constexpr int HSZB = 344 * 128, RW = BN == 128 ? 4 : 8, BSZB = BN * 128, NB = BN / 32, HS0 = RW * BSZB;
+  constexpr int HSZB = 344 * 128, RW = RES ? 9 : BN == 128 ? 4 : 8, BSZB = BN * 128, NB = BN / 32, HS0 = RW * BSZB;
   constexpr int NQ = BN == 128 ? 2 : 1;  // quads of 16-pixel fragments per multiplying wave
   constexpr int NF = 4 * NQ;             // 16-pixel fragments per wave (x 4 cout fragments of 16)
   constexpr int NC = TW == 16 ? 1 : 2;   // column groups of a wave's pixel fragments (TW = 32: fragment f sits at columns 16 (f & 1) ..)
-  static_assert(HROWS <= 344 && RW - 2 <= 8 && (RW - 2) * NB + 11 < 64, "halo pieces / ring protocol / vmcnt range");
+  static_assert(HROWS <= 344 && (RES || (RW - 2 <= 8 && (RW - 2) * NB + 11 < 64)), "halo pieces / ring protocol / vmcnt range");
+  static_assert(!RES || BN == 64, "resident weights: 64 -> 64 layers only");
   char* const lds = smemc;
   float* biasl = (float*)(lds + HS0 + 2 * HSZB);  // [Cn <= 1024] when p.bias
   const bool loader = threadIdx.x >= 256;
@@ -1339,7 +1366,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
   const int my_items = sc.my_items, nseg = sc.nseg, r_full = sc.r_full, nchunk = sc.nchunk, ncb = sc.ncb;
   if (my_items == 0) return;
   if (loader) {
-    c3_loader<BN, TW, 0, DIAG>(p, sc, lds, tid);
+    c3_loader<BN, TW, 0, DIAG, RES>(p, sc, lds, tid);
     return;
   }
 
@@ -1370,7 +1397,7 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
 #define MM_FCOL(f) (TW == 16 ? 0 : (f) & 1)                   /* its column group */
   __builtin_amdgcn_s_barrier();  // the first halo has landed
   asm volatile("" ::: "memory");
-  {  // the first quad of the first step (tap 0: filter column 0, K slice 0)
+  if (!RES) {  // the first quad of the first step (tap 0: filter column 0, K slice 0); RES requests it behind the item's barrier
     int a0[NC];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
@@ -1407,14 +1434,18 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
       int nso = (tap == 8 ? hbn : hb) + rbase + nkh * rstep;     // the next step's (the other buffer behind tap 8)
       asm volatile("" : "+s"(so), "+s"(nso));
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_barrier();  // W(g) has landed; every wave has finished step g - 1
+      if (!RES || tap == 0) __builtin_amdgcn_s_barrier();  // W(g) has landed; every wave has finished step g - 1 (RES: the item's halo has landed)
       asm volatile("" ::: "memory");
-      const int tb = bq + slot;
-#pragma unroll
-      for (int j = 0; j < NJ; j++) MM_LDSO(Bq[0][j], tb, j * 2048);
+      const int tb = bq + (RES ? tap * BSZB : slot);
       int ta[NC], tn[NC];
 #pragma unroll
       for (int c = 0; c < NC; c++) ta[c] = ab[c][kw] + so, tn[c] = ab[c][nkw] + nso;
+      if (RES && tap == 0) {  // the first quad of the item: requested behind the item's barrier (the read before it hit a buffer in flight)
+#pragma unroll
+        for (int ff = 0; ff < 4; ff++) MM_LDSO(Aq[0][ff], ta[MM_FCOL(ff)], MM_FROW(ff));
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) MM_LDSO(Bq[0][j], tb, j * 2048);
 #pragma unroll
       for (int n = 0; n < 2 * NQ; n++) {  // group n = (K slice s, quad q): 4 x NJ MFMAs
         const int s = n / NQ, q = n % NQ, set = n & 1;
@@ -1428,12 +1459,17 @@ __global__ __launch_bounds__(512, 1) void k_conv3x3s(C3P p) {
             for (int j = 0; j < NJ; j++) MM_LDSO(Bq[s2][j], tb ^ (s2 << 6), j * 2048);
             issued += NJ;
           }
+        } else if (RES && tap == 8) {  // (RES: the next item's first quad is requested behind its barrier - no request may be in
+          issued = 0;                  // flight into registers that the compiler considers rewritten by that later request)
         } else {  // the first quad of the NEXT step (behind the last step: a harmless read of the idle buffer)
 #pragma unroll
           for (int ff = 0; ff < 4; ff++) MM_LDSO(Aq[set ^ 1][ff], tn[MM_FCOL(ff)], MM_FROW(ff));
         }
         // LDS reads return in order: everything but the `issued` requests just made has arrived
-        if (issued == 4) {
+        if (issued == 0) {
+          if (NJ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]), "+v"(Bq[s][2]), "+v"(Bq[s][3]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]));
+        } else if (issued == 4) {
           if (NJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]), "+v"(Bq[s][2]), "+v"(Bq[s][3]));
           else asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(Aq[set][0]), "+v"(Aq[set][1]), "+v"(Aq[set][2]), "+v"(Aq[set][3]), "+v"(Bq[s][0]), "+v"(Bq[s][1]));
         } else if (NJ == 4) {
@@ -2858,7 +2894,16 @@ static int c3_launch(C3P p, hipStream_t s) {
       MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3w<128, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
       mm_attr_done(&once_w);
     }
-    if (Ca == 64 && Cn == 64) {  // weights resident in LDS
+    if (Ca == 64 && Cn == 64 && p.legacy == 0) {  // weights resident in LDS, k_conv3x3s's multiplying waves (round 6)
+      static unsigned once_q = 0;  // per-device bit: see mm_attr_todo (common.h)
+      if (mm_attr_todo(&once_q)) {
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3s<64, 16, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3s<64, 32, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+        mm_attr_done(&once_q);
+      }
+      if (tw == 16) hipLaunchKernelGGL((k_conv3x3s<64, 16, 0, true>), dim3((unsigned)grid), dim3(512), 163840, s, p);
+      else hipLaunchKernelGGL((k_conv3x3s<64, 32, 0, true>), dim3((unsigned)grid), dim3(512), 163840, s, p);
+    } else if (Ca == 64 && Cn == 64 && p.legacy != 3) {  // weights resident in LDS, eight multiplying waves (round 3; legacy 1 / 2: A/B, tests)
       const int hrows = tw == 16 ? 18 * 18 : 10 * 34;
 #ifdef MM_DIAG_SHARED_CU
       const size_t ldsr = (size_t)9 * 64 * 128 + 2 * (size_t)((hrows + 7) / 8) * 8 * 128 + 256;
@@ -2874,10 +2919,10 @@ static int c3_launch(C3P p, hipStream_t s) {
       }
       if (tw == 16) hipLaunchKernelGGL(k_conv3x3r<16>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
       else hipLaunchKernelGGL(k_conv3x3r<32>, dim3((unsigned)grid), dim3(512), ldsr, s, p);
-    } else if (p.legacy != 1 && !(p.legacy == 0 && bn == 64 && Ca == 64)) {  // 128 x 64 register tiles, four multiplying + four loader waves
-      // (Ca = 64 with 64-cout blocks - the data gradients of the decoder's 192 -> 64 convolutions - stays on k_conv3x3w: one chunk per
-      // item means an epilogue every nine steps, and the 16-wave kernel hides it better: 617 against 643 us at 304 x 480, 176 / 182 at
-      // 152 x 240, tools/conv3x3_bench_shapes.py)
+    } else if (p.legacy != 1) {  // four multiplying + four loader waves
+      // (Ca = 64 with 64-cout blocks - the data gradients of the decoder's 192 -> 64 convolutions, an epilogue every nine steps - was
+      // kept on k_conv3x3w while k_conv3x3s's epilogue cost 5.8 us per item; with the scalar-addressed epilogue it is 13-14 % faster
+      // there too: 541 against 625 us at 304 x 480, 142 / 165 at 152 x 240, tools/conv3x3_bench_shapes.py)
       static unsigned once_v = 0;  // per-device bit: see mm_attr_todo (common.h)
       if (mm_attr_todo(&once_v)) {
         MM_HIP(hipFuncSetAttribute((const void*)k_conv3x3v<64, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));

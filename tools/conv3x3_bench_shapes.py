@@ -23,6 +23,7 @@ L = c2.lib2d()
 
 # (name, pair, Ca, Cn, H, W, launches per step)
 SHAPES = [
+    ("layer1 64->64 pair", True, 64, 64, 152, 240, 12),
     ("layer2 128->128 pair", True, 128, 128, 76, 120, 14),
     ("layer3 256->256 pair", True, 256, 256, 38, 60, 22),
     ("layer4 512->512 pair", True, 512, 512, 19, 30, 10),
@@ -36,7 +37,7 @@ SHAPES = [
     ("dec1 dgrad 64->192", False, 64, 192, 304, 480, 1),
 ]
 B = 16
-FLAGS = (0, 8, 4)
+FLAGS = (0, 8, 4, 12)  # 12: k_conv3x3s also where the dispatch (flag 0) takes the weights-resident k_conv3x3r (64 -> 64)
 tot = {f: 0.0 for f in FLAGS}
 for name, pair, Ca, Cn, H, W, per_step in SHAPES:
     xs = [torch.randn(B, H, W, Ca, device=dev).to(dt) for _ in range(2)]
@@ -74,5 +75,5 @@ for name, pair, Ca, Cn, H, W, per_step in SHAPES:
     for f in m:
         tot[f] += m[f] * per_step
     print(f"{name:24s} {H:3d}x{W:3d}  s {m[0]:7.1f} us {gf / m[0] * 1e3:5.0f} TF/s | v {m[8]:7.1f} us {gf / m[8] * 1e3:5.0f} TF/s | w {m[4]:7.1f} us {gf / m[4] * 1e3:5.0f} TF/s | "
-          f"s/w {m[0] / m[4]:.3f} v/w {m[8] / m[4]:.3f}  v==w {same}", flush=True)
+          f"s/w {m[0] / m[4]:.3f} v/w {m[8] / m[4]:.3f}  v==w {same} | s forced {m[12]:7.1f} us", flush=True)
 print(f"per step (launch counts of the headline step): s {tot[0] / 1e3:.3f} ms, v {tot[8] / 1e3:.3f} ms, w {tot[4] / 1e3:.3f} ms")
