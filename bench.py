@@ -561,7 +561,14 @@ def main(argv=None):
         # "nccl" is RCCL on ROCm.  MM_BENCH_BACKEND=gloo is a rehearsal mode (several ranks sharing one GPU box).
         backend = os.environ.get("MM_BENCH_BACKEND", "nccl")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # WITHOUT device_id= (round 6): binding the group to the device at init ("eager" communicator) made every step of this
+            # process 1.5-1.7 ms slower on a one-rank group - with the reducer switched off and not one collective issued (34.2 against
+            # 32.5 ms, same box, back to back; profiles/r06/README.md) - the lazily created communicator does not.  The device is
+            # chosen by torch.cuda.set_device above.  MM_BENCH_PG_EAGER=1 restores the eager form (A/B record only).
+            if os.environ.get("MM_BENCH_PG_EAGER", "0") != "0":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(backend)
 
@@ -596,7 +603,10 @@ def main(argv=None):
 
     def sync():
         if world > 1:
-            dist.barrier()
+            if backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     # a loader hands the next batch over while the current step runs: fit_step(next_batch=) builds its sparse metadata one step

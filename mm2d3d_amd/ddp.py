@@ -355,25 +355,42 @@ class GradAllReducer:
         return bool(int(self._flag_host[cur][0])) or bool(int(self._flag_host[cur][1]))
 
     def broadcast_buffers(self, modules, src=0):
-        """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a
-        dtype travel in ONE coalesced broadcast (≈0.15 MB), as DDP does."""
+        """torch DDP's default ``broadcast_buffers=True``: rank 0's BN running stats win.  All buffers of a dtype
+        travel in ONE broadcast, as DDP's coalesced broadcast does - but without its per-step flatten / unflatten copies (round 6:
+        ~300 small device copies per step for the two networks' ~100 batch norms, 0.9 ms of a 34 ms step on one forced RCCL rank):
+        the buffers LIVE in one flat tensor per dtype (their ``.data`` re-pointed once, the Tensor objects stay the modules'), which
+        is broadcast in place.  A buffer that was replaced or moved since (``module.to()``, a new module) is noticed by its
+        address and the arenas are rebuilt."""
         if not self.active:
             return
-        by_dtype = {}
-        for m in modules:
-            for buf in m.buffers():
-                by_dtype.setdefault(buf.dtype, []).append(buf)
-        pg = self.group if self.group is not None else dist.group.WORLD
-        for bufs in by_dtype.values():
-            if hasattr(dist, "_broadcast_coalesced"):
-                dist._broadcast_coalesced(pg, bufs, 256 << 20, src)
-            else:  # pragma: no cover
-                flat = torch.cat([b.reshape(-1) for b in bufs])
-                dist.broadcast(flat, src=src, group=self.group)
-                off = 0
-                for b in bufs:
-                    b.copy_(flat[off : off + b.numel()].view_as(b))
-                    off += b.numel()
+        bufs = [buf for m in modules for buf in m.buffers()]
+        st = getattr(self, "_buf_state", None)
+        if st is None or len(st["bufs"]) != len(bufs) or any(a is not b or a.data_ptr() != p for a, b, p in zip(st["bufs"], bufs, st["ptrs"])):
+            st = self._flatten_buffers(bufs)
+        for flat in st["flat"]:
+            dist.broadcast(flat, src=src, group=self.group)
+
+    def _flatten_buffers(self, bufs):
+        by_key = {}
+        for b in bufs:
+            by_key.setdefault((b.dtype, b.device), []).append(b)
+        flats = []
+        with torch.no_grad():
+            for (dtype, device), group in by_key.items():
+                # every slice 16-byte aligned (the batch-norm kernels read their statistics with vector loads)
+                step = max(1, 16 // torch.empty((), dtype=dtype).element_size())
+                offs, n = [], 0
+                for b in group:
+                    offs.append(n)
+                    n += (b.numel() + step - 1) // step * step
+                flat = torch.zeros(max(n, 1), dtype=dtype, device=device)
+                for b, o in zip(group, offs):
+                    view = flat[o : o + b.numel()].view(b.shape)
+                    view.copy_(b)
+                    b.data = view
+                flats.append(flat)
+        self._buf_state = {"bufs": list(bufs), "ptrs": [b.data_ptr() for b in bufs], "flat": flats}
+        return self._buf_state
 
 
 def ranks_share_a_gpu() -> bool:

@@ -29,7 +29,7 @@ class TrainModel(nn.Module):
         self.loss = loss
         self.lambda_xm_src = train_kwargs.get("lambda_xm_src", 1.0)
         self.lambda_xm_trg = train_kwargs.get("lambda_xm_trg", 0.1)
-        self.broadcast_buffers = train_kwargs.get("broadcast_buffers", True)  # torch DDP default (run.py:264-268)
+        self.broadcast_buffers = bool(int(train_kwargs.get("broadcast_buffers", os.environ.get("MM_DDP_BROADCAST_BUFFERS", "1"))))  # torch DDP default (run.py:264-268)
         # One pass per network over [source scenes | target scenes] instead of one per domain: half the launches, twice
         # the rows per launch.  The batch-norm layers keep per-domain statistics (mm2d3d_amd/domains.py), so the
         # arithmetic is that of the reference's two calls.  False: the literal two-call sequence.

@@ -30,7 +30,7 @@ def test_forced_one_rank_rccl_step_equals_the_plain_step_bit_for_bit(monkeypatch
 
     dev = torch.device("cuda:0")
     L = _lib.lib()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         torch.manual_seed(0)
         kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
@@ -101,7 +101,7 @@ def test_fit_step_under_rccl_never_makes_the_host_wait_and_keeps_the_forward_bat
 
     dev = torch.device("cuda:0")
     _lib.lib()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         torch.manual_seed(1)
         kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
@@ -198,7 +198,7 @@ def test_the_rccl_step_keeps_the_one_gpu_step_s_side_stream_and_graphs(monkeypat
 
     dev = torch.device("cuda:0")
     _lib.lib()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         torch.manual_seed(3)
         kw = dict(in_channels=3, m=16, full_scale=4096, num_planes=7)
@@ -269,7 +269,7 @@ def test_a_flagged_step_is_skipped_on_the_device_and_the_relearn_step_does_not_r
 
     dev = torch.device("cuda:0")
     _lib.lib()
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1)
     try:
         for scaled in (False, True):
             torch.manual_seed(0)

@@ -58,6 +58,8 @@ for i in 1 2; do
   MM_DDP_FORCE=1 MM_DDP_GRAPH=1 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_graphs_$i.json 2>/dev/null
   MM_DDP_FORCE=1 MM_DDP_META_SIDE=0 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_round5_form_$i.json 2>/dev/null
   python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_none_$i.json 2>/dev/null
+  # init_process_group(device_id=) as in rounds 2-5: the eager communicator alone costs every step ~1.5 ms (reducer on / off)
+  MM_DDP_FORCE=1 MM_BENCH_PG_EAGER=1 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_eager_init_$i.json 2>/dev/null
 done
 python - > $O/ab_summary.txt <<'PY'
 import json, glob
