@@ -387,8 +387,12 @@ int64_t mm_conv2d_3x3s1_stat_rows(int B, int H, int W);
 /* 3x3 stride-1 pad-1 convolution (flip 0) or its data gradient (flip 1, Wp = [ci][tap][co]) from a halo tile staged once
  * for all 9 taps (EXP/2d_net/backbones.py ResNet34 BasicBlocks; EXP/2d_net/model.py:68-71 decoder convolutions).
  * flip | 2: a ragged last round of work items is NOT cut into half items (A/B measurements; results are the same sums).
- * flip | 4: the round-2 kernel (64-pixel x 64-cout register tiles, 16 waves) instead of the round-6 one (128 x 64 tiles, four
- * multiplying + four loader waves): bit-identical results, kept for A/B measurements and as the yardstick of the identity test. */
+ * flip bits 2-3 choose the kernel (A/B measurements and the identity tests; the results are the same sums):
+ *   0  the round-6 kernels: k_conv3x3s (four multiplying + four loader waves, 16x16x32 MFMAs; 64 -> 64 layers with the nine weight
+ *      tiles resident in LDS) - equal to the others up to the fp32 summation order inside one 32-deep product;
+ *   4  the round-2 kernel k_conv3x3w (16 waves, 32x32x16 MFMAs; 64 -> 64: the round-3 weights-resident k_conv3x3r);
+ *   8  k_conv3x3v (the 8-wave layout on 32x32x16 MFMAs): bit-identical with 4;
+ *  12  k_conv3x3s in its streaming form also for 64 -> 64. */
 int mm_conv2d_3x3s1(const void* A, int B, int H, int W, int Ca, int lda, void* O, int Cn, int ldo, const void* Wp,
                     const float* bias, int flip, float* stats, int split_b, mm_stream_t stream);
 /* Two such convolutions (or data gradients) of ONE shape - the same layer of the RGB and of the depth encoder, EXP/2d_net/model.py:43-46 -

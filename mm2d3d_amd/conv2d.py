@@ -79,7 +79,7 @@ import os as _os
 WHOLE_ITEMS = [2 if _os.environ.get("MM_CONV_WHOLE_ITEMS", "0") != "0" else 0]
 # ... bits 2-3: which 3x3 stride-1 kernel (A/B and tests; MM_CONV3X3_LEGACY = 1 / 2): 0 = k_conv3x3s (round 6, 16x16x32 MFMAs: the default),
 # 4 = the round-2 kernel k_conv3x3w, 8 = k_conv3x3v (round 6 on 32x32x16 MFMAs: bit-identical with k_conv3x3w)
-LEGACY3X3 = [{"1": 4, "2": 8}.get(_os.environ.get("MM_CONV3X3_LEGACY", "0"), 0)]
+LEGACY3X3 = [{"1": 4, "2": 8, "3": 12}.get(_os.environ.get("MM_CONV3X3_LEGACY", "0"), 0)]
 PARAM_EPOCH = [0]  # bumped by FlatAdamW.step(): packed bf16 copies of the fp32 master weights are valid for one epoch
 
 

@@ -388,6 +388,10 @@ def test_conv3x3_results_do_not_depend_on_kernels_of_other_streams():
     (192, 64, 9, (152, 240), False),   # ... with several items per workgroup and an odd chunk count
     (64, 192, 2, (33, 47), False),     # <64, .> with three cout blocks (their data gradient)
     (128, 64, 5, (8, 100), False),     # <64, 32>
+    (64, 64, 8, (152, 240), True),     # 64 -> 64: k_conv3x3s with RESIDENT weights (the default) against k_conv3x3r (flip | 4 and | 8), pair
+                                       # list split at an XCD boundary, nine items per workgroup
+    (64, 64, 5, (19, 23), False),      # ... ragged 8 x 32 tiles; 15 tiles per problem: the pair runs as two single launches
+    (64, 64, 3, (1, 1), False),        # ... one pixel
 ])
 def test_conv3x3_round6_kernels_against_the_first_kernel(cin, cout, B, hw, split, half2d):
     """Round 6: the 8-wave kernels with 128-pixel x 64-cout register tiles (four multiplying + four loader waves) against k_conv3x3w
@@ -395,7 +399,9 @@ def test_conv3x3_round6_kernels_against_the_first_kernel(cin, cout, B, hw, split
     epilogue - whole items, half items, one or two statistics groups, pair mode.
       k_conv3x3v (flip | 8, 32x32x16 MFMAs): every output element is the same chain of the same MFMAs in the same order -> bit for bit;
       k_conv3x3s (the default, 16x16x32 MFMAs): one 32-deep MFMA where the others issue two 16-deep ones -> equal up to the fp32
-      summation order, i.e. to one 16-bit ulp of the rounded outputs, and the slab sums to fp32 accuracy."""
+      summation order, i.e. to one 16-bit ulp of the rounded outputs, and the slab sums to fp32 accuracy.
+    64 -> 64 layers: flip | 4 and flip | 8 both select the round-3 weights-resident kernel k_conv3x3r, the default is k_conv3x3s with
+    resident weights (one barrier per item)."""
     from mm2d3d_amd import conv2d as c2, domains
     from mm2d3d_amd.conv2d import Conv2dFn, Conv2dPairFn
 

@@ -43,6 +43,7 @@ timeout -k 10 250 python tools/sparse_layers.py --workload c5 > $O/sparse_layers
 timeout -k 10 250 python tools/conv3x3_bench_shapes.py --reps 15 > $O/conv3x3_bench_shapes.txt 2>&1
 [ -x tools/_bin/conv3x3_diag_clk ] && timeout -k 10 300 tools/_bin/conv3x3_diag_clk > $O/conv3x3_diag_clocks.txt 2>&1
 timeout -k 10 300 python tools/dw16_ab.py > $O/dw16_ab.txt 2>&1
+[ -x tools/_bin/stream_diag ] && timeout -k 10 120 tools/_bin/stream_diag > $O/stream_diag.txt 2>&1
 python tools/bench_bn2d.py --no-shapes > $O/bn2d_layer_set.txt 2>&1
 # A/B records of the round's switches (same box, back to back)
 for i in 1 2 3; do
@@ -75,7 +76,7 @@ PY
 # copy what the judge reads; the counter records only if they still belong to this tree
 for f in smoke.log bench_n1.json bench_n1_driver_cmd.json bench_n1_profiled.json bench_n1_kernel_stats.csv bench_n1_serial_profiled.json bench_n1_serial_kernel_stats.csv \
          kernel_families_serial.txt bench_c4.json bench_c5.json bench_n1_bf16.json bench_n1_as_under_ddp.json sparse_layers_c2.txt sparse_layers_c4.txt sparse_layers_c5.txt \
-         conv3x3_bench_shapes.txt conv3x3_diag_clocks.txt dw16_ab.txt bn2d_layer_set.txt ab_summary.txt summary.txt pmc_sq_bench.json; do
+         conv3x3_bench_shapes.txt conv3x3_diag_clocks.txt dw16_ab.txt stream_diag.txt bn2d_layer_set.txt ab_summary.txt summary.txt pmc_sq_bench.json; do
   [ -f $O/$f ] && cp $O/$f $P/$f
 done
 python - <<'PY'
