@@ -252,7 +252,7 @@ GFLOP_2D_FWD_BY_IMAGE = {(302, 480): 228.9, (225, 400): 150.6}  # SURVEY.md 8d: 
 
 def conv2d_roofline(tm, batch, dev):
     """MFMA side of the step (north_star: "MFMA utilisation on the 2D GEMMs"): every launch of the 2D convolution entry points
-    (mm_conv2d_3x3s1 / mm_conv2d_3x3s1_pair = k_conv3x3s/r fwd + dgrad - one problem / the same layer of both encoders per launch -,
+    (mm_conv2d_3x3s1 / mm_conv2d_3x3s1_pair = k_conv3x3s fwd + dgrad - one problem / the same layer of both encoders per launch -,
     mm_conv2d_wgrad3x3_pair = the pairs' weight gradients, mm_conv2d_gemm = stems / strided / 1x1 / transposed convs fwd + dgrad,
     mm_conv2d_dgrad_s2 = the stride-2 data gradients by output parity, mm_conv2d_stem7 = the two 7x7 stems,
     mm_conv2d_wgrad = weight gradients incl. their slab reduction; mm_conv2d_wgrad_slabs / mm_conv2d_wgrad3x3_pair_slabs = the slab
@@ -345,7 +345,7 @@ def conv2d_roofline(tm, batch, dev):
                                    "TFLOP/s": round(tflop / (net * 1e-3), 1), "frac_of_peak": round(tflop / (net * 1e-3) / MFMA_BF16_PEAK_TFLOPS, 4)},
             "ms_by_entry_point": {n: round(v, 3) for n, v in ms.items()}, "launches": {n: len(v) for n, v in rec.items()},
             "storage": kind + " maps and packed weights, fp32 accumulate (v_mfma_f32_32x32x16_" + kind + " / 16x16x32)",
-            "kernel": "2D convolution set: k_conv3x3s<*> / k_conv3x3r (3x3 s1 fwd + dgrad), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
+            "kernel": "2D convolution set: k_conv3x3s<*> (3x3 s1 fwd + dgrad; 64 -> 64 with resident weights), k_conv_gemm<*> (stems, strided, 1x1, transposed), "
                       "k_wgrad3x3n / k_conv_wgrad2 + k_wgrad_reduce (weight gradients)",
             "mfma_busy_cycles_per_wave_cycle": busy, "mfma_busy_source": busy_src}
 

@@ -1,6 +1,8 @@
 #!/bin/bash
 # Round-6 measurement records (run on the GPU box from the repo root; $1 = git commit of the tree - the box has no .git):
-#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_r06.sh <commit>'
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_r06.sh <commit> a'   (counters, bench lines, kernel stats, workloads)
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash tools/collect_r06.sh <commit> b'   (per-layer listings, A/B records)
+# (two calls: together they take longer than one gpurun call may)
 # smoke, PMC traffic of the sparse engines, SQ counters of the 2D kernels (both BEFORE the bench: bench.py quotes roofline.traffic /
 # mfma_busy only from records whose source fingerprints match this tree), headline bench, kernel stats (default and serial) with
 # their family break-down, the other workloads, per-layer sparse listings, the 3x3 kernels at the bench's shapes and their
@@ -12,30 +14,49 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 export MM_GIT_HEAD="$1"
 O=gpurun_out/r06/final; P=profiles/r06; mkdir -p $O $P
-python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary.txt
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 tools/prof3d.py --bench-batch --steps 3 --warmup 1 > $O/prof3d_fetch.log 2>&1; echo "pmc fetch rc=$?" | tee -a $O/summary.txt
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 tools/prof3d.py --bench-batch --steps 3 --warmup 1 > $O/prof3d_write.log 2>&1; echo "pmc write rc=$?" | tee -a $O/summary.txt
+PART="${2:-ab}"
+summarise() {  # $1 = output file: one line per bench record present on this box
+python - > $1 <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r06/final/ab_*.json") + glob.glob("gpurun_out/r06/final/bench_*.json")):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); c = d["config"]
+        print(f.split("/")[-1].ljust(40), "value", d["value"], d["unit"], "| ms/step", d["ms_per_step"], "| p10/p50/p90", c.get("step_ms_p10_p50_p90"),
+              "| host enqueue (empty queue)", c.get("host_enqueue_ms_empty_queue"), "| final loss", c.get("final_loss"), "| roofline.frac", d.get("roofline", {}).get("frac"),
+              "| roofline_2d.frac", d.get("roofline_2d", {}).get("frac"))
+    except Exception as e:
+        print(f, "unreadable:", e)
+PY
+}
+if [[ "$PART" == *a* ]]; then
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $O/summary_$PART.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- python3 tools/prof3d.py --bench-batch --steps 3 --warmup 1 > $O/prof3d_fetch.log 2>&1; echo "pmc fetch rc=$?" | tee -a $O/summary_$PART.txt
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- python3 tools/prof3d.py --bench-batch --steps 3 --warmup 1 > $O/prof3d_write.log 2>&1; echo "pmc write rc=$?" | tee -a $O/summary_$PART.txt
 ALG=$(grep algorithmic_bytes_per_step $O/prof3d_fetch.log | awk '{print $2}')
-python tools/pmc_traffic.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv 5 16 $ALG "$1" > $O/traffic_3d.json 2> $O/traffic.err; echo "traffic rc=$?" | tee -a $O/summary.txt
+python tools/pmc_traffic.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv 5 16 $ALG "$1" > $O/traffic_3d.json 2> $O/traffic.err; echo "traffic rc=$?" | tee -a $O/summary_$PART.txt
 rm -rf $O/pmc_fetch $O/pmc_write   # raw counter files: tens of MB each, gpurun merges at most 64 MiB back
-MM_GRAPH2D=0 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_sq -- python3 bench.py --steps 3 --warmup 2 --no-extras > $O/pmc_sq_bench.json 2> $O/pmc_sq.err; echo "pmc sq rc=$?" | tee -a $O/summary.txt
-python tools/pmc_sq.py $O/pmc_sq fp16 > $O/pmc_sq_step.json 2>> $O/pmc_sq.err; echo "pmc_sq reduce rc=$?" | tee -a $O/summary.txt
+MM_GRAPH2D=0 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pmc_sq -- python3 bench.py --steps 3 --warmup 2 --no-extras > $O/pmc_sq_bench.json 2> $O/pmc_sq.err; echo "pmc sq rc=$?" | tee -a $O/summary_$PART.txt
+python tools/pmc_sq.py $O/pmc_sq fp16 > $O/pmc_sq_step.json 2>> $O/pmc_sq.err; echo "pmc_sq reduce rc=$?" | tee -a $O/summary_$PART.txt
 rm -rf $O/pmc_sq
 # the counter records go to profiles/ BEFORE the bench (bench.py reads them from there), and are checked again at the end
 cp $O/traffic_3d.json $P/traffic_3d.json; cp $O/pmc_sq_step.json $P/pmc_sq_step.json
-python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?" | tee -a $O/summary.txt
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_cmd.json 2> $O/bench_n1_driver_cmd.err; echo "bench (driver command) rc=$?" | tee -a $O/summary.txt
+python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?" | tee -a $O/summary_$PART.txt
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_n1_driver_cmd.json 2> $O/bench_n1_driver_cmd.err; echo "bench (driver command) rc=$?" | tee -a $O/summary_$PART.txt
 export MM_BENCH_NO_CPU=1
-rocprofv3 --kernel-trace --stats -d $O/kstats -o ks --output-format csv -- python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_profiled.json 2> $O/bench_n1_profiled.err; echo "rocprof rc=$?" | tee -a $O/summary.txt
+rocprofv3 --kernel-trace --stats -d $O/kstats -o ks --output-format csv -- python3 bench.py --steps 20 --warmup 5 > $O/bench_n1_profiled.json 2> $O/bench_n1_profiled.err; echo "rocprof rc=$?" | tee -a $O/summary_$PART.txt
 cp $O/kstats/ks_kernel_stats.csv $O/bench_n1_kernel_stats.csv 2>/dev/null; rm -rf $O/kstats
 # the same with everything on ONE stream (no dW side stream, no rulebook side stream): per-kernel durations that the roofline leg's
 # per-call event times must agree with
-MM_SPCONV_BWD_OVERLAP=0 MM_META_SIDE=0 rocprofv3 --kernel-trace --stats -d $O/kstats_serial -o ks --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-extras > $O/bench_n1_serial_profiled.json 2> $O/bench_n1_serial_profiled.err; echo "rocprof serial rc=$?" | tee -a $O/summary.txt
+MM_SPCONV_BWD_OVERLAP=0 MM_META_SIDE=0 rocprofv3 --kernel-trace --stats -d $O/kstats_serial -o ks --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-extras > $O/bench_n1_serial_profiled.json 2> $O/bench_n1_serial_profiled.err; echo "rocprof serial rc=$?" | tee -a $O/summary_$PART.txt
 cp $O/kstats_serial/ks_kernel_stats.csv $O/bench_n1_serial_kernel_stats.csv 2>/dev/null; rm -rf $O/kstats_serial
 python tools/kstats_categories.py $O/bench_n1_serial_kernel_stats.csv 16 --top 45 > $O/kernel_families_serial.txt 2>&1
 python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2>/dev/null; python bench.py --workload c5 --steps 10 --warmup 3 > $O/bench_c5.json 2>/dev/null
 python bench.py --precision bf16 --steps 20 --warmup 5 --no-extras > $O/bench_n1_bf16.json 2>/dev/null
 MM_BN2D_FUSED=1 MM_BN_FUSED=1 MM_GRAPH2D=0 MM_META_SIDE=0 python bench.py --steps 20 --warmup 5 --no-extras > $O/bench_n1_as_under_ddp.json 2>/dev/null
+summarise $O/bench_summary.txt
+fi
+if [[ "$PART" == *b* ]]; then
+export MM_BENCH_NO_CPU=1
 # per-layer records
 timeout -k 10 250 python tools/sparse_layers.py --workload c2 > $O/sparse_layers_c2.txt 2>&1
 timeout -k 10 250 python tools/sparse_layers.py --workload c4 > $O/sparse_layers_c4.txt 2>&1
@@ -62,21 +83,13 @@ for i in 1 2; do
   # init_process_group(device_id=) as in rounds 2-5: the eager communicator alone costs every step ~1.5 ms (reducer on / off)
   MM_DDP_FORCE=1 MM_BENCH_PG_EAGER=1 python bench.py --steps 40 --warmup 10 --no-extras > $O/ab_ddp1rank_eager_init_$i.json 2>/dev/null
 done
-python - > $O/ab_summary.txt <<'PY'
-import json, glob
-for f in sorted(glob.glob("gpurun_out/r06/final/ab_*.json") + glob.glob("gpurun_out/r06/final/bench_*.json")):
-    try:
-        d = json.loads(open(f).read().strip().splitlines()[-1]); c = d["config"]
-        print(f.split("/")[-1].ljust(40), "value", d["value"], d["unit"], "| ms/step", d["ms_per_step"], "| p10/p50/p90", c.get("step_ms_p10_p50_p90"),
-              "| host enqueue (empty queue)", c.get("host_enqueue_ms_empty_queue"), "| final loss", c.get("final_loss"), "| roofline.frac", d.get("roofline", {}).get("frac"),
-              "| roofline_2d.frac", d.get("roofline_2d", {}).get("frac"))
-    except Exception as e:
-        print(f, "unreadable:", e)
-PY
+summarise $O/ab_summary.txt
+fi
 # copy what the judge reads; the counter records only if they still belong to this tree
 for f in smoke.log bench_n1.json bench_n1_driver_cmd.json bench_n1_profiled.json bench_n1_kernel_stats.csv bench_n1_serial_profiled.json bench_n1_serial_kernel_stats.csv \
          kernel_families_serial.txt bench_c4.json bench_c5.json bench_n1_bf16.json bench_n1_as_under_ddp.json sparse_layers_c2.txt sparse_layers_c4.txt sparse_layers_c5.txt \
-         conv3x3_bench_shapes.txt conv3x3_diag_clocks.txt dw16_ab.txt stream_diag.txt bn2d_layer_set.txt ab_summary.txt summary.txt pmc_sq_bench.json; do
+         conv3x3_bench_shapes.txt conv3x3_diag_clocks.txt dw16_ab.txt stream_diag.txt bn2d_layer_set.txt ab_summary.txt bench_summary.txt summary_a.txt summary_b.txt summary_ab.txt pmc_sq_bench.json \
+         traffic_3d.json pmc_sq_step.json; do
   [ -f $O/$f ] && cp $O/$f $P/$f
 done
 python - <<'PY'
@@ -101,4 +114,4 @@ for name, key, files in (("pmc_sq_step.json", "conv2d_sources_sha256", ("conv2d.
     else:
         print(f"{name}: fingerprint matches this tree")
 PY
-du -sh $O; cat $O/summary.txt; cat $O/ab_summary.txt
+du -sh $O; cat $O/summary_$PART.txt; [ -f $O/bench_summary.txt ] && cat $O/bench_summary.txt; [ -f $O/ab_summary.txt ] && cat $O/ab_summary.txt
