@@ -35,7 +35,7 @@ def _units():
 
     C3 = lambda ci, co, **k: nn2d.Conv2d(ci, co, kernel_size=3, padding=1, bias=False, **k)
     return [
-        ("conv3x3 64->64 (k_conv3x3r, k_wgrad3x3n)", lambda: C3(64, 64), (16, 64, 152, 240), False),
+        ("conv3x3 64->64 (k_conv3x3s with resident weights, k_wgrad3x3n)", lambda: C3(64, 64), (16, 64, 152, 240), False),
         ("conv3x3 192->64 (k_conv3x3s<64>)", lambda: nn2d.Conv2d(192, 64, kernel_size=3, padding=1), (8, 192, 152, 240), False),
         ("conv3x3 384->128 (k_conv3x3s<128,16>)", lambda: C3(384, 128), (16, 384, 76, 120), False),
         ("conv3x3 256->256 (k_conv3x3s<128,32>, half items)", lambda: C3(256, 256), (32, 256, 38, 60), False),
