@@ -152,6 +152,22 @@ def _worker(rank, world, port, overlap, q):
         bufmod.running_mean.fill_(float(rank + 1))
         red.broadcast_buffers([bufmod])
         assert torch.equal(bufmod.running_mean, torch.ones(3))
+        # the buffers now live in flat arenas (one per dtype) that are broadcast in place: same Tensor objects, shared storage,
+        # 16-byte aligned slices; writes through the module are what the next broadcast sends
+        flats = red._buf_state["flat"]
+        assert len(flats) == 2 and {f.dtype for f in flats} == {torch.float32, torch.int64}
+        f32 = next(f for f in flats if f.dtype == torch.float32)
+        assert bufmod.running_mean.untyped_storage().data_ptr() == f32.untyped_storage().data_ptr() == bufmod.running_var.untyped_storage().data_ptr()
+        assert all(b.data_ptr() % 16 == 0 for b in bufmod.buffers()) and bufmod.num_batches_tracked.shape == ()
+        bufmod.running_var.fill_(float(5 + rank))
+        bufmod.num_batches_tracked += 7 * (rank + 1)
+        red.broadcast_buffers([bufmod])
+        assert torch.equal(bufmod.running_var, torch.full((3,), 5.0)) and int(bufmod.num_batches_tracked) == 7
+        assert red._buf_state["flat"][0] is flats[0], "unchanged buffers: the arenas are reused"
+        # a buffer replaced behind the reducer's back (module.to(), a new module) is noticed by identity / address: new arenas
+        bufmod.running_mean = torch.full((3,), float(10 * (rank + 1)))
+        red.broadcast_buffers([bufmod])
+        assert torch.equal(bufmod.running_mean, torch.full((3,), 10.0)) and red._buf_state["flat"][0] is not flats[0]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
