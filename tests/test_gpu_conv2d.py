@@ -431,12 +431,16 @@ def test_conv3x3_round6_kernels_against_the_first_kernel(cin, cout, B, hw, split
         return out
 
     try:
-        ref, v, s16 = run(4), run(8), run(0)
+        ref, v, s16, s12 = run(4), run(8), run(0), run(12)
     finally:
         c2.LEGACY3X3[0] = 0
         c2.BN_PRE[0] = old_pre
     for i, (a, r) in enumerate(zip(v, ref)):
         assert a.shape == r.shape and torch.equal(a, r), f"k_conv3x3v output {i} differs: {int((a != r).sum())} of {a.numel()} elements"
+    # flip | 12 = k_conv3x3s in its streaming form for every shape: for 64 -> 64 the resident-weight form (the default) must give the
+    # same bits (the same MFMAs on the same operands in the same order; only where the weight tiles come from differs)
+    for i, (a, r) in enumerate(zip(s12, s16)):
+        assert torch.equal(a, r), f"k_conv3x3s streaming / resident output {i} differs: {int((a != r).sum())} of {a.numel()} elements"
     ulp = 2.0 ** -10 if half2d == torch.float16 else 2.0 ** -7
     for i, (a, r) in enumerate(zip(s16, ref)):
         assert a.shape == r.shape
